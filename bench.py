@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Benchmark of the CrossNorm/SelfNorm hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one fused CNSN forward + backward (CrossNorm armed, SelfNorm in training mode) over one
+synthetic activation batch that is already resident in HBM: BASELINE.json's north-star workload
+N=256, C=256, H=W=56 (the layer-1 site of ResNet-50 at batch 256).  Every rank owns its own batch
+(the op has no cross-GPU exchange: the permutation and the BatchNorm1d statistics are local to the
+minibatch); with N>1 the SelfNorm parameter gradients (4C floats) are all-reduced
+over RCCL each step like DDP would.  `value` = all ranks' algorithmic bytes (8*E*b per step:
+3 tensor passes forward, 5 backward — SURVEY.md §8d3) / wall time, in GB/s.
+
+One JSON line is printed by rank 0; it also carries
+  roofline     — the backward launch (dominant kernel) timed with HIP events on the launch stream
+  cpu_baseline — the CPU oracle (a port of the reference's eager PyTorch path) timed on this
+                 host's cores on a bounded slice of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--shape", type=str, default="256,256,56,56")
+    ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16", "f16"])
+    ap.add_argument("--crop", type=str, default="both", choices=["neither", "style", "content", "both"])
+    ap.add_argument("--kind", type=str, default="cnsn", choices=["cnsn", "cn", "sn"])
+    ap.add_argument("--strategy", type=str, default="auto", choices=["auto", "two_pass", "resident"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    return ap.parse_args()
+
+
+def conditioned(shape, device, dtype, seed):
+    """x = randn*s + m with per-plane s~U(0.5,2), m~N(0,1): well conditioned for SelfNorm's BN."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    n, c = shape[:2]
+    x = torch.randn(shape, generator=g, device=device)
+    x.mul_(torch.rand(n, c, 1, 1, generator=g, device=device) * 1.5 + 0.5)
+    x.add_(torch.randn(n, c, 1, 1, generator=g, device=device))
+    return x.to(dtype)
+
+
+def cpu_baseline(shape, crop, kind, budget_s):
+    """Time the CPU oracle (op-for-op restatement of the reference's eager path) on a slice."""
+    import numpy as np
+    from oracle import cnsn_oracle as orc
+    n, c, h, w = shape
+    ns = max(2, min(n, 32))                          # 1/8 of the north-star batch: ~0.4 s / step on 8 cores
+    sshape = (ns, c, h, w)
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    x = conditioned(sshape, "cpu", torch.float32, 0).requires_grad_()
+    gy = torch.randn(sshape)
+    mod = orc.CNSN(orc.CrossNorm(crop, 1) if kind != "sn" else None,
+                   orc.SelfNorm(c) if kind != "cn" else None).train()
+    times = []
+    t_end = time.perf_counter() + budget_s
+    it = 0
+    while it < 2 or (time.perf_counter() < t_end and it < 40):
+        if mod.crossnorm is not None:
+            mod.crossnorm.active = True
+        x.grad = None
+        t0 = time.perf_counter()
+        y = mod(x)
+        y.backward(gy)
+        times.append(time.perf_counter() - t0)
+        it += 1
+    times = sorted(times[1:]) if len(times) > 1 else times
+    med = times[len(times) // 2]
+    e = ns * c * h * w
+    return {"value": round(8 * e * 4 / med / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": f"oracle CNSN fwd+bwd fp32 on ({ns},{c},{h},{w}) = {ns}/{n} of the batch, "
+                      f"median of {len(times)} iters, {med * 1e3:.1f} ms/iter, "
+                      f"{ns / med:.1f} img/s",
+            "cpu": _cpu_model()}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # nccl == RCCL on ROCm
+    else:
+        dist = None
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (use gpurun)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import cnsn_amd
+    cnsn_amd.lib()                                    # fail loudly now if the .so is missing
+    cnsn_amd.set_strategy(args.strategy)
+    import numpy as np
+
+    shape = tuple(int(v) for v in args.shape.split(","))
+    n, c, h, w = shape
+    dtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
+    b = 4 if dtype == torch.float32 else 2
+    e = n * c * h * w
+
+    torch.manual_seed(1234 + rank)                    # ranks draw different perms / boxes
+    np.random.seed(1234 + rank)
+    x = conditioned(shape, dev, dtype, 10 + rank).requires_grad_()
+    gy = torch.randn(shape, device=dev, generator=torch.Generator(device=dev).manual_seed(20 + rank)).to(dtype)
+    mod = cnsn_amd.CNSN(cnsn_amd.CrossNorm(args.crop, 1) if args.kind != "sn" else None,
+                        cnsn_amd.SelfNorm(c) if args.kind != "cn" else None).to(dev).train()
+    params = [p for p in mod.parameters()]
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    def step(i=None):
+        if mod.crossnorm is not None:
+            mod.crossnorm.active = True               # what _enable_cross_norm does before a forward
+        x.grad = None
+        for p in params:
+            p.grad = None
+        if i is not None:
+            ev[i][0].record()
+        y = mod(x)
+        if i is not None:
+            ev[i][1].record()
+        y.backward(gy)
+        if i is not None:
+            ev[i][2].record()
+        if dist is not None and params:               # DDP-style gradient all-reduce (RCCL over xGMI)
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            dist.all_reduce(flat)
+            flat.div_(world)
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    fwd_ms = sum(a.elapsed_time(m_) for a, m_, _ in ev) / args.steps
+    bwd_ms = sum(m_.elapsed_time(z) for _, m_, z in ev) / args.steps
+    ms_per_step = dt / args.steps * 1e3
+    step_bytes = 8 * e * b
+    value = world * step_bytes / (dt / args.steps) / 1e9
+
+    if rank == 0:
+        bwd_bytes = 5 * e * b
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(f"{args.dtype}_{args.crop}_{args.kind}_bwd_bytes")
+            except (OSError, ValueError):
+                traffic = None
+        out = {
+            "metric": "fused CNSN fwd+bwd GB/s vs HBM roofline",
+            "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"fused CrossNorm(crop={args.crop})+SelfNorm fwd+bwd, "
+                                   f"NCHW ({n},{c},{h},{w}) per GPU, kind={args.kind}",
+                       "shape": list(shape), "crop": args.crop, "kind": args.kind,
+                       "strategy": args.strategy, "algorithmic_bytes_per_step": step_bytes,
+                       "parallelism": f"dp{world} (independent minibatches; grads of 4C SN params all-reduced)"},
+            "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
+            "fwd_ms": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4),
+            "images_per_s": round(world * n / (dt / args.steps), 1),
+            "roofline": {"bound": "hbm", "kernel": "cnsn_backward launch (dominant: 5*E*b algorithmic bytes)",
+                         "achieved": round(bwd_bytes / (bwd_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(bwd_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": traffic,
+                         "forward": {"achieved": round(3 * e * b / (fwd_ms * 1e-3) / 1e9, 1),
+                                     "frac": round(3 * e * b / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(shape, args.crop, args.kind, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

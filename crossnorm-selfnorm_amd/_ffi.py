@@ -1,0 +1,105 @@
+"""ctypes binding of libcnsn_hip.so (the C ABI of include/cnsn_hip.h).  No torch types cross it:
+device pointers travel as integers, the stream as a void*.  The library must be present — there is
+no fallback: `lib()` raises if it is missing (build it with `python __graft_entry__.py`)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcnsn_hip.so")
+
+CNSN_F32, CNSN_BF16, CNSN_F16 = 0, 1, 2
+STRATEGY_AUTO, STRATEGY_TWO_PASS, STRATEGY_RESIDENT = 0, 1, 2
+ABI_VERSION = 1
+
+
+class Problem(C.Structure):
+    """cnsn_problem_t"""
+    _fields_ = [
+        ("struct_bytes", C.c_int32), ("dtype", C.c_int32),
+        ("N", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("cn_active", C.c_int32), ("content_box", C.c_int32 * 4), ("style_box", C.c_int32 * 4),
+        ("lam", C.c_float), ("eps_cn", C.c_float),
+        ("sn_active", C.c_int32), ("sn_two", C.c_int32), ("sn_training", C.c_int32),
+        ("eps_sn", C.c_float), ("eps_bn", C.c_float), ("momentum", C.c_float),
+        ("strategy", C.c_int32),
+    ]
+
+
+class Gate(C.Structure):
+    """cnsn_gate_t"""
+    _fields_ = [("fc_weight", C.c_void_p), ("bn_weight", C.c_void_p), ("bn_bias", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p)]
+
+
+class GateGrad(C.Structure):
+    """cnsn_gate_grad_t"""
+    _fields_ = [("d_fc_weight", C.c_void_p), ("d_bn_weight", C.c_void_p), ("d_bn_bias", C.c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/cnsn_hip.h declares
+SIGNATURES = {
+    "cnsn_abi_version": (C.c_int, []),
+    "cnsn_status_string": (C.c_char_p, [C.c_int]),
+    "cnsn_saved_floats": (C.c_size_t, [C.POINTER(Problem)]),
+    "cnsn_workspace_bytes": (C.c_size_t, [C.POINTER(Problem)]),
+    "cnsn_forward": (C.c_int, [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.POINTER(Gate), C.POINTER(Gate), C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cnsn_backward": (C.c_int, [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.POINTER(Gate), C.POINTER(Gate), C.c_void_p, C.c_void_p,
+                                C.POINTER(GateGrad), C.POINTER(GateGrad), C.c_void_p, C.c_size_t,
+                                C.c_void_p]),
+    "cnsn_plane_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.POINTER(C.c_int32), C.c_float, C.c_void_p, C.c_void_p]),
+    "cnsn_plane_stats_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.POINTER(C.c_int32), C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cnsn_plane_affine": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cnsn_plane_dot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+class CnsnError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the bound library; raise loudly when it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CnsnError(
+                f"{LIB_PATH} is missing: the CrossNorm/SelfNorm HIP library has not been built. "
+                "Run `python __graft_entry__.py` (hipcc --offload-arch=gfx950). There is no "
+                "CPU or eager fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        got = handle.cnsn_abi_version()
+        if got != ABI_VERSION:
+            raise CnsnError(f"libcnsn_hip.so ABI {got} != binding ABI {ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = lib().cnsn_status_string(status).decode()
+        if status == -7:   # CNSN_E_BATCH: same exception type nn.BatchNorm1d raises
+            raise ValueError(f"{what}: {msg}")
+        raise CnsnError(f"{what} failed with status {status}: {msg}")
+
+
+def box4(b):
+    arr = (C.c_int32 * 4)(-1, -1, -1, -1)
+    if b is not None:
+        for i in range(4):
+            arr[i] = int(b[i])
+    return arr

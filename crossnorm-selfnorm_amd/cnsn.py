@@ -1,0 +1,203 @@
+"""Drop-in for the reference's `models/cnsn.py`: the same seven names, signatures, attributes,
+RNG draw order and `state_dict` keys — computed by the fused HIP kernels of libcnsn_hip.so.
+
+    reference (models/cnsn.py)            here
+    calc_ins_mean_std        :8-17        one stats kernel (cnsn_plane_stats)
+    instance_norm_mix        :20-29       stats x2 + one affine kernel
+    cn_rand_bbox             :32-55       host, numpy global RNG, same draw order
+    cn_op_2ins_space_chan    :58-91       fused forward/backward (cnsn_forward / cnsn_backward)
+    CrossNorm                :94-110      flag holder; arms the fused call
+    SelfNorm                 :113-150     parameter holder (g_fc, g_bn[, f_fc, f_bn]); fused call
+    CNSN                     :152-164     ONE fused call for CrossNorm+SelfNorm on the tensor
+
+Use: replace the body of `models/cnsn.py` by `from cnsn_amd.cnsn import *` — the
+model files (`from ..cnsn import CrossNorm, SelfNorm, CNSN`), `isinstance(m, CrossNorm)` site
+collection, `m.active = True`, and checkpoints keep working unmodified.
+
+HIP device tensors only; a CPU tensor raises (there is deliberately no fallback path).
+"""
+from __future__ import annotations
+
+import functools
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import functional as _F
+from .functional import FusedConfig, GateParams
+
+__all__ = ["calc_ins_mean_std", "instance_norm_mix", "cn_rand_bbox", "cn_op_2ins_space_chan",
+           "CrossNorm", "SelfNorm", "CNSN"]
+
+Box = Tuple[int, int, int, int]
+_CROPS = ("neither", "style", "content", "both")
+
+
+def calc_ins_mean_std(x, eps=1e-5):
+    """Per-(n,c) mean and sqrt(unbiased variance + eps) over H*W, each shaped (N,C,1,1)
+    (reference models/cnsn.py:8-17).  Differentiable."""
+    assert x.dim() == 4
+    return _F.PlaneStats.apply(x, float(eps), None)
+
+
+def instance_norm_mix(content_feat, style_feat):
+    """Give `content_feat` the plane statistics of `style_feat` (reference models/cnsn.py:20-29)."""
+    assert content_feat.size()[:2] == style_feat.size()[:2]
+    s_mean, s_std = calc_ins_mean_std(style_feat)
+    c_mean, c_std = calc_ins_mean_std(content_feat)
+    scale = s_std.float() / c_std.float()          # (N,C,1,1) scalars per plane; negligible work
+    shift = s_mean.float() - c_mean.float() * scale
+    return _F.PlaneAffine.apply(content_feat, scale, shift)
+
+
+def cn_rand_bbox(size, beta, bbx_thres):
+    """Sample the crop box of CrossNorm (reference models/cnsn.py:32-55).
+
+    Same stream consumption as the reference — per attempt one `np.random.beta`, then
+    `np.random.randint(size[2])`, then `np.random.randint(size[3])` from numpy's global generator —
+    so a seeded run draws the same boxes.  Returns (x1, y1, x2, y2), x along dim 2, y along dim 3.
+    """
+    ext2, ext3 = int(size[2]), int(size[3])
+    plane = float(ext2 * ext3)
+    while True:
+        side = np.sqrt(np.random.beta(beta, beta))
+        half2, half3 = int(ext2 * side) // 2, int(ext3 * side) // 2   # truncate, then floor-halve
+        mid2 = np.random.randint(ext2)
+        mid3 = np.random.randint(ext3)
+        x1, x2 = max(mid2 - half2, 0), min(mid2 + half2, ext2)
+        y1, y2 = max(mid3 - half3, 0), min(mid3 + half3, ext3)
+        if (x2 - x1) * (y2 - y1) / plane > bbx_thres:
+            return int(x1), int(y1), int(x2), int(y2)
+
+
+@dataclass
+class CNDraws:
+    """What one CrossNorm application consumes from the RNGs (reference draw order, cnsn.py:62-76)."""
+    perm: torch.Tensor                       # int64 (N), CPU: torch.randperm(N)
+    style_box: Optional[Box] = None
+    chan_perm: Optional[torch.Tensor] = None
+    content_box: Optional[Box] = None
+
+
+def draw_cn(size, crop, beta, bbx_thres=0.1, chan=False) -> CNDraws:
+    """torch.randperm(N) [CPU generator] -> style box -> torch.randperm(C) if chan -> content box."""
+    assert crop in _CROPS
+    d = CNDraws(perm=torch.randperm(int(size[0])))
+    if crop in ("style", "both"):
+        d.style_box = cn_rand_bbox(size, beta=beta, bbx_thres=bbx_thres)
+    if chan:
+        d.chan_perm = torch.randperm(int(size[1]))
+    if crop in ("content", "both"):
+        d.content_box = cn_rand_bbox(size, beta=beta, bbx_thres=bbx_thres)
+    return d
+
+
+def _cn_config(d: CNDraws, lam) -> FusedConfig:
+    return FusedConfig(cn_active=True, content_box=d.content_box, style_box=d.style_box, lam=lam)
+
+
+def cn_op_2ins_space_chan(x, crop='neither', beta=1, bbx_thres=0.1, lam=None, chan=False, draws=None):
+    """2-instance CrossNorm with optional cropping (reference models/cnsn.py:58-91).
+
+    `draws` (a CNDraws) is an extension for tests: when given, nothing is drawn from the RNGs.
+    """
+    assert crop in _CROPS
+    if draws is None:
+        draws = draw_cn(x.size(), crop, beta, bbx_thres, chan)
+    return _F.fused_cnsn(x, _cn_config(draws, lam), perm=draws.perm, chan_perm=draws.chan_perm)
+
+
+class CrossNorm(nn.Module):
+    """CrossNorm site (reference models/cnsn.py:94-110): stateless apart from the `active` flag
+    that the network raises on randomly chosen sites before a forward (`_enable_cross_norm`)."""
+
+    def __init__(self, crop=None, beta=None):
+        super().__init__()
+        self.active = False
+        self.crop, self.beta = crop, beta
+        self.cn_op = functools.partial(cn_op_2ins_space_chan, crop=crop, beta=beta)
+        self.next_draws: Optional[CNDraws] = None      # test hook: use these instead of drawing
+
+    def _take_draws(self, x) -> CNDraws:
+        d, self.next_draws = self.next_draws, None
+        return d if d is not None else draw_cn(x.size(), self.crop, self.beta)
+
+    def forward(self, x):
+        if self.training and self.active:
+            x = self.cn_op(x, draws=self._take_draws(x))
+        self.active = False                            # always dropped, also in eval (cnsn.py:108)
+        return x
+
+
+class SelfNorm(nn.Module):
+    """SelfNorm (reference models/cnsn.py:113-150).  `g_fc`/`g_bn` (and `f_fc`/`f_bn`) are kept as
+    the same nn.Conv1d / nn.BatchNorm1d sub-modules so parameters, buffers and state_dict keys are
+    identical; they are never called — their tensors feed the fused kernel."""
+
+    def __init__(self, chan_num, is_two=False):
+        super().__init__()
+        self.g_fc = nn.Conv1d(chan_num, chan_num, kernel_size=2, bias=False, groups=chan_num)
+        self.g_bn = nn.BatchNorm1d(chan_num)
+        if is_two is True:
+            self.f_fc = nn.Conv1d(chan_num, chan_num, kernel_size=2, bias=False, groups=chan_num)
+            self.f_bn = nn.BatchNorm1d(chan_num)
+        else:
+            self.f_fc = None
+
+    @staticmethod
+    def _gate(fc, bn) -> GateParams:
+        return GateParams(fc.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+
+    def _bn_training(self) -> bool:
+        bn = self.g_bn
+        return bn.training or (bn.running_mean is None and bn.running_var is None)
+
+    def _fused_args(self):
+        """(config fields, g, f) for the fused call; does BatchNorm1d's per-call book-keeping."""
+        bn = self.g_bn
+        training = self._bn_training()
+        momentum = bn.momentum
+        bns = [bn] + ([self.f_bn] if self.f_fc is not None else [])
+        if self.training and bn.track_running_stats:
+            for b in bns:
+                b.num_batches_tracked.add_(1)           # as nn.BatchNorm1d.forward does
+            if momentum is None:                        # cumulative moving average
+                momentum = 1.0 / float(bn.num_batches_tracked)
+        g = self._gate(self.g_fc, self.g_bn)
+        f = self._gate(self.f_fc, self.f_bn) if self.f_fc is not None else None
+        kw = dict(sn_active=True, sn_two=f is not None, sn_training=training, eps_bn=bn.eps,
+                  momentum=0.0 if momentum is None else float(momentum))
+        return kw, g, f
+
+    def forward(self, x):
+        kw, g, f = self._fused_args()
+        return _F.fused_cnsn(x, FusedConfig(**kw), g=g, f=f)
+
+
+class CNSN(nn.Module):
+    """CrossNorm then SelfNorm (reference models/cnsn.py:152-164), issued as ONE fused call when
+    both apply: 2 tensor reads + 1 write forward instead of the reference's ~15 passes."""
+
+    def __init__(self, crossnorm, selfnorm):
+        super().__init__()
+        self.crossnorm = crossnorm
+        self.selfnorm = selfnorm
+
+    def forward(self, x):
+        cn, sn = self.crossnorm, self.selfnorm
+        fuse = (cn is not None and sn is not None and type(cn) is CrossNorm and type(sn) is SelfNorm
+                and cn.active and cn.training)
+        if not fuse:                                    # literal reference control flow
+            if cn and cn.active:
+                x = cn(x)
+            if sn:
+                x = sn(x)
+            return x
+        d = cn._take_draws(x)
+        cn.active = False
+        kw, g, f = sn._fused_args()
+        cfg = FusedConfig(cn_active=True, content_box=d.content_box, style_box=d.style_box, **kw)
+        return _F.fused_cnsn(x, cfg, perm=d.perm, chan_perm=d.chan_perm, g=g, f=f)

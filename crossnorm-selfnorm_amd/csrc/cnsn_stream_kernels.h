@@ -1,0 +1,337 @@
+// Streaming ("two-pass") kernels: every tensor pass of the fused op as one bandwidth-bound launch.
+//
+//   forward : plane_stats_kernel (read x)  -> mid_fwd_kernel (N*C scalars) -> apply_fwd_kernel (read x, write y)
+//   backward: bwd_reduce_kernel (read G,x) -> mid_bwd_a/b (N*C scalars)    -> apply_bwd_kernel (read G,x, write dx)
+//
+// Thread mapping (all kernels): a plane (H*W contiguous elements of one (n,c)) is owned by LPP
+// consecutive lanes — 16 (one DPP row), 64 (one wave) or 256 (the block) — chosen on the host from
+// the plane size so that every lane issues full-width vector loads (VEC elements = up to 16 B) and
+// the per-plane reduction never leaves registers/DPP for LPP <= 64.  Loads are issued UNROLL at a
+// time before any is consumed, so each lane keeps UNROLL*16 B in flight.
+#pragma once
+#include "cnsn_device.h"
+
+namespace cnsn {
+
+constexpr int kUnroll = 4;
+
+// stream one plane: consume(vec, vec_index)
+template <typename T, int VEC, int LPP, typename Consume>
+__device__ __forceinline__ void stream1(const T* __restrict__ base, int nvec, int lane, Consume&& consume) {
+    int i = lane;
+    for (; i + (kUnroll - 1) * LPP < nvec; i += kUnroll * LPP) {
+        Vec<T, VEC> v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) v[u] = load_vec<T, VEC>(base + (size_t)(i + u * LPP) * VEC);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) consume(v[u], i + u * LPP);
+    }
+    for (; i < nvec; i += LPP) {
+        Vec<T, VEC> v = load_vec<T, VEC>(base + (size_t)i * VEC);
+        consume(v, i);
+    }
+}
+
+// stream two planes in lock step: consume(vecA, vecB, vec_index)
+template <typename T, int VEC, int LPP, typename Consume>
+__device__ __forceinline__ void stream2(const T* __restrict__ a, const T* __restrict__ b, int nvec, int lane,
+                                        Consume&& consume) {
+    constexpr int U = kUnroll / 2;
+    int i = lane;
+    for (; i + (U - 1) * LPP < nvec; i += U * LPP) {
+        Vec<T, VEC> va[U], vb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            va[u] = load_vec<T, VEC>(a + (size_t)(i + u * LPP) * VEC);
+            vb[u] = load_vec<T, VEC>(b + (size_t)(i + u * LPP) * VEC);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) consume(va[u], vb[u], i + u * LPP);
+    }
+    for (; i < nvec; i += LPP) {
+        Vec<T, VEC> va = load_vec<T, VEC>(a + (size_t)i * VEC);
+        Vec<T, VEC> vb = load_vec<T, VEC>(b + (size_t)i * VEC);
+        consume(va, vb, i);
+    }
+}
+
+template <int LPP>
+struct PlaneId {
+    int p;       // plane index (clamped so that idle lanes still take part in reductions)
+    int lane;    // lane within the plane's group
+    bool valid;  // p is a real plane
+    __device__ __forceinline__ explicit PlaneId(int P) {
+        constexpr int PPB = kBlock / LPP;
+        const int q = blockIdx.x * PPB + threadIdx.x / LPP;
+        lane = threadIdx.x % LPP;
+        valid = q < P;
+        p = valid ? q : P - 1;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// pass A: plane statistics (reference: calc_ins_mean_std, models/cnsn.py:14-16)
+//   un-boxed: out[0]=mean, out[1]=M2 of the whole plane
+//   boxed   : out[0..5] = mean/M2 inside the content box, outside it, inside the style box
+//   finalize: out[0]=mean, out[1]=sqrt(M2/(cnt-1)+eps) of the (content-box) region
+// Sums are taken about a per-plane shift K (mean of the plane's first VEC elements) so that
+// S2 - S1^2/cnt does not cancel for planes with |mean| >> std (post-ReLU activations).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC, int LPP, bool BOXED>
+__global__ __launch_bounds__(kBlock) void plane_stats_kernel(const T* __restrict__ x, Geom g,
+                                                             float* __restrict__ out, float eps, int finalize) {
+    constexpr int NACC = BOXED ? 6 : 2;
+    __shared__ float lds[4 * NACC];
+    const PlaneId<LPP> id(g.P);
+    const T* base = x + (size_t)id.p * g.M;
+
+    float K = 0.f;
+    {
+        const Vec<T, VEC> f = load_vec<T, VEC>(base);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) K += to_float(f.v[j]);
+        K *= (1.0f / VEC);
+    }
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+
+    stream1<T, VEC, LPP>(base, g.nvec, id.lane, [&](const Vec<T, VEC>& v, int i) {
+        if constexpr (!BOXED) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float d = to_float(v.v[j]) - K;
+                acc[0] += d;
+                acc[1] = fmaf(d, d, acc[1]);
+            }
+        } else {
+            const int e = i * VEC;  // VEC divides the width: the whole vector lies in one row
+            const int r = e / g.Wd, c = e - r * g.Wd;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float d = to_float(v.v[j]) - K;
+                const float d2 = d * d;
+                const bool ic = g.cb.has(r, c + j), is = g.sb.has(r, c + j);
+                acc[0] += ic ? d : 0.f;
+                acc[1] += ic ? d2 : 0.f;
+                acc[2] += ic ? 0.f : d;
+                acc[3] += ic ? 0.f : d2;
+                acc[4] += is ? d : 0.f;
+                acc[5] += is ? d2 : 0.f;
+            }
+        }
+    });
+    group_sum<LPP, NACC>(acc, lds);
+
+    if (id.lane == 0 && id.valid) {
+        auto moments = [&](float s1, float s2, int cnt, float& mean, float& m2) {
+            if (cnt <= 0) {
+                mean = 0.f;
+                m2 = 0.f;
+                return;
+            }
+            const double d1 = s1, d2 = s2;
+            mean = float(double(K) + d1 / cnt);
+            const double t = d2 - d1 * d1 / cnt;
+            m2 = float(t > 0.0 ? t : 0.0);
+        };
+        const int P = g.P;
+        if constexpr (!BOXED) {
+            float mean, m2;
+            moments(acc[0], acc[1], g.M, mean, m2);
+            out[id.p] = mean;
+            out[P + id.p] = finalize ? sqrtf(m2 / float(g.M - 1) + eps) : m2;
+        } else {
+            const int Mc = g.cb.area(), Ms = g.sb.area();
+            float mean, m2;
+            moments(acc[0], acc[1], Mc, mean, m2);
+            out[id.p] = mean;
+            out[P + id.p] = finalize ? sqrtf(m2 / float(Mc - 1) + eps) : m2;
+            if (!finalize) {
+                moments(acc[2], acc[3], g.M - Mc, mean, m2);
+                out[2 * P + id.p] = mean;
+                out[3 * P + id.p] = m2;
+                moments(acc[4], acc[5], Ms, mean, m2);
+                out[4 * P + id.p] = mean;
+                out[5 * P + id.p] = m2;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass B: y = a_in*(x - xr) + b_in inside the content box, a_out*x + b_out outside
+// (reference: instance_norm_mix :27-29, the box paste :75-82, the lam blend :87, SelfNorm :148/:150
+//  — all folded into five per-plane coefficients by mid_fwd_kernel).  xr may be NULL (= 0).
+// ------------------------------------------------------------------------------------------------
+struct ApplyCoef {
+    const float* a_in;
+    const float* xr;
+    const float* b_in;
+    const float* a_out;
+    const float* b_out;
+};
+
+template <typename T, int VEC, int LPP, bool BOXED>
+__global__ __launch_bounds__(kBlock) void apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, Geom g,
+                                                           ApplyCoef cf) {
+    const PlaneId<LPP> id(g.P);
+    if (!id.valid) return;
+    const size_t off = (size_t)id.p * g.M;
+    const float a_in = cf.a_in[id.p], xr = cf.xr ? cf.xr[id.p] : 0.f, b_in = cf.b_in[id.p];
+    float a_out = 0.f, b_out = 0.f;
+    if constexpr (BOXED) {
+        a_out = cf.a_out[id.p];
+        b_out = cf.b_out[id.p];
+    }
+    T* yb = y + off;
+    stream1<T, VEC, LPP>(x + off, g.nvec, id.lane, [&](const Vec<T, VEC>& v, int i) {
+        Vec<T, VEC> o;
+        if constexpr (!BOXED) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o.v[j] = from_float<T>(fmaf(a_in, to_float(v.v[j]) - xr, b_in));
+        } else {
+            const int e = i * VEC;
+            const int r = e / g.Wd, c = e - r * g.Wd;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float f = to_float(v.v[j]);
+                o.v[j] = from_float<T>(g.cb.has(r, c + j) ? fmaf(a_in, f - xr, b_in) : fmaf(a_out, f, b_out));
+            }
+        }
+        store_vec<T, VEC>(yb + (size_t)i * VEC, o);
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass A': per-plane sums of the upstream gradient G against x
+//   un-boxed: out[0]=sum G, out[1]=sum G*(x-shift_in)
+//   boxed   : out[0..3] = the same inside the content box (shift_in) and outside it (shift_out)
+// shift pointers may be NULL (= 0).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC, int LPP, bool BOXED>
+__global__ __launch_bounds__(kBlock) void bwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ x, Geom g,
+                                                            const float* __restrict__ shift_in,
+                                                            const float* __restrict__ shift_out,
+                                                            float* __restrict__ out) {
+    constexpr int NACC = BOXED ? 4 : 2;
+    __shared__ float lds[4 * NACC];
+    const PlaneId<LPP> id(g.P);
+    const size_t off = (size_t)id.p * g.M;
+    const float si = shift_in ? shift_in[id.p] : 0.f;
+    const float so = (BOXED && shift_out) ? shift_out[id.p] : 0.f;
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+    stream2<T, VEC, LPP>(gy + off, x + off, g.nvec, id.lane,
+                         [&](const Vec<T, VEC>& vg, const Vec<T, VEC>& vx, int i) {
+                             if constexpr (!BOXED) {
+#pragma unroll
+                                 for (int j = 0; j < VEC; ++j) {
+                                     const float G = to_float(vg.v[j]);
+                                     acc[0] += G;
+                                     acc[1] = fmaf(G, to_float(vx.v[j]) - si, acc[1]);
+                                 }
+                             } else {
+                                 const int e = i * VEC;
+                                 const int r = e / g.Wd, c = e - r * g.Wd;
+#pragma unroll
+                                 for (int j = 0; j < VEC; ++j) {
+                                     const float G = to_float(vg.v[j]), X = to_float(vx.v[j]);
+                                     const bool ic = g.cb.has(r, c + j);
+                                     acc[0] += ic ? G : 0.f;
+                                     acc[1] += ic ? G * (X - si) : 0.f;
+                                     acc[2] += ic ? 0.f : G;
+                                     acc[3] += ic ? 0.f : G * (X - so);
+                                 }
+                             }
+                         });
+    group_sum<LPP, NACC>(acc, lds);
+    if (id.lane == 0 && id.valid) {
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) out[(size_t)k * g.P + id.p] = acc[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass B': dx = cG*G + cX*(x - xr) + c0, coefficients by region (inside / outside the content
+// box), plus eS*(x - xs) + e0 inside the style box (the gradient a plane receives for having been
+// another instance's style source).  Coefficients: SoA rows of `coef`, stride P (see mid_bwd_b).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC, int LPP, bool BOXED>
+__global__ __launch_bounds__(kBlock) void apply_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x,
+                                                           T* __restrict__ dx, Geom g,
+                                                           const float* __restrict__ coef) {
+    const PlaneId<LPP> id(g.P);
+    if (!id.valid) return;
+    const size_t off = (size_t)id.p * g.M;
+    const size_t P = g.P;
+    const float cG_i = coef[id.p], cX_i = coef[P + id.p], xr_i = coef[2 * P + id.p], c0_i = coef[3 * P + id.p];
+    float cG_o = 0.f, cX_o = 0.f, xr_o = 0.f, c0_o = 0.f, eS = 0.f, xs = 0.f, e0 = 0.f;
+    if constexpr (BOXED) {
+        cG_o = coef[4 * P + id.p];
+        cX_o = coef[5 * P + id.p];
+        xr_o = coef[6 * P + id.p];
+        c0_o = coef[7 * P + id.p];
+        eS = coef[8 * P + id.p];
+        xs = coef[9 * P + id.p];
+        e0 = coef[10 * P + id.p];
+    }
+    T* db = dx + off;
+    stream2<T, VEC, LPP>(gy + off, x + off, g.nvec, id.lane,
+                         [&](const Vec<T, VEC>& vg, const Vec<T, VEC>& vx, int i) {
+                             Vec<T, VEC> o;
+                             if constexpr (!BOXED) {
+#pragma unroll
+                                 for (int j = 0; j < VEC; ++j) {
+                                     const float G = to_float(vg.v[j]), X = to_float(vx.v[j]);
+                                     o.v[j] = from_float<T>(fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i)));
+                                 }
+                             } else {
+                                 const int e = i * VEC;
+                                 const int r = e / g.Wd, c = e - r * g.Wd;
+#pragma unroll
+                                 for (int j = 0; j < VEC; ++j) {
+                                     const float G = to_float(vg.v[j]), X = to_float(vx.v[j]);
+                                     const bool ic = g.cb.has(r, c + j), is = g.sb.has(r, c + j);
+                                     float d = ic ? fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i))
+                                                  : fmaf(cG_o, G, fmaf(cX_o, X - xr_o, c0_o));
+                                     d += is ? fmaf(eS, X - xs, e0) : 0.f;
+                                     o.v[j] = from_float<T>(d);
+                                 }
+                             }
+                             store_vec<T, VEC>(db + (size_t)i * VEC, o);
+                         });
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of calc_ins_mean_std alone: dx = dmean/cnt + dstd*(x-mean)/(std*(cnt-1)) in the box, else 0
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC, int LPP, bool BOXED>
+__global__ __launch_bounds__(kBlock) void plane_stats_bwd_kernel(const T* __restrict__ x, T* __restrict__ dx, Geom g,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ std,
+                                                                 const float* __restrict__ dmean,
+                                                                 const float* __restrict__ dstd) {
+    const PlaneId<LPP> id(g.P);
+    if (!id.valid) return;
+    const size_t off = (size_t)id.p * g.M;
+    const int cnt = BOXED ? g.cb.area() : g.M;
+    const float mu = mean[id.p];
+    const float cX = dstd[id.p] / (std[id.p] * float(cnt - 1));
+    const float c0 = dmean[id.p] / float(cnt);
+    T* db = dx + off;
+    stream1<T, VEC, LPP>(x + off, g.nvec, id.lane, [&](const Vec<T, VEC>& v, int i) {
+        Vec<T, VEC> o;
+        const int e = i * VEC;
+        const int r = BOXED ? e / g.Wd : 0, c = BOXED ? e - r * g.Wd : 0;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float d = fmaf(cX, to_float(v.v[j]) - mu, c0);
+            o.v[j] = from_float<T>((!BOXED || g.cb.has(r, c + j)) ? d : 0.f);
+        }
+        store_vec<T, VEC>(db + (size_t)i * VEC, o);
+    });
+}
+
+}  // namespace cnsn

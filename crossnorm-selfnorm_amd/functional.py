@@ -1,0 +1,314 @@
+"""torch.autograd glue over the C ABI (torch here is plumbing: device memory, streams, autograd
+book-keeping).  Every forward/backward below is ONE call into libcnsn_hip.so; nothing is computed
+with torch ops on the activation tensor.  HIP device tensors only — other inputs raise."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _ffi
+
+Box = Tuple[int, int, int, int]
+
+_DTYPES = {torch.float32: _ffi.CNSN_F32, torch.bfloat16: _ffi.CNSN_BF16, torch.float16: _ffi.CNSN_F16}
+
+# process-wide default for cnsn_problem_t.strategy (tests/bench switch it to force one path)
+_strategy = _ffi.STRATEGY_AUTO
+
+
+def set_strategy(name: str):
+    """'auto' | 'two_pass' | 'resident' — which kernel strategy libcnsn_hip.so uses."""
+    global _strategy
+    _strategy = {"auto": _ffi.STRATEGY_AUTO, "two_pass": _ffi.STRATEGY_TWO_PASS,
+                 "resident": _ffi.STRATEGY_RESIDENT}[name]
+
+
+def _require_device(x: torch.Tensor, what: str):
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{what}: expected a tensor")
+    if not x.is_cuda:
+        raise _ffi.CnsnError(
+            f"{what}: got a {x.device.type} tensor. This implementation runs on MI355X HIP device "
+            "tensors only; there is no CPU path.")
+    if x.dtype not in _DTYPES:
+        raise TypeError(f"{what}: dtype {x.dtype} not supported (float32, bfloat16, float16)")
+    assert x.dim() == 4, "expected an (N, C, H, W) tensor"          # reference cnsn.py:12
+
+
+def _stream(x):
+    return C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+class _PinnedRing:
+    """Host->device copies of the (tiny) permutations without stalling the launch thread.
+
+    The reference does `torch.randperm(N).to(x.device)` (cnsn.py:62): a pageable-memory copy that
+    blocks the host until everything queued on the stream has run.  Here the index vector goes
+    through a small ring of pinned staging buffers and an asynchronous copy; a slot is reused only
+    after the event recorded behind its previous copy has completed."""
+    SLOTS = 8
+
+    def __init__(self):
+        self.rings = {}
+
+    def to_device(self, idx: torch.Tensor, dev: torch.device) -> torch.Tensor:
+        if idx.is_cuda:
+            return idx.to(device=dev, dtype=torch.int64).contiguous()
+        n = idx.numel()
+        ring = self.rings.setdefault((dev.index, n), {"next": 0, "slots": [None] * self.SLOTS})
+        k = ring["next"] % self.SLOTS
+        ring["next"] += 1
+        if ring["slots"][k] is None:
+            ring["slots"][k] = (torch.empty(n, dtype=torch.int64).pin_memory(), torch.cuda.Event())
+        else:
+            ring["slots"][k][1].synchronize()
+        buf, evt = ring["slots"][k]
+        buf.copy_(idx.reshape(-1))
+        out = buf.to(dev, non_blocking=True)
+        evt.record(torch.cuda.current_stream(dev))
+        return out
+
+
+_h2d = _PinnedRing()
+
+
+@dataclass
+class GateParams:
+    """One SelfNorm gate's tensors (reference cnsn.py:118-126): Conv1d weight (C,1,2), BatchNorm1d
+    weight / bias / running_mean / running_var (C)."""
+    fc_weight: torch.Tensor
+    bn_weight: torch.Tensor
+    bn_bias: torch.Tensor
+    running_mean: torch.Tensor
+    running_var: torch.Tensor
+
+
+@dataclass
+class FusedConfig:
+    cn_active: bool = False
+    content_box: Optional[Box] = None
+    style_box: Optional[Box] = None
+    lam: Optional[float] = None
+    sn_active: bool = False
+    sn_two: bool = False
+    sn_training: bool = True
+    eps_cn: float = 1e-5
+    eps_sn: float = 1e-12
+    eps_bn: float = 1e-5
+    momentum: float = 0.1
+
+
+def _problem(x: torch.Tensor, cfg: FusedConfig) -> _ffi.Problem:
+    p = _ffi.Problem()
+    p.struct_bytes = C.sizeof(_ffi.Problem)
+    p.dtype = _DTYPES[x.dtype]
+    p.N, p.C, p.H, p.W = (int(s) for s in x.shape)
+    p.cn_active = int(cfg.cn_active)
+    p.content_box = _ffi.box4(cfg.content_box)
+    p.style_box = _ffi.box4(cfg.style_box)
+    p.lam = 0.0 if cfg.lam is None else float(cfg.lam)
+    p.eps_cn = cfg.eps_cn
+    p.sn_active = int(cfg.sn_active)
+    p.sn_two = int(cfg.sn_two)
+    p.sn_training = int(cfg.sn_training)
+    p.eps_sn, p.eps_bn, p.momentum = cfg.eps_sn, cfg.eps_bn, cfg.momentum
+    p.strategy = _strategy
+    return p
+
+
+class _GateBuffers:
+    """float32 contiguous views/copies of a gate's tensors + the cnsn_gate_t that points at them."""
+
+    def __init__(self, w, gamma, beta, rm, rv):
+        self.src_rm, self.src_rv = rm, rv
+        self.w, self.gamma, self.beta = _f32(w), _f32(gamma), _f32(beta)
+        direct = rm.dtype == torch.float32 and rm.is_contiguous() and rv.dtype == torch.float32 \
+            and rv.is_contiguous()
+        self.rm = rm.detach() if direct else _f32(rm)
+        self.rv = rv.detach() if direct else _f32(rv)
+        self.direct = direct
+        self.c = _ffi.Gate(_ptr(self.w), _ptr(self.gamma), _ptr(self.beta), _ptr(self.rm), _ptr(self.rv))
+
+    def write_back(self):
+        if not self.direct:  # running buffers kept in another dtype: copy the update back
+            self.src_rm.copy_(self.rm)
+            self.src_rv.copy_(self.rv)
+
+
+class FusedCNSN(torch.autograd.Function):
+    """y = SelfNorm(CrossNorm(x)) with either half optional — cnsn_forward / cnsn_backward."""
+
+    @staticmethod
+    def forward(ctx, x, cfg: FusedConfig, perm, chan_perm, g_w, g_gamma, g_beta, g_rm, g_rv,
+                f_w, f_gamma, f_beta, f_rm, f_rv):
+        _require_device(x, "cnsn_forward")
+        lib = _ffi.lib()
+        x = x.contiguous()                                         # reference cnsn.py:14
+        prob = _problem(x, cfg)
+        dev = x.device
+        if cfg.cn_active:
+            perm = _h2d.to_device(perm, dev)
+            if chan_perm is not None:
+                chan_perm = _h2d.to_device(chan_perm, dev)
+        gate_g = _GateBuffers(g_w, g_gamma, g_beta, g_rm, g_rv) if cfg.sn_active else None
+        gate_f = _GateBuffers(f_w, f_gamma, f_beta, f_rm, f_rv) if (cfg.sn_active and cfg.sn_two) else None
+        y = torch.empty_like(x)
+        need_bwd = any(ctx.needs_input_grad)
+        saved = torch.empty(lib.cnsn_saved_floats(C.byref(prob)), dtype=torch.float32, device=dev) \
+            if need_bwd else None
+        ws_bytes = lib.cnsn_workspace_bytes(C.byref(prob))
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+        st = lib.cnsn_forward(C.byref(prob), _ptr(x), _ptr(perm if cfg.cn_active else None),
+                              _ptr(chan_perm if cfg.cn_active else None),
+                              C.byref(gate_g.c) if gate_g else None, C.byref(gate_f.c) if gate_f else None,
+                              _ptr(y), _ptr(saved), _ptr(ws), ws_bytes, _stream(x))
+        _ffi.check(st, "cnsn_forward")
+        if cfg.sn_active and cfg.sn_training:
+            gate_g.write_back()
+            if gate_f:
+                gate_f.write_back()
+        if need_bwd:
+            ctx.cfg, ctx.prob = cfg, prob
+            ctx.gates = (gate_g, gate_f)
+            ctx.param_dtypes = tuple(t.dtype if t is not None else None
+                                     for t in (g_w, g_gamma, g_beta, f_w, f_gamma, f_beta))
+            ctx.save_for_backward(x, saved, perm if cfg.cn_active else None,
+                                  chan_perm if cfg.cn_active else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _ffi.lib()
+        x, saved, perm, chan_perm = ctx.saved_tensors
+        cfg, prob = ctx.cfg, ctx.prob
+        gate_g, gate_f = ctx.gates
+        gy = gy.contiguous()
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        dev = x.device
+        dx = torch.empty_like(x)
+        ws_bytes = lib.cnsn_workspace_bytes(C.byref(prob))
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+        Cn = x.shape[1]
+
+        def grads():
+            dw = torch.empty(Cn, 1, 2, dtype=torch.float32, device=dev)
+            dgam = torch.empty(Cn, dtype=torch.float32, device=dev)
+            dbet = torch.empty(Cn, dtype=torch.float32, device=dev)
+            return (dw, dgam, dbet), _ffi.GateGrad(_ptr(dw), _ptr(dgam), _ptr(dbet))
+
+        gg = gf = None
+        gg_c = gf_c = None
+        if cfg.sn_active:
+            gg, gg_c = grads()
+            if cfg.sn_two:
+                gf, gf_c = grads()
+        st = lib.cnsn_backward(C.byref(prob), _ptr(gy), _ptr(x), _ptr(perm), _ptr(chan_perm),
+                               C.byref(gate_g.c) if gate_g else None, C.byref(gate_f.c) if gate_f else None,
+                               _ptr(saved), _ptr(dx), C.byref(gg_c) if gg_c else None,
+                               C.byref(gf_c) if gf_c else None, _ptr(ws), ws_bytes, _stream(x))
+        _ffi.check(st, "cnsn_backward")
+        pd = ctx.param_dtypes
+        out_g = [None] * 3 if gg is None else [t.to(pd[i]) for i, t in enumerate(gg)]
+        out_f = [None] * 3 if gf is None else [t.to(pd[3 + i]) for i, t in enumerate(gf)]
+        #      x   cfg  perm  chan  g_w..g_beta   g_rm g_rv   f_w..f_beta  f_rm f_rv
+        return (dx, None, None, None, *out_g, None, None, *out_f, None, None)
+
+
+def fused_cnsn(x, cfg: FusedConfig, perm=None, chan_perm=None, g: Optional[GateParams] = None,
+               f: Optional[GateParams] = None):
+    ga = (g.fc_weight, g.bn_weight, g.bn_bias, g.running_mean, g.running_var) if g else (None,) * 5
+    fa = (f.fc_weight, f.bn_weight, f.bn_bias, f.running_mean, f.running_var) if f else (None,) * 5
+    return FusedCNSN.apply(x, cfg, perm, chan_perm, *ga, *fa)
+
+
+# ------------------------------------------------------------------------------------------------
+# building blocks exposed for the stand-alone functions of the reference (cnsn.py:8-29)
+# ------------------------------------------------------------------------------------------------
+def _dims(x):
+    return tuple(int(s) for s in x.shape)
+
+
+class PlaneStats(torch.autograd.Function):
+    """(mean, std) of every plane — cnsn_plane_stats / cnsn_plane_stats_backward."""
+
+    @staticmethod
+    def forward(ctx, x, eps, box):
+        _require_device(x, "calc_ins_mean_std")
+        lib = _ffi.lib()
+        x = x.contiguous()
+        n, c, h, w = _dims(x)
+        ms = torch.empty(2, n * c, dtype=torch.float32, device=x.device)
+        st = lib.cnsn_plane_stats(_ptr(x), _DTYPES[x.dtype], n, c, h, w, _ffi.box4(box) if box else None,
+                                  float(eps), _ptr(ms), _stream(x))
+        _ffi.check(st, "cnsn_plane_stats")
+        ctx.box = box
+        ctx.save_for_backward(x, ms)
+        mean = ms[0].view(n, c, 1, 1).to(x.dtype)
+        std = ms[1].view(n, c, 1, 1).to(x.dtype)
+        return mean, std
+
+    @staticmethod
+    def backward(ctx, gmean, gstd):
+        lib = _ffi.lib()
+        x, ms = ctx.saved_tensors
+        n, c, h, w = _dims(x)
+        gm = _f32(gmean).view(-1)
+        gs = _f32(gstd).view(-1)
+        dx = torch.empty_like(x)
+        st = lib.cnsn_plane_stats_backward(_ptr(x), _DTYPES[x.dtype], n, c, h, w,
+                                           _ffi.box4(ctx.box) if ctx.box else None, _ptr(ms[0]), _ptr(ms[1]),
+                                           _ptr(gm), _ptr(gs), _ptr(dx), _stream(x))
+        _ffi.check(st, "cnsn_plane_stats_backward")
+        return dx, None, None
+
+
+class PlaneAffine(torch.autograd.Function):
+    """y = scale[n,c]*x + shift[n,c] — cnsn_plane_affine (+ cnsn_plane_dot for the backward)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift):
+        _require_device(x, "plane_affine")
+        lib = _ffi.lib()
+        x = x.contiguous()
+        n, c, h, w = _dims(x)
+        sc, sh = _f32(scale).view(-1), _f32(shift).view(-1)
+        y = torch.empty_like(x)
+        st = lib.cnsn_plane_affine(_ptr(x), _DTYPES[x.dtype], n, c, h, w, _ptr(sc), _ptr(sh), _ptr(y), _stream(x))
+        _ffi.check(st, "cnsn_plane_affine")
+        ctx.save_for_backward(x, sc)
+        ctx.meta = (scale.shape, scale.dtype, shift.shape, shift.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _ffi.lib()
+        x, sc = ctx.saved_tensors
+        n, c, h, w = _dims(x)
+        gy = gy.contiguous().to(x.dtype)
+        dt = _DTYPES[x.dtype]
+        dx = dscale = dshift = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            zero = torch.zeros_like(sc)
+            st = lib.cnsn_plane_affine(_ptr(gy), dt, n, c, h, w, _ptr(sc), _ptr(zero), _ptr(dx), _stream(x))
+            _ffi.check(st, "cnsn_plane_affine(backward)")
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            sums = torch.empty(2, n * c, dtype=torch.float32, device=x.device)
+            st = lib.cnsn_plane_dot(_ptr(gy), _ptr(x), dt, n, c, h, w, _ptr(sums), _stream(x))
+            _ffi.check(st, "cnsn_plane_dot")
+            s_shape, s_dtype, t_shape, t_dtype = ctx.meta
+            dscale = sums[1].view(s_shape).to(s_dtype)
+            dshift = sums[0].view(t_shape).to(t_dtype)
+        return dx, dscale, dshift

@@ -1,0 +1,146 @@
+/*
+ * cnsn_hip.h — C ABI of libcnsn_hip.so: CrossNorm / SelfNorm hot path for AMD MI355X (gfx950).
+ *
+ * Drop-in boundary for the normalisation path of amazon-science/crossnorm-selfnorm
+ * (`models/cnsn.py`).  The reference has no native layer: this header is what a binding of that
+ * file's functions to native code binds to.  Each entry point names the reference interface it
+ * replaces (file:line relative to the reference repository).
+ *
+ * Conventions
+ *   - Plain C: pointers, sizes, PODs.  No C++ types, no torch types.
+ *   - Every pointer is a DEVICE pointer unless it says "host".  Activations are NCHW, contiguous,
+ *     16-byte aligned, element type `dtype`.  All per-plane / per-channel side arrays are float32.
+ *   - The caller owns every buffer (inputs, outputs, `saved`, `workspace`).  The library allocates
+ *     nothing, keeps no global state, is re-entrant, never synchronises the host, never throws.
+ *     All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *   - Randomness stays on the host: the batch permutation, channel permutation and boxes are
+ *     INPUTS (the reference draws them with torch.randperm / numpy, models/cnsn.py:62,65,71,76).
+ *   - Return value: 0 on success, <0 argument error (CNSN_E_*), >0 a hipError_t from the launch.
+ *   - A box is (x1, y1, x2, y2) and selects [:, :, x1:x2, y1:y2] exactly like
+ *     models/cnsn.py:66,77; x1 < 0 means "no box" (whole plane).
+ */
+#ifndef CNSN_HIP_H_
+#define CNSN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNSN_ABI_VERSION 1
+
+enum cnsn_dtype { CNSN_F32 = 0, CNSN_BF16 = 1, CNSN_F16 = 2 };
+
+enum cnsn_status {
+    CNSN_OK = 0,
+    CNSN_E_NULL = -1,       /* a required pointer is NULL                                   */
+    CNSN_E_SHAPE = -2,      /* N,C,H,W not positive, or N*C*H*W does not fit in int64/limits */
+    CNSN_E_DTYPE = -3,      /* unknown dtype                                               */
+    CNSN_E_ALIGN = -4,      /* activation pointer not 16-byte aligned                      */
+    CNSN_E_BOX = -5,        /* box outside the plane or empty                              */
+    CNSN_E_WORKSPACE = -6,  /* workspace smaller than cnsn_workspace_bytes()               */
+    CNSN_E_BATCH = -7,      /* SelfNorm in training mode needs N > 1 (BatchNorm1d raises)  */
+    CNSN_E_STRUCT = -8,     /* cnsn_problem_t.struct_bytes does not match this library     */
+    CNSN_E_UNSUPPORTED = -9 /* valid request this build cannot run (e.g. N too large)      */
+};
+
+enum cnsn_strategy {
+    CNSN_STRATEGY_AUTO = 0,
+    CNSN_STRATEGY_TWO_PASS = 1, /* stats kernel -> mid kernel -> apply kernel (3 / 5 tensor passes) */
+    CNSN_STRATEGY_RESIDENT = 2  /* one launch, channel kept on chip (2 / 3 tensor passes)            */
+};
+
+/* One fused CNSN.forward call (models/cnsn.py:159-164): optional CrossNorm
+ * (cn_op_2ins_space_chan, :58-91) followed by optional SelfNorm (:130-150). */
+typedef struct cnsn_problem {
+    int32_t struct_bytes; /* = sizeof(cnsn_problem_t)                                        */
+    int32_t dtype;        /* enum cnsn_dtype of x / y / grad tensors                         */
+    int32_t N, C, H, W;
+    /* CrossNorm part */
+    int32_t cn_active;    /* 0: skip CrossNorm (module idle / eval, :104)                    */
+    int32_t content_box[4]; /* crop in {content, both} (:76-78); x1<0: whole plane           */
+    int32_t style_box[4];   /* crop in {style, both}   (:65-66); x1<0: whole plane           */
+    float lam;            /* blend x*lam + out*(1-lam) (:86-87); 0 when lam is None          */
+    float eps_cn;         /* 1e-5  (calc_ins_mean_std default, :8)                           */
+    /* SelfNorm part */
+    int32_t sn_active;    /* 0: skip SelfNorm (CNSN.selfnorm is None)                        */
+    int32_t sn_two;       /* 1: second gate f (is_two, :123-126,:142-148)                    */
+    int32_t sn_training;  /* BatchNorm1d mode: batch statistics + running-buffer update      */
+    float eps_sn;         /* 1e-12 (:133)                                                    */
+    float eps_bn;         /* BatchNorm1d eps, 1e-5                                           */
+    float momentum;       /* BatchNorm1d momentum, 0.1                                       */
+    int32_t strategy;     /* enum cnsn_strategy                                              */
+} cnsn_problem_t;
+
+/* Parameters / buffers of one SelfNorm gate: g_fc + g_bn (or f_fc + f_bn), models/cnsn.py:118-126.
+ * fc_weight is the Conv1d(C,C,k=2,groups=C) weight, shape (C,1,2) = (C,2) row-major. */
+typedef struct cnsn_gate {
+    const float* fc_weight; /* (C,2)                                       */
+    const float* bn_weight; /* (C)                                         */
+    const float* bn_bias;   /* (C)                                         */
+    float* running_mean;    /* (C) updated in place when sn_training       */
+    float* running_var;     /* (C) updated in place when sn_training       */
+} cnsn_gate_t;
+
+typedef struct cnsn_gate_grad {
+    float* d_fc_weight; /* (C,2) written (not accumulated) */
+    float* d_bn_weight; /* (C)                              */
+    float* d_bn_bias;   /* (C)                              */
+} cnsn_gate_grad_t;
+
+int cnsn_abi_version(void);
+const char* cnsn_status_string(int status);
+
+/* Floats of per-plane state `cnsn_forward` writes into `saved` for `cnsn_backward`. */
+size_t cnsn_saved_floats(const cnsn_problem_t* prob);
+/* Bytes of scratch either direction needs (the larger of the two). */
+size_t cnsn_workspace_bytes(const cnsn_problem_t* prob);
+
+/* Fused forward.  Replaces CNSN.forward -> CrossNorm.forward -> cn_op_2ins_space_chan ->
+ * instance_norm_mix -> calc_ins_mean_std and SelfNorm.forward (models/cnsn.py:159-164, 103-110,
+ * 58-91, 20-29, 8-17, 130-150) for one activation tensor.
+ *   perm       int64 (N)  batch permutation (:62); required when cn_active
+ *   chan_perm  int64 (C)  channel permutation (:71) or NULL (chan=False)
+ *   g, f       gates; g required when sn_active, f when sn_two
+ *   y          output, same shape/dtype as x, must not alias x
+ *   saved      cnsn_saved_floats() floats, or NULL when no backward will follow */
+int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
+                 const int64_t* chan_perm, const cnsn_gate_t* g, const cnsn_gate_t* f, void* y,
+                 float* saved, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Fused backward: what autograd derives for the forward above (gradient flows through the content
+ * statistics, the permuted style statistics — the style source is not detached, :66-68 — and the
+ * SelfNorm gate incl. BatchNorm1d batch statistics).  grad_x must not alias grad_y or x. */
+int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
+                  const int64_t* perm, const int64_t* chan_perm, const cnsn_gate_t* g,
+                  const cnsn_gate_t* f, const float* saved, void* grad_x,
+                  const cnsn_gate_grad_t* dg, const cnsn_gate_grad_t* df, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
+/* calc_ins_mean_std (models/cnsn.py:8-17): mean and sqrt(unbiased var + eps) of every (n,c)
+ * plane, optionally of a box of it (the reference takes the box by slicing, :66,:77).
+ * mean_std: float32 (2, N*C) — row 0 the means, row 1 the stds. */
+int cnsn_plane_stats(const void* x, int dtype, int N, int C, int H, int W, const int32_t* box,
+                     float eps, float* mean_std, void* stream);
+
+/* Backward of cnsn_plane_stats: dx = dmean/M + dstd*(x-mean)/(std*(M-1)) inside the box, 0 outside. */
+int cnsn_plane_stats_backward(const void* x, int dtype, int N, int C, int H, int W,
+                              const int32_t* box, const float* mean, const float* std,
+                              const float* dmean, const float* dstd, void* dx, void* stream);
+
+/* y = scale[p] * x + shift[p] per plane p=(n,c): the re-normalise of instance_norm_mix
+ * (models/cnsn.py:27-29) and SelfNorm's x*g (:150) once the coefficients are known. */
+int cnsn_plane_affine(const void* x, int dtype, int N, int C, int H, int W, const float* scale,
+                      const float* shift, void* y, void* stream);
+
+/* Per-plane sums needed by the backward of cnsn_plane_affine.
+ * sums: float32 (2, N*C) — row 0 sum(g), row 1 sum(g*x) of every plane. */
+int cnsn_plane_dot(const void* g, const void* x, int dtype, int N, int C, int H, int W,
+                   float* sums, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNSN_HIP_H_ */

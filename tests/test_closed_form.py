@@ -2,12 +2,18 @@
 oracle, in fp64, for every mode: crop x chan x lam x {CN only, SN only, CN+SN} x is_two x train/eval."""
 import itertools
 
+import zlib
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import cnsn_oracle as orc
 from oracle import closed_form as cf
+
+
+def seed_of(*a):
+    return zlib.crc32(repr(a).encode()) % 100000
 
 
 def cond_input(shape, seed):
@@ -43,7 +49,7 @@ def test_closed_form_matches_autograd(crop, chan, lam, kind, is_two, training):
     if kind == "cn" and (is_two or not training):
         pytest.skip("SN options irrelevant for CN only")
     shape = (6, 5, 9, 11)
-    seed = abs(hash((crop, chan, lam, kind, is_two, training))) % 10000
+    seed = seed_of(crop, chan, lam, kind, is_two, training)
     torch.manual_seed(seed)
     np.random.seed(seed)
     x = cond_input(shape, seed).requires_grad_()

@@ -1,0 +1,137 @@
+"""CPU-side checks of the product (no kernels run): the C-ABI library loads and exports every
+symbol include/cnsn_hip.h declares; argument validation answers with the documented status codes;
+the host logic (box sampler, RNG draw order, module flags, state_dict surface) matches the
+reference's behaviour as pinned by the golden vectors."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import cnsn_amd
+from cnsn_amd import _ffi
+from oracle import cnsn_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "cnsn_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cnsn_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = header_functions()
+    assert len(names) >= 10
+    assert sorted(_ffi.SIGNATURES) == names              # the binding covers the whole header
+    handle = C.CDLL(_ffi.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), f"libcnsn_hip.so lacks {n}"
+    assert cnsn_amd.lib().cnsn_abi_version() == _ffi.ABI_VERSION
+
+
+def make_problem(**kw):
+    p = _ffi.Problem()
+    p.struct_bytes = C.sizeof(_ffi.Problem)
+    p.dtype, p.N, p.C, p.H, p.W = 0, 8, 4, 16, 16
+    p.content_box = _ffi.box4(None)
+    p.style_box = _ffi.box4(None)
+    p.eps_cn, p.eps_sn, p.eps_bn, p.momentum = 1e-5, 1e-12, 1e-5, 0.1
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def test_argument_validation_without_gpu():
+    lib = cnsn_amd.lib()
+    p = make_problem(sn_active=1, sn_training=1)
+    assert lib.cnsn_saved_floats(C.byref(p)) == 15 * 32 + 2 * 4
+    assert lib.cnsn_workspace_bytes(C.byref(p)) >= 4 * 23 * 32
+    # NULL tensors
+    assert lib.cnsn_forward(C.byref(p), None, None, None, None, None, None, None, None, 0, None) == -1
+    # wrong struct size
+    bad = make_problem(struct_bytes=8)
+    assert lib.cnsn_workspace_bytes(C.byref(bad)) == 0
+    assert lib.cnsn_forward(C.byref(bad), None, None, None, None, None, None, None, None, 0, None) == -8
+    # BatchNorm1d training needs N > 1
+    one = make_problem(N=1, sn_active=1, sn_training=1)
+    assert lib.cnsn_forward(C.byref(one), 16, None, None, None, None, 32, None, 48, 1 << 20, None) == -7
+    # box outside the plane
+    bx = make_problem(cn_active=1, content_box=_ffi.box4((0, 0, 17, 4)))
+    assert lib.cnsn_forward(C.byref(bx), 16, 16, None, None, None, 32, None, 48, 1 << 20, None) == -5
+    # misaligned activation pointer, unknown dtype
+    assert lib.cnsn_plane_stats(8, 0, 2, 2, 4, 4, None, 1e-5, 64, None) == -4
+    assert lib.cnsn_plane_stats(16, 7, 2, 2, 4, 4, None, 1e-5, 64, None) == -3
+    assert lib.cnsn_plane_stats(16, 0, 0, 2, 4, 4, None, 1e-5, 64, None) == -2
+    assert b"workspace" in lib.cnsn_status_string(-6)
+
+
+def test_bbox_sampler_matches_reference_vectors(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g1_bbox.npz"))
+    for si, size in enumerate(z["sizes"]):
+        for seed in range(32):
+            np.random.seed(seed)
+            b1 = cnsn_amd.cn_rand_bbox(tuple(size), beta=1, bbx_thres=0.1)
+            b2 = cnsn_amd.cn_rand_bbox(tuple(size), beta=0.5, bbx_thres=0.25)
+            assert list(b1) == list(z["boxes"][si, seed, 0]) and list(b2) == list(z["boxes"][si, seed, 1])
+
+
+def test_draw_order_matches_reference_vectors(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g3_cn.npz"))
+    for i in range(len(z["case_crop"])):
+        k = f"c{i}"
+        seed = int(z["case_seed"][i])
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        d = cnsn_amd.draw_cn(z[f"{k}_x_f32"].shape, str(z["case_crop"][i]), 1, chan=bool(z["case_chan"][i]))
+        assert torch.equal(d.perm, torch.from_numpy(z[f"{k}_perm"]))
+        sb, cb = [int(v) for v in z[f"{k}_sbox"]], [int(v) for v in z[f"{k}_cbox"]]
+        assert (d.style_box is None and sb[0] < 0) or list(d.style_box) == sb
+        assert (d.content_box is None and cb[0] < 0) or list(d.content_box) == cb
+        if bool(z["case_chan"][i]):
+            assert torch.equal(d.chan_perm, torch.from_numpy(z[f"{k}_chan_perm"]))
+
+
+@pytest.mark.parametrize("is_two", [False, True])
+def test_state_dict_surface(is_two):
+    ours, theirs = cnsn_amd.SelfNorm(6, is_two=is_two), orc.SelfNorm(6, is_two=is_two)
+    assert [(k, tuple(v.shape), v.dtype) for k, v in ours.state_dict().items()] == \
+           [(k, tuple(v.shape), v.dtype) for k, v in theirs.state_dict().items()]
+    ours.load_state_dict(theirs.state_dict())          # a reference checkpoint loads 1:1
+    m = cnsn_amd.CNSN(cnsn_amd.CrossNorm("both", 1), ours)
+    assert sorted(m.state_dict()) == sorted("selfnorm." + k for k in theirs.state_dict())
+    assert (ours.f_fc is None) == (not is_two)
+
+
+def test_flag_semantics_on_cpu_tensors():
+    """Paths that never touch the tensor work anywhere; compute paths refuse CPU tensors."""
+    x = torch.randn(4, 3, 8, 8)
+    cn = cnsn_amd.CrossNorm(crop="style", beta=1).train()
+    assert cn.active is False and cn(x) is x
+    cn.eval()
+    cn.active = True
+    assert cn(x) is x and cn.active is False            # eval: identity, flag dropped (cnsn.py:104-108)
+    wrap = cnsn_amd.CNSN(cn, None).eval()
+    cn.active = True
+    assert wrap(x) is x and cn.active is False
+    assert isinstance(cn, cnsn_amd.CrossNorm) and callable(cn.cn_op)   # what _enable_cross_norm relies on
+    cn.train()
+    cn.active = True
+    with pytest.raises(cnsn_amd.CnsnError):
+        cn(x)
+    with pytest.raises(cnsn_amd.CnsnError):
+        cnsn_amd.SelfNorm(3)(x)
+    with pytest.raises(AssertionError):
+        cnsn_amd.cn_op_2ins_space_chan(x, crop="nope")
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "crossnorm-selfnorm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no CPU or eager fallback", ""), f
