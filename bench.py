@@ -65,7 +65,9 @@ def cpu_baseline(shape, crop, kind, budget_s):
     n, c, h, w = shape
     ns = max(2, min(n, 32))                          # 1/8 of the north-star batch: ~0.4 s / step on 8 cores
     sshape = (ns, c, h, w)
-    threads = os.cpu_count() or 1
+    # measured on the MI355X host (2x EPYC 9575F, 256 hw threads): eager torch peaks at 16-32 threads and
+    # collapses beyond 64 (11 s/iter at 256), so the baseline uses the fastest setting, not all threads
+    threads = min(32, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     np.random.seed(0)

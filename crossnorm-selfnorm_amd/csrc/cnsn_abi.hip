@@ -174,11 +174,15 @@ int make_plan(const cnsn_problem_t* prob, Plan& pl) {
     return CNSN_OK;
 }
 
-inline size_t saved_floats_of(const Plan& pl) { return (size_t)SV_ROWS * pl.P + 2 * (size_t)pl.pr.C; }
-inline size_t workspace_floats_of(const Plan& pl) {
-    const size_t fwd = (size_t)(6 + FC_ROWS) * pl.P + saved_floats_of(pl);
-    const size_t bwd = (size_t)(4 + BT_ROWS + BC_ROWS) * pl.P;
-    return (fwd > bwd ? fwd : bwd) + 64;
+// `saved` holds doubles (SV_ROWS rows of P + two rows of C); it is sized in floats for the caller
+inline size_t saved_doubles_of(const Plan& pl) { return (size_t)SV_ROWS * pl.P + 2 * (size_t)pl.pr.C; }
+inline size_t saved_floats_of(const Plan& pl) { return 2 * saved_doubles_of(pl); }
+// workspace (bytes): forward  = moments[6P] f64 | saved fallback f64 | coef[FC_ROWS*P] f32
+//                    backward = tmp[BT_ROWS*P] f64 | sums[4P] f32 | coef[BC_ROWS*P] f32
+inline size_t workspace_bytes_of(const Plan& pl) {
+    const size_t fwd = 8 * (6 * pl.P + saved_doubles_of(pl)) + 4 * (size_t)FC_ROWS * pl.P;
+    const size_t bwd = 8 * (size_t)BT_ROWS * pl.P + 4 * (size_t)(4 + BC_ROWS) * pl.P;
+    return (fwd > bwd ? fwd : bwd) + 256;
 }
 
 inline GateDev gate_dev(const cnsn_gate_t* g) {
@@ -227,7 +231,7 @@ size_t cnsn_saved_floats(const cnsn_problem_t* prob) {
 size_t cnsn_workspace_bytes(const cnsn_problem_t* prob) {
     Plan pl;
     if (make_plan(prob, pl) != CNSN_OK) return 0;
-    return workspace_floats_of(pl) * sizeof(float);
+    return workspace_bytes_of(pl);
 }
 
 int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm, const int64_t* chan_perm,
@@ -242,16 +246,16 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
     if (p.cn_active && !perm) return CNSN_E_NULL;
     if (p.sn_active && !gate_ok(g)) return CNSN_E_NULL;
     if (p.sn_active && p.sn_two && !gate_ok(f)) return CNSN_E_NULL;
-    if (workspace_bytes < workspace_floats_of(pl) * sizeof(float)) return CNSN_E_WORKSPACE;
+    if (workspace_bytes < workspace_bytes_of(pl)) return CNSN_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
 
+    double* mom = (double*)workspace;
+    double* saved_d = saved ? (double*)saved : mom + 6 * pl.P;
+    float* coef = (float*)(mom + 6 * pl.P + saved_doubles_of(pl));
     float* ws = (float*)workspace;
-    float* mom = ws;
-    float* coef = mom + 6 * pl.P;
-    if (!saved) saved = coef + FC_ROWS * pl.P;
 
     if (use_resident(p, pl.boxed, chan_perm != nullptr)) {
-        return resident_forward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, x, perm, gate_dev(g), gate_dev(f), y, saved,
+        return resident_forward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, x, perm, gate_dev(g), gate_dev(f), y, saved_d,
                                 ws, stream);
     }
 
@@ -260,11 +264,11 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value, LPP = decltype(lt)::value;
         if (pl.boxed)
-            plane_stats_kernel<T, VEC, LPP, true><<<blocks, kBlock, 0, stream>>>((const T*)x, pl.geom, mom, 0.f, 0);
+            plane_stats_kernel<T, VEC, LPP, true><<<blocks, kBlock, 0, stream>>>((const T*)x, pl.geom, mom, nullptr, 0.f);
         else
-            plane_stats_kernel<T, VEC, LPP, false><<<blocks, kBlock, 0, stream>>>((const T*)x, pl.geom, mom, 0.f, 0);
+            plane_stats_kernel<T, VEC, LPP, false><<<blocks, kBlock, 0, stream>>>((const T*)x, pl.geom, mom, nullptr, 0.f);
     });
-    mid_fwd_kernel<<<p.C, kBlock, 0, stream>>>(pl.mid, mom, perm, chan_perm, gate_dev(g), gate_dev(f), coef, saved);
+    mid_fwd_kernel<<<p.C, kBlock, 0, stream>>>(pl.mid, mom, perm, chan_perm, gate_dev(g), gate_dev(f), coef, saved_d);
     const size_t P = pl.P;
     ApplyCoef cf{coef + FC_A_IN * P, coef + FC_XR * P, coef + FC_B_IN * P, coef + FC_A_OUT * P, coef + FC_B_OUT * P};
     dispatch(p.dtype, pl.shape, [&](auto tt, auto vt, auto lt) {
@@ -292,18 +296,19 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
     if (p.cn_active && !perm) return CNSN_E_NULL;
     if (p.sn_active && (!gate_ok(g) || !gate_grad_ok(dg))) return CNSN_E_NULL;
     if (p.sn_active && p.sn_two && (!gate_ok(f) || !gate_grad_ok(df))) return CNSN_E_NULL;
-    if (workspace_bytes < workspace_floats_of(pl) * sizeof(float)) return CNSN_E_WORKSPACE;
+    if (workspace_bytes < workspace_bytes_of(pl)) return CNSN_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
 
     const size_t P = pl.P;
     float* ws = (float*)workspace;
-    float* sums = ws;
-    float* tmp = sums + 4 * P;
-    float* coef = tmp + BT_ROWS * P;
+    double* tmp = (double*)workspace;
+    float* sums = (float*)(tmp + BT_ROWS * P);
+    float* coef = sums + 4 * P;
+    const double* saved_d = (const double*)saved;
 
     if (use_resident(p, pl.boxed, chan_perm != nullptr)) {
         return resident_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, grad_y, x, perm, gate_dev(g), gate_dev(f),
-                                 saved, grad_x, gate_grad_dev(dg), gate_grad_dev(df), ws, stream);
+                                 saved_d, grad_x, gate_grad_dev(dg), gate_grad_dev(df), ws, stream);
     }
 
     const int blocks = blocks_for(pl.geom.P, pl.shape.lpp);
@@ -312,14 +317,14 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
         constexpr int VEC = decltype(vt)::value, LPP = decltype(lt)::value;
         if (pl.boxed)
             bwd_reduce_kernel<T, VEC, LPP, true><<<blocks, kBlock, 0, stream>>>(
-                (const T*)grad_y, (const T*)x, pl.geom, saved + SV_MU_C * P, saved + SV_MU_O * P, sums);
+                (const T*)grad_y, (const T*)x, pl.geom, saved_d + SV_MU_C * P, saved_d + SV_MU_O * P, sums);
         else
             bwd_reduce_kernel<T, VEC, LPP, false><<<blocks, kBlock, 0, stream>>>(
-                (const T*)grad_y, (const T*)x, pl.geom, saved + SV_MU_C * P, nullptr, sums);
+                (const T*)grad_y, (const T*)x, pl.geom, saved_d + SV_MU_C * P, nullptr, sums);
     });
-    mid_bwd_a_kernel<<<p.C, kBlock, 0, stream>>>(pl.mid, sums, saved, perm, chan_perm, gate_dev(g), gate_dev(f),
+    mid_bwd_a_kernel<<<p.C, kBlock, 0, stream>>>(pl.mid, sums, saved_d, perm, chan_perm, gate_dev(g), gate_dev(f),
                                                 gate_grad_dev(dg), gate_grad_dev(df), tmp);
-    mid_bwd_b_kernel<<<(int)((P + kBlock - 1) / kBlock), kBlock, 0, stream>>>(pl.mid, saved, tmp, coef);
+    mid_bwd_b_kernel<<<(int)((P + kBlock - 1) / kBlock), kBlock, 0, stream>>>(pl.mid, saved_d, tmp, coef);
     dispatch(p.dtype, pl.shape, [&](auto tt, auto vt, auto lt) {
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value, LPP = decltype(lt)::value;
@@ -351,9 +356,9 @@ int cnsn_plane_stats(const void* x, int dtype, int N, int C, int H, int W, const
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value, LPP = decltype(lt)::value;
         if (boxed)
-            plane_stats_kernel<T, VEC, LPP, true><<<blocks, kBlock, 0, stream>>>((const T*)x, g, mean, eps, 1);
+            plane_stats_kernel<T, VEC, LPP, true><<<blocks, kBlock, 0, stream>>>((const T*)x, g, nullptr, mean, eps);
         else
-            plane_stats_kernel<T, VEC, LPP, false><<<blocks, kBlock, 0, stream>>>((const T*)x, g, mean, eps, 1);
+            plane_stats_kernel<T, VEC, LPP, false><<<blocks, kBlock, 0, stream>>>((const T*)x, g, nullptr, mean, eps);
     });
     return launch_status();
 }

@@ -62,10 +62,10 @@ struct MidArgs {
     float lam, eps_cn, eps_sn, eps_bn, momentum;
 };
 
-__global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const float* __restrict__ mom,
+__global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double* __restrict__ mom,
                                                          const int64_t* __restrict__ perm,
                                                          const int64_t* __restrict__ chan_perm, GateDev gg, GateDev gf,
-                                                         float* __restrict__ coef, float* __restrict__ saved) {
+                                                         float* __restrict__ coef, double* __restrict__ saved) {
     __shared__ double red[(kBlock / 64) * 2];
     const int c = blockIdx.x;
     const size_t P = (size_t)a.N * a.C;
@@ -109,22 +109,22 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const float*
             M2p = a1 * a1 * M2c + M2o + (m_in - mu_o) * (m_in - mu_o) * Mc * Mo / M;
         }
         const double sig_p = sqrt(M2p / (M - 1.0) + (double)a.eps_sn);
-        saved[SV_MU_C * P + p] = (float)mu_c;
-        saved[SV_MU_O * P + p] = (float)mu_o;
-        saved[SV_M2C * P + p] = (float)M2c;
-        saved[SV_SIG_C * P + p] = (float)sig_c;
-        saved[SV_MU_S * P + p] = (float)mu_s;
-        saved[SV_SIG_S * P + p] = (float)sig_s;
-        saved[SV_A * P + p] = (float)aa;
-        saved[SV_A1 * P + p] = (float)a1;
-        saved[SV_M_IN * P + p] = (float)m_in;
-        saved[SV_MU_P * P + p] = (float)mu_p;
-        saved[SV_SIG_P * P + p] = (float)sig_p;
+        saved[SV_MU_C * P + p] = mu_c;
+        saved[SV_MU_O * P + p] = mu_o;
+        saved[SV_M2C * P + p] = M2c;
+        saved[SV_SIG_C * P + p] = sig_c;
+        saved[SV_MU_S * P + p] = mu_s;
+        saved[SV_SIG_S * P + p] = sig_s;
+        saved[SV_A * P + p] = aa;
+        saved[SV_A1 * P + p] = a1;
+        saved[SV_M_IN * P + p] = m_in;
+        saved[SV_MU_P * P + p] = mu_p;
+        saved[SV_SIG_P * P + p] = sig_p;
         if (a.sn_active) {
             const double zg = wg0 * mu_p + wg1 * sig_p;  // Conv1d k=2 groups=C (cnsn.py:137)
             const double zf = wf0 * mu_p + wf1 * sig_p;
-            saved[SV_ZH_G * P + p] = (float)zg;  // parked here until normalised in sweep 3
-            saved[SV_ZH_F * P + p] = (float)zf;
+            saved[SV_ZH_G * P + p] = zg;  // parked here until normalised in sweep 3
+            saved[SV_ZH_F * P + p] = zf;
             sz[0] += zg;
             sz[1] += zf;
         }
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const float*
             double sv[2] = {0.0, 0.0};
             for (int n = threadIdx.x; n < a.N; n += kBlock) {
                 const size_t p = (size_t)n * a.C + c;
-                const double dg = (double)saved[SV_ZH_G * P + p] - mg;
-                const double df = (double)saved[SV_ZH_F * P + p] - mf;
+                const double dg = saved[SV_ZH_G * P + p] - mg;
+                const double df = saved[SV_ZH_F * P + p] - mf;
                 sv[0] += dg * dg;
                 sv[1] += df * df;
             }
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const float*
             }
         }
         if (threadIdx.x == 0) {
-            saved[SV_ROWS * P + c] = (float)rg;
-            saved[SV_ROWS * P + a.C + c] = (float)rf;
+            saved[SV_ROWS * P + c] = rg;
+            saved[SV_ROWS * P + a.C + c] = rf;
         }
     }
 
@@ -179,23 +179,26 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const float*
         const size_t p = (size_t)n * a.C + c;
         double g = 1.0, f = 1.0, zhg = 0.0, zhf = 0.0;
         if (a.sn_active) {
-            zhg = ((double)saved[SV_ZH_G * P + p] - mg) * rg;
+            zhg = (saved[SV_ZH_G * P + p] - mg) * rg;
             g = 1.0 / (1.0 + exp(-(gam_g * zhg + bet_g)));
             if (a.sn_two) {
-                zhf = ((double)saved[SV_ZH_F * P + p] - mf) * rf;
+                zhf = (saved[SV_ZH_F * P + p] - mf) * rf;
                 f = 1.0 / (1.0 + exp(-(gam_f * zhf + bet_f)));
             }
         }
-        saved[SV_G * P + p] = (float)g;
-        saved[SV_ZH_G * P + p] = (float)zhg;
-        saved[SV_F * P + p] = (float)f;
-        saved[SV_ZH_F * P + p] = (float)zhf;
+        saved[SV_G * P + p] = g;
+        saved[SV_ZH_G * P + p] = zhg;
+        saved[SV_F * P + p] = f;
+        saved[SV_ZH_F * P + p] = zhf;
         const double a1 = saved[SV_A1 * P + p], m_in = saved[SV_M_IN * P + p], mu_p = saved[SV_MU_P * P + p];
         const double shift = a.sn_two ? mu_p * (f - g) : 0.0;  // x*g + mean*(f-g)  (cnsn.py:148)
         if (a.cn_active) {
+            // the kernel evaluates A*(x - xr) + B with xr = float(mu_c): fold the rounding of xr into B
+            const double mu_c = saved[SV_MU_C * P + p];
+            const float xr = (float)mu_c;
             coef[FC_A_IN * P + p] = (float)(g * a1);
-            coef[FC_XR * P + p] = saved[SV_MU_C * P + p];
-            coef[FC_B_IN * P + p] = (float)(g * m_in + shift);
+            coef[FC_XR * P + p] = xr;
+            coef[FC_B_IN * P + p] = (float)(g * m_in + shift + g * a1 * ((double)xr - mu_c));
         } else {  // SelfNorm alone: y = g*x (+ shift), one rounding like the reference's x*g
             coef[FC_A_IN * P + p] = (float)g;
             coef[FC_XR * P + p] = 0.f;
@@ -209,10 +212,10 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const float*
 // per channel: gate / BatchNorm backward, parameter gradients, statistic gradients per plane;
 // scatters the style-statistic gradients to the planes that lent their statistics.
 __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const float* __restrict__ sums,
-                                                           const float* __restrict__ saved,
+                                                           const double* __restrict__ saved,
                                                            const int64_t* __restrict__ perm,
                                                            const int64_t* __restrict__ chan_perm, GateDev gg, GateDev gf,
-                                                           GateGradDev dg, GateGradDev df, float* __restrict__ tmp) {
+                                                           GateGradDev dg, GateGradDev df, double* __restrict__ tmp) {
     __shared__ double red[(kBlock / 64) * 4];
     const int c = blockIdx.x;
     const size_t P = (size_t)a.N * a.C;
@@ -225,9 +228,12 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
     if (a.sn_active) {
         for (int n = threadIdx.x; n < a.N; n += kBlock) {
             const size_t p = (size_t)n * a.C + c;
-            const double S1in = sums[p], S2in = sums[P + p];
-            const double S1out = a.boxed ? sums[2 * P + p] : 0.0, S2out = a.boxed ? sums[3 * P + p] : 0.0;
-            const double a1 = saved[SV_A1 * P + p], m_in = saved[SV_M_IN * P + p], mu_o = saved[SV_MU_O * P + p];
+            const double mu_c = saved[SV_MU_C * P + p], mu_o = saved[SV_MU_O * P + p];
+            // bwd_reduce_kernel shifted by float(mu): sum G*(x-mu) = S2 + (float(mu)-mu)*S1
+            const double S1in = sums[p], S2in = sums[P + p] + ((double)(float)mu_c - mu_c) * S1in;
+            const double S1out = a.boxed ? sums[2 * P + p] : 0.0;
+            const double S2out = a.boxed ? sums[3 * P + p] + ((double)(float)mu_o - mu_o) * S1out : 0.0;
+            const double a1 = saved[SV_A1 * P + p], m_in = saved[SV_M_IN * P + p];
             const double mu_p = saved[SV_MU_P * P + p];
             const double S1 = S1in + S1out;
             const double GdotU = a1 * S2in + m_in * S1in + S2out + mu_o * S1out;  // sum G*u
@@ -239,12 +245,12 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
                 const double f = saved[SV_F * P + p];
                 dtf = mu_p * S1 * f * (1.0 - f);
                 s[2] += dtf;
-                s[3] += dtf * (double)saved[SV_ZH_F * P + p];
+                s[3] += dtf * saved[SV_ZH_F * P + p];
             }
             s[0] += dtg;
             s[1] += dtg * zhg;
-            tmp[BT_DT_G * P + p] = (float)dtg;
-            tmp[BT_DT_F * P + p] = (float)dtf;
+            tmp[BT_DT_G * P + p] = dtg;
+            tmp[BT_DT_F * P + p] = dtf;
         }
         block_sum_d<4>(s, red);
         if (threadIdx.x == 0) {
@@ -262,18 +268,19 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
     if (a.sn_active) {
         wg0 = gg.w[2 * c];
         wg1 = gg.w[2 * c + 1];
-        kg = (double)gg.gamma[c] * (double)saved[SV_ROWS * P + c];
+        kg = (double)gg.gamma[c] * saved[SV_ROWS * P + c];
         if (a.sn_two) {
             wf0 = gf.w[2 * c];
             wf1 = gf.w[2 * c + 1];
-            kf = (double)gf.gamma[c] * (double)saved[SV_ROWS * P + a.C + c];
+            kf = (double)gf.gamma[c] * saved[SV_ROWS * P + a.C + c];
         }
     }
     const double invN = 1.0 / a.N;
     double sw[4] = {0, 0, 0, 0};  // sum dz_g*mu_p, dz_g*sig_p, dz_f*mu_p, dz_f*sig_p
     for (int n = threadIdx.x; n < a.N; n += kBlock) {
         const size_t p = (size_t)n * a.C + c;
-        const double S1in = sums[p], S2in = sums[P + p];
+        const double mu_c = saved[SV_MU_C * P + p];
+        const double S1in = sums[p], S2in = sums[P + p] + ((double)(float)mu_c - mu_c) * S1in;
         const double S1out = a.boxed ? sums[2 * P + p] : 0.0;
         const double a1 = saved[SV_A1 * P + p], m_in = saved[SV_M_IN * P + p];
         const double mu_p = saved[SV_MU_P * P + p], sig_p = saved[SV_SIG_P * P + p];
@@ -297,18 +304,18 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
             }
         }
         const double k = a.sn_active ? dsig_p / (sig_p * (M - 1.0)) : 0.0;
-        tmp[BT_DMU_P * P + p] = (float)dmu_p;
-        tmp[BT_K * P + p] = (float)k;
+        tmp[BT_DMU_P * P + p] = dmu_p;
+        tmp[BT_K * P + p] = k;
         if (a.cn_active) {
             const double aa = saved[SV_A * P + p], sig_c = saved[SV_SIG_C * P + p], M2c = saved[SV_M2C * P + p];
             const double T1 = g * S1in + Mc * dmu_p / M + k * Mc * (m_in - mu_p);
             const double T2 = g * S2in + k * a1 * M2c;
             const double d_a = (1.0 - lam) * T2;
-            tmp[BT_DMU_C * P + p] = (float)(-(1.0 - lam) * aa * T1);
-            tmp[BT_DSIG_C * P + p] = (float)(-d_a * aa / sig_c);
+            tmp[BT_DMU_C * P + p] = (-(1.0 - lam) * aa * T1);
+            tmp[BT_DSIG_C * P + p] = (-d_a * aa / sig_c);
             const size_t q = (size_t)perm[n] * a.C + cs;  // the plane whose statistics were borrowed
-            tmp[BT_E_MU * P + q] = (float)((1.0 - lam) * T1);
-            tmp[BT_E_SIG * P + q] = (float)(d_a / sig_c);
+            tmp[BT_E_MU * P + q] = ((1.0 - lam) * T1);
+            tmp[BT_E_SIG * P + q] = (d_a / sig_c);
         }
     }
     if (a.sn_active) {
@@ -325,8 +332,8 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
 }
 
 // per plane: assemble the coefficients of dx = cG*G + cX*(x-xr) + c0 (+ style term)
-__global__ __launch_bounds__(kBlock) void mid_bwd_b_kernel(MidArgs a, const float* __restrict__ saved,
-                                                           const float* __restrict__ tmp, float* __restrict__ coef) {
+__global__ __launch_bounds__(kBlock) void mid_bwd_b_kernel(MidArgs a, const double* __restrict__ saved,
+                                                           const double* __restrict__ tmp, float* __restrict__ coef) {
     const size_t P = (size_t)a.N * a.C;
     const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= P) return;
@@ -338,27 +345,31 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_b_kernel(MidArgs a, const floa
     double eS = 0.0, e0 = 0.0;
     if (a.cn_active) {
         const double sig_c = saved[SV_SIG_C * P + p], sig_s = saved[SV_SIG_S * P + p];
-        cX_in += (double)tmp[BT_DSIG_C * P + p] / (sig_c * (Mc - 1.0));
-        c0_in += (double)tmp[BT_DMU_C * P + p] / Mc;
-        eS = (double)tmp[BT_E_SIG * P + p] / (sig_s * (Ms - 1.0));
-        e0 = (double)tmp[BT_E_MU * P + p] / Ms;
+        cX_in += tmp[BT_DSIG_C * P + p] / (sig_c * (Mc - 1.0));
+        c0_in += tmp[BT_DMU_C * P + p] / Mc;
+        eS = tmp[BT_E_SIG * P + p] / (sig_s * (Ms - 1.0));
+        e0 = tmp[BT_E_MU * P + p] / Ms;
     }
     if (!a.boxed) {  // style region == content region == plane, mu_s == mu_c: one affine map
         cX_in += eS;
         c0_in += e0;
     }
+    // the kernel evaluates c*(x - float(ref)) + c0: fold the rounding of each reference point into c0
+    const float xr_in = (float)mu_c;
     coef[BC_CG_IN * P + p] = (float)(a1 * g);
     coef[BC_CX_IN * P + p] = (float)cX_in;
-    coef[BC_XR_IN * P + p] = (float)mu_c;
-    coef[BC_C0_IN * P + p] = (float)c0_in;
+    coef[BC_XR_IN * P + p] = xr_in;
+    coef[BC_C0_IN * P + p] = (float)(c0_in + cX_in * ((double)xr_in - mu_c));
     if (a.boxed) {
+        const double mu_s = saved[SV_MU_S * P + p];
+        const float xr_out = (float)mu_p, xs = (float)mu_s;
         coef[BC_CG_OUT * P + p] = (float)g;
         coef[BC_CX_OUT * P + p] = (float)k;
-        coef[BC_XR_OUT * P + p] = (float)mu_p;
-        coef[BC_C0_OUT * P + p] = (float)(dmu_p / M);
+        coef[BC_XR_OUT * P + p] = xr_out;
+        coef[BC_C0_OUT * P + p] = (float)(dmu_p / M + k * ((double)xr_out - mu_p));
         coef[BC_ES * P + p] = (float)eS;
-        coef[BC_XS * P + p] = saved[SV_MU_S * P + p];
-        coef[BC_E0 * P + p] = (float)e0;
+        coef[BC_XS * P + p] = xs;
+        coef[BC_E0 * P + p] = (float)(e0 + eS * ((double)xs - mu_s));
     }
 }
 

@@ -12,11 +12,11 @@ inline bool use_resident(const cnsn_problem_t& p, bool boxed, bool has_chan_perm
 }
 
 inline int resident_forward(const cnsn_problem_t&, Box, Box, bool, const MidArgs&, const void*, const int64_t*,
-                            GateDev, GateDev, void*, float*, float*, hipStream_t) {
+                            GateDev, GateDev, void*, double*, float*, hipStream_t) {
     return CNSN_E_UNSUPPORTED;
 }
 inline int resident_backward(const cnsn_problem_t&, Box, Box, bool, const MidArgs&, const void*, const void*,
-                             const int64_t*, GateDev, GateDev, const float*, void*, GateGradDev, GateGradDev, float*,
+                             const int64_t*, GateDev, GateDev, const double*, void*, GateGradDev, GateGradDev, float*,
                              hipStream_t) {
     return CNSN_E_UNSUPPORTED;
 }

@@ -73,13 +73,15 @@ struct PlaneId {
 // pass A: plane statistics (reference: calc_ins_mean_std, models/cnsn.py:14-16)
 //   un-boxed: out[0]=mean, out[1]=M2 of the whole plane
 //   boxed   : out[0..5] = mean/M2 inside the content box, outside it, inside the style box
-//   finalize: out[0]=mean, out[1]=sqrt(M2/(cnt-1)+eps) of the (content-box) region
+//   fin != NULL: fin[0]=mean, fin[1]=sqrt(M2/(cnt-1)+eps) of the (content-box) region, float32
+//   moments are written as double: the mid kernels keep every per-plane scalar in double
 // Sums are taken about a per-plane shift K (mean of the plane's first VEC elements) so that
 // S2 - S1^2/cnt does not cancel for planes with |mean| >> std (post-ReLU activations).
 // ------------------------------------------------------------------------------------------------
 template <typename T, int VEC, int LPP, bool BOXED>
 __global__ __launch_bounds__(kBlock) void plane_stats_kernel(const T* __restrict__ x, Geom g,
-                                                             float* __restrict__ out, float eps, int finalize) {
+                                                             double* __restrict__ mom, float* __restrict__ fin,
+                                                             float eps) {
     constexpr int NACC = BOXED ? 6 : 2;
     __shared__ float lds[4 * NACC];
     const PlaneId<LPP> id(g.P);
@@ -92,17 +94,21 @@ __global__ __launch_bounds__(kBlock) void plane_stats_kernel(const T* __restrict
         for (int j = 0; j < VEC; ++j) K += to_float(f.v[j]);
         K *= (1.0f / VEC);
     }
-    float acc[NACC];
+    // one accumulator per vector slot: VEC short chains instead of one long one (rounding error of
+    // a sequential fp32 sum grows with its length), folded pairwise afterwards
+    float part[NACC][VEC];
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+    for (int k = 0; k < NACC; ++k)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) part[k][j] = 0.f;
 
     stream1<T, VEC, LPP>(base, g.nvec, id.lane, [&](const Vec<T, VEC>& v, int i) {
         if constexpr (!BOXED) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const float d = to_float(v.v[j]) - K;
-                acc[0] += d;
-                acc[1] = fmaf(d, d, acc[1]);
+                part[0][j] += d;
+                part[1][j] = fmaf(d, d, part[1][j]);
             }
         } else {
             const int e = i * VEC;  // VEC divides the width: the whole vector lies in one row
@@ -112,48 +118,55 @@ __global__ __launch_bounds__(kBlock) void plane_stats_kernel(const T* __restrict
                 const float d = to_float(v.v[j]) - K;
                 const float d2 = d * d;
                 const bool ic = g.cb.has(r, c + j), is = g.sb.has(r, c + j);
-                acc[0] += ic ? d : 0.f;
-                acc[1] += ic ? d2 : 0.f;
-                acc[2] += ic ? 0.f : d;
-                acc[3] += ic ? 0.f : d2;
-                acc[4] += is ? d : 0.f;
-                acc[5] += is ? d2 : 0.f;
+                part[0][j] += ic ? d : 0.f;
+                part[1][j] += ic ? d2 : 0.f;
+                part[2][j] += ic ? 0.f : d;
+                part[3][j] += ic ? 0.f : d2;
+                part[4][j] += is ? d : 0.f;
+                part[5][j] += is ? d2 : 0.f;
             }
         }
     });
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+#pragma unroll
+        for (int w = VEC / 2; w > 0; w >>= 1)
+#pragma unroll
+            for (int j = 0; j < w; ++j) part[k][j] += part[k][j + w];
+        acc[k] = part[k][0];
+    }
     group_sum<LPP, NACC>(acc, lds);
 
     if (id.lane == 0 && id.valid) {
-        auto moments = [&](float s1, float s2, int cnt, float& mean, float& m2) {
+        auto moments = [&](float s1, float s2, int cnt, double& mean, double& m2) {
             if (cnt <= 0) {
-                mean = 0.f;
-                m2 = 0.f;
+                mean = 0.0;
+                m2 = 0.0;
                 return;
             }
             const double d1 = s1, d2 = s2;
-            mean = float(double(K) + d1 / cnt);
+            mean = double(K) + d1 / cnt;
             const double t = d2 - d1 * d1 / cnt;
-            m2 = float(t > 0.0 ? t : 0.0);
+            m2 = t > 0.0 ? t : 0.0;
         };
-        const int P = g.P;
-        if constexpr (!BOXED) {
-            float mean, m2;
-            moments(acc[0], acc[1], g.M, mean, m2);
-            out[id.p] = mean;
-            out[P + id.p] = finalize ? sqrtf(m2 / float(g.M - 1) + eps) : m2;
+        const size_t P = g.P;
+        const int Mc = BOXED ? g.cb.area() : g.M;
+        double mean, m2;
+        moments(acc[0], acc[1], Mc, mean, m2);
+        if (fin) {  // stand-alone calc_ins_mean_std: (mean, std) of the (boxed) region as float32
+            fin[id.p] = (float)mean;
+            fin[P + id.p] = (float)sqrt(m2 / double(Mc - 1) + (double)eps);
         } else {
-            const int Mc = g.cb.area(), Ms = g.sb.area();
-            float mean, m2;
-            moments(acc[0], acc[1], Mc, mean, m2);
-            out[id.p] = mean;
-            out[P + id.p] = finalize ? sqrtf(m2 / float(Mc - 1) + eps) : m2;
-            if (!finalize) {
+            mom[id.p] = mean;
+            mom[P + id.p] = m2;
+            if constexpr (BOXED) {
                 moments(acc[2], acc[3], g.M - Mc, mean, m2);
-                out[2 * P + id.p] = mean;
-                out[3 * P + id.p] = m2;
-                moments(acc[4], acc[5], Ms, mean, m2);
-                out[4 * P + id.p] = mean;
-                out[5 * P + id.p] = m2;
+                mom[2 * P + id.p] = mean;
+                mom[3 * P + id.p] = m2;
+                moments(acc[4], acc[5], g.sb.area(), mean, m2);
+                mom[4 * P + id.p] = mean;
+                mom[5 * P + id.p] = m2;
             }
         }
     }
@@ -211,26 +224,28 @@ __global__ __launch_bounds__(kBlock) void apply_fwd_kernel(const T* __restrict__
 // ------------------------------------------------------------------------------------------------
 template <typename T, int VEC, int LPP, bool BOXED>
 __global__ __launch_bounds__(kBlock) void bwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ x, Geom g,
-                                                            const float* __restrict__ shift_in,
-                                                            const float* __restrict__ shift_out,
+                                                            const double* __restrict__ shift_in,
+                                                            const double* __restrict__ shift_out,
                                                             float* __restrict__ out) {
     constexpr int NACC = BOXED ? 4 : 2;
     __shared__ float lds[4 * NACC];
     const PlaneId<LPP> id(g.P);
     const size_t off = (size_t)id.p * g.M;
-    const float si = shift_in ? shift_in[id.p] : 0.f;
-    const float so = (BOXED && shift_out) ? shift_out[id.p] : 0.f;
-    float acc[NACC];
+    const float si = shift_in ? (float)shift_in[id.p] : 0.f;  // mid_bwd_a undoes this rounding
+    const float so = (BOXED && shift_out) ? (float)shift_out[id.p] : 0.f;
+    float part[NACC][VEC];
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+    for (int k = 0; k < NACC; ++k)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) part[k][j] = 0.f;
     stream2<T, VEC, LPP>(gy + off, x + off, g.nvec, id.lane,
                          [&](const Vec<T, VEC>& vg, const Vec<T, VEC>& vx, int i) {
                              if constexpr (!BOXED) {
 #pragma unroll
                                  for (int j = 0; j < VEC; ++j) {
                                      const float G = to_float(vg.v[j]);
-                                     acc[0] += G;
-                                     acc[1] = fmaf(G, to_float(vx.v[j]) - si, acc[1]);
+                                     part[0][j] += G;
+                                     part[1][j] = fmaf(G, to_float(vx.v[j]) - si, part[1][j]);
                                  }
                              } else {
                                  const int e = i * VEC;
@@ -239,13 +254,22 @@ __global__ __launch_bounds__(kBlock) void bwd_reduce_kernel(const T* __restrict_
                                  for (int j = 0; j < VEC; ++j) {
                                      const float G = to_float(vg.v[j]), X = to_float(vx.v[j]);
                                      const bool ic = g.cb.has(r, c + j);
-                                     acc[0] += ic ? G : 0.f;
-                                     acc[1] += ic ? G * (X - si) : 0.f;
-                                     acc[2] += ic ? 0.f : G;
-                                     acc[3] += ic ? 0.f : G * (X - so);
+                                     part[0][j] += ic ? G : 0.f;
+                                     part[1][j] += ic ? G * (X - si) : 0.f;
+                                     part[2][j] += ic ? 0.f : G;
+                                     part[3][j] += ic ? 0.f : G * (X - so);
                                  }
                              }
                          });
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+#pragma unroll
+        for (int w = VEC / 2; w > 0; w >>= 1)
+#pragma unroll
+            for (int j = 0; j < w; ++j) part[k][j] += part[k][j + w];
+        acc[k] = part[k][0];
+    }
     group_sum<LPP, NACC>(acc, lds);
     if (id.lane == 0 && id.valid) {
 #pragma unroll

@@ -93,7 +93,8 @@ typedef struct cnsn_gate_grad {
 int cnsn_abi_version(void);
 const char* cnsn_status_string(int status);
 
-/* Floats of per-plane state `cnsn_forward` writes into `saved` for `cnsn_backward`. */
+/* Size, in floats, of the per-plane state `cnsn_forward` writes into `saved` for `cnsn_backward`
+ * (the block is opaque; internally it holds float64 scalars, so it must be 8-byte aligned). */
 size_t cnsn_saved_floats(const cnsn_problem_t* prob);
 /* Bytes of scratch either direction needs (the larger of the two). */
 size_t cnsn_workspace_bytes(const cnsn_problem_t* prob);

@@ -232,7 +232,7 @@ def run_pair(shape, crop, kind, dtype, seed, lam=None, chan=False, is_two=False,
     out = {}
     for tag, odt in (("t64", torch.float64), ("o32", torch.float32)):
         sn = fill_sn(orc.SelfNorm(c, is_two=is_two), seed, odt) if kind != "cn" else None
-        xr = x64.to(odt).requires_grad_()
+        xr = x64.detach().clone().to(odt).requires_grad_()
         u = xr
         if sn is not None:
             sn.train(training)
@@ -244,7 +244,7 @@ def run_pair(shape, crop, kind, dtype, seed, lam=None, chan=False, is_two=False,
                         pg={k: v.grad for k, v in sn.named_parameters()} if sn else {},
                         st={k: v for k, v in sn.state_dict().items()} if sn else {})
     sn = fill_sn(cnsn_amd.SelfNorm(c, is_two=is_two), seed, torch.float32).to(DEV) if kind != "cn" else None
-    xg = x64.to(dtype).to(DEV).requires_grad_()
+    xg = x64.detach().clone().to(dtype).to(DEV).requires_grad_()
     if kind == "sn":
         sn.train(training)
         y = sn(xg)

@@ -48,8 +48,8 @@ def make_problem(**kw):
 def test_argument_validation_without_gpu():
     lib = cnsn_amd.lib()
     p = make_problem(sn_active=1, sn_training=1)
-    assert lib.cnsn_saved_floats(C.byref(p)) == 15 * 32 + 2 * 4
-    assert lib.cnsn_workspace_bytes(C.byref(p)) >= 4 * 23 * 32
+    assert lib.cnsn_saved_floats(C.byref(p)) == 2 * (15 * 32 + 2 * 4)   # doubles, counted in floats
+    assert lib.cnsn_workspace_bytes(C.byref(p)) >= 8 * 8 * 32 + 4 * 15 * 32
     # NULL tensors
     assert lib.cnsn_forward(C.byref(p), None, None, None, None, None, None, None, None, 0, None) == -1
     # wrong struct size
