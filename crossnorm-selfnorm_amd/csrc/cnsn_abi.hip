@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "cnsn_device.h"
+#include "cnsn_host_common.h"
 #include "cnsn_mid_kernels.h"
 #include "cnsn_resident_kernels.h"
 #include "cnsn_stream_kernels.h"
@@ -14,32 +15,10 @@ using namespace cnsn;
 
 namespace {
 
-template <typename T>
-struct TypeTag {
-    using type = T;
-};
-template <int V>
-struct IntTag {
-    static constexpr int value = V;
-};
-template <bool B>
-struct BoolTag {
-    static constexpr bool value = B;
-};
-
 struct Shape {
     int vec;  // elements per vector access
     int lpp;  // lanes per plane
 };
-
-inline int elem_bytes(int dtype) { return dtype == CNSN_F32 ? 4 : 2; }
-
-// widest power-of-two vector (<= 16 B) that divides `span` elements
-inline int pick_vec(int dtype, int span) {
-    int v = 16 / elem_bytes(dtype);
-    while (v > 1 && (span % v) != 0) v >>= 1;
-    return v;
-}
 
 inline Shape pick_shape(int dtype, int M, int Wd, bool boxed) {
     Shape s;
@@ -252,11 +231,11 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
     double* mom = (double*)workspace;
     double* saved_d = saved ? (double*)saved : mom + 6 * pl.P;
     float* coef = (float*)(mom + 6 * pl.P + saved_doubles_of(pl));
-    float* ws = (float*)workspace;
 
-    if (use_resident(p, pl.boxed, chan_perm != nullptr)) {
-        return resident_forward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, x, perm, gate_dev(g), gate_dev(f), y, saved_d,
-                                ws, stream);
+    if (resident_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr).ok) {
+        st = resident_forward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, x, perm, gate_dev(g), gate_dev(f), y,
+                              saved ? saved_d : nullptr, workspace, stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;  // otherwise: fall through to the two-pass strategy
     }
 
     const int blocks = blocks_for(pl.geom.P, pl.shape.lpp);
@@ -300,15 +279,15 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
     hipStream_t stream = (hipStream_t)stream_;
 
     const size_t P = pl.P;
-    float* ws = (float*)workspace;
     double* tmp = (double*)workspace;
     float* sums = (float*)(tmp + BT_ROWS * P);
     float* coef = sums + 4 * P;
     const double* saved_d = (const double*)saved;
 
-    if (use_resident(p, pl.boxed, chan_perm != nullptr)) {
-        return resident_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, grad_y, x, perm, gate_dev(g), gate_dev(f),
-                                 saved_d, grad_x, gate_grad_dev(dg), gate_grad_dev(df), ws, stream);
+    if (resident_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr).ok) {
+        st = resident_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, grad_y, x, perm, gate_dev(g), gate_dev(f),
+                               saved_d, grad_x, gate_grad_dev(dg), gate_grad_dev(df), workspace, stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
     }
 
     const int blocks = blocks_for(pl.geom.P, pl.shape.lpp);

@@ -1,0 +1,56 @@
+// Layout of the per-plane side arrays shared by the two strategies (`saved` written by either
+// forward and read by either backward; coefficient rows consumed by the apply kernels).
+#pragma once
+#include "cnsn_algebra.h"
+
+namespace cnsn {
+
+// SoA rows of `saved` (doubles, stride P = N*C), followed by two rows of C (BatchNorm rstd of g, f)
+enum SavedRow {
+    SV_MU_C = 0,   // mean inside the content box (whole plane without one)
+    SV_MU_O,       // mean outside the content box
+    SV_M2C,        // sum of squared deviations inside the content box
+    SV_SIG_C,      // sqrt(var_c + eps_cn)
+    SV_MU_S,       // this plane's own style-box mean   (what it lends as a style source)
+    SV_SIG_S,      // this plane's own style-box std
+    SV_A,          // sig_s[q] / sig_c
+    SV_A1,         // lam + (1-lam)*a : slope applied inside the content box
+    SV_M_IN,       // mean of the CrossNorm output inside the content box
+    SV_MU_P,       // post-CrossNorm whole-plane mean  (SelfNorm's input statistic)
+    SV_SIG_P,      // post-CrossNorm whole-plane std, eps_sn
+    SV_G,          // gate g
+    SV_ZH_G,       // normalised pre-activation of g
+    SV_F,          // gate f (two-gate form)
+    SV_ZH_F,
+    SV_ROWS
+};
+
+// rows of the forward coefficient block handed to apply_fwd_kernel
+enum FwdCoefRow { FC_A_IN = 0, FC_XR, FC_B_IN, FC_A_OUT, FC_B_OUT, FC_ROWS };
+
+// rows of the backward scratch written by mid_bwd_a and read by mid_bwd_b
+enum BwdTmpRow { BT_DT_G = 0, BT_DT_F, BT_DMU_P, BT_K, BT_DMU_C, BT_DSIG_C, BT_E_MU, BT_E_SIG, BT_ROWS };
+
+// rows of the backward coefficient block handed to apply_bwd_kernel
+enum BwdCoefRow {
+    BC_CG_IN = 0, BC_CX_IN, BC_XR_IN, BC_C0_IN, BC_CG_OUT, BC_CX_OUT, BC_XR_OUT, BC_C0_OUT, BC_ES, BC_XS, BC_E0,
+    BC_ROWS
+};
+
+template <typename R>
+__device__ __forceinline__ void store_fwd_plane(double* __restrict__ saved, size_t P, size_t p,
+                                                const FwdPlaneT<R>& f) {
+    saved[SV_MU_C * P + p] = f.mu_c;
+    saved[SV_MU_O * P + p] = f.mu_o;
+    saved[SV_M2C * P + p] = f.M2c;
+    saved[SV_SIG_C * P + p] = f.sig_c;
+    saved[SV_MU_S * P + p] = f.mu_s;
+    saved[SV_SIG_S * P + p] = f.sig_s;
+    saved[SV_A * P + p] = f.aa;
+    saved[SV_A1 * P + p] = f.a1;
+    saved[SV_M_IN * P + p] = f.m_in;
+    saved[SV_MU_P * P + p] = f.mu_p;
+    saved[SV_SIG_P * P + p] = f.sig_p;
+}
+
+}  // namespace cnsn

@@ -1,0 +1,186 @@
+// Host side of the channel-resident strategy: eligibility, launch geometry, dispatch.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "cnsn_host_common.h"
+#include "cnsn_resident_kernels.h"
+
+namespace cnsn {
+
+namespace {
+
+struct Bucket {
+    int nv, ppw;
+};
+// vectors per lane and plane -> planes per wave.  Chosen so a wave keeps <= 16 vectors (64 VGPRs) per
+// tensor in flight forward, twice that backward (G and x).
+constexpr Bucket kBuckets[] = {{1, 8}, {2, 4}, {4, 2}, {7, 1}, {13, 1}, {16, 1}};
+
+int cu_count() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
+template <typename F>
+bool dispatch_res(int dtype, int vec, int nv, F&& f) {
+    auto by_nv = [&](auto tt, auto vt) -> bool {
+        switch (nv) {
+            case 1: f(tt, vt, IntTag<1>{}, IntTag<8>{}); return true;
+            case 2: f(tt, vt, IntTag<2>{}, IntTag<4>{}); return true;
+            case 4: f(tt, vt, IntTag<4>{}, IntTag<2>{}); return true;
+            case 7: f(tt, vt, IntTag<7>{}, IntTag<1>{}); return true;
+            case 13: f(tt, vt, IntTag<13>{}, IntTag<1>{}); return true;
+            case 16: f(tt, vt, IntTag<16>{}, IntTag<1>{}); return true;
+            default: return false;
+        }
+    };
+    if (dtype == CNSN_F32 && vec == 4) return by_nv(TypeTag<float>{}, IntTag<4>{});
+    if (dtype == CNSN_BF16 && vec == 8) return by_nv(TypeTag<bf16_t>{}, IntTag<8>{});
+    if (dtype == CNSN_BF16 && vec == 4) return by_nv(TypeTag<bf16_t>{}, IntTag<4>{});
+    if (dtype == CNSN_F16 && vec == 8) return by_nv(TypeTag<_Float16>{}, IntTag<8>{});
+    if (dtype == CNSN_F16 && vec == 4) return by_nv(TypeTag<_Float16>{}, IntTag<4>{});
+    return false;
+}
+
+ResArgs make_args(const cnsn_problem_t& p, Box cb, Box sb, const MidArgs& mid, const ResPlan& rp) {
+    ResArgs ra;
+    ra.mid = mid;
+    ra.M = p.H * p.W;
+    ra.Wd = p.W;
+    ra.nvec = ra.M / rp.vec;
+    ra.cb = cb;
+    ra.sb = sb;
+    ra.K = rp.K;
+    ra.items = p.C * rp.K;
+    return ra;
+}
+
+// persistent grid: every workgroup resident, a whole number of clusters
+template <typename Kern>
+int grid_for(Kern kern, size_t lds, int K, int items) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kBlock, lds) != hipSuccess) return 0;
+    // MI355X admits min(API, 8, floor(800 / (ceil(sgpr/16)*16 + 16))) workgroups of 256 threads per CU
+    // and the API over-reports by one when SGPRs are the limiter (MI355X_MICROARCH.md, "Residency").
+    // Every resident kernel here uses 106-108 SGPRs (checked at build time) -> 6.
+    if (occ > 6) occ = 6;
+    if (getenv("CNSN_DEBUG"))
+        fprintf(stderr, "[cnsn] resident grid: occupancy %d/CU x %d CUs, K=%d, items=%d, lds=%zu\n", occ, cu_count(),
+                K, items, lds);
+    long g = (long)occ * cu_count();
+    g = (g / K) * K;
+    if (g > items) g = items;  // items is a multiple of K
+    return (int)g;
+}
+
+}  // namespace
+
+ResPlan resident_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm) {
+    ResPlan rp{false, 0, 0, 0, 0};
+    if (p.strategy == CNSN_STRATEGY_TWO_PASS || has_chan_perm) return rp;
+    const int M = p.H * p.W;
+    rp.vec = pick_vec(p.dtype, boxed ? p.W : M);
+    if (!(rp.vec == 16 / elem_bytes(p.dtype) || (elem_bytes(p.dtype) == 2 && rp.vec == 4))) return rp;
+    const int nvec = M / rp.vec;
+    if (nvec <= 32) return rp;  // tiny planes: handled by the 16-lanes-per-plane streaming kernels
+    const int need = (nvec + 63) / 64;
+    for (const Bucket& b : kBuckets)
+        if (b.nv >= need) {
+            rp.nv = b.nv;
+            rp.ppw = b.ppw;
+            break;
+        }
+    if (rp.nv == 0) return rp;  // plane does not fit one wave's registers
+    const int own = 4 * rp.ppw;
+    rp.K = (p.N + own - 1) / own;
+    if (res_lds_bytes(p.N, 6, own, BC_ROWS) > 64 * 1024) return rp;
+    if (rp.K > 4 * cu_count()) return rp;
+    rp.ok = true;
+    return rp;
+}
+
+int resident_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* x,
+                     const int64_t* perm, GateDev g, GateDev f, void* y, double* saved, void* workspace,
+                     hipStream_t stream) {
+    const ResPlan rp = resident_plan(p, boxed, false);
+    if (!rp.ok) return CNSN_E_UNSUPPORTED;
+    const ResArgs ra = make_args(p, cb, sb, mid, rp);
+    const int NG = boxed ? 6 : 2;
+    const size_t lds = res_lds_bytes(p.N, NG, 4 * rp.ppw, FC_ROWS);
+    unsigned* ctl = (unsigned*)workspace;
+    unsigned long long* gran = (unsigned long long*)((char*)workspace + kCtlBytes);
+    const size_t zero_bytes = kCtlBytes + (size_t)p.N * p.C * NG * 8;
+    int status = CNSN_E_UNSUPPORTED;
+    dispatch_res(p.dtype, rp.vec, rp.nv, [&](auto tt, auto vt, auto nt, auto pt) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value, NV = decltype(nt)::value, PPW = decltype(pt)::value;
+        auto launch = [&](auto kern) {
+            const int grid = grid_for(kern, lds, rp.K, ra.items);
+            if (grid < rp.K) return;
+            hipError_t e = hipMemsetAsync(workspace, 0, zero_bytes, stream);
+            if (e != hipSuccess) {
+                status = (int)e;
+                return;
+            }
+            kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl);
+            e = hipGetLastError();
+            status = e == hipSuccess ? CNSN_OK : (int)e;
+        };
+        if (boxed)
+            launch(resident_fwd_kernel<T, VEC, NV, PPW, true>);
+        else
+            launch(resident_fwd_kernel<T, VEC, NV, PPW, false>);
+    });
+    return status;
+}
+
+int resident_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* gy,
+                      const void* x, const int64_t* perm, GateDev g, GateDev f, const double* saved, void* dx,
+                      GateGradDev dg, GateGradDev df, void* workspace, hipStream_t stream) {
+    const ResPlan rp = resident_plan(p, boxed, false);
+    if (!rp.ok) return CNSN_E_UNSUPPORTED;
+    const ResArgs ra = make_args(p, cb, sb, mid, rp);
+    const int NS = boxed ? 4 : 2;
+    const size_t lds = res_lds_bytes(p.N, NS, 4 * rp.ppw, BC_ROWS);
+    unsigned* ctl = (unsigned*)workspace;
+    unsigned long long* gran = (unsigned long long*)((char*)workspace + kCtlBytes);
+    const size_t zero_bytes = kCtlBytes + (size_t)p.N * p.C * NS * 8;
+    int status = CNSN_E_UNSUPPORTED;
+    dispatch_res(p.dtype, rp.vec, rp.nv, [&](auto tt, auto vt, auto nt, auto pt) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value, NV = decltype(nt)::value, PPW = decltype(pt)::value;
+        auto launch = [&](auto kern) {
+            const int grid = grid_for(kern, lds, rp.K, ra.items);
+            if (grid < rp.K) return;
+            hipError_t e = hipMemsetAsync(workspace, 0, zero_bytes, stream);
+            if (e != hipSuccess) {
+                status = (int)e;
+                return;
+            }
+            kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)gy, (const T*)x, (T*)dx, perm, g, f, dg, df, gran,
+                                                saved, ctl);
+            e = hipGetLastError();
+            status = e == hipSuccess ? CNSN_OK : (int)e;
+        };
+        if (boxed)
+            launch(resident_bwd_kernel<T, VEC, NV, PPW, true>);
+        else
+            launch(resident_bwd_kernel<T, VEC, NV, PPW, false>);
+    });
+    return status;
+}
+
+size_t resident_workspace_bytes(const cnsn_problem_t& p, bool boxed) {
+    return kCtlBytes + (size_t)p.N * p.C * (boxed ? 6 : 2) * 8;
+}
+
+}  // namespace cnsn

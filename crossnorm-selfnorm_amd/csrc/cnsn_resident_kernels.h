@@ -1,24 +1,628 @@
-// Channel-resident strategy (one launch per direction, the channel's planes stay on chip).
+// Channel-resident strategy: ONE launch per direction; every plane is read from HBM exactly once.
+//
+// Why it is possible: all coupling of the fused op — CrossNorm's batch permutation (cnsn.py:62,
+// same channel) and SelfNorm's BatchNorm1d over N (cnsn.py:121,138) — stays inside one channel.
+// A channel (N planes) is given to a CLUSTER of K co-resident workgroups; each wave keeps PPW
+// whole planes in its VGPRs (NV 16-byte vectors per lane and plane), so
+//     forward : read x once -> exact two-pass plane statistics from registers -> exchange N*NG
+//               scalars inside the cluster -> BatchNorm/gate algebra -> apply from registers -> write y
+//     backward: read G and x once -> per-plane sums -> exchange -> mid algebra -> apply -> write dx
+// i.e. 2*E*b and 3*E*b bytes of HBM traffic instead of the two-pass strategy's 3*E*b and 5*E*b.
+//
+// Cluster exchange (MI355X_MICROARCH.md "handoff"/"allgather", cdna_hip_programming.md G16 R2):
+// each plane's scalars are published as 8-byte {tag, float} granules with ONE relaxed agent-scope
+// (sc1, write-through) atomic store each; one wave per workgroup re-reads the channel's granules
+// with relaxed agent-scope loads until every tag matches.  No fences, no flags, no counters; the
+// granule area is zeroed by a memset node on the stream before every launch (tag 1 = valid).
+//
+// Deadlock freedom: the grid is persistent, G = (resident workgroups) rounded down to a multiple
+// of K, and workgroup b handles items b, b+G, ...; the K members of a cluster are therefore
+// always the same K co-resident workgroups working on the same iteration.  Every spin is bounded:
+// on time-out a word in the control block is raised, all waits drain, results are invalid and the
+// host can see it (`resident_ctl_word`).
 #pragma once
 #include "../../include/cnsn_hip.h"
+#include "cnsn_algebra.h"
 #include "cnsn_device.h"
-#include "cnsn_mid_kernels.h"
+#include "cnsn_layout.h"
 
 namespace cnsn {
 
-inline bool use_resident(const cnsn_problem_t& p, bool boxed, bool has_chan_perm) {
-    (void)p; (void)boxed; (void)has_chan_perm;
-    return false;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+constexpr unsigned kSpinLimit = 1u << 18;
+constexpr int kCtlBytes = 256;  // control block in front of the granule area (word 0: time-out flag)
+
+struct ResArgs {
+    MidArgs mid;
+    int M, Wd, nvec;
+    Box cb, sb;
+    int K;      // workgroups per channel
+    int items;  // C * K
+};
+
+__device__ __forceinline__ void put_granule(unsigned long long* p, float v) {
+    __hip_atomic_store((gu64*)p, (1ull << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
 }
 
-inline int resident_forward(const cnsn_problem_t&, Box, Box, bool, const MidArgs&, const void*, const int64_t*,
-                            GateDev, GateDev, void*, double*, float*, hipStream_t) {
-    return CNSN_E_UNSUPPORTED;
+// ONE wave gathers `total` granules into LDS (as floats); re-reads all of them until every tag is set.
+__device__ __forceinline__ void sweep_granules(const unsigned long long* g, int total, float* vals, unsigned* ctl) {
+    const int lane = threadIdx.x & 63;
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+        for (int i = lane; i < total; i += 64) {
+            const unsigned long long v = __hip_atomic_load((gu64*)(g + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok &= (v >> 32) == 1ull;
+            vals[i] = __uint_as_float((unsigned)v);
+        }
+        if (__all(ok)) return;
+        __builtin_amdgcn_s_sleep(4);
+        if ((spins & 15u) == 15u) {
+            const bool dead = spins > kSpinLimit ||
+                              __hip_atomic_load((gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (dead) {  // give up: raise the flag so every other wait drains too
+                if (lane == 0) __hip_atomic_store((gu32*)ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+    }
 }
-inline int resident_backward(const cnsn_problem_t&, Box, Box, bool, const MidArgs&, const void*, const void*,
-                             const int64_t*, GateDev, GateDev, const double*, void*, GateGradDev, GateGradDev, float*,
-                             hipStream_t) {
-    return CNSN_E_UNSUPPORTED;
+
+// static per-lane geometry of the register slots: slot j of this lane holds vector j*64+lane
+template <int VEC, int NV, bool BOXED>
+struct SlotGeom {
+    unsigned valid;     // bit j: slot j lies inside the plane
+    unsigned inC[NV];   // bit q of [j]: element q of slot j is inside the content box
+    unsigned inS[NV];   // ... inside the style box
+    __device__ __forceinline__ SlotGeom(const ResArgs& ra, int lane) {
+        valid = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            inC[j] = inS[j] = 0;
+            const int i = j * 64 + lane;
+            if (i < ra.nvec) {
+                valid |= 1u << j;
+                if constexpr (BOXED) {
+                    const int e = i * VEC;  // VEC divides the width: one row per vector
+                    const int r = e / ra.Wd, c = e - r * ra.Wd;
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        inC[j] |= (ra.cb.has(r, c + q) ? 1u : 0u) << q;
+                        inS[j] |= (ra.sb.has(r, c + q) ? 1u : 0u) << q;
+                    }
+                }
+            }
+        }
+    }
+};
+
+__host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+// Register budget: the planes a wave holds dominate its VGPR use, and the number of resident waves
+// per SIMD (= workgroups per CU, a workgroup being one wave per SIMD) decides how much of the sync
+// latency other workgroups can cover.  min-waves-per-SIMD handed to __launch_bounds__:
+constexpr int data_regs(int elem_bytes, int vec, int nv, int ppw) { return ppw * nv * vec * elem_bytes / 4; }
+#if defined(CNSN_WF) && defined(CNSN_WB)  // tuning builds: force the bounds
+constexpr int fwd_waves(int) { return CNSN_WF; }
+constexpr int bwd_waves(int) { return CNSN_WB; }
+#else
+constexpr int fwd_waves(int regs) { return regs <= 32 ? 6 : (regs <= 56 ? 5 : 4); }
+constexpr int bwd_waves(int regs) { return 2 * regs <= 64 ? 5 : (2 * regs <= 112 ? 3 : 2); }
+#endif
+
+// dynamic LDS carve (bytes); NG = granules per plane, OWN = planes per workgroup
+__host__ __device__ inline size_t res_lds_bytes(int N, int NG, int OWN, int coef_rows) {
+    return align16((size_t)N * NG * 4)        // vals[N][NG]
+           + align16((size_t)2 * N * 8)       // zbuf / dt [2][N]
+           + align16((size_t)N * 4)           // perm / inverse perm [N]
+           + align16((size_t)OWN * coef_rows * 4)  // coefficients of the owned planes
+           + 4 * 4 * 8;                       // block reduction scratch
 }
+
+// ================================================================================================
+// forward
+// ================================================================================================
+template <typename T, int VEC, int NV, int PPW, bool BOXED>
+__global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW))) void resident_fwd_kernel(ResArgs ra, const T* __restrict__ x, T* __restrict__ y,
+                                                              const int64_t* __restrict__ perm, GateDev gg, GateDev gf,
+                                                              unsigned long long* __restrict__ gran,
+                                                              double* __restrict__ saved, unsigned* __restrict__ ctl) {
+    constexpr int NG = BOXED ? 6 : 2;
+    constexpr int OWN = 4 * PPW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const MidArgs a = ra.mid;
+    const int N = a.N, C = a.C;
+    float* vals = (float*)smem;
+    double* zbuf = (double*)(smem + align16((size_t)N * NG * 4));
+    int* sperm = (int*)((char*)zbuf + align16((size_t)2 * N * 8));
+    float* ocoef = (float*)((char*)sperm + align16((size_t)N * 4));
+    double* red = (double*)((char*)ocoef + align16((size_t)OWN * FC_ROWS * 4));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t P = (size_t)N * C;
+    const SlotGeom<VEC, NV, BOXED> sg(ra, lane);
+
+    if (a.cn_active)
+        for (int n = threadIdx.x; n < N; n += kBlock) sperm[n] = (int)perm[n];
+
+    for (int item = blockIdx.x; item < ra.items; item += gridDim.x) {
+        const int c = item / ra.K, k = item - c * ra.K;
+        const int n0 = (k * 4 + wave) * PPW;
+
+        // ---- load this wave's planes into registers (the only read of x)
+        Vec<T, VEC> d[PPW][NV];
+#pragma unroll
+        for (int s = 0; s < PPW; ++s) {
+            const int n = n0 + s;
+            const T* base = x + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                if (n < N && ((sg.valid >> j) & 1u))
+                    d[s][j] = load_vec<T, VEC>(base + (size_t)(j * 64 + lane) * VEC);
+                else
+                    d[s][j] = Vec<T, VEC>{};
+            }
+        }
+
+        // ---- exact two-pass statistics from registers; publish them to the cluster
+#pragma unroll
+        for (int s = 0; s < PPW; ++s) {
+            const int n = n0 + s;
+            float pub[NG];
+            if constexpr (!BOXED) {
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) sum += to_float(d[s][j].v[q]);
+                const float mean = wave_sum(sum) / (float)ra.M;
+                float m2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+                    if ((sg.valid >> j) & 1u) {
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) {
+                            const float t = to_float(d[s][j].v[q]) - mean;
+                            m2 = fmaf(t, t, m2);
+                        }
+                    }
+                pub[0] = mean;
+                pub[1] = wave_sum(m2);
+            } else {
+                float sc = 0.f, so = 0.f, ss = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        const float f = to_float(d[s][j].v[q]);  // invalid slots hold 0 and no box bit
+                        const bool ic = (sg.inC[j] >> q) & 1u, is = (sg.inS[j] >> q) & 1u;
+                        sc += ic ? f : 0.f;
+                        so += ic ? 0.f : f;
+                        ss += is ? f : 0.f;
+                    }
+                const int Mo = a.M - a.Mc;
+                const float mc = wave_sum(sc) / (float)a.Mc;
+                const float mo = Mo > 0 ? wave_sum(so) / (float)Mo : 0.f;
+                const float ms = wave_sum(ss) / (float)a.Ms;
+                float qc = 0.f, qo = 0.f, qs = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+                    if ((sg.valid >> j) & 1u) {
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) {
+                            const float f = to_float(d[s][j].v[q]);
+                            const bool ic = (sg.inC[j] >> q) & 1u, is = (sg.inS[j] >> q) & 1u;
+                            const float tc = f - mc, to = f - mo, ts = f - ms;
+                            qc += ic ? tc * tc : 0.f;
+                            qo += ic ? 0.f : to * to;
+                            qs += is ? ts * ts : 0.f;
+                        }
+                    }
+                pub[0] = mc;
+                pub[1] = wave_sum(qc);
+                pub[2] = mo;
+                pub[3] = wave_sum(qo);
+                pub[4] = ms;
+                pub[5] = wave_sum(qs);
+            }
+            if (n < N && lane < NG) {
+                float v = pub[0];
+#pragma unroll
+                for (int m = 1; m < NG; ++m) v = (lane == m) ? pub[m] : v;
+                put_granule(gran + ((size_t)c * N + n) * NG + lane, v);
+            }
+        }
+
+        // ---- gather the whole channel's statistics
+        __syncthreads();  // the previous item's readers of vals/zbuf are done
+        if (wave == 0) sweep_granules(gran + (size_t)c * N * NG, N * NG, vals, ctl);
+        __syncthreads();
+
+        using R = float;  // per-plane algebra in float, cross-batch sums / normalisation in double
+        auto plane_of = [&](int n) {
+            MomentsT<R> o;
+            o.mu_c = vals[n * NG];
+            o.M2c = vals[n * NG + 1];
+            o.mu_o = BOXED ? vals[n * NG + 2] : 0.f;
+            o.M2o = BOXED ? vals[n * NG + 3] : 0.f;
+            o.mu_s = BOXED ? vals[n * NG + 4] : o.mu_c;
+            o.M2s = BOXED ? vals[n * NG + 5] : o.M2c;
+            R mu_sq = 0.f, M2_sq = 0.f;
+            if (a.cn_active) {
+                const int q = sperm[n];  // style source instance, same channel (cnsn.py:66,68)
+                mu_sq = vals[q * NG + (BOXED ? 4 : 0)];
+                M2_sq = vals[q * NG + (BOXED ? 5 : 1)];
+            }
+            return fwd_plane<R>(a, o, mu_sq, M2_sq);
+        };
+
+        // ---- SelfNorm gate statistics over the batch (every member computes them redundantly):
+        //      one pass, sums taken about the pre-activation of instance 0
+        double mg = 0, mf = 0, rg = 1, rf = 1, wg0 = 0, wg1 = 0, wf0 = 0, wf1 = 0;
+        if (a.sn_active) {
+            wg0 = gg.w[2 * c];
+            wg1 = gg.w[2 * c + 1];
+            if (a.sn_two) {
+                wf0 = gf.w[2 * c];
+                wf1 = gf.w[2 * c + 1];
+            }
+            if (a.sn_training) {
+                const FwdPlaneT<R> f0 = plane_of(0);
+                const double zs_g = wg0 * (double)f0.mu_p + wg1 * (double)f0.sig_p;
+                const double zs_f = wf0 * (double)f0.mu_p + wf1 * (double)f0.sig_p;
+                double sz[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int n = threadIdx.x; n < N; n += kBlock) {
+                    const FwdPlaneT<R> f = plane_of(n);
+                    const double dg = wg0 * (double)f.mu_p + wg1 * (double)f.sig_p - zs_g;
+                    const double df = wf0 * (double)f.mu_p + wf1 * (double)f.sig_p - zs_f;
+                    sz[0] += dg;
+                    sz[1] += dg * dg;
+                    sz[2] += df;
+                    sz[3] += df * df;
+                }
+                block_sum_d<4>(sz, red);
+                mg = zs_g + sz[0] / N;
+                mf = zs_f + sz[2] / N;
+                double vg = (sz[1] - sz[0] * sz[0] / N) / N, vf = (sz[3] - sz[2] * sz[2] / N) / N;
+                vg = vg > 0.0 ? vg : 0.0;
+                vf = vf > 0.0 ? vf : 0.0;
+                rg = 1.0 / sqrt(vg + (double)a.eps_bn);
+                rf = 1.0 / sqrt(vf + (double)a.eps_bn);
+                if (k == 0 && threadIdx.x == 0) {
+                    const double mom_ = a.momentum, unb = (double)N / ((double)N - 1.0);
+                    gg.run_mean[c] = (float)((1.0 - mom_) * gg.run_mean[c] + mom_ * mg);
+                    gg.run_var[c] = (float)((1.0 - mom_) * gg.run_var[c] + mom_ * vg * unb);
+                    if (a.sn_two) {
+                        gf.run_mean[c] = (float)((1.0 - mom_) * gf.run_mean[c] + mom_ * mf);
+                        gf.run_var[c] = (float)((1.0 - mom_) * gf.run_var[c] + mom_ * vf * unb);
+                    }
+                }
+            } else {
+                mg = gg.run_mean[c];
+                rg = 1.0 / sqrt((double)gg.run_var[c] + (double)a.eps_bn);
+                if (a.sn_two) {
+                    mf = gf.run_mean[c];
+                    rf = 1.0 / sqrt((double)gf.run_var[c] + (double)a.eps_bn);
+                }
+            }
+            if (saved && k == 0 && threadIdx.x == 0) {
+                saved[SV_ROWS * P + c] = rg;
+                saved[SV_ROWS * P + C + c] = rf;
+            }
+        }
+
+        // ---- coefficients (and saved state) of the planes this workgroup owns: one thread each
+        if (threadIdx.x < OWN) {
+            const int n = k * OWN + threadIdx.x;
+            if (n < N) {
+                const FwdPlaneT<R> f = plane_of(n);
+                R g = 1.f, fg = 1.f;
+                double zhg = 0.0, zhf = 0.0;
+                if (a.sn_active) {
+                    zhg = (wg0 * (double)f.mu_p + wg1 * (double)f.sig_p - mg) * rg;
+                    g = sigmoid_r<R>((R)((double)gg.gamma[c] * zhg + (double)gg.beta[c]));
+                    if (a.sn_two) {
+                        zhf = (wf0 * (double)f.mu_p + wf1 * (double)f.sig_p - mf) * rf;
+                        fg = sigmoid_r<R>((R)((double)gf.gamma[c] * zhf + (double)gf.beta[c]));
+                    }
+                }
+                const FwdCoefs cf = fwd_coefs<R>(a, f, g, fg);
+                float* o = ocoef + threadIdx.x * FC_ROWS;
+                o[FC_A_IN] = cf.a_in;
+                o[FC_XR] = cf.xr;
+                o[FC_B_IN] = cf.b_in;
+                o[FC_A_OUT] = cf.a_out;
+                o[FC_B_OUT] = cf.b_out;
+                if (saved) {
+                    const size_t p = (size_t)n * C + c;
+                    store_fwd_plane<R>(saved, P, p, f);
+                    saved[SV_G * P + p] = g;
+                    saved[SV_ZH_G * P + p] = zhg;
+                    saved[SV_F * P + p] = fg;
+                    saved[SV_ZH_F * P + p] = zhf;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- apply from registers, the only write of y
+#pragma unroll
+        for (int s = 0; s < PPW; ++s) {
+            const int n = n0 + s;
+            if (n < N) {
+                const float* o = ocoef + (wave * PPW + s) * FC_ROWS;
+                const float a_in = o[FC_A_IN], xr = o[FC_XR], b_in = o[FC_B_IN], a_out = o[FC_A_OUT],
+                            b_out = o[FC_B_OUT];
+                T* yb = y + ((size_t)n * C + c) * ra.M;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+                    if ((sg.valid >> j) & 1u) {
+                        Vec<T, VEC> ov;
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) {
+                            const float f = to_float(d[s][j].v[q]);
+                            const bool ic = !BOXED || ((sg.inC[j] >> q) & 1u);
+                            ov.v[q] = from_float<T>(ic ? fmaf(a_in, f - xr, b_in) : fmaf(a_out, f, b_out));
+                        }
+                        store_vec<T, VEC>(yb + (size_t)(j * 64 + lane) * VEC, ov);
+                    }
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// backward
+// ================================================================================================
+template <typename T, int VEC, int NV, int PPW, bool BOXED>
+__global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW))) void resident_bwd_kernel(ResArgs ra, const T* __restrict__ gy,
+                                                              const T* __restrict__ x, T* __restrict__ dx,
+                                                              const int64_t* __restrict__ perm, GateDev gg, GateDev gf,
+                                                              GateGradDev dgr, GateGradDev dfr,
+                                                              unsigned long long* __restrict__ gran,
+                                                              const double* __restrict__ saved,
+                                                              unsigned* __restrict__ ctl) {
+    constexpr int NS = BOXED ? 4 : 2;
+    constexpr int OWN = 4 * PPW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const MidArgs a = ra.mid;
+    const int N = a.N, C = a.C;
+    float* vals = (float*)smem;
+    double* dtb = (double*)(smem + align16((size_t)N * NS * 4));
+    int* iperm = (int*)((char*)dtb + align16((size_t)2 * N * 8));
+    float* ocoef = (float*)((char*)iperm + align16((size_t)N * 4));
+    double* red = (double*)((char*)ocoef + align16((size_t)OWN * BC_ROWS * 4));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t P = (size_t)N * C;
+    const SlotGeom<VEC, NV, BOXED> sg(ra, lane);
+
+    if (a.cn_active)  // plane r receives the style-statistic gradient of the plane that borrowed from it
+        for (int n = threadIdx.x; n < N; n += kBlock) iperm[(int)perm[n]] = n;
+
+    for (int item = blockIdx.x; item < ra.items; item += gridDim.x) {
+        const int c = item / ra.K, k = item - c * ra.K;
+        const int n0 = (k * 4 + wave) * PPW;
+
+        // ---- load G and x planes (the only reads)
+        Vec<T, VEC> dg_[PPW][NV], dx_[PPW][NV];
+#pragma unroll
+        for (int s = 0; s < PPW; ++s) {
+            const int n = n0 + s;
+            const size_t off = ((size_t)(n < N ? n : 0) * C + c) * ra.M;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                if (n < N && ((sg.valid >> j) & 1u)) {
+                    dg_[s][j] = load_vec<T, VEC>(gy + off + (size_t)(j * 64 + lane) * VEC);
+                    dx_[s][j] = load_vec<T, VEC>(x + off + (size_t)(j * 64 + lane) * VEC);
+                } else {
+                    dg_[s][j] = Vec<T, VEC>{};
+                    dx_[s][j] = Vec<T, VEC>{};
+                }
+            }
+        }
+
+        // ---- per-plane sums of G against x (shifted by the saved means, as pass A' does); publish
+#pragma unroll
+        for (int s = 0; s < PPW; ++s) {
+            const int n = n0 + s;
+            const size_t p = (size_t)(n < N ? n : 0) * C + c;
+            const float si = (float)saved[SV_MU_C * P + p];
+            const float so = BOXED ? (float)saved[SV_MU_O * P + p] : 0.f;
+            float acc[NS];
+#pragma unroll
+            for (int m = 0; m < NS; ++m) acc[m] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                if ((sg.valid >> j) & 1u) {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        const float G = to_float(dg_[s][j].v[q]), X = to_float(dx_[s][j].v[q]);
+                        if constexpr (!BOXED) {
+                            acc[0] += G;
+                            acc[1] = fmaf(G, X - si, acc[1]);
+                        } else {
+                            const bool ic = (sg.inC[j] >> q) & 1u;
+                            acc[0] += ic ? G : 0.f;
+                            acc[1] += ic ? G * (X - si) : 0.f;
+                            acc[2] += ic ? 0.f : G;
+                            acc[3] += ic ? 0.f : G * (X - so);
+                        }
+                    }
+                }
+#pragma unroll
+            for (int m = 0; m < NS; ++m) acc[m] = wave_sum(acc[m]);
+            if (n < N && lane < NS) {
+                float v = acc[0];
+#pragma unroll
+                for (int m = 1; m < NS; ++m) v = (lane == m) ? acc[m] : v;
+                put_granule(gran + ((size_t)c * N + n) * NS + lane, v);
+            }
+        }
+
+        __syncthreads();
+        if (wave == 0) sweep_granules(gran + (size_t)c * N * NS, N * NS, vals, ctl);
+        __syncthreads();
+
+        using R = float;  // per-plane algebra in float; batch sums and the dz line in double
+        auto sums_of = [&](int n) {
+            const size_t p = (size_t)n * C + c;
+            return fix_sums<R>(a, vals[n * NS], vals[n * NS + 1], BOXED ? vals[n * NS + 2] : 0.f,
+                               BOXED ? vals[n * NS + 3] : 0.f, saved[SV_MU_C * P + p], saved[SV_MU_O * P + p]);
+        };
+
+        // ---- gate backward: dt for every instance of the channel, batch sums (all members)
+        double s4[4] = {0, 0, 0, 0};
+        BnBwd b{};
+        if (a.sn_active) {
+            for (int n = threadIdx.x; n < N; n += kBlock) {
+                const size_t p = (size_t)n * C + c;
+                R dtg, dtf;
+                gate_dt<R>(a, sums_of(n), (R)saved[SV_A1 * P + p], (R)saved[SV_M_IN * P + p],
+                           (R)saved[SV_MU_O * P + p], (R)saved[SV_MU_P * P + p], (R)saved[SV_G * P + p],
+                           (R)saved[SV_F * P + p], dtg, dtf);
+                s4[0] += (double)dtg;
+                s4[1] += (double)dtg * saved[SV_ZH_G * P + p];
+                s4[2] += (double)dtf;
+                s4[3] += (double)dtf * saved[SV_ZH_F * P + p];
+                dtb[n] = dtg;
+                dtb[N + n] = dtf;
+            }
+            block_sum_d<4>(s4, red);
+            b.s_dt_g = s4[0];
+            b.s_dtz_g = s4[1];
+            b.s_dt_f = s4[2];
+            b.s_dtz_f = s4[3];
+            b.wg0 = gg.w[2 * c];
+            b.wg1 = gg.w[2 * c + 1];
+            b.kg = (double)gg.gamma[c] * saved[SV_ROWS * P + c];
+            if (a.sn_two) {
+                b.wf0 = gf.w[2 * c];
+                b.wf1 = gf.w[2 * c + 1];
+                b.kf = (double)gf.gamma[c] * saved[SV_ROWS * P + C + c];
+            }
+        }
+
+        auto bwd_of = [&](int n) {
+            const size_t p = (size_t)n * C + c;
+            return bwd_plane<R>(a, b, sums_of(n), a.sn_active ? dtb[n] : 0.0, a.sn_active ? dtb[N + n] : 0.0,
+                                saved[SV_ZH_G * P + p], saved[SV_ZH_F * P + p], (R)saved[SV_G * P + p],
+                                (R)saved[SV_F * P + p], (R)saved[SV_A * P + p], (R)saved[SV_A1 * P + p],
+                                (R)saved[SV_M_IN * P + p], (R)saved[SV_MU_P * P + p], (R)saved[SV_SIG_P * P + p],
+                                (R)saved[SV_SIG_C * P + p], (R)saved[SV_M2C * P + p]);
+        };
+
+        // ---- parameter gradients of the channel: one member per channel (rotating) does the sums
+        if (a.sn_active && k == c % ra.K) {
+            double sw[4] = {0, 0, 0, 0};
+            for (int n = threadIdx.x; n < N; n += kBlock) {
+                const size_t p = (size_t)n * C + c;
+                const BwdPlaneT<R> o = bwd_of(n);
+                const double mu_p = saved[SV_MU_P * P + p], sig_p = saved[SV_SIG_P * P + p];
+                sw[0] += (double)o.dz_g * mu_p;
+                sw[1] += (double)o.dz_g * sig_p;
+                sw[2] += (double)o.dz_f * mu_p;
+                sw[3] += (double)o.dz_f * sig_p;
+            }
+            block_sum_d<4>(sw, red);
+            if (threadIdx.x == 0) {
+                dgr.dgamma[c] = (float)s4[1];
+                dgr.dbeta[c] = (float)s4[0];
+                dgr.dw[2 * c] = (float)sw[0];
+                dgr.dw[2 * c + 1] = (float)sw[1];
+                if (a.sn_two) {
+                    dfr.dgamma[c] = (float)s4[3];
+                    dfr.dbeta[c] = (float)s4[2];
+                    dfr.dw[2 * c] = (float)sw[2];
+                    dfr.dw[2 * c + 1] = (float)sw[3];
+                }
+            }
+        }
+
+        // ---- coefficients of dx for the owned planes: one thread each
+        if (threadIdx.x < OWN) {
+            const int n = k * OWN + threadIdx.x;
+            if (n < N) {
+                const size_t p = (size_t)n * C + c;
+                const BwdPlaneT<R> o = bwd_of(n);
+                R Emu = 0.f, Esig = 0.f;
+                if (a.cn_active) {
+                    const BwdPlaneT<R> src = bwd_of(iperm[n]);  // the plane that used (n,c) as its style
+                    Emu = src.Emu;
+                    Esig = src.Esig;
+                }
+                const BwdCoefs cf =
+                    bwd_coefs<R>(a, o, Emu, Esig, (R)saved[SV_G * P + p], (R)saved[SV_A1 * P + p],
+                                 (R)saved[SV_M_IN * P + p], (R)saved[SV_MU_P * P + p], saved[SV_MU_C * P + p],
+                                 (R)saved[SV_SIG_C * P + p], saved[SV_MU_S * P + p], (R)saved[SV_SIG_S * P + p]);
+                float* oc = ocoef + threadIdx.x * BC_ROWS;
+                oc[BC_CG_IN] = cf.cG_in;
+                oc[BC_CX_IN] = cf.cX_in;
+                oc[BC_XR_IN] = cf.xr_in;
+                oc[BC_C0_IN] = cf.c0_in;
+                oc[BC_CG_OUT] = cf.cG_out;
+                oc[BC_CX_OUT] = cf.cX_out;
+                oc[BC_XR_OUT] = cf.xr_out;
+                oc[BC_C0_OUT] = cf.c0_out;
+                oc[BC_ES] = cf.eS;
+                oc[BC_XS] = cf.xs;
+                oc[BC_E0] = cf.e0;
+            }
+        }
+        __syncthreads();
+
+        // ---- apply from registers, the only write of dx
+#pragma unroll
+        for (int s = 0; s < PPW; ++s) {
+            const int n = n0 + s;
+            if (n < N) {
+                const float* oc = ocoef + (wave * PPW + s) * BC_ROWS;
+                const float cG_i = oc[BC_CG_IN], cX_i = oc[BC_CX_IN], xr_i = oc[BC_XR_IN], c0_i = oc[BC_C0_IN];
+                const float cG_o = oc[BC_CG_OUT], cX_o = oc[BC_CX_OUT], xr_o = oc[BC_XR_OUT], c0_o = oc[BC_C0_OUT];
+                const float eS = oc[BC_ES], xs = oc[BC_XS], e0 = oc[BC_E0];
+                T* db = dx + ((size_t)n * C + c) * ra.M;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+                    if ((sg.valid >> j) & 1u) {
+                        Vec<T, VEC> ov;
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) {
+                            const float G = to_float(dg_[s][j].v[q]), X = to_float(dx_[s][j].v[q]);
+                            float v;
+                            if constexpr (!BOXED) {
+                                v = fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i));
+                            } else {
+                                const bool ic = (sg.inC[j] >> q) & 1u, is = (sg.inS[j] >> q) & 1u;
+                                v = ic ? fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i))
+                                       : fmaf(cG_o, G, fmaf(cX_o, X - xr_o, c0_o));
+                                v += is ? fmaf(eS, X - xs, e0) : 0.f;
+                            }
+                            ov.v[q] = from_float<T>(v);
+                        }
+                        store_vec<T, VEC>(db + (size_t)(j * 64 + lane) * VEC, ov);
+                    }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host entry points (defined in cnsn_resident.hip)
+// ------------------------------------------------------------------------------------------------
+struct ResPlan {
+    bool ok;
+    int vec, nv, ppw, K;
+};
+// can the resident strategy run this problem?  (auto = apply the profitability heuristics too)
+ResPlan resident_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm);
+
+// both return CNSN_OK, a hipError_t, or CNSN_E_UNSUPPORTED (caller falls back to two-pass)
+int resident_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* x,
+                     const int64_t* perm, GateDev g, GateDev f, void* y, double* saved, void* workspace,
+                     hipStream_t stream);
+int resident_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* gy,
+                      const void* x, const int64_t* perm, GateDev g, GateDev f, const double* saved, void* dx,
+                      GateGradDev dg, GateGradDev df, void* workspace, hipStream_t stream);
+size_t resident_workspace_bytes(const cnsn_problem_t& p, bool boxed);
 
 }  // namespace cnsn

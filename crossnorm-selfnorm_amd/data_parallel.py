@@ -1,0 +1,56 @@
+"""Data-parallel plumbing for the CNSN hot path: one process per GPU, `torch.distributed` with the
+`nccl` backend (= RCCL over xGMI on MI355X).
+
+The op itself never communicates: CrossNorm permutes inside the local minibatch (reference
+models/cnsn.py:62) and SelfNorm's BatchNorm1d statistics are local (cnsn.py:121,138) — exactly what
+each replica sees under the reference's `nn.DataParallel` (cifar.py:395, imagenet.py:533).  The only
+exchange is the gradient all-reduce of the parameters (for a CNSN site: g_fc.weight (C,1,2),
+g_bn.weight, g_bn.bias = 4C floats), and ranks must draw DIFFERENT permutations / boxes.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def seed_rank(seed: int, rank: int) -> None:
+    """Seed the two host RNGs CrossNorm consumes (torch CPU generator for randperm, numpy global
+    for the boxes) with a per-rank offset so that ranks draw different style partners and crops."""
+    torch.manual_seed(seed + rank)
+    np.random.seed((seed + rank) % (2 ** 32))
+
+
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None,
+                        average: bool = True) -> None:
+    """One bucketed all-reduce over the gradients of `params` (what DDP does for a small model).
+    A single flat buffer per dtype: CNSN's own parameters are a few KB, so one message is optimal on
+    xGMI (latency-bound); large backbones should use torch DDP's 25 MB buckets instead."""
+    if not dist.is_available() or not dist.is_initialized():
+        return
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    by_dtype = {}
+    for p in params:
+        if p.grad is not None:
+            by_dtype.setdefault(p.grad.dtype, []).append(p.grad)
+    for grads in by_dtype.values():
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat.div_(world)
+        off = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
+
+
+def shard_batch(n_total: int, rank: int, world: int):
+    """[begin, end) of the global batch owned by `rank` (contiguous, sizes differ by at most one)."""
+    base, rem = divmod(n_total, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
