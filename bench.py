@@ -40,10 +40,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--shape", type=str, default="256,256,56,56")
     ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16", "f16"])
-    ap.add_argument("--crop", type=str, default="both", choices=["neither", "style", "content", "both"])
+    ap.add_argument("--crop", type=str, default="neither", choices=["neither", "style", "content", "both"])
     ap.add_argument("--kind", type=str, default="cnsn", choices=["cnsn", "cn", "sn"])
     ap.add_argument("--strategy", type=str, default="auto", choices=["auto", "two_pass", "resident"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (crop=both, bf16)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     return ap.parse_args()
 
@@ -95,6 +96,39 @@ def cpu_baseline(shape, crop, kind, budget_s):
                       f"median of {len(times)} iters, {med * 1e3:.1f} ms/iter, "
                       f"{ns / med:.1f} img/s",
             "cpu": _cpu_model()}
+
+
+def secondary_workloads(cnsn_amd, shape, dev, args):
+    """Same shape, other modes (not the headline): CrossNorm with both crop boxes, and bf16 I/O."""
+    n, c, h, w = shape
+    res = {}
+    for tag, dtype, crop in (("f32_crop_both", torch.float32, "both"), ("bf16_crop_neither", torch.bfloat16, "neither"),
+                             ("bf16_crop_both", torch.bfloat16, "both"), ("f32_sn_only", torch.float32, None)):
+        x = conditioned(shape, dev, dtype, 31).requires_grad_()
+        gy = torch.randn(shape, device=dev).to(dtype)
+        mod = cnsn_amd.CNSN(cnsn_amd.CrossNorm(crop, 1) if crop else None, cnsn_amd.SelfNorm(c)).to(dev).train()
+
+        def one():
+            if mod.crossnorm is not None:
+                mod.crossnorm.active = True
+            x.grad = None
+            for p in mod.parameters():
+                p.grad = None
+            mod(x).backward(gy)
+
+        for _ in range(5):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k = 20
+        for _ in range(k):
+            one()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / k * 1e3
+        b = 4 if dtype == torch.float32 else 2
+        res[tag] = {"ms_per_step": round(ms, 4), "GBps_algorithmic": round(8 * n * c * h * w * b / ms / 1e6, 1)}
+        del x, gy, mod
+    return res
 
 
 def _cpu_model():
@@ -215,6 +249,8 @@ def main():
                          "forward": {"achieved": round(3 * e * b / (fwd_ms * 1e-3) / 1e9, 1),
                                      "frac": round(3 * e * b / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
         }
+        if world == 1 and not args.no_extra:
+            out["extra"] = secondary_workloads(cnsn_amd, shape, dev, args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shape, args.crop, args.kind, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -232,7 +232,7 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
     double* saved_d = saved ? (double*)saved : mom + 6 * pl.P;
     float* coef = (float*)(mom + 6 * pl.P + saved_doubles_of(pl));
 
-    if (resident_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr).ok) {
+    if (resident_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, false).ok) {
         st = resident_forward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, x, perm, gate_dev(g), gate_dev(f), y,
                               saved ? saved_d : nullptr, workspace, stream);
         if (st != CNSN_E_UNSUPPORTED) return st;  // otherwise: fall through to the two-pass strategy
@@ -284,7 +284,7 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
     float* coef = sums + 4 * P;
     const double* saved_d = (const double*)saved;
 
-    if (resident_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr).ok) {
+    if (resident_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, true).ok) {
         st = resident_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, grad_y, x, perm, gate_dev(g), gate_dev(f),
                                saved_d, grad_x, gate_grad_dev(dg), gate_grad_dev(df), workspace, stream);
         if (st != CNSN_E_UNSUPPORTED) return st;

@@ -61,6 +61,9 @@ ResArgs make_args(const cnsn_problem_t& p, Box cb, Box sb, const MidArgs& mid, c
     ra.sb = sb;
     ra.K = rp.K;
     ra.items = p.C * rp.K;
+    const char* st = getenv("CNSN_STAGGER");
+    ra.stagger = st ? atoi(st) : 0;
+    ra.prof = nullptr;
     return ra;
 }
 
@@ -84,7 +87,7 @@ int grid_for(Kern kern, size_t lds, int K, int items) {
 
 }  // namespace
 
-ResPlan resident_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm) {
+ResPlan resident_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, bool backward) {
     ResPlan rp{false, 0, 0, 0, 0};
     if (p.strategy == CNSN_STRATEGY_TWO_PASS || has_chan_perm) return rp;
     const int M = p.H * p.W;
@@ -102,8 +105,12 @@ ResPlan resident_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm) {
     if (rp.nv == 0) return rp;  // plane does not fit one wave's registers
     const int own = 4 * rp.ppw;
     rp.K = (p.N + own - 1) / own;
-    if (res_lds_bytes(p.N, 6, own, BC_ROWS) > 64 * 1024) return rp;
-    if (rp.K > 4 * cu_count()) return rp;
+    if (res_lds_bytes(p.N, 6, own, BC_ROWS, true) > 64 * 1024) return rp;
+    if (rp.K > 2 * cu_count()) return rp;
+    // AUTO: use the resident kernel where it measured faster than two-pass on MI355X (round-1 sweep,
+    // profiles/r01_resident_tuning.md): forward wherever it is eligible; backward (two tensors resident,
+    // 2 workgroups per CU) only for the large-plane fp32 class.  RESIDENT forces it wherever eligible.
+    if (p.strategy == CNSN_STRATEGY_AUTO && backward && !(rp.nv >= 13 && p.dtype == CNSN_F32)) return rp;
     rp.ok = true;
     return rp;
 }
@@ -111,11 +118,14 @@ ResPlan resident_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm) {
 int resident_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* x,
                      const int64_t* perm, GateDev g, GateDev f, void* y, double* saved, void* workspace,
                      hipStream_t stream) {
-    const ResPlan rp = resident_plan(p, boxed, false);
+    const ResPlan rp = resident_plan(p, boxed, false, false);
     if (!rp.ok) return CNSN_E_UNSUPPORTED;
-    const ResArgs ra = make_args(p, cb, sb, mid, rp);
+    ResArgs ra = make_args(p, cb, sb, mid, rp);
     const int NG = boxed ? 6 : 2;
-    const size_t lds = res_lds_bytes(p.N, NG, 4 * rp.ppw, FC_ROWS);
+#ifdef CNSN_PROF  // tuning builds: time stamps land 4 MiB into the workspace (callers size it accordingly)
+    if (getenv("CNSN_PROF")) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
+#endif
+    const size_t lds = res_lds_bytes(p.N, NG, 4 * rp.ppw, FC_ROWS, false);
     unsigned* ctl = (unsigned*)workspace;
     unsigned long long* gran = (unsigned long long*)((char*)workspace + kCtlBytes);
     const size_t zero_bytes = kCtlBytes + (size_t)p.N * p.C * NG * 8;
@@ -146,11 +156,14 @@ int resident_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const 
 int resident_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* gy,
                       const void* x, const int64_t* perm, GateDev g, GateDev f, const double* saved, void* dx,
                       GateGradDev dg, GateGradDev df, void* workspace, hipStream_t stream) {
-    const ResPlan rp = resident_plan(p, boxed, false);
+    const ResPlan rp = resident_plan(p, boxed, false, true);
     if (!rp.ok) return CNSN_E_UNSUPPORTED;
-    const ResArgs ra = make_args(p, cb, sb, mid, rp);
+    ResArgs ra = make_args(p, cb, sb, mid, rp);
     const int NS = boxed ? 4 : 2;
-    const size_t lds = res_lds_bytes(p.N, NS, 4 * rp.ppw, BC_ROWS);
+#ifdef CNSN_PROF
+    if (getenv("CNSN_PROF")) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
+#endif
+    const size_t lds = res_lds_bytes(p.N, NS, 4 * rp.ppw, BC_ROWS, true);
     unsigned* ctl = (unsigned*)workspace;
     unsigned long long* gran = (unsigned long long*)((char*)workspace + kCtlBytes);
     const size_t zero_bytes = kCtlBytes + (size_t)p.N * p.C * NS * 8;

@@ -40,7 +40,30 @@ struct ResArgs {
     Box cb, sb;
     int K;      // workgroups per channel
     int items;  // C * K
+    int stagger;  // start-up skew between clusters, in units of s_sleep(127) (~3.4 us)
+    unsigned long long* prof;  // tuning builds (-DCNSN_PROF): [workgroup < 64][iteration < 16][8] time stamps
 };
+
+#ifdef CNSN_PROF
+#define CNSN_STAMP(slot)                                                                        \
+    do {                                                                                        \
+        if (ra.prof && threadIdx.x == 0 && blockIdx.x < 64 && iter_ < 16)                       \
+            ra.prof[((size_t)blockIdx.x * 16 + iter_) * 8 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define CNSN_STAMP(slot) \
+    do {                 \
+    } while (0)
+#endif
+
+// De-synchronise the clusters at start-up: every cluster runs the same load -> exchange -> store cycle
+// with the same period, so clusters that start together stay in lock step and the whole chip idles
+// its memory system during every exchange.  Skewing the start by a fraction of the period lets one
+// cluster's exchange overlap another's loads and stores.
+__device__ __forceinline__ void startup_skew(const ResArgs& ra) {
+    const int steps = ((blockIdx.x / ra.K) & 3) * ra.stagger;
+    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
+}
 
 __device__ __forceinline__ void put_granule(unsigned long long* p, float v) {
     __hip_atomic_store((gu64*)p, (1ull << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
@@ -108,17 +131,24 @@ constexpr int data_regs(int elem_bytes, int vec, int nv, int ppw) { return ppw *
 constexpr int fwd_waves(int) { return CNSN_WF; }
 constexpr int bwd_waves(int) { return CNSN_WB; }
 #else
-constexpr int fwd_waves(int regs) { return regs <= 32 ? 6 : (regs <= 56 ? 5 : 4); }
-constexpr int bwd_waves(int regs) { return 2 * regs <= 64 ? 5 : (2 * regs <= 112 ? 3 : 2); }
+// measured on MI355X at (256,256,56,56) fp32/bf16 (profiles/r01_resident_tuning.md): forward 4, backward 2;
+// tighter bounds make the compiler spill and every variant got slower.
+constexpr int fwd_waves(int) { return 4; }
+constexpr int bwd_waves(int) { return 2; }
 #endif
 
 // dynamic LDS carve (bytes); NG = granules per plane, OWN = planes per workgroup
-__host__ __device__ inline size_t res_lds_bytes(int N, int NG, int OWN, int coef_rows) {
+// rows of `saved` the backward algebra needs, staged in LDS per item (floats / doubles per instance)
+enum StageF { F_A1 = 0, F_M_IN, F_MU_O, F_MU_P, F_G, F_F, F_A, F_SIG_P, F_SIG_C, F_M2C, F_SIG_S, F_N };
+enum StageD { D_MU_C = 0, D_MU_S, D_ZH_G, D_ZH_F, D_N };
+
+__host__ __device__ inline size_t res_lds_bytes(int N, int NG, int OWN, int coef_rows, bool backward) {
     return align16((size_t)N * NG * 4)        // vals[N][NG]
-           + align16((size_t)2 * N * 8)       // zbuf / dt [2][N]
+           + align16((size_t)2 * N * 8)       // dt [2][N]
            + align16((size_t)N * 4)           // perm / inverse perm [N]
            + align16((size_t)OWN * coef_rows * 4)  // coefficients of the owned planes
-           + 4 * 4 * 8;                       // block reduction scratch
+           + 4 * 4 * 8                        // block reduction scratch
+           + (backward ? align16((size_t)N * D_N * 8) + align16((size_t)N * F_N * 4) : 0);  // staged `saved`
 }
 
 // ================================================================================================
@@ -139,16 +169,42 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
     int* sperm = (int*)((char*)zbuf + align16((size_t)2 * N * 8));
     float* ocoef = (float*)((char*)sperm + align16((size_t)N * 4));
     double* red = (double*)((char*)ocoef + align16((size_t)OWN * FC_ROWS * 4));
+    (void)zbuf;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t P = (size_t)N * C;
     const SlotGeom<VEC, NV, BOXED> sg(ra, lane);
 
     if (a.cn_active)
         for (int n = threadIdx.x; n < N; n += kBlock) sperm[n] = (int)perm[n];
+    startup_skew(ra);
 
+    int iter_ = -1;
     for (int item = blockIdx.x; item < ra.items; item += gridDim.x) {
         const int c = item / ra.K, k = item - c * ra.K;
         const int n0 = (k * 4 + wave) * PPW;
+        ++iter_;
+        CNSN_STAMP(0);
+
+        // ---- per-channel parameters: fetched first, ahead of the bulk loads in this CU's memory queue
+        //      (a load issued in the algebra phase would wait behind every other workgroup's planes)
+        float pw[4] = {0.f, 0.f, 0.f, 0.f}, pgam[2] = {0.f, 0.f}, pbet[2] = {0.f, 0.f}, prm[2] = {0.f, 0.f},
+              prv[2] = {1.f, 1.f};
+        if (a.sn_active) {
+            pw[0] = gg.w[2 * c];
+            pw[1] = gg.w[2 * c + 1];
+            pgam[0] = gg.gamma[c];
+            pbet[0] = gg.beta[c];
+            prm[0] = gg.run_mean[c];
+            prv[0] = gg.run_var[c];
+            if (a.sn_two) {
+                pw[2] = gf.w[2 * c];
+                pw[3] = gf.w[2 * c + 1];
+                pgam[1] = gf.gamma[c];
+                pbet[1] = gf.beta[c];
+                prm[1] = gf.run_mean[c];
+                prv[1] = gf.run_var[c];
+            }
+        }
 
         // ---- load this wave's planes into registers (the only read of x)
         Vec<T, VEC> d[PPW][NV];
@@ -235,9 +291,12 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
         }
 
         // ---- gather the whole channel's statistics
+        CNSN_STAMP(1);
         __syncthreads();  // the previous item's readers of vals/zbuf are done
+        CNSN_STAMP(2);
         if (wave == 0) sweep_granules(gran + (size_t)c * N * NG, N * NG, vals, ctl);
         __syncthreads();
+        CNSN_STAMP(3);
 
         using R = float;  // per-plane algebra in float, cross-batch sums / normalisation in double
         auto plane_of = [&](int n) {
@@ -261,12 +320,10 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
         //      one pass, sums taken about the pre-activation of instance 0
         double mg = 0, mf = 0, rg = 1, rf = 1, wg0 = 0, wg1 = 0, wf0 = 0, wf1 = 0;
         if (a.sn_active) {
-            wg0 = gg.w[2 * c];
-            wg1 = gg.w[2 * c + 1];
-            if (a.sn_two) {
-                wf0 = gf.w[2 * c];
-                wf1 = gf.w[2 * c + 1];
-            }
+            wg0 = pw[0];
+            wg1 = pw[1];
+            wf0 = pw[2];
+            wf1 = pw[3];
             if (a.sn_training) {
                 const FwdPlaneT<R> f0 = plane_of(0);
                 const double zs_g = wg0 * (double)f0.mu_p + wg1 * (double)f0.sig_p;
@@ -291,19 +348,19 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
                 rf = 1.0 / sqrt(vf + (double)a.eps_bn);
                 if (k == 0 && threadIdx.x == 0) {
                     const double mom_ = a.momentum, unb = (double)N / ((double)N - 1.0);
-                    gg.run_mean[c] = (float)((1.0 - mom_) * gg.run_mean[c] + mom_ * mg);
-                    gg.run_var[c] = (float)((1.0 - mom_) * gg.run_var[c] + mom_ * vg * unb);
+                    gg.run_mean[c] = (float)((1.0 - mom_) * (double)prm[0] + mom_ * mg);
+                    gg.run_var[c] = (float)((1.0 - mom_) * (double)prv[0] + mom_ * vg * unb);
                     if (a.sn_two) {
-                        gf.run_mean[c] = (float)((1.0 - mom_) * gf.run_mean[c] + mom_ * mf);
-                        gf.run_var[c] = (float)((1.0 - mom_) * gf.run_var[c] + mom_ * vf * unb);
+                        gf.run_mean[c] = (float)((1.0 - mom_) * (double)prm[1] + mom_ * mf);
+                        gf.run_var[c] = (float)((1.0 - mom_) * (double)prv[1] + mom_ * vf * unb);
                     }
                 }
             } else {
-                mg = gg.run_mean[c];
-                rg = 1.0 / sqrt((double)gg.run_var[c] + (double)a.eps_bn);
+                mg = prm[0];
+                rg = 1.0 / sqrt((double)prv[0] + (double)a.eps_bn);
                 if (a.sn_two) {
-                    mf = gf.run_mean[c];
-                    rf = 1.0 / sqrt((double)gf.run_var[c] + (double)a.eps_bn);
+                    mf = prm[1];
+                    rf = 1.0 / sqrt((double)prv[1] + (double)a.eps_bn);
                 }
             }
             if (saved && k == 0 && threadIdx.x == 0) {
@@ -321,10 +378,10 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
                 double zhg = 0.0, zhf = 0.0;
                 if (a.sn_active) {
                     zhg = (wg0 * (double)f.mu_p + wg1 * (double)f.sig_p - mg) * rg;
-                    g = sigmoid_r<R>((R)((double)gg.gamma[c] * zhg + (double)gg.beta[c]));
+                    g = sigmoid_r<R>((R)((double)pgam[0] * zhg + (double)pbet[0]));
                     if (a.sn_two) {
                         zhf = (wf0 * (double)f.mu_p + wf1 * (double)f.sig_p - mf) * rf;
-                        fg = sigmoid_r<R>((R)((double)gf.gamma[c] * zhf + (double)gf.beta[c]));
+                        fg = sigmoid_r<R>((R)((double)pgam[1] * zhf + (double)pbet[1]));
                     }
                 }
                 const FwdCoefs cf = fwd_coefs<R>(a, f, g, fg);
@@ -345,6 +402,7 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
             }
         }
         __syncthreads();
+        CNSN_STAMP(4);
 
         // ---- apply from registers, the only write of y
 #pragma unroll
@@ -369,6 +427,7 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
                     }
             }
         }
+        CNSN_STAMP(5);
     }
 }
 
@@ -393,16 +452,67 @@ __global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW
     int* iperm = (int*)((char*)dtb + align16((size_t)2 * N * 8));
     float* ocoef = (float*)((char*)iperm + align16((size_t)N * 4));
     double* red = (double*)((char*)ocoef + align16((size_t)OWN * BC_ROWS * 4));
+    double* svd = red + 4 * 4;                                         // [N][D_N]
+    float* svf = (float*)((char*)svd + align16((size_t)N * D_N * 8));  // [N][F_N]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t P = (size_t)N * C;
     const SlotGeom<VEC, NV, BOXED> sg(ra, lane);
 
     if (a.cn_active)  // plane r receives the style-statistic gradient of the plane that borrowed from it
         for (int n = threadIdx.x; n < N; n += kBlock) iperm[(int)perm[n]] = n;
+    startup_skew(ra);
 
+    int iter_ = -1;
     for (int item = blockIdx.x; item < ra.items; item += gridDim.x) {
         const int c = item / ra.K, k = item - c * ra.K;
         const int n0 = (k * 4 + wave) * PPW;
+        ++iter_;
+        CNSN_STAMP(0);
+
+        // ---- everything the algebra will need from `saved` and the parameters is fetched FIRST, ahead of
+        //      the bulk loads in this CU's memory queue, and staged in LDS / registers: a load issued in
+        //      the algebra phase would wait behind every other workgroup's planes (several microseconds)
+        float pw[4] = {0.f, 0.f, 0.f, 0.f}, pgam[2] = {0.f, 0.f};
+        double prs[2] = {1.0, 1.0};
+        if (a.sn_active) {
+            pw[0] = gg.w[2 * c];
+            pw[1] = gg.w[2 * c + 1];
+            pgam[0] = gg.gamma[c];
+            prs[0] = saved[SV_ROWS * P + c];
+            if (a.sn_two) {
+                pw[2] = gf.w[2 * c];
+                pw[3] = gf.w[2 * c + 1];
+                pgam[1] = gf.gamma[c];
+                prs[1] = saved[SV_ROWS * P + C + c];
+            }
+        }
+        float own_si[PPW], own_so[PPW];
+#pragma unroll
+        for (int s = 0; s < PPW; ++s) {
+            const size_t p = (size_t)(n0 + s < N ? n0 + s : 0) * C + c;
+            own_si[s] = (float)saved[SV_MU_C * P + p];
+            own_so[s] = BOXED ? (float)saved[SV_MU_O * P + p] : 0.f;
+        }
+        for (int n = threadIdx.x; n < N; n += kBlock) {
+            const size_t p = (size_t)n * C + c;
+            float* sf = svf + n * F_N;
+            double* sd = svd + n * D_N;
+            sd[D_MU_C] = saved[SV_MU_C * P + p];
+            sd[D_MU_S] = saved[SV_MU_S * P + p];
+            sd[D_ZH_G] = saved[SV_ZH_G * P + p];
+            sd[D_ZH_F] = saved[SV_ZH_F * P + p];
+            sf[F_A1] = (float)saved[SV_A1 * P + p];
+            sf[F_M_IN] = (float)saved[SV_M_IN * P + p];
+            sf[F_MU_O] = (float)saved[SV_MU_O * P + p];
+            sf[F_MU_P] = (float)saved[SV_MU_P * P + p];
+            sf[F_G] = (float)saved[SV_G * P + p];
+            sf[F_F] = (float)saved[SV_F * P + p];
+            sf[F_A] = (float)saved[SV_A * P + p];
+            sf[F_SIG_P] = (float)saved[SV_SIG_P * P + p];
+            sf[F_SIG_C] = (float)saved[SV_SIG_C * P + p];
+            sf[F_M2C] = (float)saved[SV_M2C * P + p];
+            sf[F_SIG_S] = (float)saved[SV_SIG_S * P + p];
+        }
 
         // ---- load G and x planes (the only reads)
         Vec<T, VEC> dg_[PPW][NV], dx_[PPW][NV];
@@ -426,9 +536,7 @@ __global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
             const int n = n0 + s;
-            const size_t p = (size_t)(n < N ? n : 0) * C + c;
-            const float si = (float)saved[SV_MU_C * P + p];
-            const float so = BOXED ? (float)saved[SV_MU_O * P + p] : 0.f;
+            const float si = own_si[s], so = own_so[s];
             float acc[NS];
 #pragma unroll
             for (int m = 0; m < NS; ++m) acc[m] = 0.f;
@@ -460,15 +568,17 @@ __global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW
             }
         }
 
+        CNSN_STAMP(1);
         __syncthreads();
+        CNSN_STAMP(2);
         if (wave == 0) sweep_granules(gran + (size_t)c * N * NS, N * NS, vals, ctl);
         __syncthreads();
+        CNSN_STAMP(3);
 
         using R = float;  // per-plane algebra in float; batch sums and the dz line in double
         auto sums_of = [&](int n) {
-            const size_t p = (size_t)n * C + c;
             return fix_sums<R>(a, vals[n * NS], vals[n * NS + 1], BOXED ? vals[n * NS + 2] : 0.f,
-                               BOXED ? vals[n * NS + 3] : 0.f, saved[SV_MU_C * P + p], saved[SV_MU_O * P + p]);
+                               BOXED ? vals[n * NS + 3] : 0.f, svd[n * D_N + D_MU_C], (double)svf[n * F_N + F_MU_O]);
         };
 
         // ---- gate backward: dt for every instance of the channel, batch sums (all members)
@@ -476,15 +586,13 @@ __global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW
         BnBwd b{};
         if (a.sn_active) {
             for (int n = threadIdx.x; n < N; n += kBlock) {
-                const size_t p = (size_t)n * C + c;
+                const float* sf = svf + n * F_N;
                 R dtg, dtf;
-                gate_dt<R>(a, sums_of(n), (R)saved[SV_A1 * P + p], (R)saved[SV_M_IN * P + p],
-                           (R)saved[SV_MU_O * P + p], (R)saved[SV_MU_P * P + p], (R)saved[SV_G * P + p],
-                           (R)saved[SV_F * P + p], dtg, dtf);
+                gate_dt<R>(a, sums_of(n), sf[F_A1], sf[F_M_IN], sf[F_MU_O], sf[F_MU_P], sf[F_G], sf[F_F], dtg, dtf);
                 s4[0] += (double)dtg;
-                s4[1] += (double)dtg * saved[SV_ZH_G * P + p];
+                s4[1] += (double)dtg * svd[n * D_N + D_ZH_G];
                 s4[2] += (double)dtf;
-                s4[3] += (double)dtf * saved[SV_ZH_F * P + p];
+                s4[3] += (double)dtf * svd[n * D_N + D_ZH_F];
                 dtb[n] = dtg;
                 dtb[N + n] = dtf;
             }
@@ -493,32 +601,27 @@ __global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW
             b.s_dtz_g = s4[1];
             b.s_dt_f = s4[2];
             b.s_dtz_f = s4[3];
-            b.wg0 = gg.w[2 * c];
-            b.wg1 = gg.w[2 * c + 1];
-            b.kg = (double)gg.gamma[c] * saved[SV_ROWS * P + c];
-            if (a.sn_two) {
-                b.wf0 = gf.w[2 * c];
-                b.wf1 = gf.w[2 * c + 1];
-                b.kf = (double)gf.gamma[c] * saved[SV_ROWS * P + C + c];
-            }
+            b.wg0 = pw[0];
+            b.wg1 = pw[1];
+            b.kg = (double)pgam[0] * prs[0];
+            b.wf0 = pw[2];
+            b.wf1 = pw[3];
+            b.kf = (double)pgam[1] * prs[1];
         }
 
         auto bwd_of = [&](int n) {
-            const size_t p = (size_t)n * C + c;
+            const float* sf = svf + n * F_N;
             return bwd_plane<R>(a, b, sums_of(n), a.sn_active ? dtb[n] : 0.0, a.sn_active ? dtb[N + n] : 0.0,
-                                saved[SV_ZH_G * P + p], saved[SV_ZH_F * P + p], (R)saved[SV_G * P + p],
-                                (R)saved[SV_F * P + p], (R)saved[SV_A * P + p], (R)saved[SV_A1 * P + p],
-                                (R)saved[SV_M_IN * P + p], (R)saved[SV_MU_P * P + p], (R)saved[SV_SIG_P * P + p],
-                                (R)saved[SV_SIG_C * P + p], (R)saved[SV_M2C * P + p]);
+                                svd[n * D_N + D_ZH_G], svd[n * D_N + D_ZH_F], sf[F_G], sf[F_F], sf[F_A], sf[F_A1],
+                                sf[F_M_IN], sf[F_MU_P], sf[F_SIG_P], sf[F_SIG_C], sf[F_M2C]);
         };
 
         // ---- parameter gradients of the channel: one member per channel (rotating) does the sums
         if (a.sn_active && k == c % ra.K) {
             double sw[4] = {0, 0, 0, 0};
             for (int n = threadIdx.x; n < N; n += kBlock) {
-                const size_t p = (size_t)n * C + c;
                 const BwdPlaneT<R> o = bwd_of(n);
-                const double mu_p = saved[SV_MU_P * P + p], sig_p = saved[SV_SIG_P * P + p];
+                const double mu_p = svf[n * F_N + F_MU_P], sig_p = svf[n * F_N + F_SIG_P];
                 sw[0] += (double)o.dz_g * mu_p;
                 sw[1] += (double)o.dz_g * sig_p;
                 sw[2] += (double)o.dz_f * mu_p;
@@ -543,7 +646,7 @@ __global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW
         if (threadIdx.x < OWN) {
             const int n = k * OWN + threadIdx.x;
             if (n < N) {
-                const size_t p = (size_t)n * C + c;
+                const float* sf = svf + n * F_N;
                 const BwdPlaneT<R> o = bwd_of(n);
                 R Emu = 0.f, Esig = 0.f;
                 if (a.cn_active) {
@@ -552,9 +655,8 @@ __global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW
                     Esig = src.Esig;
                 }
                 const BwdCoefs cf =
-                    bwd_coefs<R>(a, o, Emu, Esig, (R)saved[SV_G * P + p], (R)saved[SV_A1 * P + p],
-                                 (R)saved[SV_M_IN * P + p], (R)saved[SV_MU_P * P + p], saved[SV_MU_C * P + p],
-                                 (R)saved[SV_SIG_C * P + p], saved[SV_MU_S * P + p], (R)saved[SV_SIG_S * P + p]);
+                    bwd_coefs<R>(a, o, Emu, Esig, sf[F_G], sf[F_A1], sf[F_M_IN], sf[F_MU_P], svd[n * D_N + D_MU_C],
+                                 sf[F_SIG_C], svd[n * D_N + D_MU_S], sf[F_SIG_S]);
                 float* oc = ocoef + threadIdx.x * BC_ROWS;
                 oc[BC_CG_IN] = cf.cG_in;
                 oc[BC_CX_IN] = cf.cX_in;
@@ -570,6 +672,7 @@ __global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW
             }
         }
         __syncthreads();
+        CNSN_STAMP(4);
 
         // ---- apply from registers, the only write of dx
 #pragma unroll
@@ -603,6 +706,7 @@ __global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW
                     }
             }
         }
+        CNSN_STAMP(5);
     }
 }
 
@@ -614,7 +718,7 @@ struct ResPlan {
     int vec, nv, ppw, K;
 };
 // can the resident strategy run this problem?  (auto = apply the profitability heuristics too)
-ResPlan resident_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm);
+ResPlan resident_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, bool backward);
 
 // both return CNSN_OK, a hipError_t, or CNSN_E_UNSUPPORTED (caller falls back to two-pass)
 int resident_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* x,
