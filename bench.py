@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--strategy", type=str, default="auto", choices=["auto", "two_pass", "resident"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (crop=both, bf16)")
+    ap.add_argument("--workload", type=str, default="cnsn", choices=["cnsn", "resnet50", "wrn40"],
+                    help="cnsn: the fused op at the north-star shape (headline); resnet50 / wrn40: whole "
+                         "training steps of the caller backbones (images/s)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch of the model workloads (0 = config default)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     return ap.parse_args()
 
@@ -131,6 +135,74 @@ def secondary_workloads(cnsn_amd, shape, dev, args):
     return res
 
 
+def model_workload(args, dist, world, rank, dev):
+    """Whole training steps (forward, CE [+ image-space CrossNorm], backward, SGD) of the caller
+    backbones on synthetic data — BASELINE.json configs[1] (WRN-40-2+CNSN, bs128, fp32, 32x32) and
+    configs[2] (ResNet-50+SN, image-space CrossNorm as imagenet-scripts/run-cnsn.sh, bs256, bf16)."""
+    import numpy as np
+    import cnsn_amd
+    from cnsn_amd import data_parallel as dp
+    from cnsn_amd.callers import ResNet50CNSN, WideResNetCNSN, image_space_crossnorm
+    dp.seed_rank(4321, rank)
+    if args.workload == "resnet50":
+        bs, hw, ncls, amp = args.batch or 256, 224, 1000, torch.bfloat16
+        net = ResNet50CNSN(num_classes=ncls, cnsn_type="sn", pos="post").to(dev)
+        name = "ResNet-50+SN(post) + image-space CrossNorm(p=0.5, crop=neither), bf16 autocast"
+    else:
+        bs, hw, ncls, amp = args.batch or 128, 32, 100, None
+        net = WideResNetCNSN(40, ncls, 2, active_num=2, pos="post", beta=1, crop="both", cnsn_type="cnsn").to(dev)
+        name = "WideResNet-40-2+CNSN(post, crop=both, 2 of 18 sites armed with p=0.5), fp32"
+    net.train()
+    model = net
+    if dist is not None:
+        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index], broadcast_buffers=True,
+                                                          bucket_cap_mb=25)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4 if hw == 224 else 5e-4,
+                          nesterov=(hw != 224))
+    g = torch.Generator(device=dev).manual_seed(5 + rank)
+    x = torch.randn(bs, 3, hw, hw, device=dev, generator=g)
+    y = torch.randint(0, ncls, (bs,), device=dev, generator=g)
+
+    def step():
+        xb = x
+        if args.workload == "resnet50":
+            xb = image_space_crossnorm(x, 0.5, 1, "neither", cnsn_amd.cn_op_2ins_space_chan)   # imagenet.py:211-215
+            with torch.autocast("cuda", dtype=amp):
+                loss = torch.nn.functional.cross_entropy(model(xb).float(), y)
+        else:
+            r = np.random.rand(1)                                                                # cifar.py:127-131
+            loss = torch.nn.functional.cross_entropy(model(xb, aug=bool(r < 0.5)), y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "ResNet-50+CNSN images/sec" if args.workload == "resnet50" else "WideResNet-40-2+CNSN images/sec",
+            "value": round(world * bs * args.steps / dt, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if amp else "f32", "data": "synthetic",
+            "config": {"workload": name, "per_gpu_batch": bs, "global_batch": bs * world, "image": hw,
+                       "parallelism": f"ddp{world} (RCCL gradient all-reduce, 25 MB buckets)"}}), flush=True)
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -160,6 +232,11 @@ def main():
     cnsn_amd.lib()                                    # fail loudly now if the .so is missing
     cnsn_amd.set_strategy(args.strategy)
     import numpy as np
+    if args.workload != "cnsn":
+        model_workload(args, dist, world, rank, dev)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     shape = tuple(int(v) for v in args.shape.split(","))
     n, c, h, w = shape

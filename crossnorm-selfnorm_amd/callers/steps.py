@@ -1,0 +1,68 @@
+"""Training-step structure around the hot path, restated from the reference's trainers (which cannot
+be imported: torchvision missing, argparse at import time):
+
+  cifar.py:117-145    train_cn               r < cn_prob -> net(x, aug=True)
+  cifar.py:148-208    train_cn_consistency   clean + 2 CrossNorm views, CE + consist_wt * JSD
+  imagenet.py:195-250 train_cn_image         CrossNorm applied to the IMAGE batch (cn_op on (B,3,H,W))
+  imagenet.py:253-334 train_cn_image_consist clean + 2 image-space CrossNorm views, CE + wt * JSD
+  imagenet.py:337-406 train_cn_image_augmix  one CrossNorm call on the concatenated 3-view batch
+
+Only the arithmetic and the RNG draw order are reproduced; data loading, meters and logging are not."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def jsd_consistency(logits_clean, logits_aug1, logits_aug2):
+    """Jensen-Shannon consistency of three views (cifar.py:173-186, imagenet.py:367-381):
+    mixture = clamp(mean of the 3 softmaxes, 1e-7, 1).log(); mean of the three KL(mixture || p_i),
+    each with reduction 'batchmean'."""
+    p = [F.softmax(l, dim=1) for l in (logits_clean, logits_aug1, logits_aug2)]
+    log_mix = torch.clamp((p[0] + p[1] + p[2]) / 3.0, 1e-7, 1).log()
+    return sum(F.kl_div(log_mix, pi, reduction="batchmean") for pi in p) / 3.0
+
+
+def train_step_cn(net, x, target, optimizer, cn_prob):
+    """One feature-level CrossNorm step (cifar.py:123-140): draw r first, then forward with aug."""
+    r = np.random.rand(1)
+    logits = net(x, aug=bool(r < cn_prob))
+    loss = F.cross_entropy(logits, target)
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return loss.detach()
+
+
+def train_step_cn_consistency(net, x, target, optimizer, consist_wt):
+    """Clean view + two independently armed CrossNorm views (cifar.py:155-190)."""
+    logits_clean = net(x)
+    logits_aug1 = net(x, aug=True)
+    logits_aug2 = net(x, aug=True)
+    loss = F.cross_entropy(logits_clean, target) + consist_wt * jsd_consistency(logits_clean, logits_aug1,
+                                                                                 logits_aug2)
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return loss.detach()
+
+
+def image_space_crossnorm(images, cn_prob, beta, crop, cn_op):
+    """imagenet.py:211-215: r = np.random.rand(1); if r < cn_prob: images = cn_op(images, beta, crop)."""
+    r = np.random.rand(1)
+    if r < cn_prob:
+        images = cn_op(images, crop=crop, beta=beta)
+    return images
+
+
+def train_step_image_cn_views(net, views, target, optimizer, cn_prob, beta, crop, cn_op, jsd_wt=12.0):
+    """AugMix-style 3-view step (imagenet.py:352-381): concatenate the views, ONE image-space CrossNorm
+    call on the (3B,3,H,W) batch with probability cn_prob, one forward, CE on the clean third + 12*JSD."""
+    b = views[0].size(0)
+    batch = image_space_crossnorm(torch.cat(views, 0), cn_prob, beta, crop, cn_op)
+    logits = net(batch)
+    l_clean, l_a1, l_a2 = torch.split(logits, b)
+    loss = F.cross_entropy(l_clean, target) + jsd_wt * jsd_consistency(l_clean, l_a1, l_a2)
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return loss.detach()

@@ -1,0 +1,96 @@
+"""WideResNet-d-k with one CNSN unit per basic block — counterpart of the reference's
+`models/cifar/wideresnet_cnsn.py` (BasicBlockCustom :12-98, WideResNet :137-227) with the same
+sub-module names, so a reference checkpoint's `state_dict` maps 1:1.
+
+WRN-40-2 at 32x32 has 18 CNSN sites: (B,32,32,32) x6, (B,64,16,16) x6, (B,128,8,8) x6 for pos='post'."""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ._sites import CrossNormSites, make_cnsn
+
+
+class _Block(nn.Module):
+    """Pre-activation basic block: bn-relu-conv3x3-bn-relu-conv3x3 (+1x1 shortcut when widths differ);
+    the CNSN unit sits at `pos` in {'pre','residual','identity','post'} (wideresnet_cnsn.py:66-98)."""
+
+    def __init__(self, impl, c_in, c_out, stride, pos, beta, crop, cnsn_type, drop_rate):
+        super().__init__()
+        assert pos in ("residual", "identity", "pre", "post")
+        self.bn1 = nn.BatchNorm2d(c_in)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(c_in, c_out, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(c_out)
+        self.relu2 = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(c_out, c_out, 3, 1, 1, bias=False)
+        self.same_width = c_in == c_out
+        self.conv_shortcut = None if self.same_width else nn.Conv2d(c_in, c_out, 1, stride, 0, bias=False)
+        width = c_in if (pos == "pre" and not self.same_width) else c_out      # :51-54
+        self.cnsn = make_cnsn(impl, cnsn_type, crop, beta, width)
+        self.pos, self.drop_rate = pos, drop_rate
+
+    def forward(self, x):
+        if not self.same_width:
+            x = self.relu1(self.bn1(x))
+        h = self.cnsn(x) if self.pos == "pre" else x
+        if self.same_width:
+            h = self.relu1(self.bn1(h))
+        h = self.relu2(self.bn2(self.conv1(h)))
+        if self.drop_rate > 0:
+            h = F.dropout(h, p=self.drop_rate, training=self.training)
+        h = self.conv2(h)
+        skip = x if self.same_width else self.conv_shortcut(x)
+        if self.pos == "residual":
+            h = self.cnsn(h)
+        elif self.pos == "identity":
+            skip = self.cnsn(skip)
+        y = torch.add(skip, h)
+        return self.cnsn(y) if self.pos == "post" else y
+
+
+class _Stage(nn.Module):
+    def __init__(self, impl, n, c_in, c_out, stride, **kw):
+        super().__init__()
+        self.layer = nn.Sequential(*[_Block(impl, c_in if i == 0 else c_out, c_out, stride if i == 0 else 1, **kw)
+                                     for i in range(n)])
+
+    def forward(self, x):
+        return self.layer(x)
+
+
+class WideResNetCNSN(nn.Module, CrossNormSites):
+    def __init__(self, depth=40, num_classes=100, widen_factor=2, drop_rate=0.0, active_num=None, pos="post",
+                 beta=1, crop="both", cnsn_type="cnsn", impl=None):
+        super().__init__()
+        if impl is None:
+            from .. import cnsn as impl
+        assert (depth - 4) % 6 == 0
+        n = (depth - 4) // 6
+        w = [16, 16 * widen_factor, 32 * widen_factor, 64 * widen_factor]
+        kw = dict(pos=pos, beta=beta, crop=crop, cnsn_type=cnsn_type, drop_rate=drop_rate)
+        self.conv1 = nn.Conv2d(3, w[0], 3, 1, 1, bias=False)
+        self.block1 = _Stage(impl, n, w[0], w[1], 1, **kw)
+        self.block2 = _Stage(impl, n, w[1], w[2], 2, **kw)
+        self.block3 = _Stage(impl, n, w[2], w[3], 2, **kw)
+        self.bn1 = nn.BatchNorm2d(w[3])
+        self.relu = nn.ReLU(inplace=True)
+        self.fc = nn.Linear(w[3], num_classes)
+        self.n_channels = w[3]
+        for m in self.modules():                                   # initialisation as :179-187
+            if isinstance(m, nn.Conv2d):
+                m.weight.data.normal_(0, math.sqrt(2.0 / (m.kernel_size[0] * m.kernel_size[1] * m.out_channels)))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+            elif isinstance(m, nn.Linear) and m.bias is not None:
+                m.bias.data.zero_()
+        self._collect_sites(impl, cnsn_type, active_num)
+
+    def forward(self, x, aug=False):
+        if aug:
+            self._enable_cross_norm()
+        h = self.block3(self.block2(self.block1(self.conv1(x))))
+        h = F.avg_pool2d(self.relu(self.bn1(h)), 8)
+        return self.fc(h.view(h.size(0), -1))
