@@ -93,33 +93,126 @@ __device__ __forceinline__ void sweep_granules(const unsigned long long* g, int 
     }
 }
 
-// static per-lane geometry of the register slots: slot j of this lane holds vector j*64+lane
+// static per-lane geometry of the register slots: slot j of this lane holds vector j*64+lane.
+// Kept small on purpose (the planes themselves want the registers): validity is one compare against
+// nvec, box membership is one bit per element packed into (NV*VEC+31)/32 words.
 template <int VEC, int NV, bool BOXED>
 struct SlotGeom {
-    unsigned valid;     // bit j: slot j lies inside the plane
-    unsigned inC[NV];   // bit q of [j]: element q of slot j is inside the content box
-    unsigned inS[NV];   // ... inside the style box
-    __device__ __forceinline__ SlotGeom(const ResArgs& ra, int lane) {
-        valid = 0;
+    static constexpr int WORDS = BOXED ? (NV * VEC + 31) / 32 : 1;
+    int lane, nvec;
+    unsigned cbits[WORDS];  // bit j*VEC+q: element q of slot j is inside the content box
+    unsigned sbits[WORDS];  // ... inside the style box
+    __device__ __forceinline__ SlotGeom(const ResArgs& ra, int lane_) : lane(lane_), nvec(ra.nvec) {
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            inC[j] = inS[j] = 0;
-            const int i = j * 64 + lane;
-            if (i < ra.nvec) {
-                valid |= 1u << j;
-                if constexpr (BOXED) {
+        for (int w = 0; w < WORDS; ++w) cbits[w] = sbits[w] = 0;
+        if constexpr (BOXED) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = j * 64 + lane;
+                if (i < ra.nvec) {
                     const int e = i * VEC;  // VEC divides the width: one row per vector
                     const int r = e / ra.Wd, c = e - r * ra.Wd;
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
-                        inC[j] |= (ra.cb.has(r, c + q) ? 1u : 0u) << q;
-                        inS[j] |= (ra.sb.has(r, c + q) ? 1u : 0u) << q;
+                        const int p = j * VEC + q;
+                        cbits[p >> 5] |= (ra.cb.has(r, c + q) ? 1u : 0u) << (p & 31);
+                        sbits[p >> 5] |= (ra.sb.has(r, c + q) ? 1u : 0u) << (p & 31);
                     }
                 }
             }
         }
     }
+    __device__ __forceinline__ bool valid(int j) const { return j * 64 + lane < nvec; }
+    __device__ __forceinline__ bool in_c(int j, int q) const {
+        const int p = j * VEC + q;
+        return (cbits[p >> 5] & (1u << (p & 31))) != 0u;
+    }
+    __device__ __forceinline__ bool in_s(int j, int q) const {
+        const int p = j * VEC + q;
+        return (sbits[p >> 5] & (1u << (p & 31))) != 0u;
+    }
 };
+
+// Plane access through buffer instructions.  Every register slot j of a plane gets its own resource
+// descriptor (4 SGPRs, scalar ALU only): base = plane + j*64 vectors, num_records = bytes of the plane
+// left from there (clamped at 0).  All slots then share ONE per-lane VGPR offset (lane * vector bytes),
+// and the hardware range check (VGPR offset >= num_records) makes lanes past the end of the plane —
+// and whole planes past the end of the batch — read zeros and drop their stores.  No address VGPRs.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+
+template <int BYTES>
+struct RawOf;
+template <>
+struct RawOf<16> {
+    using type = v4i_t;
+};
+template <>
+struct RawOf<8> {
+    using type = v2i_t;
+};
+template <typename T, int VEC>
+using Raw = typename RawOf<(int)sizeof(T) * VEC>::type;  // VEC elements of T as 32-bit words
+
+// element q of a raw vector as float / raw vector from VEC floats (no aggregate bit-casts: handing a
+// bit-cast struct to the buffer builtins was miscompiled by ROCm 7.2 hipcc in these kernels)
+template <typename T, int VEC>
+__device__ __forceinline__ float elem(const Raw<T, VEC>& r, int q) {
+    if constexpr (sizeof(T) == 4) {
+        return __int_as_float(r[q]);
+    } else {
+        const unsigned w = (unsigned)r[q >> 1];
+        const unsigned short h = (q & 1) ? (unsigned short)(w >> 16) : (unsigned short)(w & 0xffffu);
+        if constexpr (__is_same(T, bf16_t))
+            return __uint_as_float((unsigned)h << 16);
+        else
+            return (float)__builtin_bit_cast(_Float16, h);
+    }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ Raw<T, VEC> pack(const float (&f)[VEC]) {
+    Raw<T, VEC> r;
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) r[q] = __float_as_int(f[q]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < VEC; q += 2) {
+            unsigned short lo, hi;
+            if constexpr (__is_same(T, bf16_t)) {
+                lo = from_float<bf16_t>(f[q]).bits;
+                hi = from_float<bf16_t>(f[q + 1]).bits;
+            } else {
+                lo = __builtin_bit_cast(unsigned short, from_float<_Float16>(f[q]));
+                hi = __builtin_bit_cast(unsigned short, from_float<_Float16>(f[q + 1]));
+            }
+            r[q >> 1] = (int)(((unsigned)hi << 16) | (unsigned)lo);
+        }
+    }
+    return r;
+}
+
+// descriptor of slot j of the plane starting at `base` (plane_bytes = 0 for planes past the batch end)
+template <typename T, int VEC>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slot_rsrc(const T* base, int plane_bytes, int j) {
+    constexpr int SLOT = 64 * VEC * (int)sizeof(T);
+    const int left = plane_bytes - j * SLOT;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)j * 64 * VEC), 0, left > 0 ? left : 0, 0x00020000);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ Raw<T, VEC> buf_load(__amdgpu_buffer_rsrc_t r, int voff) {
+    if constexpr (sizeof(T) * VEC == 16)
+        return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    else
+        return __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, int voff, const Raw<T, VEC>& v) {
+    if constexpr (sizeof(T) * VEC == 16)
+        __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
+    else
+        __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, 0, 0);
+}
 
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
@@ -170,9 +263,12 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
     float* ocoef = (float*)((char*)sperm + align16((size_t)N * 4));
     double* red = (double*)((char*)ocoef + align16((size_t)OWN * FC_ROWS * 4));
     (void)zbuf;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: plane bases stay in SGPRs
     const size_t P = (size_t)N * C;
     const SlotGeom<VEC, NV, BOXED> sg(ra, lane);
+    constexpr int VB = VEC * (int)sizeof(T);  // bytes per vector
+    const int voff = lane * VB;
 
     if (a.cn_active)
         for (int n = threadIdx.x; n < N; n += kBlock) sperm[n] = (int)perm[n];
@@ -207,18 +303,14 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
         }
 
         // ---- load this wave's planes into registers (the only read of x)
-        Vec<T, VEC> d[PPW][NV];
+        Raw<T, VEC> d[PPW][NV];
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
             const int n = n0 + s;
-            const T* base = x + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
+            const T* pb = x + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
+            const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;  // past the batch end: every lane reads zeros
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                if (n < N && ((sg.valid >> j) & 1u))
-                    d[s][j] = load_vec<T, VEC>(base + (size_t)(j * 64 + lane) * VEC);
-                else
-                    d[s][j] = Vec<T, VEC>{};
-            }
+            for (int j = 0; j < NV; ++j) d[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(pb, pbytes, j), voff);
         }
 
         // ---- exact two-pass statistics from registers; publish them to the cluster
@@ -231,15 +323,15 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) sum += to_float(d[s][j].v[q]);
+                    for (int q = 0; q < VEC; ++q) sum += elem<T, VEC>(d[s][j], q);
                 const float mean = wave_sum(sum) / (float)ra.M;
                 float m2 = 0.f;
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
-                    if ((sg.valid >> j) & 1u) {
+                    if (sg.valid(j)) {
 #pragma unroll
                         for (int q = 0; q < VEC; ++q) {
-                            const float t = to_float(d[s][j].v[q]) - mean;
+                            const float t = elem<T, VEC>(d[s][j], q) - mean;
                             m2 = fmaf(t, t, m2);
                         }
                     }
@@ -251,8 +343,8 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
                 for (int j = 0; j < NV; ++j)
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
-                        const float f = to_float(d[s][j].v[q]);  // invalid slots hold 0 and no box bit
-                        const bool ic = (sg.inC[j] >> q) & 1u, is = (sg.inS[j] >> q) & 1u;
+                        const float f = elem<T, VEC>(d[s][j], q);  // invalid slots hold 0 and no box bit
+                        const bool ic = sg.in_c(j, q), is = sg.in_s(j, q);
                         sc += ic ? f : 0.f;
                         so += ic ? 0.f : f;
                         ss += is ? f : 0.f;
@@ -264,11 +356,11 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
                 float qc = 0.f, qo = 0.f, qs = 0.f;
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
-                    if ((sg.valid >> j) & 1u) {
+                    if (sg.valid(j)) {
 #pragma unroll
                         for (int q = 0; q < VEC; ++q) {
-                            const float f = to_float(d[s][j].v[q]);
-                            const bool ic = (sg.inC[j] >> q) & 1u, is = (sg.inS[j] >> q) & 1u;
+                            const float f = elem<T, VEC>(d[s][j], q);
+                            const bool ic = sg.in_c(j, q), is = sg.in_s(j, q);
                             const float tc = f - mc, to = f - mo, ts = f - ms;
                             qc += ic ? tc * tc : 0.f;
                             qo += ic ? 0.f : to * to;
@@ -413,18 +505,18 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
                 const float a_in = o[FC_A_IN], xr = o[FC_XR], b_in = o[FC_B_IN], a_out = o[FC_A_OUT],
                             b_out = o[FC_B_OUT];
                 T* yb = y + ((size_t)n * C + c) * ra.M;
+                const int pbytes = ra.M * (int)sizeof(T);
 #pragma unroll
-                for (int j = 0; j < NV; ++j)
-                    if ((sg.valid >> j) & 1u) {
-                        Vec<T, VEC> ov;
+                for (int j = 0; j < NV; ++j) {
+                    float ov[VEC];
 #pragma unroll
-                        for (int q = 0; q < VEC; ++q) {
-                            const float f = to_float(d[s][j].v[q]);
-                            const bool ic = !BOXED || ((sg.inC[j] >> q) & 1u);
-                            ov.v[q] = from_float<T>(ic ? fmaf(a_in, f - xr, b_in) : fmaf(a_out, f, b_out));
-                        }
-                        store_vec<T, VEC>(yb + (size_t)(j * 64 + lane) * VEC, ov);
+                    for (int q = 0; q < VEC; ++q) {
+                        const float f = elem<T, VEC>(d[s][j], q);
+                        const bool ic = !BOXED || (sg.in_c(j, q));
+                        ov[q] = ic ? fmaf(a_in, f - xr, b_in) : fmaf(a_out, f, b_out);
                     }
+                    buf_store<T, VEC>(slot_rsrc<T, VEC>(yb, pbytes, j), voff, pack<T, VEC>(ov));
+                }
             }
         }
         CNSN_STAMP(5);
@@ -454,9 +546,12 @@ __global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW
     double* red = (double*)((char*)ocoef + align16((size_t)OWN * BC_ROWS * 4));
     double* svd = red + 4 * 4;                                         // [N][D_N]
     float* svf = (float*)((char*)svd + align16((size_t)N * D_N * 8));  // [N][F_N]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: plane bases stay in SGPRs
     const size_t P = (size_t)N * C;
     const SlotGeom<VEC, NV, BOXED> sg(ra, lane);
+    constexpr int VB = VEC * (int)sizeof(T);  // bytes per vector
+    const int voff = lane * VB;
 
     if (a.cn_active)  // plane r receives the style-statistic gradient of the plane that borrowed from it
         for (int n = threadIdx.x; n < N; n += kBlock) iperm[(int)perm[n]] = n;
@@ -515,20 +610,16 @@ __global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW
         }
 
         // ---- load G and x planes (the only reads)
-        Vec<T, VEC> dg_[PPW][NV], dx_[PPW][NV];
+        Raw<T, VEC> dg_[PPW][NV], dx_[PPW][NV];
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
             const int n = n0 + s;
             const size_t off = ((size_t)(n < N ? n : 0) * C + c) * ra.M;
+            const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                if (n < N && ((sg.valid >> j) & 1u)) {
-                    dg_[s][j] = load_vec<T, VEC>(gy + off + (size_t)(j * 64 + lane) * VEC);
-                    dx_[s][j] = load_vec<T, VEC>(x + off + (size_t)(j * 64 + lane) * VEC);
-                } else {
-                    dg_[s][j] = Vec<T, VEC>{};
-                    dx_[s][j] = Vec<T, VEC>{};
-                }
+                dg_[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(gy + off, pbytes, j), voff);
+                dx_[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(x + off, pbytes, j), voff);
             }
         }
 
@@ -542,15 +633,15 @@ __global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW
             for (int m = 0; m < NS; ++m) acc[m] = 0.f;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
-                if ((sg.valid >> j) & 1u) {
+                if (sg.valid(j)) {
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
-                        const float G = to_float(dg_[s][j].v[q]), X = to_float(dx_[s][j].v[q]);
+                        const float G = elem<T, VEC>(dg_[s][j], q), X = elem<T, VEC>(dx_[s][j], q);
                         if constexpr (!BOXED) {
                             acc[0] += G;
                             acc[1] = fmaf(G, X - si, acc[1]);
                         } else {
-                            const bool ic = (sg.inC[j] >> q) & 1u;
+                            const bool ic = sg.in_c(j, q);
                             acc[0] += ic ? G : 0.f;
                             acc[1] += ic ? G * (X - si) : 0.f;
                             acc[2] += ic ? 0.f : G;
@@ -684,25 +775,25 @@ __global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW
                 const float cG_o = oc[BC_CG_OUT], cX_o = oc[BC_CX_OUT], xr_o = oc[BC_XR_OUT], c0_o = oc[BC_C0_OUT];
                 const float eS = oc[BC_ES], xs = oc[BC_XS], e0 = oc[BC_E0];
                 T* db = dx + ((size_t)n * C + c) * ra.M;
+                const int pbytes = ra.M * (int)sizeof(T);
 #pragma unroll
-                for (int j = 0; j < NV; ++j)
-                    if ((sg.valid >> j) & 1u) {
-                        Vec<T, VEC> ov;
+                for (int j = 0; j < NV; ++j) {
+                        float ov[VEC];
 #pragma unroll
                         for (int q = 0; q < VEC; ++q) {
-                            const float G = to_float(dg_[s][j].v[q]), X = to_float(dx_[s][j].v[q]);
+                            const float G = elem<T, VEC>(dg_[s][j], q), X = elem<T, VEC>(dx_[s][j], q);
                             float v;
                             if constexpr (!BOXED) {
                                 v = fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i));
                             } else {
-                                const bool ic = (sg.inC[j] >> q) & 1u, is = (sg.inS[j] >> q) & 1u;
+                                const bool ic = sg.in_c(j, q), is = sg.in_s(j, q);
                                 v = ic ? fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i))
                                        : fmaf(cG_o, G, fmaf(cX_o, X - xr_o, c0_o));
                                 v += is ? fmaf(eS, X - xs, e0) : 0.f;
                             }
-                            ov.v[q] = from_float<T>(v);
+                            ov[q] = v;
                         }
-                        store_vec<T, VEC>(db + (size_t)(j * 64 + lane) * VEC, ov);
+                        buf_store<T, VEC>(slot_rsrc<T, VEC>(db, pbytes, j), voff, pack<T, VEC>(ov));
                     }
             }
         }

@@ -39,7 +39,7 @@ def _require_device(x: torch.Tensor, what: str):
 
 
 def _stream(x):
-    return C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(x.device.index))
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -47,7 +47,25 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype == torch.float32 and t.is_contiguous():
+        return t.detach() if t.requires_grad else t
     return t.detach().to(torch.float32).contiguous()
+
+
+# sizes of the caller-owned side buffers per problem signature (two ctypes calls saved per launch)
+_size_cache = {}
+
+
+def _sizes(prob):
+    key = (prob.dtype, prob.N, prob.C, prob.H, prob.W, prob.cn_active, prob.sn_active, prob.sn_two,
+           prob.sn_training, prob.content_box[0] >= 0, prob.style_box[0] >= 0, prob.strategy)
+    hit = _size_cache.get(key)
+    if hit is None:
+        lib = _ffi.lib()
+        hit = (lib.cnsn_saved_floats(C.byref(prob)), lib.cnsn_workspace_bytes(C.byref(prob)))
+        if hit[1] > 0:          # 0 = the library rejected the problem: let the launch report why
+            _size_cache[key] = hit
+    return hit
 
 
 class _PinnedRing:
@@ -165,9 +183,8 @@ class FusedCNSN(torch.autograd.Function):
         gate_f = _GateBuffers(f_w, f_gamma, f_beta, f_rm, f_rv) if (cfg.sn_active and cfg.sn_two) else None
         y = torch.empty_like(x)
         need_bwd = any(ctx.needs_input_grad)
-        saved = torch.empty(lib.cnsn_saved_floats(C.byref(prob)), dtype=torch.float32, device=dev) \
-            if need_bwd else None
-        ws_bytes = lib.cnsn_workspace_bytes(C.byref(prob))
+        saved_floats, ws_bytes = _sizes(prob)
+        saved = torch.empty(saved_floats, dtype=torch.float32, device=dev) if need_bwd else None
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
         st = lib.cnsn_forward(C.byref(prob), _ptr(x), _ptr(perm if cfg.cn_active else None),
                               _ptr(chan_perm if cfg.cn_active else None),
@@ -198,14 +215,13 @@ class FusedCNSN(torch.autograd.Function):
             gy = gy.to(x.dtype)
         dev = x.device
         dx = torch.empty_like(x)
-        ws_bytes = lib.cnsn_workspace_bytes(C.byref(prob))
+        ws_bytes = _sizes(prob)[1]
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
         Cn = x.shape[1]
 
-        def grads():
-            dw = torch.empty(Cn, 1, 2, dtype=torch.float32, device=dev)
-            dgam = torch.empty(Cn, dtype=torch.float32, device=dev)
-            dbet = torch.empty(Cn, dtype=torch.float32, device=dev)
+        def grads():  # one allocation, three views: d_fc_weight (C,1,2), d_bn_weight (C), d_bn_bias (C)
+            flat = torch.empty(4 * Cn, dtype=torch.float32, device=dev)
+            dw, dgam, dbet = flat[:2 * Cn].view(Cn, 1, 2), flat[2 * Cn:3 * Cn], flat[3 * Cn:]
             return (dw, dgam, dbet), _ffi.GateGrad(_ptr(dw), _ptr(dgam), _ptr(dbet))
 
         gg = gf = None
@@ -220,8 +236,9 @@ class FusedCNSN(torch.autograd.Function):
                                C.byref(gf_c) if gf_c else None, _ptr(ws), ws_bytes, _stream(x))
         _ffi.check(st, "cnsn_backward")
         pd = ctx.param_dtypes
-        out_g = [None] * 3 if gg is None else [t.to(pd[i]) for i, t in enumerate(gg)]
-        out_f = [None] * 3 if gf is None else [t.to(pd[3 + i]) for i, t in enumerate(gf)]
+        out_g = [None] * 3 if gg is None else [t if t.dtype == pd[i] else t.to(pd[i]) for i, t in enumerate(gg)]
+        out_f = [None] * 3 if gf is None else [t if t.dtype == pd[3 + i] else t.to(pd[3 + i])
+                                               for i, t in enumerate(gf)]
         #      x   cfg  perm  chan  g_w..g_beta   g_rm g_rv   f_w..f_beta  f_rm f_rv
         return (dx, None, None, None, *out_g, None, None, *out_f, None, None)
 
