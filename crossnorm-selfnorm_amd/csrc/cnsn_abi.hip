@@ -150,6 +150,8 @@ int make_plan(const cnsn_problem_t* prob, Plan& pl) {
     m.eps_sn = p.eps_sn;
     m.eps_bn = p.eps_bn;
     m.momentum = p.momentum;
+    m.inv_n = 1.0 / (double)p.N;
+    m.unbias_n = p.N > 1 ? (double)p.N / ((double)p.N - 1.0) : 1.0;
     return CNSN_OK;
 }
 
@@ -296,10 +298,10 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
         constexpr int VEC = decltype(vt)::value, LPP = decltype(lt)::value;
         if (pl.boxed)
             bwd_reduce_kernel<T, VEC, LPP, true><<<blocks, kBlock, 0, stream>>>(
-                (const T*)grad_y, (const T*)x, pl.geom, saved_d + SV_MU_C * P, saved_d + SV_MU_O * P, sums);
+                (const T*)grad_y, (const T*)x, pl.geom, saved_d + SV_MU_C, saved_d + SV_MU_O, SV_ROWS, sums);
         else
             bwd_reduce_kernel<T, VEC, LPP, false><<<blocks, kBlock, 0, stream>>>(
-                (const T*)grad_y, (const T*)x, pl.geom, saved_d + SV_MU_C * P, nullptr, sums);
+                (const T*)grad_y, (const T*)x, pl.geom, saved_d + SV_MU_C, nullptr, SV_ROWS, sums);
     });
     mid_bwd_a_kernel<<<p.C, kBlock, 0, stream>>>(pl.mid, sums, saved_d, perm, chan_perm, gate_dev(g), gate_dev(f),
                                                 gate_grad_dev(dg), gate_grad_dev(df), tmp);
@@ -406,7 +408,7 @@ int cnsn_plane_dot(const void* gr, const void* x, int dtype, int N, int C, int H
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value, LPP = decltype(lt)::value;
         bwd_reduce_kernel<T, VEC, LPP, false><<<blocks, kBlock, 0, stream>>>((const T*)gr, (const T*)x, g, nullptr,
-                                                                            nullptr, sum_g);
+                                                                            nullptr, 0, sum_g);
     });
     return launch_status();
 }

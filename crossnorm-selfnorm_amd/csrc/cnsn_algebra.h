@@ -18,6 +18,8 @@ struct MidArgs {
     int Mc, Ms;  // content / style region sizes (M without a box)
     int cn_active, boxed, sn_active, sn_two, sn_training;
     float lam, eps_cn, eps_sn, eps_bn, momentum;
+    double inv_n;     // 1/N         (host-computed: no fp64 divisions on the device)
+    double unbias_n;  // N/(N-1)     (running_var takes the unbiased batch variance)
 };
 
 struct GateDev {
@@ -49,10 +51,14 @@ struct FwdPlaneT {
 };
 using FwdPlane = FwdPlaneT<double>;
 
+// double: IEEE library routines.  float (resident kernels): the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32 —
+// a handful of instructions and no temporaries where the correctly rounded sequences need a dozen.
 __device__ __forceinline__ double sqrt_r(double v) { return sqrt(v); }
-__device__ __forceinline__ float sqrt_r(float v) { return sqrtf(v); }
+__device__ __forceinline__ float sqrt_r(float v) { return __builtin_amdgcn_sqrtf(v); }
 __device__ __forceinline__ double exp_r(double v) { return exp(v); }
-__device__ __forceinline__ float exp_r(float v) { return expf(v); }
+__device__ __forceinline__ float exp_r(float v) { return __expf(v); }
+__device__ __forceinline__ double div_r(double a, double b) { return a / b; }
+__device__ __forceinline__ float div_r(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 
 // CrossNorm algebra of one plane: own moments + the style source's style-box moments
 // (cnsn.py:24-29 folded with the box paste :75-82 and the lam blend :87), then the post-CrossNorm
@@ -64,26 +70,26 @@ CNSN_ALGEBRA_FN FwdPlaneT<R> fwd_plane(const MidArgs& a, const MomentsT<R>& o, R
     p.mu_o = o.mu_o;
     p.M2c = o.M2c;
     p.mu_s = o.mu_s;
-    p.sig_c = sqrt_r(o.M2c / (Mc - R(1)) + (R)a.eps_cn);
-    p.sig_s = sqrt_r(o.M2s / ((R)a.Ms - R(1)) + (R)a.eps_cn);
+    p.sig_c = sqrt_r(div_r(o.M2c, Mc - R(1)) + (R)a.eps_cn);
+    p.sig_s = sqrt_r(div_r(o.M2s, (R)a.Ms - R(1)) + (R)a.eps_cn);
     p.aa = R(1);
     p.a1 = R(1);
     p.m_in = o.mu_c;
     p.mu_p = o.mu_c;
     R M2p = o.M2c;
     if (a.cn_active) {
-        const R sig_sq = sqrt_r(M2_sq / ((R)a.Ms - R(1)) + (R)a.eps_cn);
-        p.aa = sig_sq / p.sig_c;
+        const R sig_sq = sqrt_r(div_r(M2_sq, (R)a.Ms - R(1)) + (R)a.eps_cn);
+        p.aa = div_r(sig_sq, p.sig_c);
         p.a1 = lam + (R(1) - lam) * p.aa;
         p.m_in = lam * o.mu_c + (R(1) - lam) * mu_sq;
-        p.mu_p = (Mc * p.m_in + Mo * o.mu_o) / M;
-        M2p = p.a1 * p.a1 * o.M2c + o.M2o + (p.m_in - o.mu_o) * (p.m_in - o.mu_o) * Mc * Mo / M;
+        p.mu_p = div_r(Mc * p.m_in + Mo * o.mu_o, M);
+        M2p = p.a1 * p.a1 * o.M2c + o.M2o + div_r((p.m_in - o.mu_o) * (p.m_in - o.mu_o) * Mc * Mo, M);
     }
-    p.sig_p = sqrt_r(M2p / (M - R(1)) + (R)a.eps_sn);
+    p.sig_p = sqrt_r(div_r(M2p, M - R(1)) + (R)a.eps_sn);
     return p;
 }
 
-CNSN_ALGEBRA_FN R sigmoid_r(R t) { return R(1) / (R(1) + exp_r(-t)); }
+CNSN_ALGEBRA_FN R sigmoid_r(R t) { return div_r(R(1), R(1) + exp_r(-t)); }
 __device__ __forceinline__ double sigmoid_d(double t) { return sigmoid_r<double>(t); }
 
 struct FwdCoefs {
@@ -161,7 +167,7 @@ CNSN_ALGEBRA_FN BwdPlaneT<R> bwd_plane(const MidArgs& a, const BnBwd& b, const B
                                        double zhg, double zhf, R g, R f, R aa, R a1, R m_in, R mu_p, R sig_p, R sig_c,
                                        R M2c) {
     const R M = a.M, Mc = a.Mc, lam = a.lam;
-    const double invN = 1.0 / a.N;
+    const double invN = a.inv_n;
     BwdPlaneT<R> o;
     o.dz_g = o.dz_f = R(0);
     R dmu_p = R(0), dsig_p = R(0);
@@ -176,16 +182,16 @@ CNSN_ALGEBRA_FN BwdPlaneT<R> bwd_plane(const MidArgs& a, const BnBwd& b, const B
         }
     }
     o.dmu_p = dmu_p;
-    o.k = a.sn_active ? dsig_p / (sig_p * (M - R(1))) : R(0);
+    o.k = a.sn_active ? div_r(dsig_p, sig_p * (M - R(1))) : R(0);
     o.Dmu_c = o.Dsig_c = o.Emu = o.Esig = R(0);
     if (a.cn_active) {
-        const R T1 = g * s.S1in + Mc * dmu_p / M + o.k * Mc * (m_in - mu_p);
+        const R T1 = g * s.S1in + div_r(Mc * dmu_p, M) + o.k * Mc * (m_in - mu_p);
         const R T2 = g * s.S2in + o.k * a1 * M2c;
         const R d_a = (R(1) - lam) * T2;
         o.Dmu_c = -(R(1) - lam) * aa * T1;
-        o.Dsig_c = -d_a * aa / sig_c;
+        o.Dsig_c = -div_r(d_a * aa, sig_c);
         o.Emu = (R(1) - lam) * T1;
-        o.Esig = d_a / sig_c;
+        o.Esig = div_r(d_a, sig_c);
     }
     return o;
 }
@@ -199,13 +205,13 @@ struct BwdCoefs {
 CNSN_ALGEBRA_FN BwdCoefs bwd_coefs(const MidArgs& a, const BwdPlaneT<R>& o, R Emu_in, R Esig_in, R g, R a1, R m_in,
                                    R mu_p, double mu_c, R sig_c, double mu_s, R sig_s) {
     const R M = a.M, Mc = a.Mc, Ms = a.Ms;
-    R cX_in = a1 * a1 * o.k, c0_in = a1 * (o.dmu_p / M + o.k * (m_in - mu_p));
+    R cX_in = a1 * a1 * o.k, c0_in = a1 * (div_r(o.dmu_p, M) + o.k * (m_in - mu_p));
     R eS = R(0), e0 = R(0);
     if (a.cn_active) {
-        cX_in += o.Dsig_c / (sig_c * (Mc - R(1)));
-        c0_in += o.Dmu_c / Mc;
-        eS = Esig_in / (sig_s * (Ms - R(1)));
-        e0 = Emu_in / Ms;
+        cX_in += div_r(o.Dsig_c, sig_c * (Mc - R(1)));
+        c0_in += div_r(o.Dmu_c, Mc);
+        eS = div_r(Esig_in, sig_s * (Ms - R(1)));
+        e0 = div_r(Emu_in, Ms);
     }
     if (!a.boxed) {  // style region == content region == plane and mu_s == mu_c: one affine map
         cX_in += eS;
@@ -221,7 +227,7 @@ CNSN_ALGEBRA_FN BwdCoefs bwd_coefs(const MidArgs& a, const BwdPlaneT<R>& o, R Em
     c.xs = (float)mu_s;
     c.cG_out = (float)g;
     c.cX_out = (float)o.k;
-    c.c0_out = (float)(o.dmu_p / M + o.k * ((R)c.xr_out - mu_p));
+    c.c0_out = (float)(div_r(o.dmu_p, M) + o.k * ((R)c.xr_out - mu_p));
     c.eS = (float)eS;
     c.e0 = (float)(e0 + eS * (R)((double)c.xs - mu_s));
     return c;

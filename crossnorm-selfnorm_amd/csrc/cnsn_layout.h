@@ -5,7 +5,9 @@
 
 namespace cnsn {
 
-// SoA rows of `saved` (doubles, stride P = N*C), followed by two rows of C (BatchNorm rstd of g, f)
+// `saved`: one record of SV_ROWS doubles per plane p = n*C + c (array of structs: every reader and writer
+// touches all fields of a plane, so one base address + constant offsets), followed by two rows of C
+// (BatchNorm rstd of g and f) at SV_ROWS*P.
 enum SavedRow {
     SV_MU_C = 0,   // mean inside the content box (whole plane without one)
     SV_MU_O,       // mean outside the content box
@@ -25,6 +27,8 @@ enum SavedRow {
     SV_ROWS
 };
 
+__host__ __device__ inline size_t sv_at(size_t p, int row) { return p * SV_ROWS + row; }
+
 // rows of the forward coefficient block handed to apply_fwd_kernel
 enum FwdCoefRow { FC_A_IN = 0, FC_XR, FC_B_IN, FC_A_OUT, FC_B_OUT, FC_ROWS };
 
@@ -40,17 +44,17 @@ enum BwdCoefRow {
 template <typename R>
 __device__ __forceinline__ void store_fwd_plane(double* __restrict__ saved, size_t P, size_t p,
                                                 const FwdPlaneT<R>& f) {
-    saved[SV_MU_C * P + p] = f.mu_c;
-    saved[SV_MU_O * P + p] = f.mu_o;
-    saved[SV_M2C * P + p] = f.M2c;
-    saved[SV_SIG_C * P + p] = f.sig_c;
-    saved[SV_MU_S * P + p] = f.mu_s;
-    saved[SV_SIG_S * P + p] = f.sig_s;
-    saved[SV_A * P + p] = f.aa;
-    saved[SV_A1 * P + p] = f.a1;
-    saved[SV_M_IN * P + p] = f.m_in;
-    saved[SV_MU_P * P + p] = f.mu_p;
-    saved[SV_SIG_P * P + p] = f.sig_p;
+    saved[sv_at(p, SV_MU_C)] = f.mu_c;
+    saved[sv_at(p, SV_MU_O)] = f.mu_o;
+    saved[sv_at(p, SV_M2C)] = f.M2c;
+    saved[sv_at(p, SV_SIG_C)] = f.sig_c;
+    saved[sv_at(p, SV_MU_S)] = f.mu_s;
+    saved[sv_at(p, SV_SIG_S)] = f.sig_s;
+    saved[sv_at(p, SV_A)] = f.aa;
+    saved[sv_at(p, SV_A1)] = f.a1;
+    saved[sv_at(p, SV_M_IN)] = f.m_in;
+    saved[sv_at(p, SV_MU_P)] = f.mu_p;
+    saved[sv_at(p, SV_SIG_P)] = f.sig_p;
 }
 
 }  // namespace cnsn

@@ -49,8 +49,8 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
         if (a.sn_active) {
             const double zg = wg0 * f.mu_p + wg1 * f.sig_p;  // Conv1d k=2 groups=C (cnsn.py:137)
             const double zf = wf0 * f.mu_p + wf1 * f.sig_p;
-            saved[SV_ZH_G * P + p] = zg;  // parked here until normalised in sweep 3
-            saved[SV_ZH_F * P + p] = zf;
+            saved[sv_at(p, SV_ZH_G)] = zg;  // parked here until normalised in sweep 3
+            saved[sv_at(p, SV_ZH_F)] = zf;
             sz[0] += zg;
             sz[1] += zf;
         }
@@ -66,8 +66,8 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
             double sv[2] = {0.0, 0.0};
             for (int n = threadIdx.x; n < a.N; n += kBlock) {
                 const size_t p = (size_t)n * a.C + c;
-                const double dg = saved[SV_ZH_G * P + p] - mg;
-                const double df = saved[SV_ZH_F * P + p] - mf;
+                const double dg = saved[sv_at(p, SV_ZH_G)] - mg;
+                const double df = saved[sv_at(p, SV_ZH_F)] - mf;
                 sv[0] += dg * dg;
                 sv[1] += df * df;
             }
@@ -105,22 +105,22 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
         const size_t p = (size_t)n * a.C + c;
         double g = 1.0, f = 1.0, zhg = 0.0, zhf = 0.0;
         if (a.sn_active) {
-            zhg = (saved[SV_ZH_G * P + p] - mg) * rg;
+            zhg = (saved[sv_at(p, SV_ZH_G)] - mg) * rg;
             g = sigmoid_d(gam_g * zhg + bet_g);
             if (a.sn_two) {
-                zhf = (saved[SV_ZH_F * P + p] - mf) * rf;
+                zhf = (saved[sv_at(p, SV_ZH_F)] - mf) * rf;
                 f = sigmoid_d(gam_f * zhf + bet_f);
             }
         }
-        saved[SV_G * P + p] = g;
-        saved[SV_ZH_G * P + p] = zhg;
-        saved[SV_F * P + p] = f;
-        saved[SV_ZH_F * P + p] = zhf;
+        saved[sv_at(p, SV_G)] = g;
+        saved[sv_at(p, SV_ZH_G)] = zhg;
+        saved[sv_at(p, SV_F)] = f;
+        saved[sv_at(p, SV_ZH_F)] = zhf;
         FwdPlane fp;
-        fp.mu_c = saved[SV_MU_C * P + p];
-        fp.a1 = saved[SV_A1 * P + p];
-        fp.m_in = saved[SV_M_IN * P + p];
-        fp.mu_p = saved[SV_MU_P * P + p];
+        fp.mu_c = saved[sv_at(p, SV_MU_C)];
+        fp.a1 = saved[sv_at(p, SV_A1)];
+        fp.m_in = saved[sv_at(p, SV_M_IN)];
+        fp.mu_p = saved[sv_at(p, SV_MU_P)];
         const FwdCoefs k = fwd_coefs<double>(a, fp, g, f);
         coef[FC_A_IN * P + p] = k.a_in;
         coef[FC_XR * P + p] = k.xr;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
 
     auto sums_of = [&](size_t p) {
         return fix_sums<double>(a, sums[p], sums[P + p], a.boxed ? sums[2 * P + p] : 0.f, a.boxed ? sums[3 * P + p] : 0.f,
-                        saved[SV_MU_C * P + p], saved[SV_MU_O * P + p]);
+                        saved[sv_at(p, SV_MU_C)], saved[sv_at(p, SV_MU_O)]);
     };
 
     // ---- sweep 1: dL/dgate -> through the sigmoid; batch sums for BatchNorm backward
@@ -153,12 +153,12 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
         for (int n = threadIdx.x; n < a.N; n += kBlock) {
             const size_t p = (size_t)n * a.C + c;
             double dtg, dtf;
-            gate_dt<double>(a, sums_of(p), saved[SV_A1 * P + p], saved[SV_M_IN * P + p], saved[SV_MU_O * P + p],
-                    saved[SV_MU_P * P + p], saved[SV_G * P + p], saved[SV_F * P + p], dtg, dtf);
+            gate_dt<double>(a, sums_of(p), saved[sv_at(p, SV_A1)], saved[sv_at(p, SV_M_IN)], saved[sv_at(p, SV_MU_O)],
+                    saved[sv_at(p, SV_MU_P)], saved[sv_at(p, SV_G)], saved[sv_at(p, SV_F)], dtg, dtf);
             s[0] += dtg;
-            s[1] += dtg * saved[SV_ZH_G * P + p];
+            s[1] += dtg * saved[sv_at(p, SV_ZH_G)];
             s[2] += dtf;
-            s[3] += dtf * saved[SV_ZH_F * P + p];
+            s[3] += dtf * saved[sv_at(p, SV_ZH_F)];
             tmp[BT_DT_G * P + p] = dtg;
             tmp[BT_DT_F * P + p] = dtf;
         }
@@ -192,12 +192,12 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
     double sw[4] = {0, 0, 0, 0};  // sum dz_g*mu_p, dz_g*sig_p, dz_f*mu_p, dz_f*sig_p
     for (int n = threadIdx.x; n < a.N; n += kBlock) {
         const size_t p = (size_t)n * a.C + c;
-        const double mu_p = saved[SV_MU_P * P + p], sig_p = saved[SV_SIG_P * P + p];
+        const double mu_p = saved[sv_at(p, SV_MU_P)], sig_p = saved[sv_at(p, SV_SIG_P)];
         const BwdPlane o =
             bwd_plane<double>(a, b, sums_of(p), a.sn_active ? tmp[BT_DT_G * P + p] : 0.0, a.sn_active ? tmp[BT_DT_F * P + p] : 0.0,
-                      saved[SV_ZH_G * P + p], saved[SV_ZH_F * P + p], saved[SV_G * P + p], saved[SV_F * P + p],
-                      saved[SV_A * P + p], saved[SV_A1 * P + p], saved[SV_M_IN * P + p], mu_p, sig_p,
-                      saved[SV_SIG_C * P + p], saved[SV_M2C * P + p]);
+                      saved[sv_at(p, SV_ZH_G)], saved[sv_at(p, SV_ZH_F)], saved[sv_at(p, SV_G)], saved[sv_at(p, SV_F)],
+                      saved[sv_at(p, SV_A)], saved[sv_at(p, SV_A1)], saved[sv_at(p, SV_M_IN)], mu_p, sig_p,
+                      saved[sv_at(p, SV_SIG_C)], saved[sv_at(p, SV_M2C)]);
         sw[0] += o.dz_g * mu_p;
         sw[1] += o.dz_g * sig_p;
         sw[2] += o.dz_f * mu_p;
@@ -241,9 +241,9 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_b_kernel(MidArgs a, const doub
         Emu = tmp[BT_E_MU * P + p];
         Esig = tmp[BT_E_SIG * P + p];
     }
-    const BwdCoefs k = bwd_coefs<double>(a, o, Emu, Esig, saved[SV_G * P + p], saved[SV_A1 * P + p], saved[SV_M_IN * P + p],
-                                 saved[SV_MU_P * P + p], saved[SV_MU_C * P + p], saved[SV_SIG_C * P + p],
-                                 saved[SV_MU_S * P + p], saved[SV_SIG_S * P + p]);
+    const BwdCoefs k = bwd_coefs<double>(a, o, Emu, Esig, saved[sv_at(p, SV_G)], saved[sv_at(p, SV_A1)], saved[sv_at(p, SV_M_IN)],
+                                 saved[sv_at(p, SV_MU_P)], saved[sv_at(p, SV_MU_C)], saved[sv_at(p, SV_SIG_C)],
+                                 saved[sv_at(p, SV_MU_S)], saved[sv_at(p, SV_SIG_S)]);
     coef[BC_CG_IN * P + p] = k.cG_in;
     coef[BC_CX_IN * P + p] = k.cX_in;
     coef[BC_XR_IN * P + p] = k.xr_in;

@@ -107,10 +107,11 @@ ResPlan resident_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, b
     rp.K = (p.N + own - 1) / own;
     if (res_lds_bytes(p.N, 6, own, BC_ROWS, true) > 64 * 1024) return rp;
     if (rp.K > 2 * cu_count()) return rp;
-    // AUTO: use the resident kernel where it measured faster than two-pass on MI355X (round-1 sweep,
-    // profiles/r01_resident_tuning.md): forward wherever it is eligible; backward (two tensors resident,
-    // 2 workgroups per CU) only for the large-plane fp32 class.  RESIDENT forces it wherever eligible.
-    if (p.strategy == CNSN_STRATEGY_AUTO && backward && !(rp.nv >= 13 && p.dtype == CNSN_F32)) return rp;
+    // AUTO: use the resident kernel where it measured faster than two-pass on MI355X (round-1 sweeps,
+    // profiles/r01_resident_tuning.md): forward wherever it is eligible; backward for every fp32 shape and,
+    // for 16-bit tensors, for the 1-vector (14x14) and >= 7-vector (56x56) plane classes — the 28x28 bf16
+    // backward still runs faster as two streaming passes.  RESIDENT forces it wherever eligible.
+    if (p.strategy == CNSN_STRATEGY_AUTO && backward && p.dtype != CNSN_F32 && !(rp.nv == 1 || rp.nv >= 7)) return rp;
     rp.ok = true;
     return rp;
 }

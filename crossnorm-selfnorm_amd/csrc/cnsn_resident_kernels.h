@@ -227,7 +227,7 @@ constexpr int bwd_waves(int) { return CNSN_WB; }
 // measured on MI355X at (256,256,56,56) fp32/bf16 (profiles/r01_resident_tuning.md): forward 4, backward 2;
 // tighter bounds make the compiler spill and every variant got slower.
 constexpr int fwd_waves(int) { return 4; }
-constexpr int bwd_waves(int) { return 2; }
+constexpr int bwd_waves(int) { return 3; }
 #endif
 
 // dynamic LDS carve (bytes); NG = granules per plane, OWN = planes per workgroup
@@ -431,15 +431,17 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
                     sz[3] += df * df;
                 }
                 block_sum_d<4>(sz, red);
-                mg = zs_g + sz[0] / N;
-                mf = zs_f + sz[2] / N;
-                double vg = (sz[1] - sz[0] * sz[0] / N) / N, vf = (sz[3] - sz[2] * sz[2] / N) / N;
+                mg = zs_g + sz[0] * a.inv_n;
+                mf = zs_f + sz[2] * a.inv_n;
+                double vg = (sz[1] - sz[0] * sz[0] * a.inv_n) * a.inv_n, vf = (sz[3] - sz[2] * sz[2] * a.inv_n) * a.inv_n;
                 vg = vg > 0.0 ? vg : 0.0;
                 vf = vf > 0.0 ? vf : 0.0;
-                rg = 1.0 / sqrt(vg + (double)a.eps_bn);
-                rf = 1.0 / sqrt(vf + (double)a.eps_bn);
+                // rstd to float accuracy: a uniform scale on the normalised value (not amplified), and the
+                // SAME number reaches the backward through `saved`
+                rg = (double)__builtin_amdgcn_rsqf((float)(vg + (double)a.eps_bn));
+                rf = (double)__builtin_amdgcn_rsqf((float)(vf + (double)a.eps_bn));
                 if (k == 0 && threadIdx.x == 0) {
-                    const double mom_ = a.momentum, unb = (double)N / ((double)N - 1.0);
+                    const double mom_ = a.momentum, unb = a.unbias_n;
                     gg.run_mean[c] = (float)((1.0 - mom_) * (double)prm[0] + mom_ * mg);
                     gg.run_var[c] = (float)((1.0 - mom_) * (double)prv[0] + mom_ * vg * unb);
                     if (a.sn_two) {
@@ -449,10 +451,10 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
                 }
             } else {
                 mg = prm[0];
-                rg = 1.0 / sqrt((double)prv[0] + (double)a.eps_bn);
+                rg = (double)__builtin_amdgcn_rsqf(prv[0] + a.eps_bn);
                 if (a.sn_two) {
                     mf = prm[1];
-                    rf = 1.0 / sqrt((double)prv[1] + (double)a.eps_bn);
+                    rf = (double)__builtin_amdgcn_rsqf(prv[1] + a.eps_bn);
                 }
             }
             if (saved && k == 0 && threadIdx.x == 0) {
@@ -486,10 +488,10 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
                 if (saved) {
                     const size_t p = (size_t)n * C + c;
                     store_fwd_plane<R>(saved, P, p, f);
-                    saved[SV_G * P + p] = g;
-                    saved[SV_ZH_G * P + p] = zhg;
-                    saved[SV_F * P + p] = fg;
-                    saved[SV_ZH_F * P + p] = zhf;
+                    saved[sv_at(p, SV_G)] = g;
+                    saved[sv_at(p, SV_ZH_G)] = zhg;
+                    saved[sv_at(p, SV_F)] = fg;
+                    saved[sv_at(p, SV_ZH_F)] = zhf;
                 }
             }
         }
@@ -585,28 +587,28 @@ __global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
             const size_t p = (size_t)(n0 + s < N ? n0 + s : 0) * C + c;
-            own_si[s] = (float)saved[SV_MU_C * P + p];
-            own_so[s] = BOXED ? (float)saved[SV_MU_O * P + p] : 0.f;
+            own_si[s] = (float)saved[sv_at(p, SV_MU_C)];
+            own_so[s] = BOXED ? (float)saved[sv_at(p, SV_MU_O)] : 0.f;
         }
         for (int n = threadIdx.x; n < N; n += kBlock) {
             const size_t p = (size_t)n * C + c;
             float* sf = svf + n * F_N;
             double* sd = svd + n * D_N;
-            sd[D_MU_C] = saved[SV_MU_C * P + p];
-            sd[D_MU_S] = saved[SV_MU_S * P + p];
-            sd[D_ZH_G] = saved[SV_ZH_G * P + p];
-            sd[D_ZH_F] = saved[SV_ZH_F * P + p];
-            sf[F_A1] = (float)saved[SV_A1 * P + p];
-            sf[F_M_IN] = (float)saved[SV_M_IN * P + p];
-            sf[F_MU_O] = (float)saved[SV_MU_O * P + p];
-            sf[F_MU_P] = (float)saved[SV_MU_P * P + p];
-            sf[F_G] = (float)saved[SV_G * P + p];
-            sf[F_F] = (float)saved[SV_F * P + p];
-            sf[F_A] = (float)saved[SV_A * P + p];
-            sf[F_SIG_P] = (float)saved[SV_SIG_P * P + p];
-            sf[F_SIG_C] = (float)saved[SV_SIG_C * P + p];
-            sf[F_M2C] = (float)saved[SV_M2C * P + p];
-            sf[F_SIG_S] = (float)saved[SV_SIG_S * P + p];
+            sd[D_MU_C] = saved[sv_at(p, SV_MU_C)];
+            sd[D_MU_S] = saved[sv_at(p, SV_MU_S)];
+            sd[D_ZH_G] = saved[sv_at(p, SV_ZH_G)];
+            sd[D_ZH_F] = saved[sv_at(p, SV_ZH_F)];
+            sf[F_A1] = (float)saved[sv_at(p, SV_A1)];
+            sf[F_M_IN] = (float)saved[sv_at(p, SV_M_IN)];
+            sf[F_MU_O] = (float)saved[sv_at(p, SV_MU_O)];
+            sf[F_MU_P] = (float)saved[sv_at(p, SV_MU_P)];
+            sf[F_G] = (float)saved[sv_at(p, SV_G)];
+            sf[F_F] = (float)saved[sv_at(p, SV_F)];
+            sf[F_A] = (float)saved[sv_at(p, SV_A)];
+            sf[F_SIG_P] = (float)saved[sv_at(p, SV_SIG_P)];
+            sf[F_SIG_C] = (float)saved[sv_at(p, SV_SIG_C)];
+            sf[F_M2C] = (float)saved[sv_at(p, SV_M2C)];
+            sf[F_SIG_S] = (float)saved[sv_at(p, SV_SIG_S)];
         }
 
         // ---- load G and x planes (the only reads)

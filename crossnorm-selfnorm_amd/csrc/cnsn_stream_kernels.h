@@ -225,14 +225,15 @@ __global__ __launch_bounds__(kBlock) void apply_fwd_kernel(const T* __restrict__
 template <typename T, int VEC, int LPP, bool BOXED>
 __global__ __launch_bounds__(kBlock) void bwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ x, Geom g,
                                                             const double* __restrict__ shift_in,
-                                                            const double* __restrict__ shift_out,
+                                                            const double* __restrict__ shift_out, int shift_stride,
                                                             float* __restrict__ out) {
     constexpr int NACC = BOXED ? 4 : 2;
     __shared__ float lds[4 * NACC];
     const PlaneId<LPP> id(g.P);
     const size_t off = (size_t)id.p * g.M;
-    const float si = shift_in ? (float)shift_in[id.p] : 0.f;  // mid_bwd_a undoes this rounding
-    const float so = (BOXED && shift_out) ? (float)shift_out[id.p] : 0.f;
+    // shifts live in the per-plane records of `saved` (stride = record length); mid_bwd_a undoes the rounding
+    const float si = shift_in ? (float)shift_in[(size_t)id.p * shift_stride] : 0.f;
+    const float so = (BOXED && shift_out) ? (float)shift_out[(size_t)id.p * shift_stride] : 0.f;
     float part[NACC][VEC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k)
