@@ -220,8 +220,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
+        ngpu = torch.cuda.device_count()
+        local = local % max(ngpu, 1)          # (smoke runs may put several ranks on one GPU)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # nccl == RCCL on ROCm
+        backend = os.environ.get("CNSN_BENCH_BACKEND", "nccl")                   # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:                                                                    # gloo: plumbing smoke test only
+            dist.init_process_group(backend)
     else:
         dist = None
     assert torch.cuda.is_available(), "bench.py needs an MI355X (use gpurun)"
@@ -229,6 +235,7 @@ def main():
     torch.cuda.set_device(dev)
 
     import cnsn_amd
+    from cnsn_amd import data_parallel as dp
     cnsn_amd.lib()                                    # fail loudly now if the .so is missing
     cnsn_amd.set_strategy(args.strategy)
     import numpy as np
@@ -244,8 +251,7 @@ def main():
     b = 4 if dtype == torch.float32 else 2
     e = n * c * h * w
 
-    torch.manual_seed(1234 + rank)                    # ranks draw different perms / boxes
-    np.random.seed(1234 + rank)
+    dp.seed_rank(1234, rank)                          # ranks draw different perms / boxes
     x = conditioned(shape, dev, dtype, 10 + rank).requires_grad_()
     gy = torch.randn(shape, device=dev, generator=torch.Generator(device=dev).manual_seed(20 + rank)).to(dtype)
     mod = cnsn_amd.CNSN(cnsn_amd.CrossNorm(args.crop, 1) if args.kind != "sn" else None,
@@ -269,9 +275,7 @@ def main():
         if i is not None:
             ev[i][2].record()
         if dist is not None and params:               # DDP-style gradient all-reduce (RCCL over xGMI)
-            flat = torch.cat([p.grad.reshape(-1) for p in params])
-            dist.all_reduce(flat)
-            flat.div_(world)
+            dp.allreduce_gradients(params)
 
     for _ in range(args.warmup):
         step()
@@ -287,7 +291,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

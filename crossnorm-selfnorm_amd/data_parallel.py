@@ -39,7 +39,12 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group: Optional[di
             by_dtype.setdefault(p.grad.dtype, []).append(p.grad)
     for grads in by_dtype.values():
         flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if flat.is_cuda and dist.get_backend(group) == "gloo":   # CPU-only backend (tests): stage on host
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         if average:
             flat.div_(world)
         off = 0
