@@ -120,11 +120,11 @@ def secondary_workloads(cnsn_amd, shape, dev, args):
                 p.grad = None
             mod(x).backward(gy)
 
-        for _ in range(5):
+        for _ in range(10):
             one()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        k = 20
+        k = 30
         for _ in range(k):
             one()
         torch.cuda.synchronize()

@@ -129,7 +129,7 @@ int resident_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const 
     const size_t lds = res_lds_bytes(p.N, NG, 4 * rp.ppw, FC_ROWS, false);
     unsigned* ctl = (unsigned*)workspace;
     unsigned long long* gran = (unsigned long long*)((char*)workspace + kCtlBytes);
-    const size_t zero_bytes = kCtlBytes + (size_t)p.N * p.C * NG * 8;
+    const size_t fill_bytes = kCtlBytes + (size_t)p.N * p.C * (NG / 2) * 8;  // control block + granules
     int status = CNSN_E_UNSUPPORTED;
     dispatch_res(p.dtype, rp.vec, rp.nv, [&](auto tt, auto vt, auto nt, auto pt) {
         using T = typename decltype(tt)::type;
@@ -137,7 +137,7 @@ int resident_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const 
         auto launch = [&](auto kern) {
             const int grid = grid_for(kern, lds, rp.K, ra.items);
             if (grid < rp.K) return;
-            hipError_t e = hipMemsetAsync(workspace, 0, zero_bytes, stream);
+            hipError_t e = hipMemsetAsync(workspace, 0xff, fill_bytes, stream);  // 'empty' granules, idle control word
             if (e != hipSuccess) {
                 status = (int)e;
                 return;
@@ -167,7 +167,7 @@ int resident_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const
     const size_t lds = res_lds_bytes(p.N, NS, 4 * rp.ppw, BC_ROWS, true);
     unsigned* ctl = (unsigned*)workspace;
     unsigned long long* gran = (unsigned long long*)((char*)workspace + kCtlBytes);
-    const size_t zero_bytes = kCtlBytes + (size_t)p.N * p.C * NS * 8;
+    const size_t fill_bytes = kCtlBytes + (size_t)p.N * p.C * (NS / 2) * 8;
     int status = CNSN_E_UNSUPPORTED;
     dispatch_res(p.dtype, rp.vec, rp.nv, [&](auto tt, auto vt, auto nt, auto pt) {
         using T = typename decltype(tt)::type;
@@ -175,7 +175,7 @@ int resident_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const
         auto launch = [&](auto kern) {
             const int grid = grid_for(kern, lds, rp.K, ra.items);
             if (grid < rp.K) return;
-            hipError_t e = hipMemsetAsync(workspace, 0, zero_bytes, stream);
+            hipError_t e = hipMemsetAsync(workspace, 0xff, fill_bytes, stream);  // 'empty' granules, idle control word
             if (e != hipSuccess) {
                 status = (int)e;
                 return;

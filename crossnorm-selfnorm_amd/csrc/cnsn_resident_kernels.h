@@ -10,10 +10,10 @@
 // i.e. 2*E*b and 3*E*b bytes of HBM traffic instead of the two-pass strategy's 3*E*b and 5*E*b.
 //
 // Cluster exchange (MI355X_MICROARCH.md "handoff"/"allgather", cdna_hip_programming.md G16 R2):
-// each plane's scalars are published as 8-byte {tag, float} granules with ONE relaxed agent-scope
-// (sc1, write-through) atomic store each; one wave per workgroup re-reads the channel's granules
-// with relaxed agent-scope loads until every tag matches.  No fences, no flags, no counters; the
-// granule area is zeroed by a memset node on the stream before every launch (tag 1 = valid).
+// each plane's scalars are published two floats at a time as 8-byte granules, ONE relaxed agent-scope
+// (sc1, write-through) atomic store each; one wave per workgroup re-reads the channel's granules with
+// relaxed agent-scope loads until none holds the 'empty' pattern.  No fences, no flags, no counters;
+// the granule area is memset to the empty pattern on the stream before every launch.
 //
 // Deadlock freedom: the grid is persistent, G = (resident workgroups) rounded down to a multiple
 // of K, and workgroup b handles items b, b+G, ...; the K members of a cluster are therefore
@@ -65,26 +65,35 @@ __device__ __forceinline__ void startup_skew(const ResArgs& ra) {
     for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
 }
 
-__device__ __forceinline__ void put_granule(unsigned long long* p, float v) {
-    __hip_atomic_store((gu64*)p, (1ull << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+// A granule is ONE naturally aligned 8-byte word holding TWO floats, written by one relaxed agent-scope
+// (sc1, write-through) atomic store.  "Not yet written" is the all-ones pattern the granule area is
+// memset to before every launch; NaNs are canonicalised on publish so a payload can never equal it.
+constexpr unsigned long long kGranuleEmpty = ~0ull;
+constexpr unsigned kCtlIdle = 0xffffffffu;  // control word 0 after the memset; anything else = give up
+
+__device__ __forceinline__ unsigned canon_bits(float v) { return v != v ? 0x7fc00000u : __float_as_uint(v); }
+
+__device__ __forceinline__ void put_granule(unsigned long long* p, float lo, float hi) {
+    __hip_atomic_store((gu64*)p, ((unsigned long long)canon_bits(hi) << 32) | (unsigned long long)canon_bits(lo),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ONE wave gathers `total` granules into LDS (as floats); re-reads all of them until every tag is set.
+// ONE wave gathers `total` granules (2*total floats) into LDS; re-reads all of them until none is empty.
 __device__ __forceinline__ void sweep_granules(const unsigned long long* g, int total, float* vals, unsigned* ctl) {
     const int lane = threadIdx.x & 63;
     for (unsigned spins = 0;; ++spins) {
         bool ok = true;
         for (int i = lane; i < total; i += 64) {
             const unsigned long long v = __hip_atomic_load((gu64*)(g + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok &= (v >> 32) == 1ull;
-            vals[i] = __uint_as_float((unsigned)v);
+            ok &= v != kGranuleEmpty;
+            vals[2 * i] = __uint_as_float((unsigned)v);
+            vals[2 * i + 1] = __uint_as_float((unsigned)(v >> 32));
         }
         if (__all(ok)) return;
         __builtin_amdgcn_s_sleep(4);
         if ((spins & 15u) == 15u) {
             const bool dead = spins > kSpinLimit ||
-                              __hip_atomic_load((gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                              __hip_atomic_load((gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kCtlIdle;
             if (dead) {  // give up: raise the flag so every other wait drains too
                 if (lane == 0) __hip_atomic_store((gu32*)ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return;
@@ -374,11 +383,14 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
                 pub[4] = ms;
                 pub[5] = wave_sum(qs);
             }
-            if (n < N && lane < NG) {
-                float v = pub[0];
+            if (n < N && lane < NG / 2) {  // lane m publishes the pair (pub[2m], pub[2m+1])
+                float lo = pub[0], hi = pub[1];
 #pragma unroll
-                for (int m = 1; m < NG; ++m) v = (lane == m) ? pub[m] : v;
-                put_granule(gran + ((size_t)c * N + n) * NG + lane, v);
+                for (int m = 1; m < NG / 2; ++m) {
+                    lo = (lane == m) ? pub[2 * m] : lo;
+                    hi = (lane == m) ? pub[2 * m + 1] : hi;
+                }
+                put_granule(gran + ((size_t)c * N + n) * (NG / 2) + lane, lo, hi);
             }
         }
 
@@ -386,7 +398,7 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
         CNSN_STAMP(1);
         __syncthreads();  // the previous item's readers of vals/zbuf are done
         CNSN_STAMP(2);
-        if (wave == 0) sweep_granules(gran + (size_t)c * N * NG, N * NG, vals, ctl);
+        if (wave == 0) sweep_granules(gran + (size_t)c * N * (NG / 2), N * (NG / 2), vals, ctl);
         __syncthreads();
         CNSN_STAMP(3);
 
@@ -653,18 +665,21 @@ __global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW
                 }
 #pragma unroll
             for (int m = 0; m < NS; ++m) acc[m] = wave_sum(acc[m]);
-            if (n < N && lane < NS) {
-                float v = acc[0];
+            if (n < N && lane < NS / 2) {
+                float lo = acc[0], hi = acc[1];
 #pragma unroll
-                for (int m = 1; m < NS; ++m) v = (lane == m) ? acc[m] : v;
-                put_granule(gran + ((size_t)c * N + n) * NS + lane, v);
+                for (int m = 1; m < NS / 2; ++m) {
+                    lo = (lane == m) ? acc[2 * m] : lo;
+                    hi = (lane == m) ? acc[2 * m + 1] : hi;
+                }
+                put_granule(gran + ((size_t)c * N + n) * (NS / 2) + lane, lo, hi);
             }
         }
 
         CNSN_STAMP(1);
         __syncthreads();
         CNSN_STAMP(2);
-        if (wave == 0) sweep_granules(gran + (size_t)c * N * NS, N * NS, vals, ctl);
+        if (wave == 0) sweep_granules(gran + (size_t)c * N * (NS / 2), N * (NS / 2), vals, ctl);
         __syncthreads();
         CNSN_STAMP(3);
 
