@@ -89,6 +89,39 @@ def lib():
     return _lib
 
 
+GLUE_DIR = os.path.join(_HERE, "_glue")
+GLUE_PATH = os.path.join(GLUE_DIR, "cnsn_glue.so")
+_glue = None
+_glue_tried = False
+
+
+def glue():
+    """The C++ autograd glue (csrc/glue/cnsn_glue.cpp) if it has been built, else None.
+
+    It calls the same C ABI as the ctypes path; it only removes ~0.1 ms of Python per call.  Its
+    undefined `cnsn_*` symbols are resolved against libcnsn_hip.so, which is therefore loaded first with
+    RTLD_GLOBAL.  `CNSN_NO_GLUE=1` forces the ctypes path (tests exercise both)."""
+    global _glue, _glue_tried
+    if _glue_tried:
+        return _glue
+    _glue_tried = True
+    if os.environ.get("CNSN_NO_GLUE") == "1" or not os.path.exists(GLUE_PATH):
+        return None
+    lib()
+    C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    import importlib.machinery
+    import importlib.util
+    import torch  # noqa: F401  (the extension links against libtorch)
+    loader = importlib.machinery.ExtensionFileLoader("cnsn_glue", GLUE_PATH)
+    spec = importlib.util.spec_from_loader("cnsn_glue", loader)
+    mod = importlib.util.module_from_spec(spec)
+    loader.exec_module(mod)
+    if mod.abi_version() != ABI_VERSION:
+        raise CnsnError(f"cnsn_glue.so was built against ABI {mod.abi_version()}, binding expects {ABI_VERSION}")
+    _glue = mod
+    return _glue
+
+
 def check(status: int, what: str):
     if status != 0:
         msg = lib().cnsn_status_string(status).decode()

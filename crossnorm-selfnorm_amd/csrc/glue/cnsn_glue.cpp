@@ -1,0 +1,315 @@
+// C++ autograd glue between PyTorch-ROCm and the C ABI of libcnsn_hip.so.
+//
+// torch here is plumbing only — device memory (caching allocator), the current HIP stream, autograd
+// book-keeping: every forward/backward is ONE call through include/cnsn_hip.h.  This file does the same
+// job as functional.py's ctypes path (which stays as the alternative when this module has not been
+// built); it exists because the Python glue costs ~0.1 ms of host time per call, which is what bounds a
+// network made of many small CNSN sites (WideResNet-40-2: 18 sites at 32x32 and below).
+#include <torch/extension.h>
+
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
+
+#include <array>
+#include <cmath>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/cnsn_hip.h"
+
+namespace {
+
+using torch::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+int dtype_code(const Tensor& x) {
+    switch (x.scalar_type()) {
+        case at::kFloat: return CNSN_F32;
+        case at::kBFloat16: return CNSN_BF16;
+        case at::kHalf: return CNSN_F16;
+        default: TORCH_CHECK_TYPE(false, "cnsn: dtype ", x.scalar_type(), " not supported (float32, bfloat16, float16)");
+    }
+}
+
+void check_status(int st, const char* what) {
+    if (st == 0) return;
+    if (st == CNSN_E_BATCH) {  // the exception type nn.BatchNorm1d raises
+        TORCH_CHECK_VALUE(false, what, ": ", cnsn_status_string(st));
+    }
+    TORCH_CHECK(false, what, " failed with status ", st, ": ", cnsn_status_string(st));
+}
+
+Tensor f32c(const Tensor& t) {
+    Tensor d = t.detach();
+    if (d.scalar_type() != at::kFloat) d = d.to(at::kFloat);
+    return d.contiguous();
+}
+
+// host -> device copy of the (tiny) permutation through a ring of pinned staging buffers, so that the
+// launch thread never waits for the stream (the reference's `torch.randperm(N).to(device)` does)
+Tensor perm_to_device(const Tensor& idx, const at::Device& dev) {
+    if (idx.is_cuda()) return idx.to(dev, at::kLong).contiguous();
+    struct Slot {
+        Tensor buf;
+        hipEvent_t ev = nullptr;
+    };
+    static std::mutex mu;
+    static std::unordered_map<int64_t, std::pair<int, std::array<Slot, 8>>> rings;
+    const int64_t n = idx.numel();
+    std::lock_guard<std::mutex> lock(mu);
+    auto& ring = rings[(int64_t)dev.index() * (1ll << 40) + n];
+    Slot& s = ring.second[ring.first++ % 8];
+    if (!s.buf.defined()) {
+        s.buf = at::empty({n}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+        TORCH_CHECK(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) == hipSuccess, "cnsn: hipEventCreate");
+    } else {
+        hipEventSynchronize(s.ev);  // the copy that last used this slot has drained
+    }
+    s.buf.copy_(idx.reshape({-1}));
+    Tensor out = s.buf.to(dev, /*non_blocking=*/true);
+    hipEventRecord(s.ev, c10::hip::getCurrentHIPStream(dev.index()).stream());
+    return out;
+}
+
+struct Config {
+    int64_t cn_active, cbox[4], sbox[4];
+    double lam;
+    int64_t sn_active, sn_two, sn_training;
+    double eps_cn, eps_sn, eps_bn, momentum;
+    int64_t strategy;
+};
+
+cnsn_problem_t make_problem(const Tensor& x, const Config& c) {
+    cnsn_problem_t p{};
+    p.struct_bytes = (int32_t)sizeof(cnsn_problem_t);
+    p.dtype = dtype_code(x);
+    p.N = (int32_t)x.size(0);
+    p.C = (int32_t)x.size(1);
+    p.H = (int32_t)x.size(2);
+    p.W = (int32_t)x.size(3);
+    p.cn_active = (int32_t)c.cn_active;
+    for (int i = 0; i < 4; ++i) {
+        p.content_box[i] = (int32_t)c.cbox[i];
+        p.style_box[i] = (int32_t)c.sbox[i];
+    }
+    p.lam = (float)c.lam;
+    p.eps_cn = (float)c.eps_cn;
+    p.sn_active = (int32_t)c.sn_active;
+    p.sn_two = (int32_t)c.sn_two;
+    p.sn_training = (int32_t)c.sn_training;
+    p.eps_sn = (float)c.eps_sn;
+    p.eps_bn = (float)c.eps_bn;
+    p.momentum = (float)c.momentum;
+    p.strategy = (int32_t)c.strategy;
+    return p;
+}
+
+struct GateTensors {  // float32 contiguous views/copies + where running stats must be copied back to
+    Tensor w, gamma, beta, rm, rv, rm_src, rv_src;
+    bool direct = true;
+    cnsn_gate_t c{};
+    void init(const Tensor& w_, const Tensor& g_, const Tensor& b_, const Tensor& rm_, const Tensor& rv_) {
+        w = f32c(w_);
+        gamma = f32c(g_);
+        beta = f32c(b_);
+        direct = rm_.scalar_type() == at::kFloat && rm_.is_contiguous() && rv_.scalar_type() == at::kFloat &&
+                 rv_.is_contiguous();
+        rm_src = rm_;
+        rv_src = rv_;
+        rm = direct ? rm_.detach() : f32c(rm_);
+        rv = direct ? rv_.detach() : f32c(rv_);
+        c.fc_weight = w.data_ptr<float>();
+        c.bn_weight = gamma.data_ptr<float>();
+        c.bn_bias = beta.data_ptr<float>();
+        c.running_mean = rm.data_ptr<float>();
+        c.running_var = rv.data_ptr<float>();
+    }
+    void write_back() {
+        if (!direct) {
+            rm_src.copy_(rm);
+            rv_src.copy_(rv);
+        }
+    }
+};
+
+class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
+   public:
+    // cfg: [cn_active, cb0..3, sb0..3, sn_active, sn_two, sn_training, strategy, need_backward]
+    // fcfg: [lam, eps_cn, eps_sn, eps_bn, momentum]
+    static Tensor forward(AutogradContext* ctx, const Tensor& x_in, std::vector<int64_t> cfg, std::vector<double> fcfg,
+                          const c10::optional<Tensor>& perm_in, const c10::optional<Tensor>& chan_in,
+                          const c10::optional<Tensor>& g_w, const c10::optional<Tensor>& g_gamma,
+                          const c10::optional<Tensor>& g_beta, const c10::optional<Tensor>& g_rm,
+                          const c10::optional<Tensor>& g_rv, const c10::optional<Tensor>& f_w,
+                          const c10::optional<Tensor>& f_gamma, const c10::optional<Tensor>& f_beta,
+                          const c10::optional<Tensor>& f_rm, const c10::optional<Tensor>& f_rv) {
+        TORCH_CHECK(x_in.is_cuda(), "cnsn_forward: got a ", x_in.device().type(),
+                    " tensor. This implementation runs on MI355X HIP device tensors only; there is no CPU path.");
+        TORCH_CHECK(x_in.dim() == 4, "expected an (N, C, H, W) tensor");
+        TORCH_CHECK(cfg.size() == 14 && fcfg.size() == 5, "cnsn glue: bad config vectors");
+        Config c{};
+        c.cn_active = cfg[0];
+        for (int i = 0; i < 4; ++i) {
+            c.cbox[i] = cfg[1 + i];
+            c.sbox[i] = cfg[5 + i];
+        }
+        c.sn_active = cfg[9];
+        c.sn_two = cfg[10];
+        c.sn_training = cfg[11];
+        c.strategy = cfg[12];
+        c.lam = fcfg[0];
+        c.eps_cn = fcfg[1];
+        c.eps_sn = fcfg[2];
+        c.eps_bn = fcfg[3];
+        c.momentum = fcfg[4];
+
+        const Tensor x = x_in.contiguous();  // reference cnsn.py:14
+        const cnsn_problem_t prob = make_problem(x, c);
+        const at::Device dev = x.device();
+        Tensor perm, chan;
+        if (c.cn_active) {
+            TORCH_CHECK(perm_in.has_value(), "cnsn_forward: CrossNorm needs the batch permutation");
+            perm = perm_to_device(*perm_in, dev);
+            if (chan_in.has_value()) chan = perm_to_device(*chan_in, dev);
+        }
+        GateTensors gg, gf;
+        const bool two = c.sn_active && c.sn_two;
+        if (c.sn_active) gg.init(*g_w, *g_gamma, *g_beta, *g_rm, *g_rv);
+        if (two) gf.init(*f_w, *f_gamma, *f_beta, *f_rm, *f_rv);
+
+        Tensor y = at::empty_like(x);
+        const bool need_bwd = cfg[13] != 0;  // decided by the caller (grad mode on and something requires grad)
+        const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
+        const size_t ws_bytes = cnsn_workspace_bytes(&prob);
+        Tensor saved;
+        if (need_bwd && ws_bytes > 0) saved = at::empty({(int64_t)cnsn_saved_floats(&prob)}, fopt);
+        Tensor ws = at::empty({(int64_t)(ws_bytes / 4) + 1}, fopt);
+        hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+        const int st = cnsn_forward(&prob, x.data_ptr(), c.cn_active ? perm.data_ptr<int64_t>() : nullptr,
+                                    chan.defined() ? chan.data_ptr<int64_t>() : nullptr, c.sn_active ? &gg.c : nullptr,
+                                    two ? &gf.c : nullptr, y.data_ptr(), saved.defined() ? saved.data_ptr<float>() : nullptr,
+                                    ws.data_ptr(), ws_bytes, (void*)stream);
+        check_status(st, "cnsn_forward");
+        if (c.sn_active && c.sn_training) {
+            gg.write_back();
+            if (two) gf.write_back();
+        }
+        if (need_bwd) {
+            ctx->saved_data["cfg"] = cfg;
+            ctx->saved_data["fcfg"] = fcfg;
+            ctx->saved_data["pd"] = std::vector<int64_t>{
+                c.sn_active ? (int64_t)g_w->scalar_type() : -1, c.sn_active ? (int64_t)g_gamma->scalar_type() : -1,
+                c.sn_active ? (int64_t)g_beta->scalar_type() : -1, two ? (int64_t)f_w->scalar_type() : -1,
+                two ? (int64_t)f_gamma->scalar_type() : -1, two ? (int64_t)f_beta->scalar_type() : -1};
+            Tensor none;
+            ctx->save_for_backward({x, saved, perm.defined() ? perm : none, chan.defined() ? chan : none,
+                                    c.sn_active ? gg.w : none, c.sn_active ? gg.gamma : none, c.sn_active ? gg.beta : none,
+                                    c.sn_active ? gg.rm : none, c.sn_active ? gg.rv : none, two ? gf.w : none,
+                                    two ? gf.gamma : none, two ? gf.beta : none, two ? gf.rm : none, two ? gf.rv : none});
+        }
+        return y;
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const auto sv = ctx->get_saved_variables();
+        const Tensor &x = sv[0], &saved = sv[1], &perm = sv[2], &chan = sv[3];
+        const auto cfg = ctx->saved_data["cfg"].toIntVector();
+        const auto fcfg = ctx->saved_data["fcfg"].toDoubleVector();
+        const auto pd = ctx->saved_data["pd"].toIntVector();
+        Config c{};
+        c.cn_active = cfg[0];
+        for (int i = 0; i < 4; ++i) {
+            c.cbox[i] = cfg[1 + i];
+            c.sbox[i] = cfg[5 + i];
+        }
+        c.sn_active = cfg[9];
+        c.sn_two = cfg[10];
+        c.sn_training = cfg[11];
+        c.strategy = cfg[12];
+        c.lam = fcfg[0];
+        c.eps_cn = fcfg[1];
+        c.eps_sn = fcfg[2];
+        c.eps_bn = fcfg[3];
+        c.momentum = fcfg[4];
+        const cnsn_problem_t prob = make_problem(x, c);
+        const bool two = c.sn_active && c.sn_two;
+        const at::Device dev = x.device();
+
+        Tensor gy = grads[0].contiguous();
+        if (gy.scalar_type() != x.scalar_type()) gy = gy.to(x.scalar_type());
+        Tensor dx = at::empty_like(x);
+        const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
+        const size_t ws_bytes = cnsn_workspace_bytes(&prob);
+        Tensor ws = at::empty({(int64_t)(ws_bytes / 4) + 1}, fopt);
+        const int64_t Cn = x.size(1);
+
+        cnsn_gate_t gg{}, gf{};
+        cnsn_gate_grad_t dgg{}, dgf{};
+        Tensor flat_g, flat_f;
+        auto fill_gate = [&](cnsn_gate_t& g, int base) {
+            g.fc_weight = sv[base].data_ptr<float>();
+            g.bn_weight = sv[base + 1].data_ptr<float>();
+            g.bn_bias = sv[base + 2].data_ptr<float>();
+            g.running_mean = sv[base + 3].data_ptr<float>();
+            g.running_var = sv[base + 4].data_ptr<float>();
+        };
+        auto make_grads = [&](Tensor& flat, cnsn_gate_grad_t& d) {  // one allocation: dw (C,1,2) | dgamma (C) | dbeta (C)
+            flat = at::empty({4 * Cn}, fopt);
+            d.d_fc_weight = flat.data_ptr<float>();
+            d.d_bn_weight = flat.data_ptr<float>() + 2 * Cn;
+            d.d_bn_bias = flat.data_ptr<float>() + 3 * Cn;
+        };
+        if (c.sn_active) {
+            fill_gate(gg, 4);
+            make_grads(flat_g, dgg);
+            if (two) {
+                fill_gate(gf, 9);
+                make_grads(flat_f, dgf);
+            }
+        }
+        hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+        const int st = cnsn_backward(&prob, gy.data_ptr(), x.data_ptr(), perm.defined() ? perm.data_ptr<int64_t>() : nullptr,
+                                     chan.defined() ? chan.data_ptr<int64_t>() : nullptr, c.sn_active ? &gg : nullptr,
+                                     two ? &gf : nullptr, saved.data_ptr<float>(), dx.data_ptr(),
+                                     c.sn_active ? &dgg : nullptr, two ? &dgf : nullptr, ws.data_ptr(), ws_bytes,
+                                     (void*)stream);
+        check_status(st, "cnsn_backward");
+
+        auto cast = [](const Tensor& t, int64_t code) {
+            return (code >= 0 && (int64_t)t.scalar_type() != code) ? t.to((at::ScalarType)code) : t;
+        };
+        Tensor none;
+        variable_list out(15, none);
+        out[0] = dx;
+        if (c.sn_active) {
+            out[5] = cast(flat_g.narrow(0, 0, 2 * Cn).view({Cn, 1, 2}), pd[0]);
+            out[6] = cast(flat_g.narrow(0, 2 * Cn, Cn), pd[1]);
+            out[7] = cast(flat_g.narrow(0, 3 * Cn, Cn), pd[2]);
+            if (two) {
+                out[10] = cast(flat_f.narrow(0, 0, 2 * Cn).view({Cn, 1, 2}), pd[3]);
+                out[11] = cast(flat_f.narrow(0, 2 * Cn, Cn), pd[4]);
+                out[12] = cast(flat_f.narrow(0, 3 * Cn, Cn), pd[5]);
+            }
+        }
+        return out;
+    }
+};
+
+Tensor fused_cnsn(const Tensor& x, std::vector<int64_t> cfg, std::vector<double> fcfg, const c10::optional<Tensor>& perm,
+                  const c10::optional<Tensor>& chan, const c10::optional<Tensor>& g_w,
+                  const c10::optional<Tensor>& g_gamma, const c10::optional<Tensor>& g_beta,
+                  const c10::optional<Tensor>& g_rm, const c10::optional<Tensor>& g_rv, const c10::optional<Tensor>& f_w,
+                  const c10::optional<Tensor>& f_gamma, const c10::optional<Tensor>& f_beta,
+                  const c10::optional<Tensor>& f_rm, const c10::optional<Tensor>& f_rv) {
+    return FusedCNSN::apply(x, cfg, fcfg, perm, chan, g_w, g_gamma, g_beta, g_rm, g_rv, f_w, f_gamma, f_beta, f_rm, f_rv);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "C++ autograd glue over the C ABI of libcnsn_hip.so";
+    m.def("fused_cnsn", &fused_cnsn, "fused CrossNorm+SelfNorm forward (autograd-aware)");
+    m.def("abi_version", []() { return cnsn_abi_version(); });
+}

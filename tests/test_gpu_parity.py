@@ -450,3 +450,32 @@ def test_full_size_properties(strategy, dtype, crop):
     gw_h, gw_o = sn_h.g_fc.weight.grad, sn_o.g_fc.weight.grad
     assert float((gw_h - gw_o).abs().max()) <= (5e-2 if dtype != torch.float32 else 1e-3) * float(gw_o.abs().max())
     close(sn_h.g_bn.running_var, sn_o.g_bn.running_var, 1e-4, "running_var")
+
+
+def test_ctypes_and_cpp_glue_paths_agree():
+    """functional.fused_cnsn goes through the C++ autograd glue when it is built, through ctypes
+    otherwise; both call the same C ABI and must give identical bits."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch, numpy as np
+sys.path.insert(0, %r)
+import cnsn_amd
+from tests.golden.gen_golden_fill import fill_sn
+torch.manual_seed(0); np.random.seed(0)
+m = cnsn_amd.CNSN(cnsn_amd.CrossNorm("both", 1), fill_sn(cnsn_amd.SelfNorm(8), 5, torch.float32)).cuda().train()
+x = torch.randn(6, 8, 20, 24).cuda().requires_grad_()
+m.crossnorm.active = True
+y = m(x); y.backward(torch.ones_like(y))
+print(float(y.double().sum()), float(x.grad.double().abs().sum()), float(m.selfnorm.g_fc.weight.grad.double().abs().sum()),
+      int(cnsn_amd._ffi.glue() is not None))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env_extra in ({}, {"CNSN_NO_GLUE": "1"}):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, "-c", code % root], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().split("\n")[-1].split())
+    assert outs[1][3] == "0"                                   # the second run really took the ctypes path
+    assert outs[0][:3] == outs[1][:3], outs
