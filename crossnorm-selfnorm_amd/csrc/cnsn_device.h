@@ -57,6 +57,38 @@ __device__ __forceinline__ void store_vec(T* p, const Vec<T, VEC>& v) {
     *reinterpret_cast<Vec<T, VEC>*>(p) = v;
 }
 
+// streaming variants (nt = non-temporal hint): every tensor here is far larger than the caches and each
+// line is used once per kernel, so keeping it resident only evicts something useful.  Measured on the
+// two-pass kernels at (256,256,56,56) fp32: apply_fwd 337 -> 262 us, apply_bwd 498 -> 418 us.
+#ifndef CNSN_NO_NT
+#define CNSN_NT_LOAD 1
+#define CNSN_NT_STORE 1
+#endif
+typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
+template <typename T, int VEC>
+__device__ __forceinline__ Vec<T, VEC> load_vec_nt(const T* p) {
+#ifdef CNSN_NT_LOAD
+    if constexpr (sizeof(T) * VEC == 16)
+        return __builtin_bit_cast(Vec<T, VEC>, __builtin_nontemporal_load(reinterpret_cast<const nt_u4*>(p)));
+    else if constexpr (sizeof(T) * VEC == 8)
+        return __builtin_bit_cast(Vec<T, VEC>, __builtin_nontemporal_load(reinterpret_cast<const nt_u2*>(p)));
+    else
+#endif
+        return load_vec<T, VEC>(p);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_vec_nt(T* p, const Vec<T, VEC>& v) {
+#ifdef CNSN_NT_STORE
+    if constexpr (sizeof(T) * VEC == 16)
+        __builtin_nontemporal_store(__builtin_bit_cast(nt_u4, v), reinterpret_cast<nt_u4*>(p));
+    else if constexpr (sizeof(T) * VEC == 8)
+        __builtin_nontemporal_store(__builtin_bit_cast(nt_u2, v), reinterpret_cast<nt_u2*>(p));
+    else
+#endif
+        store_vec<T, VEC>(p, v);
+}
+
 // ------------------------------------------------------------------------------------------------
 // cross-lane sums.  DPP inside a 16-lane row (no LDS traffic), v_readlane across the four rows.
 // ------------------------------------------------------------------------------------------------

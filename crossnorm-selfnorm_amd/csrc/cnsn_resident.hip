@@ -107,11 +107,17 @@ ResPlan resident_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, b
     rp.K = (p.N + own - 1) / own;
     if (res_lds_bytes(p.N, 6, own, BC_ROWS, true) > 64 * 1024) return rp;
     if (rp.K > 2 * cu_count()) return rp;
-    // AUTO: use the resident kernel where it measured faster than two-pass on MI355X (round-1 sweeps,
-    // profiles/r01_resident_tuning.md): forward wherever it is eligible; backward for every fp32 shape and,
-    // for 16-bit tensors, for the 1-vector (14x14) and >= 7-vector (56x56) plane classes — the 28x28 bf16
-    // backward still runs faster as two streaming passes.  RESIDENT forces it wherever eligible.
-    if (p.strategy == CNSN_STRATEGY_AUTO && backward && p.dtype != CNSN_F32 && !(rp.nv == 1 || rp.nv >= 7)) return rp;
+    // AUTO: use the resident kernels where they measured faster than the (non-temporal) two-pass kernels on
+    // MI355X (profiles/r01_resident_tuning.md, last sweep): every eligible fp32 shape, both directions; for
+    // 16-bit tensors only the 1-vector plane class (14x14) — the resident kernels are bound by the latency
+    // of the cluster exchange, which halving the bytes does not shorten, while two-pass bf16 streams at
+    // 5.5 TB/s.  A register bucket more than 25 % larger than the plane needs is not worth it either.
+    // CNSN_STRATEGY_RESIDENT forces the resident kernels wherever they are eligible.
+    if (p.strategy == CNSN_STRATEGY_AUTO) {
+        if ((rp.nv - need) * 4 > need) return rp;
+        if (p.dtype != CNSN_F32 && rp.nv != 1) return rp;
+    }
+    (void)backward;
     rp.ok = true;
     return rp;
 }

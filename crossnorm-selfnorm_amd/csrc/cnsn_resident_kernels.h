@@ -208,19 +208,27 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t slot_rsrc(const T* base, int p
     const int left = plane_bytes - j * SLOT;
     return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)j * 64 * VEC), 0, left > 0 ? left : 0, 0x00020000);
 }
+// cache policy of the plane traffic: aux bit 1 = nt (non-temporal) — each line is used once.  Measured at
+// (256,256,56,56) fp32: nt on loads and stores 0.921 ms/step vs 0.971 with the default policy.
+#ifndef CNSN_RES_LOAD_AUX
+#define CNSN_RES_LOAD_AUX 2
+#endif
+#ifndef CNSN_RES_STORE_AUX
+#define CNSN_RES_STORE_AUX 2
+#endif
 template <typename T, int VEC>
 __device__ __forceinline__ Raw<T, VEC> buf_load(__amdgpu_buffer_rsrc_t r, int voff) {
     if constexpr (sizeof(T) * VEC == 16)
-        return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, CNSN_RES_LOAD_AUX);
     else
-        return __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+        return __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, CNSN_RES_LOAD_AUX);
 }
 template <typename T, int VEC>
 __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, int voff, const Raw<T, VEC>& v) {
     if constexpr (sizeof(T) * VEC == 16)
-        __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, CNSN_RES_STORE_AUX);
     else
-        __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, 0, CNSN_RES_STORE_AUX);
 }
 
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }

@@ -13,27 +13,31 @@
 
 namespace cnsn {
 
-constexpr int kUnroll = 4;
+#ifndef CNSN_UNROLL
+#define CNSN_UNROLL 4
+#endif
+constexpr int kUnroll = CNSN_UNROLL;
 
 // stream one plane: consume(vec, vec_index)
-template <typename T, int VEC, int LPP, typename Consume>
+template <typename T, int VEC, int LPP, bool NT = false, typename Consume>
 __device__ __forceinline__ void stream1(const T* __restrict__ base, int nvec, int lane, Consume&& consume) {
     int i = lane;
     for (; i + (kUnroll - 1) * LPP < nvec; i += kUnroll * LPP) {
         Vec<T, VEC> v[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) v[u] = load_vec<T, VEC>(base + (size_t)(i + u * LPP) * VEC);
+        for (int u = 0; u < kUnroll; ++u)
+            v[u] = NT ? load_vec_nt<T, VEC>(base + (size_t)(i + u * LPP) * VEC) : load_vec<T, VEC>(base + (size_t)(i + u * LPP) * VEC);
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) consume(v[u], i + u * LPP);
     }
     for (; i < nvec; i += LPP) {
-        Vec<T, VEC> v = load_vec<T, VEC>(base + (size_t)i * VEC);
+        Vec<T, VEC> v = NT ? load_vec_nt<T, VEC>(base + (size_t)i * VEC) : load_vec<T, VEC>(base + (size_t)i * VEC);
         consume(v, i);
     }
 }
 
 // stream two planes in lock step: consume(vecA, vecB, vec_index)
-template <typename T, int VEC, int LPP, typename Consume>
+template <typename T, int VEC, int LPP, bool NT = false, typename Consume>
 __device__ __forceinline__ void stream2(const T* __restrict__ a, const T* __restrict__ b, int nvec, int lane,
                                         Consume&& consume) {
     constexpr int U = kUnroll / 2;
@@ -42,15 +46,15 @@ __device__ __forceinline__ void stream2(const T* __restrict__ a, const T* __rest
         Vec<T, VEC> va[U], vb[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            va[u] = load_vec<T, VEC>(a + (size_t)(i + u * LPP) * VEC);
-            vb[u] = load_vec<T, VEC>(b + (size_t)(i + u * LPP) * VEC);
+            va[u] = NT ? load_vec_nt<T, VEC>(a + (size_t)(i + u * LPP) * VEC) : load_vec<T, VEC>(a + (size_t)(i + u * LPP) * VEC);
+            vb[u] = NT ? load_vec_nt<T, VEC>(b + (size_t)(i + u * LPP) * VEC) : load_vec<T, VEC>(b + (size_t)(i + u * LPP) * VEC);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) consume(va[u], vb[u], i + u * LPP);
     }
     for (; i < nvec; i += LPP) {
-        Vec<T, VEC> va = load_vec<T, VEC>(a + (size_t)i * VEC);
-        Vec<T, VEC> vb = load_vec<T, VEC>(b + (size_t)i * VEC);
+        Vec<T, VEC> va = NT ? load_vec_nt<T, VEC>(a + (size_t)i * VEC) : load_vec<T, VEC>(a + (size_t)i * VEC);
+        Vec<T, VEC> vb = NT ? load_vec_nt<T, VEC>(b + (size_t)i * VEC) : load_vec<T, VEC>(b + (size_t)i * VEC);
         consume(va, vb, i);
     }
 }
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void plane_stats_kernel(const T* __restrict
 #pragma unroll
         for (int j = 0; j < VEC; ++j) part[k][j] = 0.f;
 
-    stream1<T, VEC, LPP>(base, g.nvec, id.lane, [&](const Vec<T, VEC>& v, int i) {
+    stream1<T, VEC, LPP, true>(base, g.nvec, id.lane, [&](const Vec<T, VEC>& v, int i) {
         if constexpr (!BOXED) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(kBlock) void apply_fwd_kernel(const T* __restrict__
         b_out = cf.b_out[id.p];
     }
     T* yb = y + off;
-    stream1<T, VEC, LPP>(x + off, g.nvec, id.lane, [&](const Vec<T, VEC>& v, int i) {
+    stream1<T, VEC, LPP, true>(x + off, g.nvec, id.lane, [&](const Vec<T, VEC>& v, int i) {
         Vec<T, VEC> o;
         if constexpr (!BOXED) {
 #pragma unroll
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void apply_fwd_kernel(const T* __restrict__
                 o.v[j] = from_float<T>(g.cb.has(r, c + j) ? fmaf(a_in, f - xr, b_in) : fmaf(a_out, f, b_out));
             }
         }
-        store_vec<T, VEC>(yb + (size_t)i * VEC, o);
+        store_vec_nt<T, VEC>(yb + (size_t)i * VEC, o);
     });
 }
 
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void bwd_reduce_kernel(const T* __restrict_
     for (int k = 0; k < NACC; ++k)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) part[k][j] = 0.f;
-    stream2<T, VEC, LPP>(gy + off, x + off, g.nvec, id.lane,
+    stream2<T, VEC, LPP, true>(gy + off, x + off, g.nvec, id.lane,
                          [&](const Vec<T, VEC>& vg, const Vec<T, VEC>& vx, int i) {
                              if constexpr (!BOXED) {
 #pragma unroll
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void apply_bwd_kernel(const T* __restrict__
         e0 = coef[10 * P + id.p];
     }
     T* db = dx + off;
-    stream2<T, VEC, LPP>(gy + off, x + off, g.nvec, id.lane,
+    stream2<T, VEC, LPP, true>(gy + off, x + off, g.nvec, id.lane,
                          [&](const Vec<T, VEC>& vg, const Vec<T, VEC>& vx, int i) {
                              Vec<T, VEC> o;
                              if constexpr (!BOXED) {
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void apply_bwd_kernel(const T* __restrict__
                                      o.v[j] = from_float<T>(d);
                                  }
                              }
-                             store_vec<T, VEC>(db + (size_t)i * VEC, o);
+                             store_vec_nt<T, VEC>(db + (size_t)i * VEC, o);
                          });
 }
 
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void plane_stats_bwd_kernel(const T* __rest
     const float cX = dstd[id.p] / (std[id.p] * float(cnt - 1));
     const float c0 = dmean[id.p] / float(cnt);
     T* db = dx + off;
-    stream1<T, VEC, LPP>(x + off, g.nvec, id.lane, [&](const Vec<T, VEC>& v, int i) {
+    stream1<T, VEC, LPP, true>(x + off, g.nvec, id.lane, [&](const Vec<T, VEC>& v, int i) {
         Vec<T, VEC> o;
         const int e = i * VEC;
         const int r = BOXED ? e / g.Wd : 0, c = BOXED ? e - r * g.Wd : 0;
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void plane_stats_bwd_kernel(const T* __rest
             const float d = fmaf(cX, to_float(v.v[j]) - mu, c0);
             o.v[j] = from_float<T>((!BOXED || g.cb.has(r, c + j)) ? d : 0.f);
         }
-        store_vec<T, VEC>(db + (size_t)i * VEC, o);
+        store_vec_nt<T, VEC>(db + (size_t)i * VEC, o);
     });
 }
 
