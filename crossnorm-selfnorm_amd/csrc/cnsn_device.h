@@ -26,14 +26,9 @@ __device__ __forceinline__ float from_float<float>(float f) {
 }
 template <>
 __device__ __forceinline__ bf16_t from_float<bf16_t>(float f) {
-    uint32_t u = __float_as_uint(f);
+    // gfx950 converts in hardware (v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN)
     bf16_t r;
-    if ((u & 0x7fffffffu) > 0x7f800000u) {  // NaN: keep it a NaN
-        r.bits = uint16_t((u >> 16) | 0x0040u);
-    } else {
-        u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
-        r.bits = uint16_t(u >> 16);
-    }
+    r.bits = __builtin_bit_cast(uint16_t, (__bf16)f);
     return r;
 }
 template <>

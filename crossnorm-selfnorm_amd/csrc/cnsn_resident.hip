@@ -16,7 +16,7 @@ struct Bucket {
 };
 // vectors per lane and plane -> planes per wave.  Chosen so a wave keeps <= 16 vectors (64 VGPRs) per
 // tensor in flight forward, twice that backward (G and x).
-constexpr Bucket kBuckets[] = {{1, 8}, {2, 4}, {4, 4}, {7, 1}, {13, 1}, {16, 1}};
+constexpr Bucket kBuckets[] = {{1, 8}, {2, 4}, {4, 4}, {7, 1}, {8, 1}, {13, 1}, {16, 1}};
 
 int cu_count() {
     static int cached[16] = {0};
@@ -38,6 +38,7 @@ bool dispatch_res(int dtype, int vec, int nv, F&& f) {
             case 2: f(tt, vt, IntTag<2>{}, IntTag<4>{}); return true;
             case 4: f(tt, vt, IntTag<4>{}, IntTag<4>{}); return true;
             case 7: f(tt, vt, IntTag<7>{}, IntTag<1>{}); return true;
+            case 8: f(tt, vt, IntTag<8>{}, IntTag<1>{}); return true;
             case 13: f(tt, vt, IntTag<13>{}, IntTag<1>{}); return true;
             case 16: f(tt, vt, IntTag<16>{}, IntTag<1>{}); return true;
             default: return false;

@@ -17,9 +17,10 @@
 //
 // Deadlock freedom: the grid is persistent, G = (resident workgroups) rounded down to a multiple
 // of K, and workgroup b handles items b, b+G, ...; the K members of a cluster are therefore
-// always the same K co-resident workgroups working on the same iteration.  Every spin is bounded:
-// on time-out a word in the control block is raised, all waits drain, results are invalid and the
-// host can see it (`resident_ctl_word`).
+// always the same K co-resident workgroups working on the same iteration.  Kernels of other streams
+// (RCCL all-reduce, MIOpen) may delay residency but always finish, so waiting is safe; every spin is
+// nevertheless bounded (seconds): on time-out the kernel raises a word in the control block and traps,
+// which surfaces as a launch failure on the host — never as silently wrong results.
 #pragma once
 #include "../../include/cnsn_hip.h"
 #include "cnsn_algebra.h"
@@ -31,7 +32,7 @@ namespace cnsn {
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 
-constexpr unsigned kSpinLimit = 1u << 18;
+constexpr long long kWaitLimitTicks = 5ll * 100000000ll;  // 5 s of the 100 MHz wall clock (s_memrealtime)
 constexpr int kCtlBytes = 256;  // control block in front of the granule area (word 0: time-out flag)
 
 struct ResArgs {
@@ -81,6 +82,7 @@ __device__ __forceinline__ void put_granule(unsigned long long* p, float lo, flo
 // ONE wave gathers `total` granules (2*total floats) into LDS; re-reads all of them until none is empty.
 __device__ __forceinline__ void sweep_granules(const unsigned long long* g, int total, float* vals, unsigned* ctl) {
     const int lane = threadIdx.x & 63;
+    long long t_start = 0;
     for (unsigned spins = 0;; ++spins) {
         bool ok = true;
         for (int i = lane; i < total; i += 64) {
@@ -92,11 +94,17 @@ __device__ __forceinline__ void sweep_granules(const unsigned long long* g, int 
         if (__all(ok)) return;
         __builtin_amdgcn_s_sleep(4);
         if ((spins & 15u) == 15u) {
-            const bool dead = spins > kSpinLimit ||
+            const long long now = (long long)wall_clock64();
+            if (t_start == 0) t_start = now;
+            const bool dead = now - t_start > kWaitLimitTicks ||
                               __hip_atomic_load((gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kCtlIdle;
-            if (dead) {  // give up: raise the flag so every other wait drains too
+            if (dead) {
+                // A cluster member never published: the grid was not fully resident for seconds (it
+                // shares the GPU with something that never yields) or the launch geometry is wrong.
+                // Raise the flag so every other wait drains too, then fail LOUDLY: the trap turns into a
+                // launch failure at the host's next synchronisation instead of silently wrong numbers.
                 if (lane == 0) __hip_atomic_store((gu32*)ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
+                __builtin_trap();
             }
         }
     }

@@ -312,6 +312,29 @@ def test_oracle_sweep_sn(strategy, shape, is_two, training):
     assert_parity(out, torch.float32, (shape, "sn", is_two, training, strategy))
 
 
+# shapes on the edges of the resident kernels' launch geometry: partial last register slot, batch not a
+# multiple of the planes a workgroup owns (K=1 and K>1), every register bucket (1,2,4,7,8,13,16), C=1,
+# 16-bit tensors with 8- and 4-element vectors
+EDGE_SHAPES = [
+    (5, 3, 12, 11),     # 33 vectors: bucket 1, 33 of 64 lanes; N=5 < planes per workgroup
+    (7, 2, 20, 13),     # 65 vectors: bucket 2, one lane in the last slot
+    (9, 3, 30, 30),     # 225 vectors: bucket 4
+    (37, 2, 36, 44),    # 396 vectors: bucket 7; N=37 -> 10 workgroups per channel, last one partial
+    (4, 2, 50, 36),     # 450 vectors: bucket 8
+    (3, 2, 52, 64),     # 832 vectors: bucket 13, full
+    (3, 3, 60, 68),     # 1020 vectors: bucket 16, partial (N=2 would make BatchNorm1d over the batch singular)
+    (6, 1, 40, 40),     # a single channel
+]
+
+
+@pytest.mark.parametrize("shape", EDGE_SHAPES, ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("crop", ["neither", "both"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_edge_geometry(strategy, shape, crop, dtype):
+    seed = seed_of(shape, crop, str(dtype), "edge")
+    assert_parity(run_pair(shape, crop, "cnsn", dtype, seed), dtype, (shape, crop, dtype, strategy))
+
+
 @pytest.mark.parametrize("lam,chan,is_two", [(0.3, False, False), (None, True, False), (0.7, True, True)])
 @pytest.mark.parametrize("crop", ["neither", "both"])
 def test_oracle_options(strategy, lam, chan, is_two, crop):
