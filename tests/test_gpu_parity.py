@@ -502,3 +502,29 @@ print(float(y.double().sum()), float(x.grad.double().abs().sum()), float(m.selfn
         outs.append(r.stdout.strip().split("\n")[-1].split())
     assert outs[1][3] == "0"                                   # the second run really took the ctypes path
     assert outs[0][:3] == outs[1][:3], outs
+
+
+def _fuzz_cases(count=48):
+    rng = np.random.RandomState(20260928)
+    cases = []
+    for i in range(count):
+        n = int(rng.randint(3, 41))
+        c = int(rng.randint(1, 7))
+        h, w = int(rng.randint(6, 65)), int(rng.choice([8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 60, 64, 7, 9, 14, 30]))
+        dtype = [torch.float32, torch.float32, torch.bfloat16, torch.float16][int(rng.randint(4))]
+        crop = orc.CROPS[int(rng.randint(4))]
+        kind = ["cnsn", "cnsn", "cn", "sn"][int(rng.randint(4))]
+        is_two = bool(rng.rand() < 0.2) and kind != "cn"
+        training = not (kind == "sn" and rng.rand() < 0.3)
+        lam = 0.4 if (kind != "sn" and rng.rand() < 0.2) else None
+        cases.append((i, (n, c, h, w), dtype, crop if kind != "sn" else "neither", kind, is_two, training, lam))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(), ids=lambda c: f"{c[0]}-{'x'.join(map(str, c[1]))}-{str(c[2])[6:]}-{c[3]}-{c[4]}")
+def test_fuzz_shapes_and_modes(strategy, case):
+    """Seeded random shapes x dtypes x modes through both strategies (the launch geometry of the resident
+    kernels has many corner cases: register bucket, partial slot, partial cluster, vector width)."""
+    i, shape, dtype, crop, kind, is_two, training, lam = case
+    out = run_pair(shape, crop, kind, dtype, 1000 + i, lam=lam, is_two=is_two, training=training)
+    assert_parity(out, dtype, (case, strategy))
