@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(_HERE, "libcnsn_hip.so")
 
 CNSN_F32, CNSN_BF16, CNSN_F16 = 0, 1, 2
 STRATEGY_AUTO, STRATEGY_TWO_PASS, STRATEGY_RESIDENT = 0, 1, 2
-ABI_VERSION = 1
+ADD_NONE, ADD_PRE, ADD_POST = 0, 1, 2
+ABI_VERSION = 2
 
 
 class Problem(C.Structure):
@@ -38,6 +39,12 @@ class GateGrad(C.Structure):
     _fields_ = [("d_fc_weight", C.c_void_p), ("d_bn_weight", C.c_void_p), ("d_bn_bias", C.c_void_p)]
 
 
+class Epilogue(C.Structure):
+    """cnsn_epilogue_t"""
+    _fields_ = [("struct_bytes", C.c_int32), ("add_mode", C.c_int32), ("relu", C.c_int32),
+                ("reserved", C.c_int32), ("addend", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/cnsn_hip.h declares
 SIGNATURES = {
     "cnsn_abi_version": (C.c_int, []),
@@ -51,6 +58,13 @@ SIGNATURES = {
                                 C.POINTER(Gate), C.POINTER(Gate), C.c_void_p, C.c_void_p,
                                 C.POINTER(GateGrad), C.POINTER(GateGrad), C.c_void_p, C.c_size_t,
                                 C.c_void_p]),
+    "cnsn_forward_fused": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.POINTER(Gate), C.POINTER(Gate), C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cnsn_backward_fused": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.POINTER(Gate), C.POINTER(Gate),
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GateGrad),
+                                      C.POINTER(GateGrad), C.c_void_p, C.c_size_t, C.c_void_p]),
     "cnsn_plane_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.POINTER(C.c_int32), C.c_float, C.c_void_p, C.c_void_p]),
     "cnsn_plane_stats_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

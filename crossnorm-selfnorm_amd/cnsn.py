@@ -201,3 +201,36 @@ class CNSN(nn.Module):
         kw, g, f = sn._fused_args()
         cfg = FusedConfig(cn_active=True, content_box=d.content_box, style_box=d.style_box, **kw)
         return _F.fused_cnsn(x, cfg, perm=d.perm, chan_perm=d.chan_perm, g=g, f=f)
+
+    def forward_block(self, x, addend=None, add_mode="none", relu=False):
+        """`act(self(x [+ addend]) [+ addend])` — the op together with the residual block's element-wise
+        neighbours, in the op's own launches (cnsn_forward_fused).  What the reference spells as
+          out += identity; out = self.cnsn(out); out = self.relu(out)   (imagenet/resnet_cnsn.py:117-122, pos='post')
+          out = self.cnsn(out); out += identity; out = self.relu(out)   (:112-122, pos='residual'/'identity')
+          out = torch.add(x, out); return self.cnsn(out)                (cifar/wideresnet_cnsn.py:93-96, pos='post')
+        add_mode: 'none' | 'pre' (sum feeds the op) | 'post' (sum after the op); relu: ReLU last.
+        RNG draws, `active` reset and BatchNorm1d book-keeping are those of `forward`."""
+        assert add_mode in ("none", "pre", "post")
+        assert (addend is None) == (add_mode == "none")
+        cn, sn = self.crossnorm, self.selfnorm
+        ours = (cn is None or type(cn) is CrossNorm) and (sn is None or type(sn) is SelfNorm)
+        cn_on = cn is not None and cn.active and cn.training
+        if not ours or not (cn_on or sn is not None):       # nothing of ours to fuse into: plain ops
+            if add_mode == "pre":
+                x = x + addend
+            x = self.forward(x)
+            if add_mode == "post":
+                x = x + addend
+            return torch.relu(x) if relu else x
+        kw, g, f, perm, chan = {}, None, None, None, None
+        if cn is not None and cn.active:
+            if cn_on:
+                d = cn._take_draws(x)
+                kw.update(cn_active=True, content_box=d.content_box, style_box=d.style_box)
+                perm, chan = d.perm, d.chan_perm
+            cn.active = False                               # always dropped (cnsn.py:108)
+        if sn is not None:
+            skw, g, f = sn._fused_args()
+            kw.update(skw)
+        cfg = FusedConfig(add_mode=add_mode, relu=bool(relu), **kw)
+        return _F.fused_cnsn(x, cfg, perm=perm, chan_perm=chan, g=g, f=f, addend=addend)

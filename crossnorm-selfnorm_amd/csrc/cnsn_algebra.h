@@ -20,6 +20,7 @@ struct MidArgs {
     float lam, eps_cn, eps_sn, eps_bn, momentum;
     double inv_n;     // 1/N         (host-computed: no fp64 divisions on the device)
     double unbias_n;  // N/(N-1)     (running_var takes the unbiased batch variance)
+    int save_coefs;   // forward: also keep the five apply coefficients in `saved` (ReLU-fused backward)
 };
 
 struct GateDev {

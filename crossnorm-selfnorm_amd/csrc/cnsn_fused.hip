@@ -1,0 +1,190 @@
+// cnsn_forward_fused / cnsn_backward_fused: the op with the residual block's add and ReLU folded into
+// its own launches (include/cnsn_hip.h, "residual-block epilogue").
+#include "../../include/cnsn_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include "cnsn_fused_stream_kernels.h"
+#include "cnsn_host_plan.h"
+#include "cnsn_resident_fused.h"
+
+using namespace cnsn;
+
+namespace {
+
+struct EpiPlan {
+    int add;  // AddMode
+    int relu;
+    const void* addend;
+};
+
+int parse_epilogue(const cnsn_epilogue_t* epi, EpiPlan& e) {
+    e = EpiPlan{ADD_NONE, 0, nullptr};
+    if (!epi) return CNSN_OK;
+    if (epi->struct_bytes != (int32_t)sizeof(cnsn_epilogue_t)) return CNSN_E_STRUCT;
+    if (epi->add_mode != CNSN_ADD_NONE && epi->add_mode != CNSN_ADD_PRE && epi->add_mode != CNSN_ADD_POST)
+        return CNSN_E_UNSUPPORTED;
+    e.add = epi->add_mode;
+    e.relu = epi->relu ? 1 : 0;
+    e.addend = epi->addend;
+    if (e.add != ADD_NONE) {
+        if (!e.addend) return CNSN_E_NULL;
+        if (((uintptr_t)e.addend & 15u) != 0) return CNSN_E_ALIGN;
+    }
+    return CNSN_OK;
+}
+
+// call f(IntTag<ADD>) for the runtime add mode
+template <typename F>
+inline void with_add(int add, F&& f) {
+    if (add == ADD_PRE)
+        f(IntTag<ADD_PRE>{});
+    else if (add == ADD_POST)
+        f(IntTag<ADD_POST>{});
+    else
+        f(IntTag<ADD_NONE>{});
+}
+
+}  // namespace
+
+extern "C" {
+
+int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const void* x, const int64_t* perm,
+                       const int64_t* chan_perm, const cnsn_gate_t* g, const cnsn_gate_t* f, void* y, float* saved,
+                       void* workspace, size_t workspace_bytes, void* stream_) {
+    EpiPlan e;
+    int st = parse_epilogue(epi, e);
+    if (st) return st;
+    if (e.add == ADD_NONE && !e.relu)
+        return cnsn_forward(prob, x, perm, chan_perm, g, f, y, saved, workspace, workspace_bytes, stream_);
+    Plan pl;
+    st = make_plan(prob, pl);
+    if (st) return st;
+    const cnsn_problem_t& p = pl.pr;
+    if (!x || !y || !workspace) return CNSN_E_NULL;
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)workspace) & 15u) != 0) return CNSN_E_ALIGN;
+    if (p.cn_active && !perm) return CNSN_E_NULL;
+    if (p.sn_active && !gate_ok(g)) return CNSN_E_NULL;
+    if (p.sn_active && p.sn_two && !gate_ok(f)) return CNSN_E_NULL;
+    if (workspace_bytes < workspace_bytes_of(pl)) return CNSN_E_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    pl.mid.save_coefs = (e.relu && saved) ? 1 : 0;
+
+    double* mom = (double*)workspace;
+    double* saved_d = saved ? (double*)saved : mom + 6 * pl.P;
+    float* coef = (float*)(mom + 6 * pl.P + saved_doubles_of(pl));
+
+    if (resident_fused_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, e.add, false).ok) {
+        st = resident_fused_forward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, e.add, e.relu, x, e.addend, perm, gate_dev(g),
+                                    gate_dev(f), y, saved ? saved_d : nullptr, workspace, stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
+    }
+
+    const int blocks = blocks_for(pl.geom.P, pl.shape.lpp);
+    dispatch(p.dtype, pl.shape, [&](auto tt, auto vt, auto lt) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value, LPP = decltype(lt)::value;
+        if (e.add == ADD_PRE) {
+            if (pl.boxed)
+                fused_stats_kernel<T, VEC, LPP, true><<<blocks, kBlock, 0, stream>>>((const T*)x, (const T*)e.addend, pl.geom, mom);
+            else
+                fused_stats_kernel<T, VEC, LPP, false><<<blocks, kBlock, 0, stream>>>((const T*)x, (const T*)e.addend, pl.geom, mom);
+        } else {
+            if (pl.boxed)
+                plane_stats_kernel<T, VEC, LPP, true><<<blocks, kBlock, 0, stream>>>((const T*)x, pl.geom, mom, nullptr, 0.f);
+            else
+                plane_stats_kernel<T, VEC, LPP, false><<<blocks, kBlock, 0, stream>>>((const T*)x, pl.geom, mom, nullptr, 0.f);
+        }
+    });
+    launch_mid_fwd(pl, mom, perm, chan_perm, gate_dev(g), gate_dev(f), coef, saved_d, stream);
+    const size_t P = pl.P;
+    ApplyCoef cf{coef + FC_A_IN * P, coef + FC_XR * P, coef + FC_B_IN * P, coef + FC_A_OUT * P, coef + FC_B_OUT * P};
+    dispatch(p.dtype, pl.shape, [&](auto tt, auto vt, auto lt) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value, LPP = decltype(lt)::value;
+        with_add(e.add, [&](auto at) {
+            constexpr int ADD = decltype(at)::value;
+            if (pl.boxed)
+                fused_apply_fwd_kernel<T, VEC, LPP, true, ADD><<<blocks, kBlock, 0, stream>>>(
+                    (const T*)x, (const T*)e.addend, (T*)y, pl.geom, cf, e.relu);
+            else
+                fused_apply_fwd_kernel<T, VEC, LPP, false, ADD><<<blocks, kBlock, 0, stream>>>(
+                    (const T*)x, (const T*)e.addend, (T*)y, pl.geom, cf, e.relu);
+        });
+    });
+    return launch_status();
+}
+
+int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const void* grad_y, const void* x,
+                        const int64_t* perm, const int64_t* chan_perm, const cnsn_gate_t* g, const cnsn_gate_t* f,
+                        const float* saved, void* grad_x, void* grad_addend, const cnsn_gate_grad_t* dg,
+                        const cnsn_gate_grad_t* df, void* workspace, size_t workspace_bytes, void* stream_) {
+    EpiPlan e;
+    int st = parse_epilogue(epi, e);
+    if (st) return st;
+    // without a ReLU the gradient of a POST addend is grad_y itself and nothing else changes
+    if (!e.relu && e.add != ADD_PRE)
+        return cnsn_backward(prob, grad_y, x, perm, chan_perm, g, f, saved, grad_x, dg, df, workspace, workspace_bytes,
+                             stream_);
+    Plan pl;
+    st = make_plan(prob, pl);
+    if (st) return st;
+    const cnsn_problem_t& p = pl.pr;
+    if (!grad_y || !x || !grad_x || !saved || !workspace) return CNSN_E_NULL;
+    if (e.add == ADD_POST && !grad_addend) return CNSN_E_NULL;
+    if ((((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)grad_addend | (uintptr_t)workspace) & 15u) != 0)
+        return CNSN_E_ALIGN;
+    if (p.cn_active && !perm) return CNSN_E_NULL;
+    if (p.sn_active && (!gate_ok(g) || !gate_grad_ok(dg))) return CNSN_E_NULL;
+    if (p.sn_active && p.sn_two && (!gate_ok(f) || !gate_grad_ok(df))) return CNSN_E_NULL;
+    if (workspace_bytes < workspace_bytes_of(pl)) return CNSN_E_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+
+    const size_t P = pl.P;
+    double* tmp = (double*)workspace;
+    float* sums = (float*)(tmp + BT_ROWS * P);
+    float* coef = sums + 4 * P;
+    const double* saved_d = (const double*)saved;
+
+    if (resident_fused_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, e.add, true).ok) {
+        st = resident_fused_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, e.add, e.relu, grad_y, x, e.addend, perm,
+                                     gate_dev(g), gate_dev(f), saved_d, grad_x, gate_grad_dev(dg), gate_grad_dev(df),
+                                     workspace, stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
+    }
+
+    const int blocks = blocks_for(pl.geom.P, pl.shape.lpp);
+    dispatch(p.dtype, pl.shape, [&](auto tt, auto vt, auto lt) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value, LPP = decltype(lt)::value;
+        with_add(e.add, [&](auto at) {
+            constexpr int ADD = decltype(at)::value;
+            if (pl.boxed)
+                fused_bwd_reduce_kernel<T, VEC, LPP, true, ADD><<<blocks, kBlock, 0, stream>>>(
+                    (const T*)grad_y, (const T*)x, (const T*)e.addend, pl.geom, saved_d, e.relu, sums);
+            else
+                fused_bwd_reduce_kernel<T, VEC, LPP, false, ADD><<<blocks, kBlock, 0, stream>>>(
+                    (const T*)grad_y, (const T*)x, (const T*)e.addend, pl.geom, saved_d, e.relu, sums);
+        });
+    });
+    launch_mid_bwd(pl, sums, saved_d, perm, chan_perm, gate_dev(g), gate_dev(f), gate_grad_dev(dg), gate_grad_dev(df), tmp,
+                   coef, stream);
+    dispatch(p.dtype, pl.shape, [&](auto tt, auto vt, auto lt) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value, LPP = decltype(lt)::value;
+        with_add(e.add, [&](auto at) {
+            constexpr int ADD = decltype(at)::value;
+            if (pl.boxed)
+                fused_apply_bwd_kernel<T, VEC, LPP, true, ADD><<<blocks, kBlock, 0, stream>>>(
+                    (const T*)grad_y, (const T*)x, (const T*)e.addend, (T*)grad_x, (T*)grad_addend, pl.geom, coef, saved_d,
+                    e.relu);
+            else
+                fused_apply_bwd_kernel<T, VEC, LPP, false, ADD><<<blocks, kBlock, 0, stream>>>(
+                    (const T*)grad_y, (const T*)x, (const T*)e.addend, (T*)grad_x, (T*)grad_addend, pl.geom, coef, saved_d,
+                    e.relu);
+        });
+    });
+    return launch_status();
+}
+
+}  // extern "C"

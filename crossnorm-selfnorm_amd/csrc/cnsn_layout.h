@@ -24,7 +24,10 @@ enum SavedRow {
     SV_ZH_G,       // normalised pre-activation of g
     SV_F,          // gate f (two-gate form)
     SV_ZH_F,
-    SV_ROWS
+    // the forward's apply coefficients (floats, exact in a double): written only for a ReLU-fused call, whose
+    // backward re-evaluates the forward affine bit-for-bit to recover the ReLU mask without reading y
+    SV_FC0,
+    SV_ROWS = SV_FC0 + 5
 };
 
 __host__ __device__ inline size_t sv_at(size_t p, int row) { return p * SV_ROWS + row; }
@@ -55,6 +58,14 @@ __device__ __forceinline__ void store_fwd_plane(double* __restrict__ saved, size
     saved[sv_at(p, SV_M_IN)] = f.m_in;
     saved[sv_at(p, SV_MU_P)] = f.mu_p;
     saved[sv_at(p, SV_SIG_P)] = f.sig_p;
+}
+
+__device__ __forceinline__ void store_fwd_coefs(double* __restrict__ saved, size_t p, const FwdCoefs& k) {
+    saved[sv_at(p, SV_FC0 + FC_A_IN)] = k.a_in;
+    saved[sv_at(p, SV_FC0 + FC_XR)] = k.xr;
+    saved[sv_at(p, SV_FC0 + FC_B_IN)] = k.b_in;
+    saved[sv_at(p, SV_FC0 + FC_A_OUT)] = k.a_out;
+    saved[sv_at(p, SV_FC0 + FC_B_OUT)] = k.b_out;
 }
 
 }  // namespace cnsn

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
         coef[FC_B_IN * P + p] = k.b_in;
         coef[FC_A_OUT * P + p] = k.a_out;
         coef[FC_B_OUT * P + p] = k.b_out;
+        if (a.save_coefs) store_fwd_coefs(saved, p, k);
     }
 }
 

@@ -520,6 +520,7 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
                     saved[sv_at(p, SV_ZH_G)] = zhg;
                     saved[sv_at(p, SV_F)] = fg;
                     saved[sv_at(p, SV_ZH_F)] = zhf;
+                    if (a.save_coefs) store_fwd_coefs(saved, p, cf);
                 }
             }
         }

@@ -125,6 +125,25 @@ class FusedConfig:
     eps_sn: float = 1e-12
     eps_bn: float = 1e-5
     momentum: float = 0.1
+    # residual-block epilogue (cnsn_forward_fused): y = act(CNSN(x [+ addend]) [+ addend])
+    add_mode: str = "none"          # 'none' | 'pre' | 'post'
+    relu: bool = False
+
+    @property
+    def has_epilogue(self):
+        return self.add_mode != "none" or self.relu
+
+
+_ADD_MODES = {"none": _ffi.ADD_NONE, "pre": _ffi.ADD_PRE, "post": _ffi.ADD_POST}
+
+
+def _epilogue(cfg: FusedConfig, addend):
+    e = _ffi.Epilogue()
+    e.struct_bytes = C.sizeof(_ffi.Epilogue)
+    e.add_mode = _ADD_MODES[cfg.add_mode]
+    e.relu = int(cfg.relu)
+    e.addend = addend.data_ptr() if addend is not None else None
+    return e
 
 
 def _problem(x: torch.Tensor, cfg: FusedConfig) -> _ffi.Problem:
@@ -169,10 +188,16 @@ class FusedCNSN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, cfg: FusedConfig, perm, chan_perm, g_w, g_gamma, g_beta, g_rm, g_rv,
-                f_w, f_gamma, f_beta, f_rm, f_rv):
+                f_w, f_gamma, f_beta, f_rm, f_rv, addend=None):
         _require_device(x, "cnsn_forward")
         lib = _ffi.lib()
         x = x.contiguous()                                         # reference cnsn.py:14
+        if cfg.add_mode != "none":
+            _require_device(addend, "cnsn_forward(addend)")
+            assert addend.shape == x.shape and addend.dtype == x.dtype, "addend must match x"
+            addend = addend.contiguous()
+        else:
+            addend = None
         prob = _problem(x, cfg)
         dev = x.device
         if cfg.cn_active:
@@ -186,10 +211,12 @@ class FusedCNSN(torch.autograd.Function):
         saved_floats, ws_bytes = _sizes(prob)
         saved = torch.empty(saved_floats, dtype=torch.float32, device=dev) if need_bwd else None
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
-        st = lib.cnsn_forward(C.byref(prob), _ptr(x), _ptr(perm if cfg.cn_active else None),
-                              _ptr(chan_perm if cfg.cn_active else None),
-                              C.byref(gate_g.c) if gate_g else None, C.byref(gate_f.c) if gate_f else None,
-                              _ptr(y), _ptr(saved), _ptr(ws), ws_bytes, _stream(x))
+        epi = _epilogue(cfg, addend) if cfg.has_epilogue else None
+        st = lib.cnsn_forward_fused(C.byref(prob), C.byref(epi) if epi else None, _ptr(x),
+                                    _ptr(perm if cfg.cn_active else None),
+                                    _ptr(chan_perm if cfg.cn_active else None),
+                                    C.byref(gate_g.c) if gate_g else None, C.byref(gate_f.c) if gate_f else None,
+                                    _ptr(y), _ptr(saved), _ptr(ws), ws_bytes, _stream(x))
         _ffi.check(st, "cnsn_forward")
         if cfg.sn_active and cfg.sn_training:
             gate_g.write_back()
@@ -201,13 +228,13 @@ class FusedCNSN(torch.autograd.Function):
             ctx.param_dtypes = tuple(t.dtype if t is not None else None
                                      for t in (g_w, g_gamma, g_beta, f_w, f_gamma, f_beta))
             ctx.save_for_backward(x, saved, perm if cfg.cn_active else None,
-                                  chan_perm if cfg.cn_active else None)
+                                  chan_perm if cfg.cn_active else None, addend)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         lib = _ffi.lib()
-        x, saved, perm, chan_perm = ctx.saved_tensors
+        x, saved, perm, chan_perm, addend = ctx.saved_tensors
         cfg, prob = ctx.cfg, ctx.prob
         gate_g, gate_f = ctx.gates
         gy = gy.contiguous()
@@ -230,26 +257,34 @@ class FusedCNSN(torch.autograd.Function):
             gg, gg_c = grads()
             if cfg.sn_two:
                 gf, gf_c = grads()
-        st = lib.cnsn_backward(C.byref(prob), _ptr(gy), _ptr(x), _ptr(perm), _ptr(chan_perm),
-                               C.byref(gate_g.c) if gate_g else None, C.byref(gate_f.c) if gate_f else None,
-                               _ptr(saved), _ptr(dx), C.byref(gg_c) if gg_c else None,
-                               C.byref(gf_c) if gf_c else None, _ptr(ws), ws_bytes, _stream(x))
+        epi = _epilogue(cfg, addend) if cfg.has_epilogue else None
+        d_add = None
+        if cfg.add_mode == "post":      # gradient of a POST addend: grad_y behind the ReLU mask
+            d_add = torch.empty_like(x) if cfg.relu else gy
+        st = lib.cnsn_backward_fused(C.byref(prob), C.byref(epi) if epi else None, _ptr(gy), _ptr(x), _ptr(perm),
+                                     _ptr(chan_perm), C.byref(gate_g.c) if gate_g else None,
+                                     C.byref(gate_f.c) if gate_f else None, _ptr(saved), _ptr(dx),
+                                     _ptr(d_add) if (cfg.add_mode == "post" and cfg.relu) else None,
+                                     C.byref(gg_c) if gg_c else None, C.byref(gf_c) if gf_c else None,
+                                     _ptr(ws), ws_bytes, _stream(x))
         _ffi.check(st, "cnsn_backward")
+        if cfg.add_mode == "pre":       # d(x + addend) reaches both terms unchanged
+            d_add = dx
         pd = ctx.param_dtypes
         out_g = [None] * 3 if gg is None else [t if t.dtype == pd[i] else t.to(pd[i]) for i, t in enumerate(gg)]
         out_f = [None] * 3 if gf is None else [t if t.dtype == pd[3 + i] else t.to(pd[3 + i])
                                                for i, t in enumerate(gf)]
-        #      x   cfg  perm  chan  g_w..g_beta   g_rm g_rv   f_w..f_beta  f_rm f_rv
-        return (dx, None, None, None, *out_g, None, None, *out_f, None, None)
+        #      x   cfg  perm  chan  g_w..g_beta   g_rm g_rv   f_w..f_beta  f_rm f_rv  addend
+        return (dx, None, None, None, *out_g, None, None, *out_f, None, None, d_add)
 
 
 def fused_cnsn(x, cfg: FusedConfig, perm=None, chan_perm=None, g: Optional[GateParams] = None,
-               f: Optional[GateParams] = None):
+               f: Optional[GateParams] = None, addend: Optional[torch.Tensor] = None):
     ga = (g.fc_weight, g.bn_weight, g.bn_bias, g.running_mean, g.running_var) if g else (None,) * 5
     fa = (f.fc_weight, f.bn_weight, f.bn_bias, f.running_mean, f.running_var) if f else (None,) * 5
     glue = _ffi.glue()
-    if glue is None:
-        return FusedCNSN.apply(x, cfg, perm, chan_perm, *ga, *fa)
+    if glue is None or cfg.has_epilogue:
+        return FusedCNSN.apply(x, cfg, perm, chan_perm, *ga, *fa, addend)
     # C++ glue: same C ABI calls, without the Python per-call overhead
     _require_device(x, "cnsn_forward")
     need_bwd = torch.is_grad_enabled() and (x.requires_grad or any(

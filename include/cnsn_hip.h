@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CNSN_ABI_VERSION 1
+#define CNSN_ABI_VERSION 2
 
 enum cnsn_dtype { CNSN_F32 = 0, CNSN_BF16 = 1, CNSN_F16 = 2 };
 
@@ -119,6 +119,48 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
                   const cnsn_gate_t* f, const float* saved, void* grad_x,
                   const cnsn_gate_grad_t* dg, const cnsn_gate_grad_t* df, void* workspace,
                   size_t workspace_bytes, void* stream);
+
+/* ---- residual-block epilogue fused around the op -------------------------------
+ * The callers wrap CNSN in element-wise neighbours that each cost a full tensor pass:
+ *   models/imagenet/resnet_cnsn.py:117-122  out += identity ; out = cnsn(out) ; out = relu(out)    (pos='post')
+ *   models/imagenet/resnet_cnsn.py:112-122  out = cnsn(out) ; out += identity ; relu               (pos='residual',
+ *                                            and 'identity' with the roles of the two tensors swapped)
+ *   models/cifar/wideresnet_cnsn.py:93-96   out = torch.add(x, out) ; return cnsn(out)             (pos='post')
+ * cnsn_forward_fused / cnsn_backward_fused evaluate  y = act( CNSN(x [+ addend]) [+ addend] )  in the
+ * same launches as the op itself: the sum is formed in registers on the way in (PRE) or on the way
+ * out (POST), the ReLU on the way out; the backward recomputes the ReLU mask from the forward
+ * coefficients kept in `saved` instead of reading y. */
+enum cnsn_add_mode {
+    CNSN_ADD_NONE = 0,
+    CNSN_ADD_PRE = 1, /* CNSN input is x + addend                     */
+    CNSN_ADD_POST = 2 /* addend is added to CNSN's output            */
+};
+
+typedef struct cnsn_epilogue {
+    int32_t struct_bytes; /* = sizeof(cnsn_epilogue_t)                                        */
+    int32_t add_mode;     /* enum cnsn_add_mode                                               */
+    int32_t relu;         /* 1: y = max(y, 0) last (nn.ReLU, resnet_cnsn.py:122)              */
+    int32_t reserved;
+    const void* addend;   /* same shape / dtype / layout as x; NULL iff add_mode == NONE       */
+} cnsn_epilogue_t;
+
+/* As cnsn_forward with the epilogue `epi` (NULL = none).  `saved` from this call must go to
+ * cnsn_backward_fused with the same `epi`. */
+int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const void* x,
+                       const int64_t* perm, const int64_t* chan_perm, const cnsn_gate_t* g,
+                       const cnsn_gate_t* f, void* y, float* saved, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* Backward of cnsn_forward_fused.  grad_x is the gradient of x.
+ *   add_mode PRE : the gradient of addend equals grad_x (same values) — the caller aliases it.
+ *   add_mode POST: the gradient of addend is grad_y masked by the ReLU; it is written to
+ *                  grad_addend when relu == 1 (required then), and equals grad_y otherwise
+ *                  (grad_addend ignored, may be NULL). */
+int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const void* grad_y,
+                        const void* x, const int64_t* perm, const int64_t* chan_perm,
+                        const cnsn_gate_t* g, const cnsn_gate_t* f, const float* saved, void* grad_x,
+                        void* grad_addend, const cnsn_gate_grad_t* dg, const cnsn_gate_grad_t* df,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* calc_ins_mean_std (models/cnsn.py:8-17): mean and sqrt(unbiased var + eps) of every (n,c)
  * plane, optionally of a box of it (the reference takes the box by slicing, :66,:77).

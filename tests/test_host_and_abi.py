@@ -48,7 +48,7 @@ def make_problem(**kw):
 def test_argument_validation_without_gpu():
     lib = cnsn_amd.lib()
     p = make_problem(sn_active=1, sn_training=1)
-    assert lib.cnsn_saved_floats(C.byref(p)) == 2 * (15 * 32 + 2 * 4)   # doubles, counted in floats
+    assert lib.cnsn_saved_floats(C.byref(p)) == 2 * (20 * 32 + 2 * 4)   # doubles, counted in floats
     assert lib.cnsn_workspace_bytes(C.byref(p)) >= 8 * 8 * 32 + 4 * 15 * 32
     # NULL tensors
     assert lib.cnsn_forward(C.byref(p), None, None, None, None, None, None, None, None, 0, None) == -1
@@ -67,6 +67,17 @@ def test_argument_validation_without_gpu():
     assert lib.cnsn_plane_stats(16, 7, 2, 2, 4, 4, None, 1e-5, 64, None) == -3
     assert lib.cnsn_plane_stats(16, 0, 0, 2, 4, 4, None, 1e-5, 64, None) == -2
     assert b"workspace" in lib.cnsn_status_string(-6)
+    # fused epilogue: struct size, unknown mode, missing / misaligned addend are refused before any launch
+    epi = _ffi.Epilogue(C.sizeof(_ffi.Epilogue), _ffi.ADD_PRE, 1, 0, None)
+    q = make_problem()
+    assert lib.cnsn_forward_fused(C.byref(q), C.byref(epi), 16, None, None, None, None, 32, None, 48, 1 << 20, None) == -1
+    epi.addend = 24
+    assert lib.cnsn_forward_fused(C.byref(q), C.byref(epi), 16, None, None, None, None, 32, None, 48, 1 << 20, None) == -4
+    epi.add_mode = 5
+    assert lib.cnsn_forward_fused(C.byref(q), C.byref(epi), 16, None, None, None, None, 32, None, 48, 1 << 20, None) == -9
+    epi.struct_bytes = 4
+    assert lib.cnsn_backward_fused(C.byref(q), C.byref(epi), 16, 16, None, None, None, None, 16, 16, None, None, None,
+                                   48, 1 << 20, None) == -8
 
 
 def test_bbox_sampler_matches_reference_vectors(golden_dir):
