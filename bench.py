@@ -135,6 +135,43 @@ def secondary_workloads(cnsn_amd, shape, dev, args):
     return res
 
 
+def residual_block_workloads(cnsn_amd, shape, dev):
+    """The op inside the reference's residual block (resnet_cnsn.py:117-122, pos='post'):
+    `out += identity; out = cnsn(out); out = relu(out)` forward+backward — as three separate ops
+    (torch add, this library's CNSN, torch relu) and as ONE fused call (CNSN.forward_block)."""
+    n, c, h, w = shape
+    res = {}
+    for tag, dtype in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+        a = conditioned(shape, dev, dtype, 41).requires_grad_()
+        idt = (conditioned(shape, dev, dtype, 42) * 0.5).detach().requires_grad_()
+        gy = torch.randn(shape, device=dev).to(dtype)
+        mod = cnsn_amd.CNSN(None, cnsn_amd.SelfNorm(c)).to(dev).train()
+
+        ins = [a, idt] + list(mod.parameters())
+
+        def run(fused):
+            if fused:
+                y = mod.forward_block(a, idt, add_mode="pre", relu=True)
+            else:
+                y = torch.relu(mod(a + idt))
+            # autograd.grad, not .backward(): inside a network neither tensor is a leaf; a leaf's AccumulateGrad
+            # would deep-copy the gradient tensor that `out` and `identity` share
+            torch.autograd.grad(y, ins, gy)
+
+        for fused in (False, True):
+            for _ in range(5):
+                run(fused)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            k = 20
+            for _ in range(k):
+                run(fused)
+            torch.cuda.synchronize()
+            res[f"{tag}_{'fused' if fused else 'three_ops'}_ms"] = round((time.perf_counter() - t0) / k * 1e3, 4)
+        del a, idt, gy, mod
+    return res
+
+
 def model_workload(args, dist, world, rank, dev):
     """Whole training steps (forward, CE [+ image-space CrossNorm], backward, SGD) of the caller
     backbones on synthetic data — BASELINE.json configs[1] (WRN-40-2+CNSN, bs128, fp32, 32x32) and
@@ -332,6 +369,7 @@ def main():
         }
         if world == 1 and not args.no_extra:
             out["extra"] = secondary_workloads(cnsn_amd, shape, dev, args)
+            out["extra"]["residual_block_add_cnsn_relu"] = residual_block_workloads(cnsn_amd, shape, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shape, args.crop, args.kind, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -1,6 +1,39 @@
 """What the two backbones share: building a CNSN unit from the reference's option strings and arming
 CrossNorm sites at random before a forward."""
+import os
+
 import numpy as np
+import torch
+
+# Fold the block's `sum of the two branches -> CNSN -> ReLU` into the op's own launches (CNSN.forward_block,
+# cnsn_forward_fused).  CNSN_FUSE_BLOCK=0 (or setting this to False) keeps the three separate ops.
+FUSE_BLOCK = os.environ.get("CNSN_FUSE_BLOCK", "1") != "0"
+
+
+def residual_sum(cnsn, pos, residual, skip, relu, skip_first=False):
+    """`residual + skip` (or `skip + residual` when `skip_first`, the order WideResNet writes) with CNSN at
+    `pos` in {'post', 'residual', 'identity', other = none here} and the block's final ReLU if `relu`:
+        resnet_cnsn.py:112-122      out(+=)identity, pos in {'residual','identity','post'}, relu
+        wideresnet_cnsn.py:86-96    torch.add(x, out), same positions, no relu
+    One fused call when the CNSN unit offers it (this library's, on device tensors); the literal ops otherwise."""
+    fb = getattr(cnsn, "forward_block", None) if (FUSE_BLOCK and cnsn is not None) else None
+    fusable = (fb is not None and pos in ("post", "residual", "identity") and residual.is_cuda
+               and residual.shape == skip.shape and residual.dtype == skip.dtype)
+    if fusable:
+        if pos == "post":
+            a, b = (skip, residual) if skip_first else (residual, skip)
+            return fb(a, b, add_mode="pre", relu=relu)
+        if pos == "residual":
+            return fb(residual, skip, add_mode="post", relu=relu)
+        return fb(skip, residual, add_mode="post", relu=relu)
+    if pos == "residual":
+        residual = cnsn(residual)
+    elif pos == "identity":
+        skip = cnsn(skip)
+    y = torch.add(skip, residual) if skip_first else residual + skip
+    if pos == "post":
+        y = cnsn(y)
+    return torch.relu(y) if relu else y
 
 
 def make_cnsn(impl, cnsn_type, crop, beta, width):

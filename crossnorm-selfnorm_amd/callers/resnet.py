@@ -7,7 +7,7 @@ SelfNorm sites per forward at batch B, pos='post' (SURVEY.md §3.2): (B,256,56,5
 import torch
 import torch.nn as nn
 
-from ._sites import CrossNormSites, make_cnsn
+from ._sites import CrossNormSites, make_cnsn, residual_sum
 
 
 class _Bottleneck(nn.Module):
@@ -35,14 +35,7 @@ class _Bottleneck(nn.Module):
         h = self.relu(self.bn2(self.conv2(h)))
         h = self.bn3(self.conv3(h))
         skip = x if self.downsample is None else self.downsample(x)
-        if self.pos == "residual":
-            h = self.cnsn(h)
-        elif self.pos == "identity":
-            skip = self.cnsn(skip)
-        h = h + skip
-        if self.pos == "post":
-            h = self.cnsn(h)
-        return self.relu(h)
+        return residual_sum(getattr(self, "cnsn", None), self.pos, h, skip, relu=True)      # :112-122
 
 
 class ResNet50CNSN(nn.Module, CrossNormSites):

@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ._sites import CrossNormSites, make_cnsn
+from ._sites import CrossNormSites, make_cnsn, residual_sum
 
 
 class _Block(nn.Module):
@@ -42,12 +42,7 @@ class _Block(nn.Module):
             h = F.dropout(h, p=self.drop_rate, training=self.training)
         h = self.conv2(h)
         skip = x if self.same_width else self.conv_shortcut(x)
-        if self.pos == "residual":
-            h = self.cnsn(h)
-        elif self.pos == "identity":
-            skip = self.cnsn(skip)
-        y = torch.add(skip, h)
-        return self.cnsn(y) if self.pos == "post" else y
+        return residual_sum(self.cnsn, self.pos, h, skip, relu=False, skip_first=True)         # :86-96
 
 
 class _Stage(nn.Module):

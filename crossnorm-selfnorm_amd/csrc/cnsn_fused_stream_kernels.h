@@ -2,7 +2,8 @@
 //     y = act( CNSN(x [+ addend]) [+ addend] ),   act = ReLU or identity
 // (reference call sites: models/imagenet/resnet_cnsn.py:112-122, models/cifar/wideresnet_cnsn.py:86-96).
 // Same thread mapping and streaming discipline as cnsn_stream_kernels.h; what changes is
-//   ADD_PRE : the op's input is formed in registers as x + addend in every pass (never materialised),
+//   ADD_PRE : the op's input is formed in registers as x + addend in every pass (never materialised;
+//             rounded to the tensor's type like the reference's in-place `out += identity`),
 //   ADD_POST: addend joins on the way out of the forward apply,
 //   relu    : max(.,0) on the way out; the backward re-evaluates the forward affine with the very
 //             coefficients the forward used (kept in `saved`) to recover the mask instead of reading y.
@@ -55,6 +56,15 @@ struct FwdAffine {
     __device__ __forceinline__ float out(float x) const { return fmaf(a_out, x, b_out); }
 };
 
+// x + addend as the reference's `out += identity` leaves it: a value of the tensor's own type
+template <typename T>
+__device__ __forceinline__ float sum_t(float a, float b) {
+    if constexpr (sizeof(T) == 4)
+        return a + b;
+    else
+        return to_float(from_float<T>(a + b));
+}
+
 // is the stored output element positive?  (what nn.ReLU's backward tests; for 16-bit tensors the value is
 // rounded the way the forward stored it first)
 template <typename T>
@@ -79,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void fused_stats_kernel(const T* __restrict
     {
         const Vec<T, VEC> fa = load_vec<T, VEC>(x + off), fb = load_vec<T, VEC>(addend + off);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) K += to_float(fa.v[j]) + to_float(fb.v[j]);
+        for (int j = 0; j < VEC; ++j) K += sum_t<T>(to_float(fa.v[j]), to_float(fb.v[j]));
         K *= (1.0f / VEC);
     }
     float part[NACC][VEC];
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void fused_stats_kernel(const T* __restrict
                                    const int r = BOXED ? e / g.Wd : 0, c = BOXED ? e - r * g.Wd : 0;
 #pragma unroll
                                    for (int j = 0; j < VEC; ++j) {
-                                       const float d = (to_float(va.v[j]) + to_float(vb.v[j])) - K;
+                                       const float d = sum_t<T>(to_float(va.v[j]), to_float(vb.v[j])) - K;
                                        if constexpr (!BOXED) {
                                            part[0][j] += d;
                                            part[1][j] = fmaf(d, d, part[1][j]);
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void fused_apply_fwd_kernel(const T* __rest
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             float f = to_float(vx.v[j]);
-            if constexpr (ADD == ADD_PRE) f += to_float(vb.v[j]);
+            if constexpr (ADD == ADD_PRE) f = sum_t<T>(f, to_float(vb.v[j]));
             float t = (!BOXED || g.cb.has(r, c + j)) ? fmaf(a_in, f - xr, b_in) : fmaf(a_out, f, b_out);
             if constexpr (ADD == ADD_POST) t += to_float(vb.v[j]);
             o.v[j] = from_float<T>(relu ? fmaxf(t, 0.f) : t);
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void fused_apply_fwd_kernel(const T* __rest
 template <typename T, int ADD, bool BOXED>
 __device__ __forceinline__ void masked_pair(float Gin, float xin, float bin, bool ic, const FwdAffine& fa, int relu,
                                             float& G, float& X) {
-    X = ADD == ADD_PRE ? xin + bin : xin;
+    X = ADD == ADD_PRE ? sum_t<T>(xin, bin) : xin;
     G = Gin;
     if (relu) {
         float t = (!BOXED || ic) ? fa.in(X) : fa.out(X);

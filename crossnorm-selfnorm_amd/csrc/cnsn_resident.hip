@@ -1,212 +1,23 @@
-// Host side of the channel-resident strategy: eligibility, launch geometry, dispatch.
-#include <hip/hip_runtime.h>
-
-#include <cstdio>
-#include <cstdlib>
-
-#include "cnsn_host_common.h"
-#include "cnsn_resident_kernels.h"
+// Channel-resident strategy, the op alone: host entry points (shared logic in cnsn_resident_host.h).
+#include "cnsn_resident_host.h"
 
 namespace cnsn {
 
-namespace {
-
-struct Bucket {
-    int nv, ppw_fwd, ppw_bwd;
-};
-// vectors per lane and plane -> planes per wave.  Chosen so a wave keeps <= 16 vectors (64 VGPRs) per
-// tensor in flight forward, twice that backward (G and x).
-// (the backward of the 7/8-slot buckets takes two planes per wave: measured 0.283 vs 0.355 ms on the
-// (256,256,56,56) bf16 backward; the forward is faster with one)
-constexpr Bucket kBuckets[] = {{1, 8, 8}, {2, 4, 4}, {4, 4, 4}, {7, 1, 2}, {8, 1, 2}, {13, 1, 1}, {16, 1, 1}};
-
-int cu_count() {
-    static int cached[16] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (cached[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cached[dev] = n;
-    }
-    return cached[dev];
-}
-
-template <typename F>
-bool dispatch_res(int dtype, int vec, int nv, bool backward, F&& f) {
-    auto by_nv = [&](auto tt, auto vt) -> bool {
-        if (backward && nv == 7) {
-            f(tt, vt, IntTag<7>{}, IntTag<2>{});
-            return true;
-        }
-        if (backward && nv == 8) {
-            f(tt, vt, IntTag<8>{}, IntTag<2>{});
-            return true;
-        }
-        switch (nv) {
-            case 1: f(tt, vt, IntTag<1>{}, IntTag<8>{}); return true;
-            case 2: f(tt, vt, IntTag<2>{}, IntTag<4>{}); return true;
-            case 4: f(tt, vt, IntTag<4>{}, IntTag<4>{}); return true;
-            case 7: f(tt, vt, IntTag<7>{}, IntTag<1>{}); return true;
-            case 8: f(tt, vt, IntTag<8>{}, IntTag<1>{}); return true;
-            case 13: f(tt, vt, IntTag<13>{}, IntTag<1>{}); return true;
-            case 16: f(tt, vt, IntTag<16>{}, IntTag<1>{}); return true;
-            default: return false;
-        }
-    };
-    if (dtype == CNSN_F32 && vec == 4) return by_nv(TypeTag<float>{}, IntTag<4>{});
-    if (dtype == CNSN_BF16 && vec == 8) return by_nv(TypeTag<bf16_t>{}, IntTag<8>{});
-    if (dtype == CNSN_BF16 && vec == 4) return by_nv(TypeTag<bf16_t>{}, IntTag<4>{});
-    if (dtype == CNSN_F16 && vec == 8) return by_nv(TypeTag<_Float16>{}, IntTag<8>{});
-    if (dtype == CNSN_F16 && vec == 4) return by_nv(TypeTag<_Float16>{}, IntTag<4>{});
-    return false;
-}
-
-ResArgs make_args(const cnsn_problem_t& p, Box cb, Box sb, const MidArgs& mid, const ResPlan& rp) {
-    ResArgs ra;
-    ra.mid = mid;
-    ra.M = p.H * p.W;
-    ra.Wd = p.W;
-    ra.nvec = ra.M / rp.vec;
-    ra.cb = cb;
-    ra.sb = sb;
-    ra.K = rp.K;
-    ra.items = p.C * rp.K;
-    const char* st = getenv("CNSN_STAGGER");
-    ra.stagger = st ? atoi(st) : 0;
-    ra.prof = nullptr;
-    return ra;
-}
-
-// persistent grid: every workgroup resident, a whole number of clusters
-template <typename Kern>
-int grid_for(Kern kern, size_t lds, int K, int items) {
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kBlock, lds) != hipSuccess) return 0;
-    // MI355X admits min(API, 8, floor(800 / (ceil(sgpr/16)*16 + 16))) workgroups of 256 threads per CU
-    // and the API over-reports by one when SGPRs are the limiter (MI355X_MICROARCH.md, "Residency").
-    // Every resident kernel here uses 106-108 SGPRs (checked at build time) -> 6.
-    if (occ > 6) occ = 6;
-    if (getenv("CNSN_DEBUG"))
-        fprintf(stderr, "[cnsn] resident grid: occupancy %d/CU x %d CUs, K=%d, items=%d, lds=%zu\n", occ, cu_count(),
-                K, items, lds);
-    long g = (long)occ * cu_count();
-    g = (g / K) * K;
-    if (g > items) g = items;  // items is a multiple of K
-    return (int)g;
-}
-
-}  // namespace
-
 ResPlan resident_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, bool backward) {
-    ResPlan rp{false, 0, 0, 0, 0};
-    if (p.strategy == CNSN_STRATEGY_TWO_PASS || has_chan_perm) return rp;
-    const int M = p.H * p.W;
-    rp.vec = pick_vec(p.dtype, boxed ? p.W : M);
-    if (!(rp.vec == 16 / elem_bytes(p.dtype) || (elem_bytes(p.dtype) == 2 && rp.vec == 4))) return rp;
-    const int nvec = M / rp.vec;
-    if (nvec <= 32) return rp;  // tiny planes: handled by the 16-lanes-per-plane streaming kernels
-    const int need = (nvec + 63) / 64;
-    for (const Bucket& b : kBuckets)
-        if (b.nv >= need) {
-            rp.nv = b.nv;
-            rp.ppw = backward ? b.ppw_bwd : b.ppw_fwd;
-            break;
-        }
-    if (rp.nv == 0) return rp;  // plane does not fit one wave's registers
-    const int own = 4 * rp.ppw;
-    rp.K = (p.N + own - 1) / own;
-    if (res_lds_bytes(p.N, 6, own, BC_ROWS, true) > 64 * 1024) return rp;
-    if (rp.K > 2 * cu_count()) return rp;
-    // AUTO: use the resident kernels where they measured faster than the (non-temporal) two-pass kernels on
-    // MI355X (profiles/r01_resident_tuning.md, last sweep): every eligible fp32 shape, both directions; for
-    // 16-bit tensors only the 1-vector plane class (14x14) — the resident kernels are bound by the latency
-    // of the cluster exchange, which halving the bytes does not shorten, while two-pass bf16 streams at
-    // 5.5 TB/s.  A register bucket more than 25 % larger than the plane needs is not worth it either.
-    // CNSN_STRATEGY_RESIDENT forces the resident kernels wherever they are eligible.
-    if (p.strategy == CNSN_STRATEGY_AUTO) {
-        if ((rp.nv - need) * 4 > need) return rp;
-        if (p.dtype != CNSN_F32 && !(rp.nv == 1 || (backward && (rp.nv == 7 || rp.nv == 8)))) return rp;
-    }
-    rp.ok = true;
-    return rp;
+    return reshost::plan_impl(p, boxed, has_chan_perm, backward, false);
 }
 
 int resident_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* x,
                      const int64_t* perm, GateDev g, GateDev f, void* y, double* saved, void* workspace,
                      hipStream_t stream) {
-    const ResPlan rp = resident_plan(p, boxed, false, false);
-    if (!rp.ok) return CNSN_E_UNSUPPORTED;
-    ResArgs ra = make_args(p, cb, sb, mid, rp);
-    const int NG = boxed ? 6 : 2;
-#ifdef CNSN_PROF  // tuning builds: time stamps land 4 MiB into the workspace (callers size it accordingly)
-    if (getenv("CNSN_PROF")) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
-#endif
-    const size_t lds = res_lds_bytes(p.N, NG, 4 * rp.ppw, FC_ROWS, false);
-    unsigned* ctl = (unsigned*)workspace;
-    unsigned long long* gran = (unsigned long long*)((char*)workspace + kCtlBytes);
-    const size_t fill_bytes = kCtlBytes + (size_t)p.N * p.C * (NG / 2) * 8;  // control block + granules
-    int status = CNSN_E_UNSUPPORTED;
-    dispatch_res(p.dtype, rp.vec, rp.nv, false, [&](auto tt, auto vt, auto nt, auto pt) {
-        using T = typename decltype(tt)::type;
-        constexpr int VEC = decltype(vt)::value, NV = decltype(nt)::value, PPW = decltype(pt)::value;
-        auto launch = [&](auto kern) {
-            const int grid = grid_for(kern, lds, rp.K, ra.items);
-            if (grid < rp.K) return;
-            hipError_t e = hipMemsetAsync(workspace, 0xff, fill_bytes, stream);  // 'empty' granules, idle control word
-            if (e != hipSuccess) {
-                status = (int)e;
-                return;
-            }
-            kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl);
-            e = hipGetLastError();
-            status = e == hipSuccess ? CNSN_OK : (int)e;
-        };
-        if (boxed)
-            launch(resident_fwd_kernel<T, VEC, NV, PPW, true>);
-        else
-            launch(resident_fwd_kernel<T, VEC, NV, PPW, false>);
-    });
-    return status;
+    return reshost::forward_impl<false>(p, cb, sb, boxed, mid, x, nullptr, 0, perm, g, f, y, saved, workspace, stream);
 }
 
 int resident_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* gy,
                       const void* x, const int64_t* perm, GateDev g, GateDev f, const double* saved, void* dx,
                       GateGradDev dg, GateGradDev df, void* workspace, hipStream_t stream) {
-    const ResPlan rp = resident_plan(p, boxed, false, true);
-    if (!rp.ok) return CNSN_E_UNSUPPORTED;
-    ResArgs ra = make_args(p, cb, sb, mid, rp);
-    const int NS = boxed ? 4 : 2;
-#ifdef CNSN_PROF
-    if (getenv("CNSN_PROF")) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
-#endif
-    const size_t lds = res_lds_bytes(p.N, NS, 4 * rp.ppw, BC_ROWS, true);
-    unsigned* ctl = (unsigned*)workspace;
-    unsigned long long* gran = (unsigned long long*)((char*)workspace + kCtlBytes);
-    const size_t fill_bytes = kCtlBytes + (size_t)p.N * p.C * (NS / 2) * 8;
-    int status = CNSN_E_UNSUPPORTED;
-    dispatch_res(p.dtype, rp.vec, rp.nv, true, [&](auto tt, auto vt, auto nt, auto pt) {
-        using T = typename decltype(tt)::type;
-        constexpr int VEC = decltype(vt)::value, NV = decltype(nt)::value, PPW = decltype(pt)::value;
-        auto launch = [&](auto kern) {
-            const int grid = grid_for(kern, lds, rp.K, ra.items);
-            if (grid < rp.K) return;
-            hipError_t e = hipMemsetAsync(workspace, 0xff, fill_bytes, stream);  // 'empty' granules, idle control word
-            if (e != hipSuccess) {
-                status = (int)e;
-                return;
-            }
-            kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)gy, (const T*)x, (T*)dx, perm, g, f, dg, df, gran,
-                                                saved, ctl);
-            e = hipGetLastError();
-            status = e == hipSuccess ? CNSN_OK : (int)e;
-        };
-        if (boxed)
-            launch(resident_bwd_kernel<T, VEC, NV, PPW, true>);
-        else
-            launch(resident_bwd_kernel<T, VEC, NV, PPW, false>);
-    });
-    return status;
+    return reshost::backward_impl<false>(p, cb, sb, boxed, mid, gy, x, nullptr, 0, perm, g, f, saved, dx, dg, df,
+                                         workspace, stream);
 }
 
 size_t resident_workspace_bytes(const cnsn_problem_t& p, bool boxed) {

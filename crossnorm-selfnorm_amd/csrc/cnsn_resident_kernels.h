@@ -254,6 +254,32 @@ constexpr int bwd_waves(int) { return CNSN_WB; }
 constexpr int fwd_waves(int) { return 4; }
 constexpr int bwd_waves(int) { return 3; }
 #endif
+// with the residual-block epilogue a second / third tensor is in flight next to the planes held
+#ifndef CNSN_WFE
+#define CNSN_WFE 3
+#endif
+#ifndef CNSN_WBE
+#define CNSN_WBE 2
+#endif
+constexpr int fwd_waves_epi(int) { return CNSN_WFE; }
+constexpr int bwd_waves_epi(int) { return CNSN_WBE; }
+
+// residual-block epilogue of the resident kernels (template flag EPI): the op's input is x + addend when
+// `addend` is not NULL (rounded to T like the reference's `out += identity`), ReLU on the way out when `relu`
+template <typename T>
+__device__ __forceinline__ bool relu_open_r(float t) {
+    if constexpr (sizeof(T) == 4)
+        return t > 0.f;
+    else
+        return to_float(from_float<T>(t)) > 0.f;
+}
+template <typename T, int VEC>
+__device__ __forceinline__ Raw<T, VEC> add_raw(const Raw<T, VEC>& a, const Raw<T, VEC>& b) {
+    float f[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) f[q] = elem<T, VEC>(a, q) + elem<T, VEC>(b, q);
+    return pack<T, VEC>(f);
+}
 
 // dynamic LDS carve (bytes); NG = granules per plane, OWN = planes per workgroup
 // rows of `saved` the backward algebra needs, staged in LDS per item (floats / doubles per instance)
@@ -272,11 +298,12 @@ __host__ __device__ inline size_t res_lds_bytes(int N, int NG, int OWN, int coef
 // ================================================================================================
 // forward
 // ================================================================================================
-template <typename T, int VEC, int NV, int PPW, bool BOXED>
-__global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW))) void resident_fwd_kernel(ResArgs ra, const T* __restrict__ x, T* __restrict__ y,
+template <typename T, int VEC, int NV, int PPW, bool BOXED, bool EPI = false>
+__global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi(0) : fwd_waves(data_regs(sizeof(T), VEC, NV, PPW))) void resident_fwd_kernel(ResArgs ra, const T* __restrict__ x, T* __restrict__ y,
                                                               const int64_t* __restrict__ perm, GateDev gg, GateDev gf,
                                                               unsigned long long* __restrict__ gran,
-                                                              double* __restrict__ saved, unsigned* __restrict__ ctl) {
+                                                              double* __restrict__ saved, unsigned* __restrict__ ctl,
+                                                              const T* __restrict__ addend, int relu) {
     constexpr int NG = BOXED ? 6 : 2;
     constexpr int OWN = 4 * PPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -336,6 +363,14 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
             const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;  // past the batch end: every lane reads zeros
 #pragma unroll
             for (int j = 0; j < NV; ++j) d[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(pb, pbytes, j), voff);
+            if constexpr (EPI) {
+                if (addend) {  // the op's input is x + addend, formed here and never written anywhere
+                    const T* ab = addend + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
+#pragma unroll
+                    for (int j = 0; j < NV; ++j)
+                        d[s][j] = add_raw<T, VEC>(d[s][j], buf_load<T, VEC>(slot_rsrc<T, VEC>(ab, pbytes, j), voff));
+                }
+            }
         }
 
         // ---- exact two-pass statistics from registers; publish them to the cluster
@@ -545,6 +580,7 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
                         const float f = elem<T, VEC>(d[s][j], q);
                         const bool ic = !BOXED || (sg.in_c(j, q));
                         ov[q] = ic ? fmaf(a_in, f - xr, b_in) : fmaf(a_out, f, b_out);
+                        if constexpr (EPI) ov[q] = relu ? fmaxf(ov[q], 0.f) : ov[q];
                     }
                     buf_store<T, VEC>(slot_rsrc<T, VEC>(yb, pbytes, j), voff, pack<T, VEC>(ov));
                 }
@@ -557,14 +593,15 @@ __global__ __launch_bounds__(kBlock, fwd_waves(data_regs(sizeof(T), VEC, NV, PPW
 // ================================================================================================
 // backward
 // ================================================================================================
-template <typename T, int VEC, int NV, int PPW, bool BOXED>
-__global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW))) void resident_bwd_kernel(ResArgs ra, const T* __restrict__ gy,
+template <typename T, int VEC, int NV, int PPW, bool BOXED, bool EPI = false>
+__global__ __launch_bounds__(kBlock, EPI ? bwd_waves_epi(0) : bwd_waves(data_regs(sizeof(T), VEC, NV, PPW))) void resident_bwd_kernel(ResArgs ra, const T* __restrict__ gy,
                                                               const T* __restrict__ x, T* __restrict__ dx,
                                                               const int64_t* __restrict__ perm, GateDev gg, GateDev gf,
                                                               GateGradDev dgr, GateGradDev dfr,
                                                               unsigned long long* __restrict__ gran,
                                                               const double* __restrict__ saved,
-                                                              unsigned* __restrict__ ctl) {
+                                                              unsigned* __restrict__ ctl,
+                                                              const T* __restrict__ addend, int relu) {
     constexpr int NS = BOXED ? 4 : 2;
     constexpr int OWN = 4 * PPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -613,11 +650,18 @@ __global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW
             }
         }
         float own_si[PPW], own_so[PPW];
+        float own_fc[EPI ? PPW : 1][FC_ROWS];  // the forward's apply coefficients of the owned planes (ReLU mask)
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
             const size_t p = (size_t)(n0 + s < N ? n0 + s : 0) * C + c;
             own_si[s] = (float)saved[sv_at(p, SV_MU_C)];
             own_so[s] = BOXED ? (float)saved[sv_at(p, SV_MU_O)] : 0.f;
+            if constexpr (EPI) {
+                if (relu) {
+#pragma unroll
+                    for (int r = 0; r < FC_ROWS; ++r) own_fc[s][r] = (float)saved[sv_at(p, SV_FC0 + r)];
+                }
+            }
         }
         for (int n = threadIdx.x; n < N; n += kBlock) {
             const size_t p = (size_t)n * C + c;
@@ -651,6 +695,31 @@ __global__ __launch_bounds__(kBlock, bwd_waves(data_regs(sizeof(T), VEC, NV, PPW
             for (int j = 0; j < NV; ++j) {
                 dg_[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(gy + off, pbytes, j), voff);
                 dx_[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(x + off, pbytes, j), voff);
+            }
+            if constexpr (EPI) {
+                if (addend) {
+#pragma unroll
+                    for (int j = 0; j < NV; ++j)
+                        dx_[s][j] =
+                            add_raw<T, VEC>(dx_[s][j], buf_load<T, VEC>(slot_rsrc<T, VEC>(addend + off, pbytes, j), voff));
+                }
+                if (relu) {  // shut the gradient where the forward's output was not positive: the forward affine
+                             // is re-evaluated with the coefficients the forward itself used
+                    const float a_in = own_fc[s][FC_A_IN], xr = own_fc[s][FC_XR], b_in = own_fc[s][FC_B_IN],
+                                a_out = own_fc[s][FC_A_OUT], b_out = own_fc[s][FC_B_OUT];
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) {
+                        float gm[VEC];
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) {
+                            const float X = elem<T, VEC>(dx_[s][j], q);
+                            const bool ic = !BOXED || sg.in_c(j, q);
+                            const float t = ic ? fmaf(a_in, X - xr, b_in) : fmaf(a_out, X, b_out);
+                            gm[q] = relu_open_r<T>(t) ? elem<T, VEC>(dg_[s][j], q) : 0.f;
+                        }
+                        dg_[s][j] = pack<T, VEC>(gm);
+                    }
+                }
             }
         }
 

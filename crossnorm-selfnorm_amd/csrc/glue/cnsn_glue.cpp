@@ -79,7 +79,39 @@ struct Config {
     int64_t sn_active, sn_two, sn_training;
     double eps_cn, eps_sn, eps_bn, momentum;
     int64_t strategy;
+    int64_t add_mode, relu;  // residual-block epilogue (cnsn_epilogue_t)
 };
+
+Config parse_config(const std::vector<int64_t>& cfg, const std::vector<double>& fcfg) {
+    TORCH_CHECK(cfg.size() == 16 && fcfg.size() == 5, "cnsn glue: bad config vectors");
+    Config c{};
+    c.cn_active = cfg[0];
+    for (int i = 0; i < 4; ++i) {
+        c.cbox[i] = cfg[1 + i];
+        c.sbox[i] = cfg[5 + i];
+    }
+    c.sn_active = cfg[9];
+    c.sn_two = cfg[10];
+    c.sn_training = cfg[11];
+    c.strategy = cfg[12];
+    c.add_mode = cfg[14];
+    c.relu = cfg[15];
+    c.lam = fcfg[0];
+    c.eps_cn = fcfg[1];
+    c.eps_sn = fcfg[2];
+    c.eps_bn = fcfg[3];
+    c.momentum = fcfg[4];
+    return c;
+}
+
+cnsn_epilogue_t make_epilogue(const Config& c, const Tensor& addend) {
+    cnsn_epilogue_t e{};
+    e.struct_bytes = (int32_t)sizeof(cnsn_epilogue_t);
+    e.add_mode = (int32_t)c.add_mode;
+    e.relu = (int32_t)c.relu;
+    e.addend = addend.defined() ? addend.data_ptr() : nullptr;
+    return e;
+}
 
 cnsn_problem_t make_problem(const Tensor& x, const Config& c) {
     cnsn_problem_t p{};
@@ -136,7 +168,7 @@ struct GateTensors {  // float32 contiguous views/copies + where running stats m
 
 class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
    public:
-    // cfg: [cn_active, cb0..3, sb0..3, sn_active, sn_two, sn_training, strategy, need_backward]
+    // cfg: [cn_active, cb0..3, sb0..3, sn_active, sn_two, sn_training, strategy, need_backward, add_mode, relu]
     // fcfg: [lam, eps_cn, eps_sn, eps_bn, momentum]
     static Tensor forward(AutogradContext* ctx, const Tensor& x_in, std::vector<int64_t> cfg, std::vector<double> fcfg,
                           const c10::optional<Tensor>& perm_in, const c10::optional<Tensor>& chan_in,
@@ -144,29 +176,24 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
                           const c10::optional<Tensor>& g_beta, const c10::optional<Tensor>& g_rm,
                           const c10::optional<Tensor>& g_rv, const c10::optional<Tensor>& f_w,
                           const c10::optional<Tensor>& f_gamma, const c10::optional<Tensor>& f_beta,
-                          const c10::optional<Tensor>& f_rm, const c10::optional<Tensor>& f_rv) {
+                          const c10::optional<Tensor>& f_rm, const c10::optional<Tensor>& f_rv,
+                          const c10::optional<Tensor>& addend_in) {
         TORCH_CHECK(x_in.is_cuda(), "cnsn_forward: got a ", x_in.device().type(),
                     " tensor. This implementation runs on MI355X HIP device tensors only; there is no CPU path.");
         TORCH_CHECK(x_in.dim() == 4, "expected an (N, C, H, W) tensor");
-        TORCH_CHECK(cfg.size() == 14 && fcfg.size() == 5, "cnsn glue: bad config vectors");
-        Config c{};
-        c.cn_active = cfg[0];
-        for (int i = 0; i < 4; ++i) {
-            c.cbox[i] = cfg[1 + i];
-            c.sbox[i] = cfg[5 + i];
-        }
-        c.sn_active = cfg[9];
-        c.sn_two = cfg[10];
-        c.sn_training = cfg[11];
-        c.strategy = cfg[12];
-        c.lam = fcfg[0];
-        c.eps_cn = fcfg[1];
-        c.eps_sn = fcfg[2];
-        c.eps_bn = fcfg[3];
-        c.momentum = fcfg[4];
+        const Config c = parse_config(cfg, fcfg);
 
         const Tensor x = x_in.contiguous();  // reference cnsn.py:14
+        Tensor addend;
+        if (c.add_mode != CNSN_ADD_NONE) {
+            TORCH_CHECK(addend_in.has_value() && addend_in->is_cuda() && addend_in->sizes() == x.sizes() &&
+                            addend_in->scalar_type() == x.scalar_type(),
+                        "cnsn_forward: the addend must be a device tensor of x's shape and dtype");
+            addend = addend_in->contiguous();
+        }
         const cnsn_problem_t prob = make_problem(x, c);
+        const cnsn_epilogue_t epi = make_epilogue(c, addend);
+        const bool has_epi = c.add_mode != CNSN_ADD_NONE || c.relu;
         const at::Device dev = x.device();
         Tensor perm, chan;
         if (c.cn_active) {
@@ -187,10 +214,12 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
         if (need_bwd && ws_bytes > 0) saved = at::empty({(int64_t)cnsn_saved_floats(&prob)}, fopt);
         Tensor ws = at::empty({(int64_t)(ws_bytes / 4) + 1}, fopt);
         hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
-        const int st = cnsn_forward(&prob, x.data_ptr(), c.cn_active ? perm.data_ptr<int64_t>() : nullptr,
-                                    chan.defined() ? chan.data_ptr<int64_t>() : nullptr, c.sn_active ? &gg.c : nullptr,
-                                    two ? &gf.c : nullptr, y.data_ptr(), saved.defined() ? saved.data_ptr<float>() : nullptr,
-                                    ws.data_ptr(), ws_bytes, (void*)stream);
+        const int st = cnsn_forward_fused(&prob, has_epi ? &epi : nullptr, x.data_ptr(),
+                                          c.cn_active ? perm.data_ptr<int64_t>() : nullptr,
+                                          chan.defined() ? chan.data_ptr<int64_t>() : nullptr, c.sn_active ? &gg.c : nullptr,
+                                          two ? &gf.c : nullptr, y.data_ptr(),
+                                          saved.defined() ? saved.data_ptr<float>() : nullptr, ws.data_ptr(), ws_bytes,
+                                          (void*)stream);
         check_status(st, "cnsn_forward");
         if (c.sn_active && c.sn_training) {
             gg.write_back();
@@ -207,32 +236,19 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
             ctx->save_for_backward({x, saved, perm.defined() ? perm : none, chan.defined() ? chan : none,
                                     c.sn_active ? gg.w : none, c.sn_active ? gg.gamma : none, c.sn_active ? gg.beta : none,
                                     c.sn_active ? gg.rm : none, c.sn_active ? gg.rv : none, two ? gf.w : none,
-                                    two ? gf.gamma : none, two ? gf.beta : none, two ? gf.rm : none, two ? gf.rv : none});
+                                    two ? gf.gamma : none, two ? gf.beta : none, two ? gf.rm : none, two ? gf.rv : none,
+                                    addend.defined() ? addend : none});
         }
         return y;
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list grads) {
         const auto sv = ctx->get_saved_variables();
-        const Tensor &x = sv[0], &saved = sv[1], &perm = sv[2], &chan = sv[3];
+        const Tensor &x = sv[0], &saved = sv[1], &perm = sv[2], &chan = sv[3], &addend = sv[14];
         const auto cfg = ctx->saved_data["cfg"].toIntVector();
         const auto fcfg = ctx->saved_data["fcfg"].toDoubleVector();
         const auto pd = ctx->saved_data["pd"].toIntVector();
-        Config c{};
-        c.cn_active = cfg[0];
-        for (int i = 0; i < 4; ++i) {
-            c.cbox[i] = cfg[1 + i];
-            c.sbox[i] = cfg[5 + i];
-        }
-        c.sn_active = cfg[9];
-        c.sn_two = cfg[10];
-        c.sn_training = cfg[11];
-        c.strategy = cfg[12];
-        c.lam = fcfg[0];
-        c.eps_cn = fcfg[1];
-        c.eps_sn = fcfg[2];
-        c.eps_bn = fcfg[3];
-        c.momentum = fcfg[4];
+        const Config c = parse_config(cfg, fcfg);
         const cnsn_problem_t prob = make_problem(x, c);
         const bool two = c.sn_active && c.sn_two;
         const at::Device dev = x.device();
@@ -270,19 +286,25 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
             }
         }
         hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
-        const int st = cnsn_backward(&prob, gy.data_ptr(), x.data_ptr(), perm.defined() ? perm.data_ptr<int64_t>() : nullptr,
-                                     chan.defined() ? chan.data_ptr<int64_t>() : nullptr, c.sn_active ? &gg : nullptr,
-                                     two ? &gf : nullptr, saved.data_ptr<float>(), dx.data_ptr(),
-                                     c.sn_active ? &dgg : nullptr, two ? &dgf : nullptr, ws.data_ptr(), ws_bytes,
-                                     (void*)stream);
+        const cnsn_epilogue_t epi = make_epilogue(c, addend);
+        const bool has_epi = c.add_mode != CNSN_ADD_NONE || c.relu;
+        Tensor d_add;  // gradient of the addend: dx itself (PRE), grad_y behind the ReLU mask (POST)
+        if (c.add_mode == CNSN_ADD_POST) d_add = c.relu ? at::empty_like(x) : gy;
+        const int st = cnsn_backward_fused(
+            &prob, has_epi ? &epi : nullptr, gy.data_ptr(), x.data_ptr(), perm.defined() ? perm.data_ptr<int64_t>() : nullptr,
+            chan.defined() ? chan.data_ptr<int64_t>() : nullptr, c.sn_active ? &gg : nullptr, two ? &gf : nullptr,
+            saved.data_ptr<float>(), dx.data_ptr(), (c.add_mode == CNSN_ADD_POST && c.relu) ? d_add.data_ptr() : nullptr,
+            c.sn_active ? &dgg : nullptr, two ? &dgf : nullptr, ws.data_ptr(), ws_bytes, (void*)stream);
+        if (c.add_mode == CNSN_ADD_PRE) d_add = dx;
         check_status(st, "cnsn_backward");
 
         auto cast = [](const Tensor& t, int64_t code) {
             return (code >= 0 && (int64_t)t.scalar_type() != code) ? t.to((at::ScalarType)code) : t;
         };
         Tensor none;
-        variable_list out(15, none);
+        variable_list out(16, none);
         out[0] = dx;
+        out[15] = d_add;
         if (c.sn_active) {
             out[5] = cast(flat_g.narrow(0, 0, 2 * Cn).view({Cn, 1, 2}), pd[0]);
             out[6] = cast(flat_g.narrow(0, 2 * Cn, Cn), pd[1]);
@@ -302,8 +324,10 @@ Tensor fused_cnsn(const Tensor& x, std::vector<int64_t> cfg, std::vector<double>
                   const c10::optional<Tensor>& g_gamma, const c10::optional<Tensor>& g_beta,
                   const c10::optional<Tensor>& g_rm, const c10::optional<Tensor>& g_rv, const c10::optional<Tensor>& f_w,
                   const c10::optional<Tensor>& f_gamma, const c10::optional<Tensor>& f_beta,
-                  const c10::optional<Tensor>& f_rm, const c10::optional<Tensor>& f_rv) {
-    return FusedCNSN::apply(x, cfg, fcfg, perm, chan, g_w, g_gamma, g_beta, g_rm, g_rv, f_w, f_gamma, f_beta, f_rm, f_rv);
+                  const c10::optional<Tensor>& f_rm, const c10::optional<Tensor>& f_rv,
+                  const c10::optional<Tensor>& addend) {
+    return FusedCNSN::apply(x, cfg, fcfg, perm, chan, g_w, g_gamma, g_beta, g_rm, g_rv, f_w, f_gamma, f_beta, f_rm, f_rv,
+                            addend);
 }
 
 }  // namespace

@@ -283,19 +283,21 @@ def fused_cnsn(x, cfg: FusedConfig, perm=None, chan_perm=None, g: Optional[GateP
     ga = (g.fc_weight, g.bn_weight, g.bn_bias, g.running_mean, g.running_var) if g else (None,) * 5
     fa = (f.fc_weight, f.bn_weight, f.bn_bias, f.running_mean, f.running_var) if f else (None,) * 5
     glue = _ffi.glue()
-    if glue is None or cfg.has_epilogue:
+    if glue is None:
         return FusedCNSN.apply(x, cfg, perm, chan_perm, *ga, *fa, addend)
     # C++ glue: same C ABI calls, without the Python per-call overhead
     _require_device(x, "cnsn_forward")
+    if cfg.add_mode == "none":
+        addend = None
     need_bwd = torch.is_grad_enabled() and (x.requires_grad or any(
-        t is not None and t.requires_grad for t in (*ga[:3], *fa[:3])))
+        t is not None and t.requires_grad for t in (*ga[:3], *fa[:3], addend)))
     cb = cfg.content_box if cfg.content_box is not None else (-1, -1, -1, -1)
     sb = cfg.style_box if cfg.style_box is not None else (-1, -1, -1, -1)
     icfg = [int(cfg.cn_active), *(int(v) for v in cb), *(int(v) for v in sb), int(cfg.sn_active), int(cfg.sn_two),
-            int(cfg.sn_training), _strategy, int(need_bwd)]
+            int(cfg.sn_training), _strategy, int(need_bwd), _ADD_MODES[cfg.add_mode], int(cfg.relu)]
     fcfg = [0.0 if cfg.lam is None else float(cfg.lam), cfg.eps_cn, cfg.eps_sn, cfg.eps_bn, cfg.momentum]
     return glue.fused_cnsn(x, icfg, fcfg, perm if cfg.cn_active else None, chan_perm if cfg.cn_active else None,
-                           *ga, *fa)
+                           *ga, *fa, addend)
 
 
 # ------------------------------------------------------------------------------------------------
