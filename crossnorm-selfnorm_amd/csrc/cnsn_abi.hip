@@ -8,6 +8,7 @@
 #include "cnsn_device.h"
 #include "cnsn_host_plan.h"
 #include "cnsn_mid_kernels.h"
+#include "cnsn_packed.h"
 #include "cnsn_resident_kernels.h"
 #include "cnsn_stream_kernels.h"
 
@@ -86,6 +87,14 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
         if (st != CNSN_E_UNSUPPORTED) return st;  // otherwise: fall through to the two-pass strategy
     }
 
+    PackedGeom pg;
+    if (packed_plan(pl, pg)) {  // small planes: runs of planes staged through LDS (cnsn_packed_kernels.h)
+        packed_stats(pl, pg, 0, x, nullptr, mom, stream);
+        launch_mid_fwd(pl, mom, perm, chan_perm, gate_dev(g), gate_dev(f), coef, saved_d, stream);
+        packed_apply_fwd(pl, pg, 0, 0, x, nullptr, y, coef, stream);
+        return launch_status();
+    }
+
     const int blocks = blocks_for(pl.geom.P, pl.shape.lpp);
     dispatch(p.dtype, pl.shape, [&](auto tt, auto vt, auto lt) {
         using T = typename decltype(tt)::type;
@@ -136,6 +145,15 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
         st = resident_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, grad_y, x, perm, gate_dev(g), gate_dev(f),
                                saved_d, grad_x, gate_grad_dev(dg), gate_grad_dev(df), workspace, stream);
         if (st != CNSN_E_UNSUPPORTED) return st;
+    }
+
+    PackedGeom pg;
+    if (packed_plan(pl, pg)) {
+        packed_reduce(pl, pg, 0, 0, grad_y, x, nullptr, saved_d, sums, stream);
+        launch_mid_bwd(pl, sums, saved_d, perm, chan_perm, gate_dev(g), gate_dev(f), gate_grad_dev(dg), gate_grad_dev(df),
+                       tmp, coef, stream);
+        packed_apply_bwd(pl, pg, 0, 0, grad_y, x, nullptr, grad_x, nullptr, coef, saved_d, stream);
+        return launch_status();
     }
 
     const int blocks = blocks_for(pl.geom.P, pl.shape.lpp);

@@ -6,6 +6,7 @@
 
 #include "cnsn_fused_stream_kernels.h"
 #include "cnsn_host_plan.h"
+#include "cnsn_packed.h"
 #include "cnsn_resident_fused.h"
 
 using namespace cnsn;
@@ -80,6 +81,14 @@ int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, c
         if (st != CNSN_E_UNSUPPORTED) return st;
     }
 
+    PackedGeom pg;
+    if (packed_plan(pl, pg)) {
+        packed_stats(pl, pg, e.add, x, e.addend, mom, stream);
+        launch_mid_fwd(pl, mom, perm, chan_perm, gate_dev(g), gate_dev(f), coef, saved_d, stream);
+        packed_apply_fwd(pl, pg, e.add, e.relu, x, e.addend, y, coef, stream);
+        return launch_status();
+    }
+
     const int blocks = blocks_for(pl.geom.P, pl.shape.lpp);
     dispatch(p.dtype, pl.shape, [&](auto tt, auto vt, auto lt) {
         using T = typename decltype(tt)::type;
@@ -151,6 +160,15 @@ int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, 
                                      gate_dev(g), gate_dev(f), saved_d, grad_x, gate_grad_dev(dg), gate_grad_dev(df),
                                      workspace, stream);
         if (st != CNSN_E_UNSUPPORTED) return st;
+    }
+
+    PackedGeom pg;
+    if (packed_plan(pl, pg)) {
+        packed_reduce(pl, pg, e.add, e.relu, grad_y, x, e.addend, saved_d, sums, stream);
+        launch_mid_bwd(pl, sums, saved_d, perm, chan_perm, gate_dev(g), gate_dev(f), gate_grad_dev(dg), gate_grad_dev(df),
+                       tmp, coef, stream);
+        packed_apply_bwd(pl, pg, e.add, e.relu, grad_y, x, e.addend, grad_x, grad_addend, coef, saved_d, stream);
+        return launch_status();
     }
 
     const int blocks = blocks_for(pl.geom.P, pl.shape.lpp);
