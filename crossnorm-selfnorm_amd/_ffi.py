@@ -65,6 +65,9 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p, C.POINTER(Gate), C.POINTER(Gate),
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GateGrad),
                                       C.POINTER(GateGrad), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cnsn_jsd_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "cnsn_jsd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cnsn_plane_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.POINTER(C.c_int32), C.c_float, C.c_void_p, C.c_void_p]),
     "cnsn_plane_stats_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

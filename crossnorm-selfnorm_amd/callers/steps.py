@@ -17,6 +17,10 @@ def jsd_consistency(logits_clean, logits_aug1, logits_aug2):
     """Jensen-Shannon consistency of three views (cifar.py:173-186, imagenet.py:367-381):
     mixture = clamp(mean of the 3 softmaxes, 1e-7, 1).log(); mean of the three KL(mixture || p_i),
     each with reduction 'batchmean'."""
+    if logits_clean.is_cuda:                       # one fused launch (cnsn_jsd), loss and gradient
+        from ..functional import jsd_consistency as _jsd
+        return _jsd(logits_clean, logits_aug1, logits_aug2)
+    # host tensors (step-structure tests): the reference's own sequence of ops
     p = [F.softmax(l, dim=1) for l in (logits_clean, logits_aug1, logits_aug2)]
     log_mix = torch.clamp((p[0] + p[1] + p[2]) / 3.0, 1e-7, 1).log()
     return sum(F.kl_div(log_mix, pi, reduction="batchmean") for pi in p) / 3.0

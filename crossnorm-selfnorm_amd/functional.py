@@ -379,3 +379,42 @@ class PlaneAffine(torch.autograd.Function):
             dscale = sums[1].view(s_shape).to(s_dtype)
             dshift = sums[0].view(t_shape).to(t_dtype)
         return dx, dscale, dshift
+
+
+class JsdConsistency(torch.autograd.Function):
+    """Jensen-Shannon consistency of three (B, K) logit tensors — cnsn_jsd: loss and gradient in one launch
+    (reference imagenet.py:367-381, cifar.py:173-186)."""
+
+    @staticmethod
+    def forward(ctx, l0, l1, l2):
+        lib = _ffi.lib()
+        for t in (l0, l1, l2):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda):
+                raise _ffi.CnsnError("jsd_consistency: HIP device tensors only")
+        assert l0.dim() == 2 and l0.shape == l1.shape == l2.shape and l0.dtype == l1.dtype == l2.dtype
+        if l0.dtype not in _DTYPES:
+            raise TypeError(f"jsd_consistency: dtype {l0.dtype} not supported")
+        l0, l1, l2 = l0.contiguous(), l1.contiguous(), l2.contiguous()
+        b, k = int(l0.shape[0]), int(l0.shape[1])
+        need = any(ctx.needs_input_grad)
+        loss = torch.empty((), dtype=torch.float32, device=l0.device)
+        grads = torch.empty((3, b, k), dtype=l0.dtype, device=l0.device) if need else None
+        wsb = lib.cnsn_jsd_workspace_bytes(b)
+        ws = torch.empty(wsb // 4 + 1, dtype=torch.float32, device=l0.device)
+        st = lib.cnsn_jsd(_ptr(l0), _ptr(l1), _ptr(l2), _DTYPES[l0.dtype], b, k, _ptr(loss),
+                          _ptr(grads[0]) if need else None, _ptr(grads[1]) if need else None,
+                          _ptr(grads[2]) if need else None, _ptr(ws), wsb, _stream(l0))
+        _ffi.check(st, "cnsn_jsd")
+        if need:
+            ctx.save_for_backward(grads)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (grads,) = ctx.saved_tensors
+        g = grads * gloss.to(grads.dtype)          # the loss is a scalar: chain rule is one scale of 3*B*K values
+        return g[0], g[1], g[2]
+
+
+def jsd_consistency(logits_clean, logits_aug1, logits_aug2):
+    return JsdConsistency.apply(logits_clean, logits_aug1, logits_aug2)

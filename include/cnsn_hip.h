@@ -183,6 +183,18 @@ int cnsn_plane_affine(const void* x, int dtype, int N, int C, int H, int W, cons
 int cnsn_plane_dot(const void* g, const void* x, int dtype, int N, int C, int H, int W,
                    float* sums, void* stream);
 
+/* ---- Jensen-Shannon consistency of three views ----------------------------------
+ * imagenet.py:367-381 / cifar.py:173-186: p_i = softmax(logits_i, 1); lm = clamp(mean_i p_i, 1e-7, 1).log();
+ * loss = mean_i F.kl_div(lm, p_i, reduction='batchmean').  One launch computes the loss and, when the three
+ * gradient pointers are given, d loss / d logits_i (same dtype as the logits; scale by the upstream gradient
+ * of the scalar loss on the caller's side).  logits: (B, K) row-major, contiguous.
+ *   loss       float32 scalar (device)
+ *   workspace  cnsn_jsd_workspace_bytes(B) bytes */
+size_t cnsn_jsd_workspace_bytes(int B);
+int cnsn_jsd(const void* logits_clean, const void* logits_aug1, const void* logits_aug2, int dtype, int B,
+             int K, float* loss, void* d_clean, void* d_aug1, void* d_aug2, void* workspace,
+             size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,8 +107,11 @@ def test_resnet50_logits_match_reference_on_gpu(g6):
 
 
 def test_jsd_properties_and_steps_on_cpu():
+    from oracle import jsd_oracle
     torch.manual_seed(0)
     a, b, c = (torch.randn(8, 10) for _ in range(3))
+    assert float(jsd_oracle.jsd_consistency(a, a, a)) == pytest.approx(0.0, abs=1e-6)
+    assert float(jsd_oracle.jsd_consistency(a, b, c)) == pytest.approx(float(jsd_consistency(a, b, c)), rel=1e-6)
     assert float(jsd_consistency(a, a, a)) == pytest.approx(0.0, abs=1e-6)     # identical views
     assert float(jsd_consistency(a, b, c)) > 0                                  # JSD >= 0
     assert float(jsd_consistency(a, b, c)) == pytest.approx(float(jsd_consistency(c, a, b)), rel=1e-5)
