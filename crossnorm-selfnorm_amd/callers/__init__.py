@@ -3,10 +3,11 @@ the reference's configs name — WideResNet-40-2 (CIFAR) and ResNet-50 (ImageNet
 exactly the sites, widths and `state_dict` keys of the reference model files, plus the training-step
 structure (random CrossNorm site activation, 3-view JSD consistency).  Stock `nn.Conv2d` /
 `nn.BatchNorm2d` (MIOpen) everywhere else: only the CNSN path is this repository's own kernels."""
+from .ibn import IBN, InstanceNorm2d
 from .resnet import ResNet50CNSN
 from .steps import (image_space_crossnorm, jsd_consistency, train_step_cn, train_step_cn_consistency,
                     train_step_image_cn_views)
 from .wideresnet import WideResNetCNSN
 
-__all__ = ["WideResNetCNSN", "ResNet50CNSN", "jsd_consistency", "train_step_cn", "train_step_cn_consistency",
+__all__ = ["WideResNetCNSN", "ResNet50CNSN", "IBN", "InstanceNorm2d", "jsd_consistency", "train_step_cn", "train_step_cn_consistency",
            "image_space_crossnorm", "train_step_image_cn_views"]

@@ -311,7 +311,7 @@ class PlaneStats(torch.autograd.Function):
     """(mean, std) of every plane — cnsn_plane_stats / cnsn_plane_stats_backward."""
 
     @staticmethod
-    def forward(ctx, x, eps, box):
+    def forward(ctx, x, eps, box, keep_fp32=False):
         _require_device(x, "calc_ins_mean_std")
         lib = _ffi.lib()
         x = x.contiguous()
@@ -322,8 +322,9 @@ class PlaneStats(torch.autograd.Function):
         _ffi.check(st, "cnsn_plane_stats")
         ctx.box = box
         ctx.save_for_backward(x, ms)
-        mean = ms[0].view(n, c, 1, 1).to(x.dtype)
-        std = ms[1].view(n, c, 1, 1).to(x.dtype)
+        out_dtype = torch.float32 if keep_fp32 else x.dtype
+        mean = ms[0].view(n, c, 1, 1).to(out_dtype)
+        std = ms[1].view(n, c, 1, 1).to(out_dtype)
         return mean, std
 
     @staticmethod
@@ -338,7 +339,7 @@ class PlaneStats(torch.autograd.Function):
                                            _ffi.box4(ctx.box) if ctx.box else None, _ptr(ms[0]), _ptr(ms[1]),
                                            _ptr(gm), _ptr(gs), _ptr(dx), _stream(x))
         _ffi.check(st, "cnsn_plane_stats_backward")
-        return dx, None, None
+        return dx, None, None, None
 
 
 class PlaneAffine(torch.autograd.Function):
