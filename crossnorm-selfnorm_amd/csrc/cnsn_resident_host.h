@@ -23,15 +23,19 @@ constexpr int kBucketNv[] = {1, 2, 4, 7, 8, 13, 16};
 #ifndef CNSN_PPW78_F32
 #define CNSN_PPW78_F32 2
 #endif
+#ifndef CNSN_PPW78_FWD16
+#define CNSN_PPW78_FWD16 2
+#endif
 constexpr int ppw_of(int nv, bool backward, bool epi, int elem_bytes) {
     return nv == 1 ? 8
            : nv == 2 ? 4
            : nv == 4 ? (epi ? 2 : 4)
-           : (nv == 7 || nv == 8) ? ((backward && !epi) ? (elem_bytes == 4 ? CNSN_PPW78_F32 : 2) : 1)
+           : (nv == 7 || nv == 8) ? ((backward && !epi) ? (elem_bytes == 4 ? CNSN_PPW78_F32 : 2)
+                                                     : ((!epi && elem_bytes == 2) ? CNSN_PPW78_FWD16 : 1))
                                   : 1;
 }
 
-inline int cu_count() {
+static inline int cu_count() {
     static int cached[16] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
@@ -65,7 +69,7 @@ bool dispatch_res(int dtype, int vec, int nv, F&& f) {
     return false;
 }
 
-inline ResArgs make_args(const cnsn_problem_t& p, Box cb, Box sb, const MidArgs& mid, const ResPlan& rp) {
+static inline ResArgs make_args(const cnsn_problem_t& p, Box cb, Box sb, const MidArgs& mid, const ResPlan& rp) {
     ResArgs ra;
     ra.mid = mid;
     ra.M = p.H * p.W;
@@ -100,7 +104,7 @@ int grid_for(Kern kern, size_t lds, int K, int items) {
 }
 
 // epi: the call carries the residual-block epilogue (EPI kernels; their AUTO rule is separate)
-inline ResPlan plan_impl(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, bool backward, bool epi) {
+static inline ResPlan plan_impl(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, bool backward, bool epi) {
     ResPlan rp{false, 0, 0, 0, 0};
     if (p.strategy == CNSN_STRATEGY_TWO_PASS || has_chan_perm) return rp;
     const int M = p.H * p.W;
@@ -121,14 +125,15 @@ inline ResPlan plan_impl(const cnsn_problem_t& p, bool boxed, bool has_chan_perm
     if (res_lds_bytes(p.N, 6, own, BC_ROWS, true) > 64 * 1024) return rp;
     if (rp.K > 2 * cu_count()) return rp;
     // AUTO: use the resident kernels where they measured faster than the (non-temporal) two-pass kernels on
-    // MI355X (profiles/r01_resident_tuning.md, last sweep): every eligible fp32 shape, both directions; for
-    // 16-bit tensors only the 1-vector plane class (14x14) — the resident kernels are bound by the latency
-    // of the cluster exchange, which halving the bytes does not shorten, while two-pass bf16 streams at
-    // 5.5 TB/s.  A register bucket more than 25 % larger than the plane needs is not worth it either.
+    // MI355X (profiles/r01_resident_tuning.md, last sweeps): every eligible fp32 shape, both directions; for
+    // 16-bit tensors the plane classes listed below — the resident kernels are bound by the latency of the
+    // cluster exchange, which halving the bytes does not shorten, while two-pass bf16 streams at 5.5 TB/s.
+    // A register bucket more than 25 % larger than the plane needs is not worth it either.
     // CNSN_STRATEGY_RESIDENT forces the resident kernels wherever they are eligible.
     if (p.strategy == CNSN_STRATEGY_AUTO) {
         if ((rp.nv - need) * 4 > need) return rp;
-        if (!epi && p.dtype != CNSN_F32 && !(rp.nv == 1 || (backward && (rp.nv == 7 || rp.nv == 8)))) return rp;
+        // 16-bit: the 1-vector class, and the 7/8-slot class (56x56) except its boxed forward (two-pass 0.331 vs 0.366 ms)
+        if (!epi && p.dtype != CNSN_F32 && !(rp.nv == 1 || ((rp.nv == 7 || rp.nv == 8) && (backward || !boxed)))) return rp;
         if (epi && p.dtype != CNSN_F32 && rp.nv > 8) return rp;  // (those instantiations spill registers)
     }
     rp.ok = true;

@@ -246,12 +246,14 @@ __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t
 // latency other workgroups can cover.  min-waves-per-SIMD handed to __launch_bounds__:
 constexpr int data_regs(int elem_bytes, int vec, int nv, int ppw) { return ppw * nv * vec * elem_bytes / 4; }
 #if defined(CNSN_WF) && defined(CNSN_WB)  // tuning builds: force the bounds
-constexpr int fwd_waves(int) { return CNSN_WF; }
+constexpr int fwd_waves(int, int = 4) { return CNSN_WF; }
 constexpr int bwd_waves(int) { return CNSN_WB; }
 #else
 // measured on MI355X at (256,256,56,56) fp32/bf16 (profiles/r01_resident_tuning.md): forward 4, backward 2;
 // tighter bounds make the compiler spill and every variant got slower.
-constexpr int fwd_waves(int) { return 4; }
+// (16-bit planes held two per wave — 56+ data registers plus the unpacked floats of the vector being worked on —
+//  spill at 128 VGPRs: 3 waves there; measured 0.204 vs 0.225 ms on the (256,256,56,56) bf16 forward)
+constexpr int fwd_waves(int regs, int elem_bytes = 4) { return (elem_bytes == 2 && regs >= 56) ? 3 : 4; }
 constexpr int bwd_waves(int) { return 3; }
 #endif
 // with the residual-block epilogue a second / third tensor is in flight next to the planes held
@@ -299,7 +301,7 @@ __host__ __device__ inline size_t res_lds_bytes(int N, int NG, int OWN, int coef
 // forward
 // ================================================================================================
 template <typename T, int VEC, int NV, int PPW, bool BOXED, bool EPI = false>
-__global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi(0) : fwd_waves(data_regs(sizeof(T), VEC, NV, PPW))) void resident_fwd_kernel(ResArgs ra, const T* __restrict__ x, T* __restrict__ y,
+__global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi(0) : fwd_waves(data_regs(sizeof(T), VEC, NV, PPW), (int)sizeof(T))) void resident_fwd_kernel(ResArgs ra, const T* __restrict__ x, T* __restrict__ y,
                                                               const int64_t* __restrict__ perm, GateDev gg, GateDev gf,
                                                               unsigned long long* __restrict__ gran,
                                                               double* __restrict__ saved, unsigned* __restrict__ ctl,
