@@ -132,8 +132,12 @@ static inline ResPlan plan_impl(const cnsn_problem_t& p, bool boxed, bool has_ch
     // CNSN_STRATEGY_RESIDENT forces the resident kernels wherever they are eligible.
     if (p.strategy == CNSN_STRATEGY_AUTO) {
         if ((rp.nv - need) * 4 > need) return rp;
-        // 16-bit: the 1-vector class, and the 7/8-slot class (56x56) except its boxed forward (two-pass 0.331 vs 0.366 ms)
-        if (!epi && p.dtype != CNSN_F32 && !(rp.nv == 1 || ((rp.nv == 7 || rp.nv == 8) && (backward || !boxed)))) return rp;
+        // 16-bit (sweeps of round 1, profiles/r01_resident_tuning.md): up to 4 slots per lane (14x14 .. 44x44)
+        // always; 7/8 slots (56x56, 64x64) except the boxed forward; 13/16 slots only the un-boxed backward
+        if (!epi && p.dtype != CNSN_F32) {
+            const bool ok16 = rp.nv <= 4 ? true : rp.nv <= 8 ? (backward || !boxed) : (backward && !boxed);
+            if (!ok16) return rp;
+        }
         if (epi && p.dtype != CNSN_F32 && rp.nv > 8) return rp;  // (those instantiations spill registers)
     }
     rp.ok = true;
