@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--strategy", type=str, default="auto", choices=["auto", "two_pass", "resident"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (crop=both, bf16)")
-    ap.add_argument("--workload", type=str, default="cnsn", choices=["cnsn", "resnet50", "wrn40"],
+    ap.add_argument("--workload", type=str, default="cnsn", choices=["cnsn", "resnet50", "resnet50_jsd", "wrn40"],
                     help="cnsn: the fused op at the north-star shape (headline); resnet50 / wrn40: whole "
                          "training steps of the caller backbones (images/s)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch of the model workloads (0 = config default)")
@@ -179,9 +179,15 @@ def model_workload(args, dist, world, rank, dev):
     import numpy as np
     import cnsn_amd
     from cnsn_amd import data_parallel as dp
-    from cnsn_amd.callers import ResNet50CNSN, WideResNetCNSN, image_space_crossnorm
+    from cnsn_amd.callers import ResNet50CNSN, WideResNetCNSN, image_space_crossnorm, jsd_consistency
     dp.seed_rank(4321, rank)
-    if args.workload == "resnet50":
+    views = 1
+    if args.workload == "resnet50_jsd":          # BASELINE.json configs[3]: 3 views x 32 per GPU, CE + 12 * JSD
+        bs, hw, ncls, amp, views = args.batch or 32, 224, 1000, torch.bfloat16, 3
+        net = ResNet50CNSN(num_classes=ncls, cnsn_type="sn", pos="post").to(dev)
+        name = ("ResNet-50+SN(post), 3 views, ONE image-space CrossNorm(p=0.5) on the concatenated batch, "
+                "CE(clean) + 12*JSD (imagenet.py:337-406), bf16 autocast")
+    elif args.workload == "resnet50":
         bs, hw, ncls, amp = args.batch or 256, 224, 1000, torch.bfloat16
         net = ResNet50CNSN(num_classes=ncls, cnsn_type="sn", pos="post").to(dev)
         name = "ResNet-50+SN(post) + image-space CrossNorm(p=0.5, crop=neither), bf16 autocast"
@@ -200,9 +206,18 @@ def model_workload(args, dist, world, rank, dev):
     x = torch.randn(bs, 3, hw, hw, device=dev, generator=g)
     y = torch.randint(0, ncls, (bs,), device=dev, generator=g)
 
+    if views == 3:
+        x = torch.cat([x, x + 0.1 * torch.randn_like(x), x + 0.1 * torch.randn_like(x)], 0)   # clean + two "augmented"
+
     def step():
         xb = x
-        if args.workload == "resnet50":
+        if views == 3:
+            xb = image_space_crossnorm(x, 0.5, 1, "neither", cnsn_amd.cn_op_2ins_space_chan)   # imagenet.py:352-358
+            with torch.autocast("cuda", dtype=amp):
+                logits = model(xb).float()
+            l_clean, l_a1, l_a2 = torch.split(logits, bs)
+            loss = torch.nn.functional.cross_entropy(l_clean, y) + 12.0 * jsd_consistency(l_clean, l_a1, l_a2)
+        elif args.workload == "resnet50":
             xb = image_space_crossnorm(x, 0.5, 1, "neither", cnsn_amd.cn_op_2ins_space_chan)   # imagenet.py:211-215
             with torch.autocast("cuda", dtype=amp):
                 loss = torch.nn.functional.cross_entropy(model(xb).float(), y)
@@ -232,11 +247,11 @@ def model_workload(args, dist, world, rank, dev):
         dt = float(tt.item())
     if rank == 0:
         print(json.dumps({
-            "metric": "ResNet-50+CNSN images/sec" if args.workload == "resnet50" else "WideResNet-40-2+CNSN images/sec",
-            "value": round(world * bs * args.steps / dt, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "metric": "ResNet-50+CNSN images/sec" if args.workload.startswith("resnet50") else "WideResNet-40-2+CNSN images/sec",
+            "value": round(world * bs * views * args.steps / dt, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if amp else "f32", "data": "synthetic",
-            "config": {"workload": name, "per_gpu_batch": bs, "global_batch": bs * world, "image": hw,
+            "config": {"workload": name, "per_gpu_batch": bs * views, "global_batch": bs * views * world, "image": hw,
                        "parallelism": f"ddp{world} (RCCL gradient all-reduce, 25 MB buckets)"}}), flush=True)
 
 
