@@ -172,6 +172,34 @@ def residual_block_workloads(cnsn_amd, shape, dev):
     return res
 
 
+def inference_workloads(cnsn_amd, shape, dev):
+    """Serving path: SelfNorm in eval mode (running statistics; CrossNorm is idle in eval), forward only under
+    no_grad — nothing couples the planes, so the op is one streaming launch over 2*E*b bytes."""
+    n, c, h, w = shape
+    res = {}
+    for tag, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        x = conditioned(shape, dev, dtype, 51)
+        idt = conditioned(shape, dev, dtype, 52) * 0.5
+        mod = cnsn_amd.CNSN(None, cnsn_amd.SelfNorm(c)).to(dev).eval()
+        b = 4 if dtype == torch.float32 else 2
+        for name, fn, passes in (("sn_eval_forward", lambda: mod(x), 2),
+                                 ("block_eval_forward", lambda: mod.forward_block(x, idt, add_mode="pre", relu=True), 3)):
+            with torch.no_grad():
+                for _ in range(5):
+                    fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(30):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 30
+            res[f"{tag}_{name}"] = {"ms": round(ms, 4), "GBps_moved": round(passes * n * c * h * w * b / ms / 1e6, 1)}
+        del x, idt, mod
+    return res
+
+
 def model_workload(args, dist, world, rank, dev):
     """Whole training steps (forward, CE [+ image-space CrossNorm], backward, SGD) of the caller
     backbones on synthetic data — BASELINE.json configs[1] (WRN-40-2+CNSN, bs128, fp32, 32x32) and
@@ -385,6 +413,7 @@ def main():
         if world == 1 and not args.no_extra:
             out["extra"] = secondary_workloads(cnsn_amd, shape, dev, args)
             out["extra"]["residual_block_add_cnsn_relu"] = residual_block_workloads(cnsn_amd, shape, dev)
+            out["extra"]["inference"] = inference_workloads(cnsn_amd, shape, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shape, args.crop, args.kind, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -134,7 +134,8 @@ static inline ResPlan plan_impl(const cnsn_problem_t& p, bool boxed, bool has_ch
         if ((rp.nv - need) * 4 > need) return rp;
         // 16-bit (sweeps of round 1, profiles/r01_resident_tuning.md): up to 4 slots per lane (14x14 .. 44x44)
         // always; 7/8 slots (56x56, 64x64) except the boxed forward; 13/16 slots only the un-boxed backward
-        if (!epi && p.dtype != CNSN_F32) {
+        const bool solo = !backward && !boxed && !p.cn_active && !(p.sn_active && p.sn_training);  // inference
+        if (!epi && !solo && p.dtype != CNSN_F32) {
             const bool ok16 = rp.nv <= 4 ? true : rp.nv <= 8 ? (backward || !boxed) : (backward && !boxed);
             if (!ok16) return rp;
         }
@@ -151,6 +152,8 @@ int forward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidA
     const ResPlan rp = plan_impl(p, boxed, false, false, EPI);
     if (!rp.ok) return CNSN_E_UNSUPPORTED;
     ResArgs ra = make_args(p, cb, sb, mid, rp);
+    // nothing couples the planes of a channel (inference: SelfNorm on running statistics, no CrossNorm)
+    const bool solo = !boxed && !p.cn_active && !(p.sn_active && p.sn_training);
     const int NG = boxed ? 6 : 2;
 #ifdef CNSN_PROF  // tuning builds: time stamps land 4 MiB into the workspace (callers size it accordingly)
     if (getenv("CNSN_PROF")) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
@@ -166,7 +169,8 @@ int forward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidA
         auto launch = [&](auto kern) {
             const int grid = grid_for(kern, lds, rp.K, ra.items);
             if (grid < rp.K) return;
-            hipError_t e = hipMemsetAsync(workspace, 0xff, fill_bytes, stream);  // 'empty' granules, idle control word
+            hipError_t e = hipSuccess;
+            if (!solo) e = hipMemsetAsync(workspace, 0xff, fill_bytes, stream);  // 'empty' granules, idle control word
             if (e != hipSuccess) {
                 status = (int)e;
                 return;
@@ -177,6 +181,8 @@ int forward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidA
         };
         if (boxed)
             launch(resident_fwd_kernel<T, VEC, NV, PPW, true, EPI>);
+        else if (solo)
+            launch(resident_fwd_kernel<T, VEC, NV, PPW, false, EPI, true>);
         else
             launch(resident_fwd_kernel<T, VEC, NV, PPW, false, EPI>);
     });

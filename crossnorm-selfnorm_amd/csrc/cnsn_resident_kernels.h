@@ -300,7 +300,10 @@ __host__ __device__ inline size_t res_lds_bytes(int N, int NG, int OWN, int coef
 // ================================================================================================
 // forward
 // ================================================================================================
-template <typename T, int VEC, int NV, int PPW, bool BOXED, bool EPI = false>
+// SOLO (un-boxed only): nothing couples the planes of a channel — SelfNorm in eval mode (running statistics), no
+// CrossNorm: the inference forward.  Every wave finishes its planes on its own: no publish, no cluster wait, no
+// workgroup barrier; 2*E*b bytes at streaming speed.
+template <typename T, int VEC, int NV, int PPW, bool BOXED, bool EPI = false, bool SOLO = false>
 __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi(0) : fwd_waves(data_regs(sizeof(T), VEC, NV, PPW), (int)sizeof(T))) void resident_fwd_kernel(ResArgs ra, const T* __restrict__ x, T* __restrict__ y,
                                                               const int64_t* __restrict__ perm, GateDev gg, GateDev gf,
                                                               unsigned long long* __restrict__ gran,
@@ -376,6 +379,7 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi(0) : fwd_waves(data_reg
         }
 
         // ---- exact two-pass statistics from registers; publish them to the cluster
+        float solo_mean[SOLO ? PPW : 1], solo_m2[SOLO ? PPW : 1];
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
             const int n = n0 + s;
@@ -436,6 +440,11 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi(0) : fwd_waves(data_reg
                 pub[4] = ms;
                 pub[5] = wave_sum(qs);
             }
+            if constexpr (SOLO) {
+                solo_mean[s] = pub[0];
+                solo_m2[s] = pub[1];
+                continue;
+            }
             if (n < N && lane < NG / 2) {  // lane m publishes the pair (pub[2m], pub[2m+1])
                 float lo = pub[0], hi = pub[1];
 #pragma unroll
@@ -445,6 +454,59 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi(0) : fwd_waves(data_reg
                 }
                 put_granule(gran + ((size_t)c * N + n) * (NG / 2) + lane, lo, hi);
             }
+        }
+
+        if constexpr (SOLO && !BOXED) {
+            // every wave on its own: gate of each of its planes from the running statistics, apply, store
+#pragma unroll
+            for (int s = 0; s < PPW; ++s) {
+                const int n = n0 + s;
+                if (n >= N) continue;  // wave-uniform
+                MomentsT<float> o;
+                o.mu_c = o.mu_s = solo_mean[s];
+                o.M2c = o.M2s = solo_m2[s];
+                o.mu_o = o.M2o = 0.f;
+                const FwdPlaneT<float> f = fwd_plane<float>(a, o, 0.f, 0.f);
+                float g = 1.f, fg = 1.f;
+                double zhg = 0.0, zhf = 0.0;
+                if (a.sn_active) {
+                    const double rg = (double)__builtin_amdgcn_rsqf(prv[0] + a.eps_bn);
+                    zhg = ((double)pw[0] * (double)f.mu_p + (double)pw[1] * (double)f.sig_p - (double)prm[0]) * rg;
+                    g = sigmoid_r<float>((float)((double)pgam[0] * zhg + (double)pbet[0]));
+                    if (a.sn_two) {
+                        const double rf = (double)__builtin_amdgcn_rsqf(prv[1] + a.eps_bn);
+                        zhf = ((double)pw[2] * (double)f.mu_p + (double)pw[3] * (double)f.sig_p - (double)prm[1]) * rf;
+                        fg = sigmoid_r<float>((float)((double)pgam[1] * zhf + (double)pbet[1]));
+                    }
+                    if (saved && n == 0 && lane == 0) {
+                        saved[SV_ROWS * P + c] = rg;
+                        saved[SV_ROWS * P + C + c] = (double)__builtin_amdgcn_rsqf(prv[1] + a.eps_bn);
+                    }
+                }
+                const FwdCoefs cf = fwd_coefs<float>(a, f, g, fg);
+                if (saved && lane == 0) {
+                    const size_t p = (size_t)n * C + c;
+                    store_fwd_plane<float>(saved, P, p, f);
+                    saved[sv_at(p, SV_G)] = g;
+                    saved[sv_at(p, SV_ZH_G)] = zhg;
+                    saved[sv_at(p, SV_F)] = fg;
+                    saved[sv_at(p, SV_ZH_F)] = zhf;
+                    if (a.save_coefs) store_fwd_coefs(saved, p, cf);
+                }
+                T* yb = y + ((size_t)n * C + c) * ra.M;
+                const int pbytes = ra.M * (int)sizeof(T);
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    float ov[VEC];
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        ov[q] = fmaf(cf.a_in, elem<T, VEC>(d[s][j], q) - cf.xr, cf.b_in);
+                        if constexpr (EPI) ov[q] = relu ? fmaxf(ov[q], 0.f) : ov[q];
+                    }
+                    buf_store<T, VEC>(slot_rsrc<T, VEC>(yb, pbytes, j), voff, pack<T, VEC>(ov));
+                }
+            }
+            continue;
         }
 
         // ---- gather the whole channel's statistics
