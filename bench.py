@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16", "f16"])
     ap.add_argument("--crop", type=str, default="neither", choices=["neither", "style", "content", "both"])
     ap.add_argument("--kind", type=str, default="cnsn", choices=["cnsn", "cn", "sn"])
-    ap.add_argument("--strategy", type=str, default="auto", choices=["auto", "two_pass", "resident"])
+    ap.add_argument("--strategy", type=str, default="auto", choices=["auto", "two_pass", "resident", "local"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (crop=both, bf16)")
     ap.add_argument("--workload", type=str, default="cnsn", choices=["cnsn", "resnet50", "resnet50_jsd", "wrn40"],

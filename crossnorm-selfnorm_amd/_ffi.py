@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcnsn_hip.so")
 
 CNSN_F32, CNSN_BF16, CNSN_F16 = 0, 1, 2
-STRATEGY_AUTO, STRATEGY_TWO_PASS, STRATEGY_RESIDENT = 0, 1, 2
+STRATEGY_AUTO, STRATEGY_TWO_PASS, STRATEGY_RESIDENT, STRATEGY_LOCAL = 0, 1, 2, 3
 ADD_NONE, ADD_PRE, ADD_POST = 0, 1, 2
 ABI_VERSION = 2
 

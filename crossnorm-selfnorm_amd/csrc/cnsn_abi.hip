@@ -7,6 +7,7 @@
 
 #include "cnsn_device.h"
 #include "cnsn_host_plan.h"
+#include "cnsn_local.h"
 #include "cnsn_mid_kernels.h"
 #include "cnsn_packed.h"
 #include "cnsn_resident_kernels.h"
@@ -81,6 +82,13 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
     double* saved_d = saved ? (double*)saved : mom + 6 * pl.P;
     float* coef = (float*)(mom + 6 * pl.P + saved_doubles_of(pl));
 
+    {
+        const LocalPlan lp = local_plan(pl, 0, false);  // small planes, SelfNorm alone: no exchange, no side arrays
+        if (lp.ok) {
+            st = local_forward(pl, lp, 0, 0, x, nullptr, gate_dev(g), gate_dev(f), y, saved ? saved_d : nullptr, stream);
+            if (st != CNSN_E_UNSUPPORTED) return st;
+        }
+    }
     if (resident_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, false).ok) {
         st = resident_forward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, x, perm, gate_dev(g), gate_dev(f), y,
                               saved ? saved_d : nullptr, workspace, stream);
@@ -141,6 +149,14 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
     float* coef = sums + 4 * P;
     const double* saved_d = (const double*)saved;
 
+    {
+        const LocalPlan lp = local_plan(pl, 0, true);
+        if (lp.ok) {
+            st = local_backward(pl, lp, 0, 0, grad_y, x, nullptr, gate_dev(g), gate_dev(f), saved_d, grad_x, gate_grad_dev(dg),
+                                gate_grad_dev(df), stream);
+            if (st != CNSN_E_UNSUPPORTED) return st;
+        }
+    }
     if (resident_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, true).ok) {
         st = resident_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, grad_y, x, perm, gate_dev(g), gate_dev(f),
                                saved_d, grad_x, gate_grad_dev(dg), gate_grad_dev(df), workspace, stream);

@@ -6,6 +6,7 @@
 
 #include "cnsn_fused_stream_kernels.h"
 #include "cnsn_host_plan.h"
+#include "cnsn_local.h"
 #include "cnsn_packed.h"
 #include "cnsn_resident_fused.h"
 
@@ -75,6 +76,14 @@ int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, c
     double* saved_d = saved ? (double*)saved : mom + 6 * pl.P;
     float* coef = (float*)(mom + 6 * pl.P + saved_doubles_of(pl));
 
+    {
+        const LocalPlan lp = local_plan(pl, e.add, false);
+        if (lp.ok) {
+            st = local_forward(pl, lp, e.add, e.relu, x, e.addend, gate_dev(g), gate_dev(f), y, saved ? saved_d : nullptr,
+                               stream);
+            if (st != CNSN_E_UNSUPPORTED) return st;
+        }
+    }
     if (resident_fused_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, e.add, false).ok) {
         st = resident_fused_forward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, e.add, e.relu, x, e.addend, perm, gate_dev(g),
                                     gate_dev(f), y, saved ? saved_d : nullptr, workspace, stream);
@@ -155,6 +164,14 @@ int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, 
     float* coef = sums + 4 * P;
     const double* saved_d = (const double*)saved;
 
+    {
+        const LocalPlan lp = local_plan(pl, e.add, true);
+        if (lp.ok) {
+            st = local_backward(pl, lp, e.add, e.relu, grad_y, x, e.addend, gate_dev(g), gate_dev(f), saved_d, grad_x,
+                                gate_grad_dev(dg), gate_grad_dev(df), stream);
+            if (st != CNSN_E_UNSUPPORTED) return st;
+        }
+    }
     if (resident_fused_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, e.add, true).ok) {
         st = resident_fused_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, e.add, e.relu, grad_y, x, e.addend, perm,
                                      gate_dev(g), gate_dev(f), saved_d, grad_x, gate_grad_dev(dg), gate_grad_dev(df),

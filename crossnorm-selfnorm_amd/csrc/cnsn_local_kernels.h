@@ -1,0 +1,437 @@
+// Channel-local strategy for SMALL planes without CrossNorm (SelfNorm alone — every site of the ResNet-50
+// configs — optionally with the residual block's add and ReLU): ONE launch per direction, every byte touched once,
+// and no inter-workgroup exchange at all.
+//
+// When a plane is small (7x7, 8x8, 14x14 ...) all N planes of a channel — even of a few adjacent channels — fit in
+// ONE workgroup's LDS (N*M*b bytes per channel: 25 KiB for (256,.,7,7) bf16).  SelfNorm's BatchNorm1d couples only
+// the N planes of a channel, so a workgroup that owns a whole channel group needs nobody else:
+//     forward : pieces (n, c0..c0+CG-1) of x [+ addend] -> LDS; per-plane exact two-pass statistics (16 lanes per
+//               plane); BatchNorm over n / gate per plane (a thread per plane, cnsn_algebra.h in float, batch sums
+//               in double); apply from LDS -> y.
+//     backward: G, x [+ addend] -> LDS; ReLU mask + per-plane sums; gate / BatchNorm backward; dx.
+// Compared with the two-pass kernels this removes the three mid kernels and every per-plane side array except
+// `saved` (for 98-byte planes those arrays are as large as the tensor itself), and compared with the cluster-
+// resident kernels it removes the exchange whose latency dominates when a plane is only a few hundred bytes.
+//
+// Memory access: for fixed n the CG channels are one contiguous piece of CG*M*b bytes; pieces are copied with the
+// widest vector (16/8/4/2 bytes) that divides both the piece and the distance between pieces, consecutive lanes on
+// consecutive vectors.  The LDS image is plane-major: plane (n, cc) starts at element (n*CG + cc)*M.
+#pragma once
+#include "../../include/cnsn_hip.h"
+#include "cnsn_algebra.h"
+#include "cnsn_device.h"
+#include "cnsn_fused_stream_kernels.h"
+#include "cnsn_layout.h"
+
+namespace cnsn {
+
+struct LocalArgs {
+    MidArgs mid;
+    int CG;          // channels per workgroup
+    int W;           // bytes per copy vector
+    int piece_vecs;  // vectors per piece = CG*M*b / W
+    int planes;      // N * CG
+    float inv_m;     // 1/M (element index -> plane index)
+};
+
+constexpr int kLocalMaxCG = 8;
+
+// LDS carve (bytes): data of `tensors` staged tensors | per-plane float arrays | per-channel params | reduction
+__host__ __device__ inline size_t local_align(size_t v) { return (v + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t local_lds_bytes(int N, int CG, int M, int elem_bytes, int tensors, int plane_floats) {
+    return (size_t)tensors * local_align((size_t)N * CG * M * elem_bytes) + local_align((size_t)plane_floats * N * CG * 4) +
+           local_align((size_t)kLocalMaxCG * 16 * 8) + 4 * 4 * 8;
+}
+
+// copy vector v (of `W` bytes) of the channel group between HBM and registers
+template <int W>
+struct RawW;
+template <>
+struct RawW<16> {
+    typedef unsigned type __attribute__((ext_vector_type(4)));
+};
+template <>
+struct RawW<8> {
+    typedef unsigned type __attribute__((ext_vector_type(2)));
+};
+template <>
+struct RawW<4> {
+    typedef unsigned type;
+};
+template <>
+struct RawW<2> {
+    typedef unsigned short type;
+};
+
+// x [+ addend] -> LDS, vector by vector (U loads in flight per thread)
+template <typename T, int W, bool ADD>
+__device__ __forceinline__ void local_stage(const LocalArgs& la, const T* __restrict__ src, const T* __restrict__ add,
+                                            int c0, char* lds) {
+    using V = typename RawW<W>::type;
+    // loads in flight per thread: up to 256 bytes (a workgroup with a large image is alone on its CU, so the memory-level
+    // parallelism has to come from within it)
+    constexpr int U = W == 16 ? 16 : 32, E = W / (int)sizeof(T);
+    const MidArgs& a = la.mid;
+    const int total = a.N * la.piece_vecs;
+    const size_t row = (size_t)a.C * a.M * sizeof(T);  // bytes between the pieces of consecutive instances
+    const char* s = (const char*)src + (size_t)c0 * a.M * sizeof(T);
+    const char* d = ADD ? (const char*)add + (size_t)c0 * a.M * sizeof(T) : nullptr;
+    for (int v0 = threadIdx.x; v0 < total; v0 += kBlock * U) {
+        V r[U], q[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = v0 + u * kBlock;
+            if (v < total) {
+                const int n = v / la.piece_vecs, k = v - n * la.piece_vecs;
+                const size_t off = (size_t)n * row + (size_t)k * W;
+                r[u] = __builtin_nontemporal_load((const V*)(s + off));
+                if constexpr (ADD) q[u] = __builtin_nontemporal_load((const V*)(d + off));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = v0 + u * kBlock;
+            if (v < total) {
+                if constexpr (ADD) {  // the op's input is x + addend, a value of the tensor's own type
+                    T xe[E], ae[E];
+                    __builtin_memcpy(xe, &r[u], W);
+                    __builtin_memcpy(ae, &q[u], W);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) xe[e] = from_float<T>(to_float(xe[e]) + to_float(ae[e]));
+                    __builtin_memcpy(&r[u], xe, W);
+                }
+                *(V*)(lds + (size_t)v * W) = r[u];
+            }
+        }
+    }
+}
+
+// apply a per-plane affine map to the staged image and write it out: emit(plane, elems in, elems out)
+template <typename T, int W, typename F>
+__device__ __forceinline__ void local_emit(const LocalArgs& la, T* __restrict__ dst, int c0, F&& f) {
+    using V = typename RawW<W>::type;
+    constexpr int E = W / (int)sizeof(T);
+    const MidArgs& a = la.mid;
+    const int total = a.N * la.piece_vecs;
+    const size_t row = (size_t)a.C * a.M * sizeof(T);
+    char* d = (char*)dst + (size_t)c0 * a.M * sizeof(T);
+    for (int v = threadIdx.x; v < total; v += kBlock) {
+        const int n = v / la.piece_vecs, k = v - n * la.piece_vecs;
+        const int e0 = v * E;  // first element of the vector in the plane-major image
+        T o[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int idx = e0 + e;
+            int pl = (int)(((float)idx + 0.5f) * la.inv_m);  // idx / M (exact for idx < 2^22)
+            o[e] = f(pl, idx);
+        }
+        V r;
+        __builtin_memcpy(&r, o, W);
+        __builtin_nontemporal_store(r, (V*)(d + (size_t)n * row + (size_t)k * W));
+    }
+}
+
+// sum of NACC doubles over the threads of the workgroup that pass `mine` (others contribute zeros)
+template <int NACC>
+__device__ __forceinline__ void local_block_sum(double (&acc)[NACC], double* red) {
+    block_sum_d<NACC>(acc, red);
+}
+
+// ================================================================================================
+// forward
+// ================================================================================================
+template <typename T, int W, bool EPI>
+__global__ __launch_bounds__(kBlock) void local_fwd_kernel(LocalArgs la, const T* __restrict__ x,
+                                                           const T* __restrict__ addend, T* __restrict__ y, GateDev gg,
+                                                           GateDev gf, double* __restrict__ saved, int relu) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const MidArgs a = la.mid;
+    const int N = a.N, C = a.C, M = a.M, CG = la.CG, planes = la.planes;
+    const int c0 = blockIdx.x * CG;
+    T* img = (T*)smem;
+    float* pmu = (float*)(smem + local_align((size_t)planes * M * sizeof(T)));  // [planes]: mean, later slope
+    float* pm2 = pmu + planes;                                                   // [planes]: M2, later offset
+    double* par = (double*)((char*)pmu + local_align((size_t)2 * planes * 4));    // [CG][16] per-channel parameters
+    double* red = par + kLocalMaxCG * 16;
+    const size_t P = (size_t)N * C;
+
+    // per-channel parameters -> LDS (issued before the bulk loads)
+    if ((int)threadIdx.x < CG) {
+        const int c = c0 + threadIdx.x;
+        double* q = par + threadIdx.x * 16;
+        q[0] = gg.w[2 * c];
+        q[1] = gg.w[2 * c + 1];
+        q[2] = gg.gamma[c];
+        q[3] = gg.beta[c];
+        q[4] = gg.run_mean[c];
+        q[5] = gg.run_var[c];
+        if (a.sn_two) {
+            q[6] = gf.w[2 * c];
+            q[7] = gf.w[2 * c + 1];
+            q[8] = gf.gamma[c];
+            q[9] = gf.beta[c];
+            q[10] = gf.run_mean[c];
+            q[11] = gf.run_var[c];
+        }
+    }
+    if (EPI && addend)
+        local_stage<T, W, true>(la, x, addend, c0, smem);
+    else
+        local_stage<T, W, false>(la, x, nullptr, c0, smem);
+    __syncthreads();
+
+    // ---- exact two-pass statistics of every plane: 16 lanes per plane
+    {
+        const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+        for (int pl = grp; pl < planes; pl += kBlock / 16) {
+            const T* pp = img + (size_t)pl * M;
+            float s = 0.f;
+            for (int e = l16; e < M; e += 16) s += to_float(pp[e]);
+            const float mean = row16_sum(s) / (float)M;
+            float q = 0.f;
+            for (int e = l16; e < M; e += 16) {
+                const float t = to_float(pp[e]) - mean;
+                q = fmaf(t, t, q);
+            }
+            q = row16_sum(q);
+            if (l16 == 0) {
+                pmu[pl] = mean;
+                pm2[pl] = q;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- gates: BatchNorm1d over the N planes of each channel, one channel at a time
+    using R = float;
+    for (int cc = 0; cc < CG; ++cc) {
+        const int c = c0 + cc;
+        const double* q = par + cc * 16;
+        const double wg0 = q[0], wg1 = q[1], wf0 = q[6], wf1 = q[7];
+        auto plane_of = [&](int n) {
+            MomentsT<R> o;
+            const int pl = n * CG + cc;
+            o.mu_c = o.mu_s = pmu[pl];
+            o.M2c = o.M2s = pm2[pl];
+            o.mu_o = o.M2o = 0.f;
+            return fwd_plane<R>(a, o, 0.f, 0.f);
+        };
+        double mg = q[4], mf = q[10], rg, rf;
+        if (a.sn_training) {
+            const FwdPlaneT<R> f0 = plane_of(0);
+            const double zs_g = wg0 * (double)f0.mu_p + wg1 * (double)f0.sig_p;
+            const double zs_f = wf0 * (double)f0.mu_p + wf1 * (double)f0.sig_p;
+            double sz[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int n = threadIdx.x; n < N; n += kBlock) {
+                const FwdPlaneT<R> f = plane_of(n);
+                const double dg = wg0 * (double)f.mu_p + wg1 * (double)f.sig_p - zs_g;
+                const double df = wf0 * (double)f.mu_p + wf1 * (double)f.sig_p - zs_f;
+                sz[0] += dg;
+                sz[1] += dg * dg;
+                sz[2] += df;
+                sz[3] += df * df;
+            }
+            block_sum_d<4>(sz, red);
+            mg = zs_g + sz[0] * a.inv_n;
+            mf = zs_f + sz[2] * a.inv_n;
+            double vg = (sz[1] - sz[0] * sz[0] * a.inv_n) * a.inv_n, vf = (sz[3] - sz[2] * sz[2] * a.inv_n) * a.inv_n;
+            vg = vg > 0.0 ? vg : 0.0;
+            vf = vf > 0.0 ? vf : 0.0;
+            rg = (double)__builtin_amdgcn_rsqf((float)(vg + (double)a.eps_bn));
+            rf = (double)__builtin_amdgcn_rsqf((float)(vf + (double)a.eps_bn));
+            if (threadIdx.x == 0) {
+                const double mom_ = a.momentum, unb = a.unbias_n;
+                gg.run_mean[c] = (float)((1.0 - mom_) * q[4] + mom_ * mg);
+                gg.run_var[c] = (float)((1.0 - mom_) * q[5] + mom_ * vg * unb);
+                if (a.sn_two) {
+                    gf.run_mean[c] = (float)((1.0 - mom_) * q[10] + mom_ * mf);
+                    gf.run_var[c] = (float)((1.0 - mom_) * q[11] + mom_ * vf * unb);
+                }
+            }
+        } else {
+            rg = (double)__builtin_amdgcn_rsqf((float)q[5] + a.eps_bn);
+            rf = a.sn_two ? (double)__builtin_amdgcn_rsqf((float)q[11] + a.eps_bn) : 1.0;
+        }
+        if (saved && threadIdx.x == 0) {
+            saved[SV_ROWS * P + c] = rg;
+            saved[SV_ROWS * P + C + c] = rf;
+        }
+        __syncthreads();  // every reader of pmu/pm2 of this channel's statistics sums is done before they are replaced
+        for (int n = threadIdx.x; n < N; n += kBlock) {
+            const FwdPlaneT<R> f = plane_of(n);
+            const double zhg = (wg0 * (double)f.mu_p + wg1 * (double)f.sig_p - mg) * rg;
+            const R g = sigmoid_r<R>((R)(q[2] * zhg + q[3]));
+            double zhf = 0.0;
+            R fg = 1.f;
+            if (a.sn_two) {
+                zhf = (wf0 * (double)f.mu_p + wf1 * (double)f.sig_p - mf) * rf;
+                fg = sigmoid_r<R>((R)(q[8] * zhf + q[9]));
+            }
+            const FwdCoefs cf = fwd_coefs<R>(a, f, g, fg);
+            if (saved) {
+                const size_t p = (size_t)n * C + c;
+                store_fwd_plane<R>(saved, P, p, f);
+                saved[sv_at(p, SV_G)] = g;
+                saved[sv_at(p, SV_ZH_G)] = zhg;
+                saved[sv_at(p, SV_F)] = fg;
+                saved[sv_at(p, SV_ZH_F)] = zhf;
+                if (a.save_coefs) store_fwd_coefs(saved, p, cf);
+            }
+            const int pl = n * CG + cc;
+            pmu[pl] = cf.a_in;  // SelfNorm alone: y = a_in * x + b_in  (xr = 0)
+            pm2[pl] = cf.b_in;
+        }
+    }
+    __syncthreads();
+
+    // ---- apply from LDS, the only write of y
+    local_emit<T, W>(la, y, c0, [&](int pl, int idx) {
+        float t = fmaf(pmu[pl], to_float(img[idx]), pm2[pl]);
+        if (EPI) t = relu ? fmaxf(t, 0.f) : t;
+        return from_float<T>(t);
+    });
+}
+
+// ================================================================================================
+// backward
+// ================================================================================================
+template <typename T, int W, bool EPI>
+__global__ __launch_bounds__(kBlock) void local_bwd_kernel(LocalArgs la, const T* __restrict__ gy,
+                                                           const T* __restrict__ x, const T* __restrict__ addend,
+                                                           T* __restrict__ dx, GateDev gg, GateDev gf, GateGradDev dgr,
+                                                           GateGradDev dfr, const double* __restrict__ saved, int relu) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const MidArgs a = la.mid;
+    const int N = a.N, C = a.C, M = a.M, CG = la.CG, planes = la.planes;
+    const int c0 = blockIdx.x * CG;
+    const size_t img_bytes = local_align((size_t)planes * M * sizeof(T));
+    T* gimg = (T*)smem;
+    T* ximg = (T*)(smem + img_bytes);
+    float* ps1 = (float*)(smem + 2 * img_bytes);  // [planes] sum G        -> later cG
+    float* ps2 = ps1 + planes;                    // [planes] sum G*(x-mu) -> later cX
+    float* pxr = ps2 + planes;                    // [planes] xr
+    float* pc0 = pxr + planes;                    // [planes] c0
+    double* pdt = (double*)((char*)ps1 + local_align((size_t)4 * planes * 4));  // [2][N] dt of the channel in work
+    double* red = pdt + 2 * N;
+    const size_t P = (size_t)N * C;
+
+    local_stage<T, W, false>(la, gy, nullptr, c0, smem);
+    if (EPI && addend)
+        local_stage<T, W, true>(la, x, addend, c0, smem + img_bytes);
+    else
+        local_stage<T, W, false>(la, x, nullptr, c0, smem + img_bytes);
+    __syncthreads();
+
+    // ---- ReLU mask (forward affine re-evaluated with the saved coefficients) and per-plane sums
+    {
+        const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+        for (int pl = grp; pl < planes; pl += kBlock / 16) {
+            const int n = pl / CG, cc = pl - n * CG;
+            const size_t p = (size_t)n * C + c0 + cc;
+            const float si = (float)saved[sv_at(p, SV_MU_C)];
+            float fa = 0.f, fb = 0.f;
+            if (EPI && relu) {
+                fa = (float)saved[sv_at(p, SV_FC0 + FC_A_IN)];
+                fb = (float)saved[sv_at(p, SV_FC0 + FC_B_IN)];
+            }
+            T* gp = gimg + (size_t)pl * M;
+            const T* xp = ximg + (size_t)pl * M;
+            float s1 = 0.f, s2 = 0.f;
+            for (int e = l16; e < M; e += 16) {
+                const float X = to_float(xp[e]);
+                float G = to_float(gp[e]);
+                if (EPI && relu) {
+                    if (!relu_open<T>(fmaf(fa, X, fb))) {
+                        G = 0.f;
+                        gp[e] = from_float<T>(0.f);
+                    }
+                }
+                s1 += G;
+                s2 = fmaf(G, X - si, s2);
+            }
+            s1 = row16_sum(s1);
+            s2 = row16_sum(s2);
+            if (l16 == 0) {
+                ps1[pl] = s1;
+                ps2[pl] = s2;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- gate / BatchNorm backward per channel; coefficients of dx per plane
+    using R = float;
+    for (int cc = 0; cc < CG; ++cc) {
+        const int c = c0 + cc;
+        auto rec = [&](int n, int row) { return saved[sv_at((size_t)n * C + c, row)]; };
+        auto sums_of = [&](int n) {
+            const int pl = n * CG + cc;
+            return fix_sums<R>(a, ps1[pl], ps2[pl], 0.f, 0.f, rec(n, SV_MU_C), 0.0);
+        };
+        double s4[4] = {0, 0, 0, 0};
+        for (int n = threadIdx.x; n < N; n += kBlock) {
+            R dtg, dtf;
+            const R mu = (R)rec(n, SV_MU_C);
+            gate_dt<R>(a, sums_of(n), R(1), mu, R(0), (R)rec(n, SV_MU_P), (R)rec(n, SV_G), (R)rec(n, SV_F), dtg, dtf);
+            s4[0] += (double)dtg;
+            s4[1] += (double)dtg * rec(n, SV_ZH_G);
+            s4[2] += (double)dtf;
+            s4[3] += (double)dtf * rec(n, SV_ZH_F);
+            pdt[n] = dtg;
+            pdt[N + n] = dtf;
+        }
+        block_sum_d<4>(s4, red);
+        BnBwd b{};
+        b.s_dt_g = s4[0];
+        b.s_dtz_g = s4[1];
+        b.s_dt_f = s4[2];
+        b.s_dtz_f = s4[3];
+        b.wg0 = gg.w[2 * c];
+        b.wg1 = gg.w[2 * c + 1];
+        b.kg = (double)gg.gamma[c] * saved[SV_ROWS * P + c];
+        if (a.sn_two) {
+            b.wf0 = gf.w[2 * c];
+            b.wf1 = gf.w[2 * c + 1];
+            b.kf = (double)gf.gamma[c] * saved[SV_ROWS * P + C + c];
+        }
+        double sw[4] = {0, 0, 0, 0};
+        for (int n = threadIdx.x; n < N; n += kBlock) {
+            const R mu = (R)rec(n, SV_MU_C), mu_p = (R)rec(n, SV_MU_P), sig_p = (R)rec(n, SV_SIG_P);
+            const R g = (R)rec(n, SV_G), f = (R)rec(n, SV_F);
+            const BwdPlaneT<R> o = bwd_plane<R>(a, b, sums_of(n), pdt[n], pdt[N + n], rec(n, SV_ZH_G), rec(n, SV_ZH_F), g, f,
+                                                R(1), R(1), mu, mu_p, sig_p, R(1), R(0));
+            sw[0] += (double)o.dz_g * (double)mu_p;
+            sw[1] += (double)o.dz_g * (double)sig_p;
+            sw[2] += (double)o.dz_f * (double)mu_p;
+            sw[3] += (double)o.dz_f * (double)sig_p;
+            const BwdCoefs k = bwd_coefs<R>(a, o, R(0), R(0), g, R(1), mu, mu_p, rec(n, SV_MU_C), R(1), rec(n, SV_MU_C), R(1));
+            const int pl = n * CG + cc;
+            ps1[pl] = k.cG_in;
+            ps2[pl] = k.cX_in;
+            pxr[pl] = k.xr_in;
+            pc0[pl] = k.c0_in;
+        }
+        block_sum_d<4>(sw, red);
+        if (threadIdx.x == 0) {
+            dgr.dgamma[c] = (float)s4[1];
+            dgr.dbeta[c] = (float)s4[0];
+            dgr.dw[2 * c] = (float)sw[0];
+            dgr.dw[2 * c + 1] = (float)sw[1];
+            if (a.sn_two) {
+                dfr.dgamma[c] = (float)s4[3];
+                dfr.dbeta[c] = (float)s4[2];
+                dfr.dw[2 * c] = (float)sw[2];
+                dfr.dw[2 * c + 1] = (float)sw[3];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- dx from LDS, the only write
+    local_emit<T, W>(la, dx, c0, [&](int pl, int idx) {
+        const float G = to_float(gimg[idx]), X = to_float(ximg[idx]);
+        return from_float<T>(fmaf(ps1[pl], G, fmaf(ps2[pl], X - pxr[pl], pc0[pl])));
+    });
+}
+
+}  // namespace cnsn

@@ -106,7 +106,7 @@ int grid_for(Kern kern, size_t lds, int K, int items) {
 // epi: the call carries the residual-block epilogue (EPI kernels; their AUTO rule is separate)
 static inline ResPlan plan_impl(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, bool backward, bool epi) {
     ResPlan rp{false, 0, 0, 0, 0};
-    if (p.strategy == CNSN_STRATEGY_TWO_PASS || has_chan_perm) return rp;
+    if (p.strategy == CNSN_STRATEGY_TWO_PASS || p.strategy == CNSN_STRATEGY_LOCAL || has_chan_perm) return rp;
     const int M = p.H * p.W;
     rp.vec = pick_vec(p.dtype, boxed ? p.W : M);
     if (!(rp.vec == 16 / elem_bytes(p.dtype) || (elem_bytes(p.dtype) == 2 && rp.vec == 4))) return rp;

@@ -20,10 +20,10 @@ _strategy = _ffi.STRATEGY_AUTO
 
 
 def set_strategy(name: str):
-    """'auto' | 'two_pass' | 'resident' — which kernel strategy libcnsn_hip.so uses."""
+    """'auto' | 'two_pass' | 'resident' | 'local' — which kernel strategy libcnsn_hip.so uses."""
     global _strategy
     _strategy = {"auto": _ffi.STRATEGY_AUTO, "two_pass": _ffi.STRATEGY_TWO_PASS,
-                 "resident": _ffi.STRATEGY_RESIDENT}[name]
+                 "resident": _ffi.STRATEGY_RESIDENT, "local": _ffi.STRATEGY_LOCAL}[name]
 
 
 def _require_device(x: torch.Tensor, what: str):

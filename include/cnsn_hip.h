@@ -49,7 +49,9 @@ enum cnsn_status {
 enum cnsn_strategy {
     CNSN_STRATEGY_AUTO = 0,
     CNSN_STRATEGY_TWO_PASS = 1, /* stats kernel -> mid kernel -> apply kernel (3 / 5 tensor passes) */
-    CNSN_STRATEGY_RESIDENT = 2  /* one launch, channel kept on chip (2 / 3 tensor passes)            */
+    CNSN_STRATEGY_RESIDENT = 2, /* one launch, channel kept on chip (2 / 3 tensor passes)            */
+    CNSN_STRATEGY_LOCAL = 3     /* small planes, SelfNorm alone: a whole channel group per workgroup; falls
+                                   back to two-pass where that does not apply                      */
 };
 
 /* One fused CNSN.forward call (models/cnsn.py:159-164): optional CrossNorm
