@@ -256,15 +256,17 @@ constexpr int bwd_waves(int) { return CNSN_WB; }
 constexpr int fwd_waves(int regs, int elem_bytes = 4) { return (elem_bytes == 2 && regs >= 56) ? 3 : 4; }
 constexpr int bwd_waves(int) { return 3; }
 #endif
-// with the residual-block epilogue a second / third tensor is in flight next to the planes held
-#ifndef CNSN_WFE
-#define CNSN_WFE 3
+// with the residual-block epilogue a second / third tensor is in flight next to the planes held.  Measured per
+// instantiation class on the block shapes of ResNet-50 (profiles/r01_fused_block.md, "occupancy bounds"):
+//   forward : 4 waves/SIMD, except 16-bit planes in 16-byte vectors (unpacking eight values per vector costs
+//             registers): 3;   backward: 3, except the 16-bit 16-byte-vector planes of 7+ slots (56x56): 2.
+#if defined(CNSN_WFE) && defined(CNSN_WBE)  // tuning builds
+constexpr int fwd_waves_epi(int, int, int) { return CNSN_WFE; }
+constexpr int bwd_waves_epi(int, int, int) { return CNSN_WBE; }
+#else
+constexpr int fwd_waves_epi(int elem_bytes, int vec, int) { return (elem_bytes == 2 && vec == 8) ? 3 : 4; }
+constexpr int bwd_waves_epi(int elem_bytes, int vec, int nv) { return (elem_bytes == 2 && vec == 8 && nv >= 7) ? 2 : 3; }
 #endif
-#ifndef CNSN_WBE
-#define CNSN_WBE 2
-#endif
-constexpr int fwd_waves_epi(int) { return CNSN_WFE; }
-constexpr int bwd_waves_epi(int) { return CNSN_WBE; }
 
 // residual-block epilogue of the resident kernels (template flag EPI): the op's input is x + addend when
 // `addend` is not NULL (rounded to T like the reference's `out += identity`), ReLU on the way out when `relu`
@@ -304,7 +306,7 @@ __host__ __device__ inline size_t res_lds_bytes(int N, int NG, int OWN, int coef
 // CrossNorm: the inference forward.  Every wave finishes its planes on its own: no publish, no cluster wait, no
 // workgroup barrier; 2*E*b bytes at streaming speed.
 template <typename T, int VEC, int NV, int PPW, bool BOXED, bool EPI = false, bool SOLO = false>
-__global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi(0) : fwd_waves(data_regs(sizeof(T), VEC, NV, PPW), (int)sizeof(T))) void resident_fwd_kernel(ResArgs ra, const T* __restrict__ x, T* __restrict__ y,
+__global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV) : fwd_waves(data_regs(sizeof(T), VEC, NV, PPW), (int)sizeof(T))) void resident_fwd_kernel(ResArgs ra, const T* __restrict__ x, T* __restrict__ y,
                                                               const int64_t* __restrict__ perm, GateDev gg, GateDev gf,
                                                               unsigned long long* __restrict__ gran,
                                                               double* __restrict__ saved, unsigned* __restrict__ ctl,
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi(0) : fwd_waves(data_reg
 // backward
 // ================================================================================================
 template <typename T, int VEC, int NV, int PPW, bool BOXED, bool EPI = false>
-__global__ __launch_bounds__(kBlock, EPI ? bwd_waves_epi(0) : bwd_waves(data_regs(sizeof(T), VEC, NV, PPW))) void resident_bwd_kernel(ResArgs ra, const T* __restrict__ gy,
+__global__ __launch_bounds__(kBlock, EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV) : bwd_waves(data_regs(sizeof(T), VEC, NV, PPW))) void resident_bwd_kernel(ResArgs ra, const T* __restrict__ gy,
                                                               const T* __restrict__ x, T* __restrict__ dx,
                                                               const int64_t* __restrict__ perm, GateDev gg, GateDev gf,
                                                               GateGradDev dgr, GateGradDev dfr,
