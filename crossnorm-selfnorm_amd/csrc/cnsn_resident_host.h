@@ -26,12 +26,20 @@ constexpr int kBucketNv[] = {1, 2, 4, 7, 8, 13, 16};
 #ifndef CNSN_PPW78_FWD16
 #define CNSN_PPW78_FWD16 2
 #endif
+#ifndef CNSN_PPW78_EPI16_BWD
+#define CNSN_PPW78_EPI16_BWD 1
+#endif
+#ifndef CNSN_PPW78_EPI16_FWD
+#define CNSN_PPW78_EPI16_FWD 1
+#endif
 constexpr int ppw_of(int nv, bool backward, bool epi, int elem_bytes) {
     return nv == 1 ? 8
            : nv == 2 ? 4
            : nv == 4 ? (epi ? 2 : 4)
            : (nv == 7 || nv == 8) ? ((backward && !epi) ? (elem_bytes == 4 ? CNSN_PPW78_F32 : 2)
-                                                     : ((!epi && elem_bytes == 2) ? CNSN_PPW78_FWD16 : 1))
+                                                     : (elem_bytes == 2 ? (epi ? (backward ? CNSN_PPW78_EPI16_BWD : CNSN_PPW78_EPI16_FWD)
+                                                                               : CNSN_PPW78_FWD16)
+                                                                        : 1))
                                   : 1;
 }
 
