@@ -26,6 +26,9 @@ constexpr int kBucketNv[] = {1, 2, 4, 7, 8, 13, 16};
 #ifndef CNSN_PPW78_FWD16
 #define CNSN_PPW78_FWD16 2
 #endif
+#ifndef CNSN_PPW1
+#define CNSN_PPW1 8
+#endif
 #ifndef CNSN_PPW78_EPI16_BWD
 #define CNSN_PPW78_EPI16_BWD 1
 #endif
@@ -33,7 +36,7 @@ constexpr int kBucketNv[] = {1, 2, 4, 7, 8, 13, 16};
 #define CNSN_PPW78_EPI16_FWD 1
 #endif
 constexpr int ppw_of(int nv, bool backward, bool epi, int elem_bytes) {
-    return nv == 1 ? 8
+    return nv == 1 ? CNSN_PPW1
            : nv == 2 ? 4
            : nv == 4 ? (epi ? 2 : 4)
            : (nv == 7 || nv == 8) ? ((backward && !epi) ? (elem_bytes == 4 ? CNSN_PPW78_F32 : 2)
