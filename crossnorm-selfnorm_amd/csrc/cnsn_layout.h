@@ -9,7 +9,18 @@ namespace cnsn {
 // touches all fields of a plane, so one base address + constant offsets), followed by two rows of C
 // (BatchNorm rstd of g and f) at SV_ROWS*P.
 enum SavedRow {
+    // ---- rows every mode needs, first and contiguous: a SelfNorm-only forward writes just these seven (one or
+    //      two 64-byte sectors per plane instead of scattered 8-byte writes over a 160-byte record — for planes of
+    //      a few hundred bytes the side-array traffic is otherwise comparable to the tensor's own)
     SV_MU_C = 0,   // mean inside the content box (whole plane without one)
+    SV_MU_P,       // post-CrossNorm whole-plane mean  (SelfNorm's input statistic; = SV_MU_C without CrossNorm)
+    SV_SIG_P,      // post-CrossNorm whole-plane std, eps_sn
+    SV_G,          // gate g
+    SV_ZH_G,       // normalised pre-activation of g
+    SV_F,          // gate f (two-gate form; 1 otherwise)
+    SV_ZH_F,
+    // ---- CrossNorm only: NOT WRITTEN when the call has no CrossNorm — readers substitute the constants of
+    //      load_cn_rows() (a = a1 = 1, m_in = mu_s = mu_c, mu_o = 0, ...)
     SV_MU_O,       // mean outside the content box
     SV_M2C,        // sum of squared deviations inside the content box
     SV_SIG_C,      // sqrt(var_c + eps_cn)
@@ -18,12 +29,6 @@ enum SavedRow {
     SV_A,          // sig_s[q] / sig_c
     SV_A1,         // lam + (1-lam)*a : slope applied inside the content box
     SV_M_IN,       // mean of the CrossNorm output inside the content box
-    SV_MU_P,       // post-CrossNorm whole-plane mean  (SelfNorm's input statistic)
-    SV_SIG_P,      // post-CrossNorm whole-plane std, eps_sn
-    SV_G,          // gate g
-    SV_ZH_G,       // normalised pre-activation of g
-    SV_F,          // gate f (two-gate form)
-    SV_ZH_F,
     // the forward's apply coefficients (floats, exact in a double): written only for a ReLU-fused call, whose
     // backward re-evaluates the forward affine bit-for-bit to recover the ReLU mask without reading y
     SV_FC0,
@@ -46,18 +51,52 @@ enum BwdCoefRow {
 
 template <typename R>
 __device__ __forceinline__ void store_fwd_plane(double* __restrict__ saved, size_t P, size_t p,
-                                                const FwdPlaneT<R>& f) {
+                                                const FwdPlaneT<R>& f, int cn_active) {
     saved[sv_at(p, SV_MU_C)] = f.mu_c;
-    saved[sv_at(p, SV_MU_O)] = f.mu_o;
-    saved[sv_at(p, SV_M2C)] = f.M2c;
-    saved[sv_at(p, SV_SIG_C)] = f.sig_c;
-    saved[sv_at(p, SV_MU_S)] = f.mu_s;
-    saved[sv_at(p, SV_SIG_S)] = f.sig_s;
-    saved[sv_at(p, SV_A)] = f.aa;
-    saved[sv_at(p, SV_A1)] = f.a1;
-    saved[sv_at(p, SV_M_IN)] = f.m_in;
     saved[sv_at(p, SV_MU_P)] = f.mu_p;
     saved[sv_at(p, SV_SIG_P)] = f.sig_p;
+    if (cn_active) {
+        saved[sv_at(p, SV_MU_O)] = f.mu_o;
+        saved[sv_at(p, SV_M2C)] = f.M2c;
+        saved[sv_at(p, SV_SIG_C)] = f.sig_c;
+        saved[sv_at(p, SV_MU_S)] = f.mu_s;
+        saved[sv_at(p, SV_SIG_S)] = f.sig_s;
+        saved[sv_at(p, SV_A)] = f.aa;
+        saved[sv_at(p, SV_A1)] = f.a1;
+        saved[sv_at(p, SV_M_IN)] = f.m_in;
+    }
+}
+
+// the CrossNorm-only rows of plane p, or what they amount to when the call has no CrossNorm
+template <typename R>
+struct CnRowsT {
+    R mu_o, M2c, sig_c, sig_s, aa, a1, m_in;
+    double mu_s;
+};
+template <typename R>
+__device__ __forceinline__ CnRowsT<R> load_cn_rows(const MidArgs& a, const double* __restrict__ saved, size_t p,
+                                                   double mu_c) {
+    CnRowsT<R> r;
+    if (a.cn_active) {
+        r.mu_o = (R)saved[sv_at(p, SV_MU_O)];
+        r.M2c = (R)saved[sv_at(p, SV_M2C)];
+        r.sig_c = (R)saved[sv_at(p, SV_SIG_C)];
+        r.mu_s = saved[sv_at(p, SV_MU_S)];
+        r.sig_s = (R)saved[sv_at(p, SV_SIG_S)];
+        r.aa = (R)saved[sv_at(p, SV_A)];
+        r.a1 = (R)saved[sv_at(p, SV_A1)];
+        r.m_in = (R)saved[sv_at(p, SV_M_IN)];
+    } else {
+        r.mu_o = R(0);
+        r.M2c = R(0);
+        r.sig_c = R(1);
+        r.mu_s = mu_c;
+        r.sig_s = R(1);
+        r.aa = R(1);
+        r.a1 = R(1);
+        r.m_in = (R)mu_c;
+    }
+    return r;
 }
 
 __device__ __forceinline__ void store_fwd_coefs(double* __restrict__ saved, size_t p, const FwdCoefs& k) {

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void local_fwd_kernel(LocalArgs la, const T
             const FwdCoefs cf = fwd_coefs<R>(a, f, g, fg);
             if (saved) {
                 const size_t p = (size_t)n * C + c;
-                store_fwd_plane<R>(saved, P, p, f);
+                store_fwd_plane<R>(saved, P, p, f, 0);
                 saved[sv_at(p, SV_G)] = g;
                 saved[sv_at(p, SV_ZH_G)] = zhg;
                 saved[sv_at(p, SV_F)] = fg;

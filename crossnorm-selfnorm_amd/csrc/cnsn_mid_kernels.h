@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
             M2_sq = a.boxed ? mom[5 * P + q] : mom[P + q];
         }
         const FwdPlane f = fwd_plane<double>(a, o, mu_sq, M2_sq);
-        store_fwd_plane(saved, P, p, f);
+        store_fwd_plane(saved, P, p, f, a.cn_active);
         if (a.sn_active) {
             const double zg = wg0 * f.mu_p + wg1 * f.sig_p;  // Conv1d k=2 groups=C (cnsn.py:137)
             const double zf = wf0 * f.mu_p + wf1 * f.sig_p;
@@ -118,8 +118,9 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
         saved[sv_at(p, SV_ZH_F)] = zhf;
         FwdPlane fp;
         fp.mu_c = saved[sv_at(p, SV_MU_C)];
-        fp.a1 = saved[sv_at(p, SV_A1)];
-        fp.m_in = saved[sv_at(p, SV_M_IN)];
+        const CnRowsT<double> cr = load_cn_rows<double>(a, saved, p, fp.mu_c);
+        fp.a1 = cr.a1;
+        fp.m_in = cr.m_in;
         fp.mu_p = saved[sv_at(p, SV_MU_P)];
         const FwdCoefs k = fwd_coefs<double>(a, fp, g, f);
         coef[FC_A_IN * P + p] = k.a_in;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
 
     auto sums_of = [&](size_t p) {
         return fix_sums<double>(a, sums[p], sums[P + p], a.boxed ? sums[2 * P + p] : 0.f, a.boxed ? sums[3 * P + p] : 0.f,
-                        saved[sv_at(p, SV_MU_C)], saved[sv_at(p, SV_MU_O)]);
+                        saved[sv_at(p, SV_MU_C)], a.boxed ? saved[sv_at(p, SV_MU_O)] : 0.0);
     };
 
     // ---- sweep 1: dL/dgate -> through the sigmoid; batch sums for BatchNorm backward
@@ -154,8 +155,9 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
         for (int n = threadIdx.x; n < a.N; n += kBlock) {
             const size_t p = (size_t)n * a.C + c;
             double dtg, dtf;
-            gate_dt<double>(a, sums_of(p), saved[sv_at(p, SV_A1)], saved[sv_at(p, SV_M_IN)], saved[sv_at(p, SV_MU_O)],
-                    saved[sv_at(p, SV_MU_P)], saved[sv_at(p, SV_G)], saved[sv_at(p, SV_F)], dtg, dtf);
+            const CnRowsT<double> cr = load_cn_rows<double>(a, saved, p, saved[sv_at(p, SV_MU_C)]);
+            gate_dt<double>(a, sums_of(p), cr.a1, cr.m_in, cr.mu_o, saved[sv_at(p, SV_MU_P)], saved[sv_at(p, SV_G)],
+                            saved[sv_at(p, SV_F)], dtg, dtf);
             s[0] += dtg;
             s[1] += dtg * saved[sv_at(p, SV_ZH_G)];
             s[2] += dtf;
@@ -194,11 +196,11 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
     for (int n = threadIdx.x; n < a.N; n += kBlock) {
         const size_t p = (size_t)n * a.C + c;
         const double mu_p = saved[sv_at(p, SV_MU_P)], sig_p = saved[sv_at(p, SV_SIG_P)];
+        const CnRowsT<double> cr = load_cn_rows<double>(a, saved, p, saved[sv_at(p, SV_MU_C)]);
         const BwdPlane o =
             bwd_plane<double>(a, b, sums_of(p), a.sn_active ? tmp[BT_DT_G * P + p] : 0.0, a.sn_active ? tmp[BT_DT_F * P + p] : 0.0,
                       saved[sv_at(p, SV_ZH_G)], saved[sv_at(p, SV_ZH_F)], saved[sv_at(p, SV_G)], saved[sv_at(p, SV_F)],
-                      saved[sv_at(p, SV_A)], saved[sv_at(p, SV_A1)], saved[sv_at(p, SV_M_IN)], mu_p, sig_p,
-                      saved[sv_at(p, SV_SIG_C)], saved[sv_at(p, SV_M2C)]);
+                      cr.aa, cr.a1, cr.m_in, mu_p, sig_p, cr.sig_c, cr.M2c);
         sw[0] += o.dz_g * mu_p;
         sw[1] += o.dz_g * sig_p;
         sw[2] += o.dz_f * mu_p;
@@ -242,9 +244,9 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_b_kernel(MidArgs a, const doub
         Emu = tmp[BT_E_MU * P + p];
         Esig = tmp[BT_E_SIG * P + p];
     }
-    const BwdCoefs k = bwd_coefs<double>(a, o, Emu, Esig, saved[sv_at(p, SV_G)], saved[sv_at(p, SV_A1)], saved[sv_at(p, SV_M_IN)],
-                                 saved[sv_at(p, SV_MU_P)], saved[sv_at(p, SV_MU_C)], saved[sv_at(p, SV_SIG_C)],
-                                 saved[sv_at(p, SV_MU_S)], saved[sv_at(p, SV_SIG_S)]);
+    const CnRowsT<double> cr = load_cn_rows<double>(a, saved, p, saved[sv_at(p, SV_MU_C)]);
+    const BwdCoefs k = bwd_coefs<double>(a, o, Emu, Esig, saved[sv_at(p, SV_G)], cr.a1, cr.m_in, saved[sv_at(p, SV_MU_P)],
+                                         saved[sv_at(p, SV_MU_C)], cr.sig_c, cr.mu_s, cr.sig_s);
     coef[BC_CG_IN * P + p] = k.cG_in;
     coef[BC_CX_IN * P + p] = k.cX_in;
     coef[BC_XR_IN * P + p] = k.xr_in;

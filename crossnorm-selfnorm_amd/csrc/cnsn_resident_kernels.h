@@ -488,7 +488,7 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
                 const FwdCoefs cf = fwd_coefs<float>(a, f, g, fg);
                 if (saved && lane == 0) {
                     const size_t p = (size_t)n * C + c;
-                    store_fwd_plane<float>(saved, P, p, f);
+                    store_fwd_plane<float>(saved, P, p, f, a.cn_active);
                     saved[sv_at(p, SV_G)] = g;
                     saved[sv_at(p, SV_ZH_G)] = zhg;
                     saved[sv_at(p, SV_F)] = fg;
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
                 o[FC_B_OUT] = cf.b_out;
                 if (saved) {
                     const size_t p = (size_t)n * C + c;
-                    store_fwd_plane<R>(saved, P, p, f);
+                    store_fwd_plane<R>(saved, P, p, f, a.cn_active);
                     saved[sv_at(p, SV_G)] = g;
                     saved[sv_at(p, SV_ZH_G)] = zhg;
                     saved[sv_at(p, SV_F)] = fg;
@@ -734,20 +734,21 @@ __global__ __launch_bounds__(kBlock, EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV
             float* sf = svf + n * F_N;
             double* sd = svd + n * D_N;
             sd[D_MU_C] = saved[sv_at(p, SV_MU_C)];
-            sd[D_MU_S] = saved[sv_at(p, SV_MU_S)];
             sd[D_ZH_G] = saved[sv_at(p, SV_ZH_G)];
             sd[D_ZH_F] = saved[sv_at(p, SV_ZH_F)];
-            sf[F_A1] = (float)saved[sv_at(p, SV_A1)];
-            sf[F_M_IN] = (float)saved[sv_at(p, SV_M_IN)];
-            sf[F_MU_O] = (float)saved[sv_at(p, SV_MU_O)];
+            const CnRowsT<float> cr = load_cn_rows<float>(a, saved, p, sd[D_MU_C]);
+            sd[D_MU_S] = cr.mu_s;
+            sf[F_A1] = cr.a1;
+            sf[F_M_IN] = cr.m_in;
+            sf[F_MU_O] = cr.mu_o;
             sf[F_MU_P] = (float)saved[sv_at(p, SV_MU_P)];
             sf[F_G] = (float)saved[sv_at(p, SV_G)];
             sf[F_F] = (float)saved[sv_at(p, SV_F)];
-            sf[F_A] = (float)saved[sv_at(p, SV_A)];
+            sf[F_A] = cr.aa;
             sf[F_SIG_P] = (float)saved[sv_at(p, SV_SIG_P)];
-            sf[F_SIG_C] = (float)saved[sv_at(p, SV_SIG_C)];
-            sf[F_M2C] = (float)saved[sv_at(p, SV_M2C)];
-            sf[F_SIG_S] = (float)saved[sv_at(p, SV_SIG_S)];
+            sf[F_SIG_C] = cr.sig_c;
+            sf[F_M2C] = cr.M2c;
+            sf[F_SIG_S] = cr.sig_s;
         }
 
         // ---- load G and x planes (the only reads)
