@@ -8,6 +8,7 @@ struct LocalPlan {
     bool ok;
     int CG, W;
     size_t lds;
+    int block;  // threads per workgroup
 };
 
 // SelfNorm alone (no CrossNorm) on planes small enough that a whole channel (group) fits one workgroup's LDS

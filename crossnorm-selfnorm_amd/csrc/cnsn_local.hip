@@ -2,6 +2,8 @@
 #include "cnsn_local.h"
 
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 #include "cnsn_local_kernels.h"
 
@@ -11,17 +13,37 @@ namespace {
 
 constexpr size_t kLocalLdsCap = 128 * 1024;  // of the 160 KiB a gfx950 workgroup may have
 
-size_t fwd_lds(int N, int CG, int M, int b) {
-    return local_align((size_t)N * CG * M * b) + local_align((size_t)2 * N * CG * 4) + kLocalMaxCG * 16 * 8 + 4 * 4 * 8;
+// threads per workgroup: 256 for a small image (several workgroups per CU overlap their phases), 1024 for a large one
+// (measured, profiles/r01_small_planes.md: 256 threads win whenever two or more workgroups fit a CU — images up to
+// 64 KiB —, 1024 threads when a workgroup is alone on its CU)
+int block_for(size_t lds256) {
+    if (const char* e = getenv("CNSN_LOCAL_LB")) return atoi(e) == 256 ? 256 : kLocalBigBlock;
+    return lds256 > 64 * 1024 ? kLocalBigBlock : 256;
 }
-size_t bwd_lds(int N, int CG, int M, int b) {
-    return 2 * local_align((size_t)N * CG * M * b) + local_align((size_t)4 * N * CG * 4) + (size_t)2 * N * 8 + 4 * 4 * 8;
+size_t fwd_lds_lb(int N, int CG, int M, int b, int LB) {
+    return local_align((size_t)N * CG * M * b) + local_align((size_t)2 * N * CG * 4) + kLocalMaxCG * 16 * 8 + (size_t)(LB / 64) * 4 * 8;
 }
+size_t bwd_lds_lb(int N, int CG, int M, int b, int LB) {
+    return 2 * local_align((size_t)N * CG * M * b) + local_align((size_t)4 * N * CG * 4) + (size_t)(LB / 256) * 2 * N * 8 +
+           (size_t)(LB / 64) * 4 * 8;
+}
+size_t fwd_lds(int N, int CG, int M, int b) { return fwd_lds_lb(N, CG, M, b, block_for(fwd_lds_lb(N, CG, M, b, 256))); }
+size_t bwd_lds(int N, int CG, int M, int b) { return bwd_lds_lb(N, CG, M, b, block_for(bwd_lds_lb(N, CG, M, b, 256))); }
 
+// more than 64 KiB of dynamic LDS has to be allowed per kernel once (idempotent; remembered per kernel so that the
+// launch path stays free of runtime calls)
 template <typename Kern>
 bool allow_lds(Kern kern, size_t lds) {
     if (lds <= 64 * 1024) return true;
-    return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> allowed;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = allowed[(const void*)kern];
+    if (have >= lds) return true;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLocalLdsCap) != hipSuccess)
+        return false;
+    have = kLocalLdsCap;
+    return true;
 }
 
 LocalArgs make_local_args(const Plan& pl, const LocalPlan& lp) {
@@ -61,7 +83,7 @@ bool dispatch_l(int dtype, int W, F&& f) {
 }  // namespace
 
 LocalPlan local_plan(const Plan& pl, int add, bool backward) {
-    LocalPlan lp{false, 0, 0, 0};
+    LocalPlan lp{false, 0, 0, 0, 256};
     const cnsn_problem_t& p = pl.pr;
     if (p.strategy != CNSN_STRATEGY_AUTO && p.strategy != CNSN_STRATEGY_LOCAL) return lp;
     if (p.cn_active || !p.sn_active || add == ADD_POST) return lp;
@@ -90,9 +112,17 @@ LocalPlan local_plan(const Plan& pl, int add, bool backward) {
         }
     }
     if (CG == 0) return lp;
-    if (p.strategy == CNSN_STRATEGY_AUTO && (lp.lds > 64 * 1024 || W < 4)) return lp;
+    // AUTO: copies of at least 4 bytes; an image over 64 KiB (a workgroup alone on its CU) only where the cluster-
+    // resident kernels cannot take the plane (fewer than 33 vectors, or no 8/16-byte vectors) — there it replaces
+    // the two-pass path ((256,2048,7,7) bf16 backward 0.115 vs 0.199 ms); where they can, they are as fast or faster
+    if (p.strategy == CNSN_STRATEGY_AUTO) {
+        const int rv = pick_vec(p.dtype, M);
+        const bool resident_can = (rv * b == 16 || (b == 2 && rv == 4)) && M / rv > 32;
+        if (W < 4 || (lp.lds > 64 * 1024 && resident_can)) return lp;
+    }
     lp.CG = CG;
     lp.W = W;
+    lp.block = block_for(backward ? bwd_lds_lb(p.N, CG, M, b, 256) : fwd_lds_lb(p.N, CG, M, b, 256));
     lp.ok = true;
     return lp;
 }
@@ -106,17 +136,24 @@ int local_forward(const Plan& pl, const LocalPlan& lp, int add, int relu, const 
     dispatch_l(pl.pr.dtype, lp.W, [&](auto tt, auto wt) {
         using T = typename decltype(tt)::type;
         constexpr int W = decltype(wt)::value;
-        auto go = [&](auto kern) {
+        auto go = [&](auto kern, int lb) {
             if (!allow_lds(kern, lp.lds)) return;
-            kern<<<grid, kBlock, lp.lds, stream>>>(la, (const T*)x, (const T*)(add == ADD_PRE ? addend : nullptr), (T*)y, g, f,
-                                                  saved, relu);
+            kern<<<grid, lb, lp.lds, stream>>>(la, (const T*)x, (const T*)(add == ADD_PRE ? addend : nullptr), (T*)y, g, f, saved,
+                                             relu);
             const hipError_t e = hipGetLastError();
             status = e == hipSuccess ? CNSN_OK : (int)e;
         };
-        if (epi)
-            go(local_fwd_kernel<T, W, true>);
-        else
-            go(local_fwd_kernel<T, W, false>);
+        if (lp.block == 256) {
+            if (epi)
+                go(local_fwd_kernel<T, W, true, 256>, 256);
+            else
+                go(local_fwd_kernel<T, W, false, 256>, 256);
+        } else {
+            if (epi)
+                go(local_fwd_kernel<T, W, true, kLocalBigBlock>, kLocalBigBlock);
+            else
+                go(local_fwd_kernel<T, W, false, kLocalBigBlock>, kLocalBigBlock);
+        }
     });
     return status;
 }
@@ -131,17 +168,24 @@ int local_backward(const Plan& pl, const LocalPlan& lp, int add, int relu, const
     dispatch_l(pl.pr.dtype, lp.W, [&](auto tt, auto wt) {
         using T = typename decltype(tt)::type;
         constexpr int W = decltype(wt)::value;
-        auto go = [&](auto kern) {
+        auto go = [&](auto kern, int lb) {
             if (!allow_lds(kern, lp.lds)) return;
-            kern<<<grid, kBlock, lp.lds, stream>>>(la, (const T*)gy, (const T*)x, (const T*)(add == ADD_PRE ? addend : nullptr),
-                                                  (T*)dx, g, f, dg, df, saved, relu);
+            kern<<<grid, lb, lp.lds, stream>>>(la, (const T*)gy, (const T*)x, (const T*)(add == ADD_PRE ? addend : nullptr),
+                                             (T*)dx, g, f, dg, df, saved, relu);
             const hipError_t e = hipGetLastError();
             status = e == hipSuccess ? CNSN_OK : (int)e;
         };
-        if (epi)
-            go(local_bwd_kernel<T, W, true>);
-        else
-            go(local_bwd_kernel<T, W, false>);
+        if (lp.block == 256) {
+            if (epi)
+                go(local_bwd_kernel<T, W, true, 256>, 256);
+            else
+                go(local_bwd_kernel<T, W, false, 256>, 256);
+        } else {
+            if (epi)
+                go(local_bwd_kernel<T, W, true, kLocalBigBlock>, kLocalBigBlock);
+            else
+                go(local_bwd_kernel<T, W, false, kLocalBigBlock>, kLocalBigBlock);
+        }
     });
     return status;
 }
