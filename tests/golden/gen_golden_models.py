@@ -12,6 +12,8 @@ import io
 import os
 import sys
 
+sys.dont_write_bytecode = True   # the reference tree is read-only material: leave no __pycache__ in it
+
 import numpy as np
 import torch
 

@@ -130,3 +130,76 @@ def test_jsd_properties_and_steps_on_cpu():
                                    cn_op=orc.cn_op_2ins_space_chan)
     assert np.isfinite(float(l2)) and np.isfinite(float(l3))
     assert all(not c.active for c in net.cn_modules)
+
+
+# ------------------------------------------------------------------------------------------------
+# segmentation backbone: dilated ResNet-50, SelfNorm at 'residual' + a separate CrossNorm at 'post'
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def g7(golden_dir):
+    return np.load(os.path.join(golden_dir, "g7_seg.npz"))
+
+
+def make_seg(impl, dtype=torch.float32):
+    from cnsn_amd.callers import SegResNet50CNSN
+    return fill_by_name(SegResNet50CNSN(impl=impl), 3).to(dtype)
+
+
+def seg_sequence(model, x):
+    """What gen_golden_seg.py ran on the reference: train idle, train with one site armed (seed 91), eval."""
+    res = {}
+
+    def put(key, t):
+        res[key + "_pool"], res[key + "_head"] = t.mean((2, 3)), t[:, :8]
+
+    model.train()
+    with torch.no_grad():
+        o = model(x)
+        put("train_out", o["out"]), put("train_aux", o["aux"])
+        torch.manual_seed(91)
+        np.random.seed(91)
+        armed = model._enable_cross_norm()
+        o = model(x)
+        put("aug_out", o["out"]), put("aug_aux", o["aux"])
+        model.eval()
+        put("eval_out", model(x)["out"])
+    return res, armed
+
+
+def seg_check(res, g7, tol, what):
+    for k, v in res.items():
+        t64, t32 = torch.from_numpy(g7[f"f64_{k}"]), torch.from_numpy(g7[f"f32_{k}"]).double()
+        err = float((v.detach().cpu().double() - t64).abs().max())
+        ref_err = float((t32 - t64).abs().max())
+        assert err <= max(tol * float(t64.abs().max()), 3 * ref_err), f"{what} {k}: err {err:.3e} (reference fp32 {ref_err:.3e})"
+
+
+def test_segmentation_backbone_matches_reference_with_oracle_modules(g7):
+    torch.set_num_threads(8)
+    m = make_seg(orc)
+    assert keys_of(m) == [str(k) for k in g7["keys"]]
+    assert m.cn_num == int(g7["cn_num"]) == 16
+    res, armed = seg_sequence(m, torch.from_numpy(g7["x"]))
+    assert armed == [int(v) for v in g7["f32_armed"]]
+    seg_check(res, g7, 1e-5, "dilated ResNet-50 (oracle CNSN, CPU)")
+    assert all(not c.active for c in m.cn_modules)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs an MI355X")
+def test_segmentation_backbone_matches_reference_on_gpu(g7):
+    import cnsn_amd
+    m = make_seg(cnsn_amd.cnsn).cuda()
+    res, armed = seg_sequence(m, torch.from_numpy(g7["x"]).cuda())
+    assert armed == [int(v) for v in g7["f32_armed"]]
+    seg_check(res, g7, 1e-3, "dilated ResNet-50 (HIP CNSN)")
+
+
+def test_poly_learning_rate_and_fcn_head():
+    from cnsn_amd.callers import FCNHead, poly_learning_rate
+    assert poly_learning_rate(0.01, 0, 100) == pytest.approx(0.01)
+    assert poly_learning_rate(0.01, 50, 100) == pytest.approx(0.01 * 0.5 ** 0.9)
+    assert poly_learning_rate(0.01, 100, 100) == 0.0
+    head = FCNHead(2048, 19).eval()
+    assert head(torch.randn(2, 2048, 8, 8)).shape == (2, 19, 8, 8)
+    assert [tuple(p.shape) for p in head.parameters()] == [(512, 2048, 3, 3), (512,), (512,), (19, 512, 1, 1), (19,)]
