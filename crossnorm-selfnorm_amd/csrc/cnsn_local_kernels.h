@@ -40,12 +40,7 @@ constexpr int kLocalMaxCG = 8;
 // a large image (one or two workgroups per CU) gets 1024 threads so that the parallelism is inside the workgroup.
 constexpr int kLocalBigBlock = 1024;
 
-// LDS carve (bytes): data of `tensors` staged tensors | per-plane float arrays | per-channel params | reduction
 __host__ __device__ inline size_t local_align(size_t v) { return (v + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t local_lds_bytes(int N, int CG, int M, int elem_bytes, int tensors, int plane_floats) {
-    return (size_t)tensors * local_align((size_t)N * CG * M * elem_bytes) + local_align((size_t)plane_floats * N * CG * 4) +
-           local_align((size_t)kLocalMaxCG * 16 * 8) + 4 * 4 * 8;
-}
 
 // copy vector v (of `W` bytes) of the channel group between HBM and registers
 template <int W>
