@@ -115,19 +115,28 @@ __global__ __launch_bounds__(kBlock) void plane_stats_kernel(const T* __restrict
                 part[1][j] = fmaf(d, d, part[1][j]);
             }
         } else {
-            const int e = i * VEC;  // VEC divides the width: the whole vector lies in one row
+            // boxed: the kernel is VALU-bound for 16-bit tensors, so the per-element work is kept minimal — the row
+            // tests are per vector (VEC divides the width: a vector lies in one row), membership becomes a 0/1
+            // factor, and the sums OUTSIDE the content box are obtained as (whole plane) - (inside) afterwards
+            // (all sums are about the same shift K, so the subtraction does not cancel catastrophically; what it
+            // loses is scaled by the weight Mo/M the outside region has in the merged statistics)
+            const int e = i * VEC;
             const int r = e / g.Wd, c = e - r * g.Wd;
+            const bool row_c = (unsigned)(r - g.cb.r0) < (unsigned)(g.cb.r1 - g.cb.r0);
+            const bool row_s = (unsigned)(r - g.sb.r0) < (unsigned)(g.sb.r1 - g.sb.r0);
+            const unsigned wc = row_c ? (unsigned)(g.cb.c1 - g.cb.c0) : 0u, ws = row_s ? (unsigned)(g.sb.c1 - g.sb.c0) : 0u;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const float d = to_float(v.v[j]) - K;
                 const float d2 = d * d;
-                const bool ic = g.cb.has(r, c + j), is = g.sb.has(r, c + j);
-                part[0][j] += ic ? d : 0.f;
-                part[1][j] += ic ? d2 : 0.f;
-                part[2][j] += ic ? 0.f : d;
-                part[3][j] += ic ? 0.f : d2;
-                part[4][j] += is ? d : 0.f;
-                part[5][j] += is ? d2 : 0.f;
+                const float mc = (unsigned)(c + j - g.cb.c0) < wc ? 1.f : 0.f;
+                const float ms = (unsigned)(c + j - g.sb.c0) < ws ? 1.f : 0.f;
+                part[0][j] = fmaf(mc, d, part[0][j]);
+                part[1][j] = fmaf(mc, d2, part[1][j]);
+                part[2][j] += d;   // whole plane here; the inside is subtracted below
+                part[3][j] += d2;
+                part[4][j] = fmaf(ms, d, part[4][j]);
+                part[5][j] = fmaf(ms, d2, part[5][j]);
             }
         }
     });
@@ -141,6 +150,10 @@ __global__ __launch_bounds__(kBlock) void plane_stats_kernel(const T* __restrict
         acc[k] = part[k][0];
     }
     group_sum<LPP, NACC>(acc, lds);
+    if constexpr (BOXED) {  // outside = whole plane - inside
+        acc[2] -= acc[0];
+        acc[3] -= acc[1];
+    }
 
     if (id.lane == 0 && id.valid) {
         auto moments = [&](float s1, float s2, int cnt, double& mean, double& m2) {
@@ -252,17 +265,21 @@ __global__ __launch_bounds__(kBlock) void bwd_reduce_kernel(const T* __restrict_
                                      part[0][j] += G;
                                      part[1][j] = fmaf(G, to_float(vx.v[j]) - si, part[1][j]);
                                  }
-                             } else {
+                             } else {  // (see plane_stats_kernel: row test per vector, 0/1 factor, outside = whole - inside)
                                  const int e = i * VEC;
                                  const int r = e / g.Wd, c = e - r * g.Wd;
+                                 const unsigned wc = (unsigned)(r - g.cb.r0) < (unsigned)(g.cb.r1 - g.cb.r0)
+                                                         ? (unsigned)(g.cb.c1 - g.cb.c0)
+                                                         : 0u;
 #pragma unroll
                                  for (int j = 0; j < VEC; ++j) {
                                      const float G = to_float(vg.v[j]), X = to_float(vx.v[j]);
-                                     const bool ic = g.cb.has(r, c + j);
-                                     part[0][j] += ic ? G : 0.f;
-                                     part[1][j] += ic ? G * (X - si) : 0.f;
-                                     part[2][j] += ic ? 0.f : G;
-                                     part[3][j] += ic ? 0.f : G * (X - so);
+                                     const float mc = (unsigned)(c + j - g.cb.c0) < wc ? 1.f : 0.f;
+                                     const float pr = G * (X - si);
+                                     part[0][j] = fmaf(mc, G, part[0][j]);
+                                     part[1][j] = fmaf(mc, pr, part[1][j]);
+                                     part[2][j] += G;
+                                     part[3][j] += pr;
                                  }
                              }
                          });
@@ -276,6 +293,10 @@ __global__ __launch_bounds__(kBlock) void bwd_reduce_kernel(const T* __restrict_
         acc[k] = part[k][0];
     }
     group_sum<LPP, NACC>(acc, lds);
+    if constexpr (BOXED) {  // sum_out G*(X-so) = sum_out G*(X-si) - (so-si)*sum_out G
+        acc[2] -= acc[0];
+        acc[3] = (acc[3] - acc[1]) - (so - si) * acc[2];
+    }
     if (id.lane == 0 && id.valid) {
 #pragma unroll
         for (int k = 0; k < NACC; ++k) out[(size_t)k * g.P + id.p] = acc[k];
