@@ -146,6 +146,7 @@ static inline ResPlan plan_impl(const cnsn_problem_t& p, bool boxed, bool has_ch
         // 16-bit (sweeps of round 1, profiles/r01_resident_tuning.md): up to 4 slots per lane (14x14 .. 44x44)
         // always; 7/8 slots (56x56, 64x64) un-boxed only (boxed: two-pass 0.689 vs 0.725 ms at the north-star
         // shape); 13/16 slots only the un-boxed backward
+        const bool solo = !backward && !boxed && !p.cn_active && !(p.sn_active && p.sn_training);  // inference
         if (!epi && !solo && p.dtype != CNSN_F32) {
             const bool ok16 = rp.nv <= 4 ? true : rp.nv <= 8 ? !boxed : (backward && !boxed);
             if (!ok16) return rp;
