@@ -23,6 +23,11 @@ constexpr int kBucketNv[] = {1, 2, 4, 7, 8, 13, 16};
 #ifndef CNSN_PPW78_F32
 #define CNSN_PPW78_F32 2
 #endif
+// (16-bit, 8 slots, TWO planes per wave, boxed: hipcc of ROCm 7.2 produces wrong gradients for that instantiation —
+//  caught by tests/test_gpu_resident_instantiations.py; the 8-slot class therefore holds one plane per wave)
+#ifndef CNSN_PPW8_BWD16
+#define CNSN_PPW8_BWD16 1
+#endif
 #ifndef CNSN_PPW78_FWD16
 #define CNSN_PPW78_FWD16 2
 #endif
@@ -39,7 +44,7 @@ constexpr int ppw_of(int nv, bool backward, bool epi, int elem_bytes) {
     return nv == 1 ? CNSN_PPW1
            : nv == 2 ? 4
            : nv == 4 ? (epi ? 2 : 4)
-           : (nv == 7 || nv == 8) ? ((backward && !epi) ? (elem_bytes == 4 ? CNSN_PPW78_F32 : 2)
+           : (nv == 7 || nv == 8) ? ((backward && !epi) ? (elem_bytes == 4 ? CNSN_PPW78_F32 : (nv == 8 ? CNSN_PPW8_BWD16 : 2))
                                                      : (elem_bytes == 2 ? (epi ? (backward ? CNSN_PPW78_EPI16_BWD : CNSN_PPW78_EPI16_FWD)
                                                                                : CNSN_PPW78_FWD16)
                                                                         : 1))

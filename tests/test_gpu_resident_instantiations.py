@@ -1,0 +1,54 @@
+"""Every instantiation class of the channel-resident kernels at least once: element type x vector width x register
+bucket (1, 2, 4, 7, 8, 13, 16 vectors per lane) x boxed / un-boxed x with / without the residual-block epilogue,
+forward and backward, forced with strategy='resident' (AUTO never reaches some of them — e.g. 16-bit boxed planes of
+the 7/8-slot class run two-pass — but CNSN_STRATEGY_RESIDENT does).  Several of these instantiations spill registers;
+one (16-bit, 8 slots, two planes per wave, boxed) was miscompiled until it was given one plane per wave."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import cnsn_amd  # noqa: E402
+from tests.test_gpu_fused_block import check as check_block, run_case as run_block  # noqa: E402
+from tests.test_gpu_parity import assert_parity, run_pair  # noqa: E402
+
+# (H, W) per bucket; 16-byte vectors: W % 8 == 0 for 16-bit (8 elements), W % 4 == 0 for fp32
+PLANES_V16 = {1: (8, 64), 2: (12, 64), 4: (28, 64), 7: (56, 56), 8: (60, 64), 13: (96, 64), 16: (120, 64)}
+PLANES_F32 = {1: (8, 32), 2: (12, 32), 4: (28, 32), 7: (40, 40), 8: (60, 32), 13: (56, 56), 16: (60, 64)}
+# 16-bit planes whose width is a multiple of 4 only: 8-byte vectors
+PLANES_V8 = {1: (14, 12), 2: (30, 12), 4: (36, 20), 7: (60, 28), 8: (44, 44), 13: (84, 36), 16: (92, 44)}
+
+CASES = []
+for nv, hw in PLANES_F32.items():
+    CASES.append(("f32", nv, hw))
+for nv, hw in PLANES_V16.items():
+    CASES.append(("bf16", nv, hw))
+    CASES.append(("f16", nv, hw))
+for nv, hw in PLANES_V8.items():
+    CASES.append(("bf16v4", nv, hw))
+DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "bf16v4": torch.bfloat16}
+
+
+@pytest.fixture(autouse=True)
+def resident():
+    cnsn_amd.set_strategy("resident")
+    yield
+    cnsn_amd.set_strategy("auto")
+
+
+@pytest.mark.parametrize("tag,nv,hw", CASES, ids=lambda v: str(v).replace(" ", ""))
+@pytest.mark.parametrize("crop", ["neither", "both"])
+def test_op(tag, nv, hw, crop):
+    shape = (5, 2, *hw)
+    out = run_pair(shape, crop, "cnsn", DT[tag], 500 + nv, training=True)
+    assert_parity(out, DT[tag], (tag, nv, shape, crop))
+
+
+@pytest.mark.parametrize("tag,nv,hw", CASES, ids=lambda v: str(v).replace(" ", ""))
+@pytest.mark.parametrize("kind,crop", [("sn", "neither"), ("cnsn", "both")])
+def test_block(tag, nv, hw, kind, crop):
+    shape = (5, 2, *hw)
+    check_block(run_block(shape, kind, crop, "pre", True, DT[tag], 700 + nv), DT[tag], True, (tag, nv, shape, kind, crop))
