@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libcnsn_hip.so")
 CNSN_F32, CNSN_BF16, CNSN_F16 = 0, 1, 2
 STRATEGY_AUTO, STRATEGY_TWO_PASS, STRATEGY_RESIDENT, STRATEGY_LOCAL = 0, 1, 2, 3
 ADD_NONE, ADD_PRE, ADD_POST = 0, 1, 2
+PATHS = {0: "streaming", 1: "packed", 2: "resident", 3: "local"}
 ABI_VERSION = 2
 
 
@@ -65,6 +66,7 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p, C.POINTER(Gate), C.POINTER(Gate),
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GateGrad),
                                       C.POINTER(GateGrad), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cnsn_which_path": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.c_int, C.c_int]),
     "cnsn_jsd_workspace_bytes": (C.c_size_t, [C.c_int]),
     "cnsn_jsd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -36,6 +36,18 @@ int parse_epilogue(const cnsn_epilogue_t* epi, EpiPlan& e) {
     return CNSN_OK;
 }
 
+// the same without looking at the addend pointer (cnsn_which_path)
+int parse_epilogue_shape(const cnsn_epilogue_t* epi, EpiPlan& e) {
+    e = EpiPlan{ADD_NONE, 0, nullptr};
+    if (!epi) return CNSN_OK;
+    if (epi->struct_bytes != (int32_t)sizeof(cnsn_epilogue_t)) return CNSN_E_STRUCT;
+    if (epi->add_mode != CNSN_ADD_NONE && epi->add_mode != CNSN_ADD_PRE && epi->add_mode != CNSN_ADD_POST)
+        return CNSN_E_UNSUPPORTED;
+    e.add = epi->add_mode;
+    e.relu = epi->relu ? 1 : 0;
+    return CNSN_OK;
+}
+
 // call f(IntTag<ADD>) for the runtime add mode
 template <typename F>
 inline void with_add(int add, F&& f) {
@@ -50,6 +62,25 @@ inline void with_add(int add, F&& f) {
 }  // namespace
 
 extern "C" {
+
+int cnsn_which_path(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int has_chan_perm, int backward) {
+    EpiPlan e;
+    int st = parse_epilogue_shape(epi, e);
+    if (st) return st;
+    Plan pl;
+    st = make_plan(prob, pl);
+    if (st) return st;
+    const cnsn_problem_t& p = pl.pr;
+    const bool chan = p.cn_active && has_chan_perm;
+    const bool bwd = backward != 0;
+    // the backward of an epilogue without ReLU and without PRE add is the plain backward
+    const bool fused = bwd ? (e.relu || e.add == ADD_PRE) : (e.relu || e.add != ADD_NONE);
+    if (local_plan(pl, fused ? e.add : 0, bwd).ok) return CNSN_PATH_LOCAL;
+    if (fused ? resident_fused_plan(p, pl.boxed, chan, e.add, bwd).ok : resident_plan(p, pl.boxed, chan, bwd).ok)
+        return CNSN_PATH_RESIDENT;
+    PackedGeom pg;
+    return packed_plan(pl, pg) ? CNSN_PATH_PACKED : CNSN_PATH_STREAMING;
+}
 
 int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const void* x, const int64_t* perm,
                        const int64_t* chan_perm, const cnsn_gate_t* g, const cnsn_gate_t* f, void* y, float* saved,

@@ -146,6 +146,17 @@ def _epilogue(cfg: FusedConfig, addend):
     return e
 
 
+def which_path(x: torch.Tensor, cfg: FusedConfig, backward: bool = False, chan_perm: bool = False) -> str:
+    """'streaming' | 'packed' | 'resident' | 'local': the kernels a call with this tensor / configuration would run
+    under the current strategy setting (cnsn_which_path; nothing is launched)."""
+    prob = _problem(x, cfg)
+    epi = _epilogue(cfg, None) if cfg.has_epilogue else None
+    st = _ffi.lib().cnsn_which_path(C.byref(prob), C.byref(epi) if epi else None, int(chan_perm), int(backward))
+    if st < 0:
+        _ffi.check(st, "cnsn_which_path")
+    return _ffi.PATHS[st]
+
+
 def _problem(x: torch.Tensor, cfg: FusedConfig) -> _ffi.Problem:
     p = _ffi.Problem()
     p.struct_bytes = C.sizeof(_ffi.Problem)

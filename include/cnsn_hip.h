@@ -185,6 +185,16 @@ int cnsn_plane_affine(const void* x, int dtype, int N, int C, int H, int W, cons
 int cnsn_plane_dot(const void* g, const void* x, int dtype, int N, int C, int H, int W,
                    float* sums, void* stream);
 
+/* Which kernels a call would run (pure function of the problem; nothing is launched): lets a caller, a test or a
+ * benchmark see what CNSN_STRATEGY_AUTO — or a forced strategy with its fall-backs — resolves to. */
+enum cnsn_path {
+    CNSN_PATH_STREAMING = 0, /* two-pass, 16/64/256 lanes per plane                       */
+    CNSN_PATH_PACKED = 1,    /* two-pass, runs of small planes staged through LDS         */
+    CNSN_PATH_RESIDENT = 2,  /* one launch, cluster of workgroups per channel             */
+    CNSN_PATH_LOCAL = 3      /* one launch, a whole channel group per workgroup           */
+};
+int cnsn_which_path(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int has_chan_perm, int backward);
+
 /* ---- Jensen-Shannon consistency of three views ----------------------------------
  * imagenet.py:367-381 / cifar.py:173-186: p_i = softmax(logits_i, 1); lm = clamp(mean_i p_i, 1e-7, 1).log();
  * loss = mean_i F.kl_div(lm, p_i, reduction='batchmean').  One launch computes the loss and, when the three

@@ -1,0 +1,59 @@
+"""What CNSN_STRATEGY_AUTO resolves to for the shapes of the scope contract — `cnsn_which_path` is a
+pure function of the problem, so these run without a GPU.  The table is the measured outcome recorded in
+profiles/r01_resident_tuning.md and r01_small_planes.md; a change of a rule has to change this file with it."""
+import pytest
+import torch
+
+import cnsn_amd
+from cnsn_amd import FusedConfig as FC
+from cnsn_amd import which_path
+
+SN = dict(sn_active=True)
+CN = dict(cn_active=True)
+BOTH = dict(cn_active=True, content_box=(1, 1, 5, 5), style_box=(0, 0, 4, 4))
+BLOCK = dict(sn_active=True, add_mode="pre", relu=True)
+F32, BF16 = torch.float32, torch.bfloat16
+
+TABLE = [
+    # shape, dtype, config, forward, backward
+    ((256, 256, 56, 56), F32, FC(**SN, **CN), "resident", "resident"),         # the north-star workload
+    ((256, 256, 56, 56), F32, FC(**SN, **BOTH), "resident", "resident"),
+    ((256, 256, 56, 56), BF16, FC(**SN, **CN), "resident", "resident"),
+    ((256, 256, 56, 56), BF16, FC(**SN, **BOTH), "streaming", "streaming"),    # 16-bit boxed 56x56: two-pass
+    ((256, 512, 28, 28), BF16, FC(**SN, **BOTH), "resident", "resident"),      # <= 4 slots: always resident
+    ((256, 1024, 14, 14), BF16, FC(**SN), "resident", "resident"),             # image of a channel does not fit LDS
+    ((96, 1024, 14, 14), BF16, FC(**SN), "local", "resident"),                 # fwd fits (38 KiB), bwd would need 75
+    ((256, 2048, 7, 7), BF16, FC(**SN), "local", "local"),                     # resident cannot take 98-byte planes
+    ((256, 2048, 7, 7), BF16, FC(**BLOCK), "local", "local"),
+    ((256, 2048, 7, 7), BF16, FC(**SN, **CN), "packed", "packed"),             # CrossNorm: not channel-local
+    ((256, 2048, 7, 7), F32, FC(**SN), "local", "local"),
+    ((128, 128, 8, 8), F32, FC(**SN), "local", "local"),
+    ((128, 32, 32, 32), F32, FC(**SN, **BOTH), "resident", "resident"),        # WideResNet stage 1
+    ((768, 3, 224, 224), F32, FC(**CN), "streaming", "streaming"),             # image-level CrossNorm: 12544 vectors
+    ((16, 256, 128, 128), F32, FC(**SN), "streaming", "streaming"),
+    ((256, 256, 56, 56), F32, FC(sn_active=True, sn_training=False), "resident", "resident"),   # inference (SOLO)
+    ((64, 128, 88, 88), BF16, FC(**SN, **CN), "streaming", "resident"),        # 16 slots, 16-bit: un-boxed backward only
+]
+
+
+@pytest.mark.parametrize("shape,dtype,cfg,fwd,bwd", TABLE, ids=lambda v: str(v)[:28].replace(" ", ""))
+def test_auto_resolves_as_measured(shape, dtype, cfg, fwd, bwd):
+    x = torch.empty(shape, dtype=dtype, device="meta")
+    cnsn_amd.set_strategy("auto")
+    assert which_path(x, cfg, backward=False) == fwd
+    assert which_path(x, cfg, backward=True) == bwd
+
+
+def test_forced_strategies_fall_back():
+    x = torch.empty((8, 4, 224, 224), dtype=F32, device="meta")
+    try:
+        for name in ("two_pass", "resident", "local"):
+            cnsn_amd.set_strategy(name)
+            assert which_path(x, FC(**SN)) == "streaming"          # too large for any single-touch strategy
+        cnsn_amd.set_strategy("two_pass")
+        assert which_path(torch.empty((8, 4, 7, 7), dtype=BF16, device="meta"), FC(**SN)) == "packed"
+        cnsn_amd.set_strategy("local")
+        assert which_path(torch.empty((8, 4, 7, 7), dtype=BF16, device="meta"), FC(**SN)) == "local"
+        assert which_path(torch.empty((8, 4, 7, 7), dtype=BF16, device="meta"), FC(**SN, **CN)) == "packed"
+    finally:
+        cnsn_amd.set_strategy("auto")
