@@ -59,6 +59,8 @@ __device__ __forceinline__ void stream2(const T* __restrict__ a, const T* __rest
     }
 }
 
+typedef float pk2f __attribute__((ext_vector_type(2)));
+
 template <int LPP>
 struct PlaneId {
     int p;       // plane index (clamped so that idle lanes still take part in reductions)
@@ -125,18 +127,38 @@ __global__ __launch_bounds__(kBlock) void plane_stats_kernel(const T* __restrict
             const bool row_c = (unsigned)(r - g.cb.r0) < (unsigned)(g.cb.r1 - g.cb.r0);
             const bool row_s = (unsigned)(r - g.sb.r0) < (unsigned)(g.sb.r1 - g.sb.r0);
             const unsigned wc = row_c ? (unsigned)(g.cb.c1 - g.cb.c0) : 0u, ws = row_s ? (unsigned)(g.sb.c1 - g.sb.c0) : 0u;
+            const int cc = c - g.cb.c0, cs = c - g.sb.c0;
+            if constexpr (VEC >= 2) {
+                // two elements per instruction (v_pk_add/mul/fma_f32): the accumulators of slots j, j+1 as a pair
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const float d = to_float(v.v[j]) - K;
+                for (int j = 0; j < VEC; j += 2) {
+                    const pk2f d = pk2f{to_float(v.v[j]), to_float(v.v[j + 1])} - pk2f{K, K};
+                    const pk2f d2 = d * d;
+                    const pk2f mc = {(unsigned)(cc + j) < wc ? 1.f : 0.f, (unsigned)(cc + j + 1) < wc ? 1.f : 0.f};
+                    const pk2f ms = {(unsigned)(cs + j) < ws ? 1.f : 0.f, (unsigned)(cs + j + 1) < ws ? 1.f : 0.f};
+                    pk2f a0 = {part[0][j], part[0][j + 1]}, a1 = {part[1][j], part[1][j + 1]};
+                    pk2f a2 = {part[2][j], part[2][j + 1]}, a3 = {part[3][j], part[3][j + 1]};
+                    pk2f a4 = {part[4][j], part[4][j + 1]}, a5 = {part[5][j], part[5][j + 1]};
+                    a0 = __builtin_elementwise_fma(mc, d, a0);
+                    a1 = __builtin_elementwise_fma(mc, d2, a1);
+                    a2 += d;   // whole plane here; the inside is subtracted below
+                    a3 += d2;
+                    a4 = __builtin_elementwise_fma(ms, d, a4);
+                    a5 = __builtin_elementwise_fma(ms, d2, a5);
+                    part[0][j] = a0.x, part[0][j + 1] = a0.y, part[1][j] = a1.x, part[1][j + 1] = a1.y;
+                    part[2][j] = a2.x, part[2][j + 1] = a2.y, part[3][j] = a3.x, part[3][j + 1] = a3.y;
+                    part[4][j] = a4.x, part[4][j + 1] = a4.y, part[5][j] = a5.x, part[5][j + 1] = a5.y;
+                }
+            } else {
+                const float d = to_float(v.v[0]) - K;
                 const float d2 = d * d;
-                const float mc = (unsigned)(c + j - g.cb.c0) < wc ? 1.f : 0.f;
-                const float ms = (unsigned)(c + j - g.sb.c0) < ws ? 1.f : 0.f;
-                part[0][j] = fmaf(mc, d, part[0][j]);
-                part[1][j] = fmaf(mc, d2, part[1][j]);
-                part[2][j] += d;   // whole plane here; the inside is subtracted below
-                part[3][j] += d2;
-                part[4][j] = fmaf(ms, d, part[4][j]);
-                part[5][j] = fmaf(ms, d2, part[5][j]);
+                const float mc = (unsigned)cc < wc ? 1.f : 0.f, ms = (unsigned)cs < ws ? 1.f : 0.f;
+                part[0][0] = fmaf(mc, d, part[0][0]);
+                part[1][0] = fmaf(mc, d2, part[1][0]);
+                part[2][0] += d;
+                part[3][0] += d2;
+                part[4][0] = fmaf(ms, d, part[4][0]);
+                part[5][0] = fmaf(ms, d2, part[5][0]);
             }
         }
     });
