@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec,
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--shape", type=str, default="256,256,56,56")
     ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16", "f16"])
     ap.add_argument("--crop", type=str, default="neither", choices=["neither", "style", "content", "both"])
