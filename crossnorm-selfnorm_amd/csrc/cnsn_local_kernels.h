@@ -34,6 +34,15 @@ struct LocalArgs {
     float inv_m;     // 1/M (element index -> plane index)
 };
 
+// tuning builds (-DCNSN_LPROF): per-phase wall-clock stamps of the first and last workgroup, printed by the kernel
+#ifdef CNSN_LPROF
+#define LSTAMP() t_[ti_++] = (long long)wall_clock64()
+#else
+#define LSTAMP() \
+    do {         \
+    } while (0)
+#endif
+
 constexpr int kLocalMaxCG = 8;
 // threads per workgroup (template parameter LB): the phases of a workgroup run one after the other and each is
 // bound by latency.  A small image (many workgroups per CU) gets 256 threads and lets the workgroups of a CU overlap;
@@ -173,11 +182,6 @@ __global__ __launch_bounds__(LB) void local_fwd_kernel(LocalArgs la, const T* __
 #ifdef CNSN_LPROF
     long long t_[8];
     int ti_ = 0;
-#define LSTAMP() t_[ti_++] = (long long)wall_clock64()
-#else
-#define LSTAMP() \
-    do {         \
-    } while (0)
 #endif
     LSTAMP();
 
