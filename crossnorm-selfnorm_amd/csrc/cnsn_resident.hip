@@ -1,7 +1,45 @@
 // Channel-resident strategy, the op alone: host entry points (shared logic in cnsn_resident_host.h).
 #include "cnsn_resident_host.h"
 
+#include <mutex>
+
 namespace cnsn {
+
+namespace {
+struct ChainState {
+    std::mutex mu;
+    hipEvent_t ev = nullptr;
+    hipStream_t last = nullptr;
+    bool valid = false;
+};
+ChainState g_chain[16];
+}  // namespace
+
+ResidentChain::ResidentChain(hipStream_t stream) : stream_(stream), dev_(0), active_(false) {
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 16) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return;
+    }
+    ChainState& c = g_chain[dev_];
+    c.mu.lock();
+    active_ = true;
+    if (c.valid && c.last != stream) (void)hipStreamWaitEvent(stream, c.ev, 0);
+}
+
+ResidentChain::~ResidentChain() {
+    if (!active_) return;
+    ChainState& c = g_chain[dev_];
+    if (!c.ev && hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) c.ev = nullptr;
+    if (c.ev && hipEventRecord(c.ev, stream_) == hipSuccess) {
+        c.last = stream_;
+        c.valid = true;
+    } else {
+        c.valid = false;
+    }
+    c.mu.unlock();
+}
 
 ResPlan resident_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, bool backward) {
     return reshost::plan_impl(p, boxed, has_chan_perm, backward, false);

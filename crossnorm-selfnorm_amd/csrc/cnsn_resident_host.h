@@ -187,12 +187,19 @@ int forward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidA
             const int grid = grid_for(kern, lds, rp.K, ra.items);
             if (grid < rp.K) return;
             hipError_t e = hipSuccess;
-            if (!solo) e = hipMemsetAsync(workspace, 0xff, fill_bytes, stream);  // 'empty' granules, idle control word
-            if (e != hipSuccess) {
-                status = (int)e;
-                return;
+            if (solo) {  // no cluster, nothing to wait for
+                kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, (const T*)addend,
+                                                    relu);
+            } else {
+                ResidentChain chain(stream);  // cluster grids of different streams never overlap
+                e = hipMemsetAsync(workspace, 0xff, fill_bytes, stream);  // 'empty' granules, idle control word
+                if (e != hipSuccess) {
+                    status = (int)e;
+                    return;
+                }
+                kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, (const T*)addend,
+                                                    relu);
             }
-            kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, (const T*)addend, relu);
             e = hipGetLastError();
             status = e == hipSuccess ? CNSN_OK : (int)e;
         };
@@ -228,6 +235,7 @@ int backward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const Mid
         auto launch = [&](auto kern) {
             const int grid = grid_for(kern, lds, rp.K, ra.items);
             if (grid < rp.K) return;
+            ResidentChain chain(stream);  // cluster grids of different streams never overlap
             hipError_t e = hipMemsetAsync(workspace, 0xff, fill_bytes, stream);  // 'empty' granules, idle control word
             if (e != hipSuccess) {
                 status = (int)e;

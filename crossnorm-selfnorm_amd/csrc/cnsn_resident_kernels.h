@@ -990,4 +990,18 @@ int resident_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const
                       GateGradDev dg, GateGradDev df, void* workspace, hipStream_t stream);
 size_t resident_workspace_bytes(const cnsn_problem_t& p, bool boxed);
 
+// A persistent cluster grid assumes that ALL its workgroups become resident.  Two such grids started on DIFFERENT
+// streams of one device could each end up partially resident and wait for each other (until the bounded spin
+// traps).  Cluster launches of a process are therefore chained per device: a launch on another stream than the
+// previous one first waits (stream-side, hipStreamWaitEvent) for the previous one's completion event.  Same-stream
+// sequences — the normal case — pay one hipEventRecord.  Streams under graph capture are left alone (a captured
+// graph replays on one stream).  This is the only state the library keeps.
+struct ResidentChain {
+    explicit ResidentChain(hipStream_t stream);
+    ~ResidentChain();
+    hipStream_t stream_;
+    int dev_;
+    bool active_;
+};
+
 }  // namespace cnsn

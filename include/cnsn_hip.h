@@ -11,7 +11,8 @@
  *   - Every pointer is a DEVICE pointer unless it says "host".  Activations are NCHW, contiguous,
  *     16-byte aligned, element type `dtype`.  All per-plane / per-channel side arrays are float32.
  *   - The caller owns every buffer (inputs, outputs, `saved`, `workspace`).  The library allocates
- *     nothing, keeps no global state, is re-entrant, never synchronises the host, never throws.
+ *     nothing, is re-entrant, never synchronises the host, never throws; the only state it keeps is a per-device
+ *     event that orders its persistent launches across streams.
  *     All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream).
  *   - Randomness stays on the host: the batch permutation, channel permutation and boxes are
  *     INPUTS (the reference draws them with torch.randperm / numpy, models/cnsn.py:62,65,71,76).
