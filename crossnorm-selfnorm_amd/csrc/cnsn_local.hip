@@ -30,15 +30,17 @@ size_t bwd_lds_lb(int N, int CG, int M, int b, int LB) {
 size_t fwd_lds(int N, int CG, int M, int b) { return fwd_lds_lb(N, CG, M, b, block_for(fwd_lds_lb(N, CG, M, b, 256))); }
 size_t bwd_lds(int N, int CG, int M, int b) { return bwd_lds_lb(N, CG, M, b, block_for(bwd_lds_lb(N, CG, M, b, 256))); }
 
-// more than 64 KiB of dynamic LDS has to be allowed per kernel once (idempotent; remembered per kernel so that the
+// more than 64 KiB of dynamic LDS has to be allowed per kernel and device once (idempotent; remembered so that the
 // launch path stays free of runtime calls)
 template <typename Kern>
 bool allow_lds(Kern kern, size_t lds) {
     if (lds <= 64 * 1024) return true;
     static std::mutex mu;
-    static std::unordered_map<const void*, size_t> allowed;
+    static std::unordered_map<uintptr_t, size_t> allowed;  // per (device, kernel): the attribute is per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     std::lock_guard<std::mutex> lock(mu);
-    size_t& have = allowed[(const void*)kern];
+    size_t& have = allowed[(uintptr_t)(const void*)kern * 31u + (uintptr_t)dev];
     if (have >= lds) return true;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLocalLdsCap) != hipSuccess)
         return false;
