@@ -50,6 +50,7 @@ def parse():
                          "training steps of the caller backbones (images/s)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch of the model workloads (0 = config default)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--sweep", action="store_true", help="print the SURVEY d1 shape sweep as a markdown table and exit")
     return ap.parse_args()
 
 
@@ -200,6 +201,69 @@ def inference_workloads(cnsn_amd, shape, dev):
     return res
 
 
+SWEEP_SHAPES = [(8, 64, 32, 32), (128, 32, 32, 32), (128, 64, 16, 16), (128, 128, 8, 8), (256, 256, 56, 56),
+                (256, 512, 28, 28), (256, 1024, 14, 14), (256, 2048, 7, 7), (96, 256, 56, 56), (96, 512, 28, 28),
+                (96, 1024, 14, 14), (96, 2048, 7, 7), (768, 3, 224, 224), (16, 256, 128, 128), (16, 2048, 64, 64)]
+
+
+def sweep(cnsn_amd, dev):
+    """`python bench.py --sweep`: every shape of SURVEY §8 d1 x dtype x mode — ms per forward+backward (HIP events),
+    algorithmic GB/s (8*E*b / t) and the kernels AUTO resolved to (forward/backward) — as a markdown table
+    (profiles/r01_shape_sweep.md).  Not the one-line contract: a measurement aid."""
+    def timeit(fn, k=20, w=5):
+        for _ in range(w):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(k):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / k
+
+    a = torch.empty(205520896, device=dev)
+    b = torch.empty_like(a)
+    c = torch.empty_like(a)
+    t = timeit(lambda: b.copy_(a))
+    print(f"copy fp32 822 MB: {2 * a.numel() * 4 / t / 1e6:.0f} GB/s (read+write)")
+    t = timeit(lambda: torch.add(a, b, alpha=2.0, out=c))
+    print(f"triad fp32: {3 * a.numel() * 4 / t / 1e6:.0f} GB/s\n")
+    del a, b, c
+    modes = [("sn", "neither", True), ("sn", "neither", False), ("cn", "neither", True), ("cn", "both", True),
+             ("cnsn", "neither", True), ("cnsn", "both", True)]
+    print("| shape | dtype | " + " | ".join(f"{k}{'' if k == 'sn' else '/' + cr}{'' if tr else ' eval'}" for k, cr, tr in modes) + " |")
+    print("|---|---|" + "---|" * len(modes))
+    short = {"streaming": "S", "packed": "P", "resident": "R", "local": "L"}
+    for shape in SWEEP_SHAPES:
+        for dt, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+            x = conditioned(shape, dev, dtype, 1).requires_grad_()
+            gy = torch.randn(shape, device=dev).to(dtype)
+            e = shape[0] * shape[1] * shape[2] * shape[3]
+            eb = e * (4 if dtype == torch.float32 else 2)
+            cells = []
+            for kind, crop, train in modes:
+                mod = cnsn_amd.CNSN(cnsn_amd.CrossNorm(crop, 1) if kind != "sn" else None,
+                                    cnsn_amd.SelfNorm(shape[1]) if kind != "cn" else None).to(dev)
+                mod.train(train)
+                if kind != "sn":
+                    mod.crossnorm.train(True)
+                ins = [x] + list(mod.parameters())
+
+                def run():
+                    if mod.crossnorm is not None:
+                        mod.crossnorm.active = True
+                    torch.autograd.grad(mod(x), ins, gy)
+
+                cfg = cnsn_amd.FusedConfig(cn_active=kind != "sn", sn_active=kind != "cn", sn_training=train,
+                                           content_box=(1, 1, 3, 3) if crop == "both" else None,
+                                           style_box=(0, 0, 2, 2) if crop == "both" else None)
+                path = short[cnsn_amd.which_path(x, cfg, False)] + short[cnsn_amd.which_path(x, cfg, True)]
+                t = timeit(run)
+                cells.append(f"{t:.3f} ms {8 * eb / t / 1e6:.0f} {path}")
+            print(f"| {shape} | {dt} | " + " | ".join(cells) + " |", flush=True)
+
+
 def model_workload(args, dist, world, rank, dev):
     """Whole training steps (forward, CE [+ image-space CrossNorm], backward, SGD) of the caller
     backbones on synthetic data — BASELINE.json configs[1] (WRN-40-2+CNSN, bs128, fp32, 32x32) and
@@ -319,6 +383,9 @@ def main():
     cnsn_amd.lib()                                    # fail loudly now if the .so is missing
     cnsn_amd.set_strategy(args.strategy)
     import numpy as np
+    if args.sweep:
+        sweep(cnsn_amd, dev)
+        return
     if args.workload != "cnsn":
         model_workload(args, dist, world, rank, dev)
         if dist is not None:
