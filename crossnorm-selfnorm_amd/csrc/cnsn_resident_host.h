@@ -34,6 +34,12 @@ constexpr int kBucketNv[] = {1, 2, 4, 7, 8, 13, 16};
 #ifndef CNSN_PPW1
 #define CNSN_PPW1 8
 #endif
+#ifndef CNSN_PPW4
+#define CNSN_PPW4 4
+#endif
+#ifndef CNSN_PPW4_EPI
+#define CNSN_PPW4_EPI 2
+#endif
 #ifndef CNSN_PPW78_EPI16_BWD
 #define CNSN_PPW78_EPI16_BWD 1
 #endif
@@ -43,7 +49,7 @@ constexpr int kBucketNv[] = {1, 2, 4, 7, 8, 13, 16};
 constexpr int ppw_of(int nv, bool backward, bool epi, int elem_bytes) {
     return nv == 1 ? CNSN_PPW1
            : nv == 2 ? 4
-           : nv == 4 ? (epi ? 2 : 4)
+           : nv == 4 ? (epi ? CNSN_PPW4_EPI : CNSN_PPW4)
            : (nv == 7 || nv == 8) ? ((backward && !epi) ? (elem_bytes == 4 ? CNSN_PPW78_F32 : (nv == 8 ? CNSN_PPW8_BWD16 : 2))
                                                      : (elem_bytes == 2 ? (epi ? (backward ? CNSN_PPW78_EPI16_BWD : CNSN_PPW78_EPI16_FWD)
                                                                                : CNSN_PPW78_FWD16)
