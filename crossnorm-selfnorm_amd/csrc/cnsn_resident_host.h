@@ -23,8 +23,10 @@ constexpr int kBucketNv[] = {1, 2, 4, 7, 8, 13, 16};
 #ifndef CNSN_PPW78_F32
 #define CNSN_PPW78_F32 2
 #endif
-// (16-bit, 8 slots, TWO planes per wave, boxed: hipcc of ROCm 7.2 produces wrong gradients for that instantiation —
-//  caught by tests/test_gpu_resident_instantiations.py; the 8-slot class therefore holds one plane per wave)
+// (16-bit, 8 slots, TWO planes per wave, boxed: hipcc of ROCm 7.2 produces wrong gradients for that instantiation at
+//  168 VGPRs + scratch, and right ones when given 256 VGPRs — a spill-path miscompile; caught by
+//  tests/test_gpu_resident_instantiations.py.  The 8-slot class therefore holds one plane per wave, which is also
+//  faster: 0.087 vs 0.094 ms on the (64,256,64,64) bf16 backward)
 #ifndef CNSN_PPW8_BWD16
 #define CNSN_PPW8_BWD16 1
 #endif
