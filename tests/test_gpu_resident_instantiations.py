@@ -40,15 +40,17 @@ def resident():
 
 
 @pytest.mark.parametrize("tag,nv,hw", CASES, ids=lambda v: str(v).replace(" ", ""))
-@pytest.mark.parametrize("crop", ["neither", "both"])
-def test_op(tag, nv, hw, crop):
-    shape = (5, 2, *hw)
-    out = run_pair(shape, crop, "cnsn", DT[tag], 500 + nv, training=True)
+@pytest.mark.parametrize("crop", ["neither", "both", "content", "style"])
+@pytest.mark.parametrize("n", [5, 37])       # fewer / more instances than one workgroup owns
+def test_op(tag, nv, hw, crop, n):
+    shape = (n, 2, *hw)
+    out = run_pair(shape, crop, "cnsn", DT[tag], 500 + nv + n, training=True)
     assert_parity(out, DT[tag], (tag, nv, shape, crop))
 
 
 @pytest.mark.parametrize("tag,nv,hw", CASES, ids=lambda v: str(v).replace(" ", ""))
-@pytest.mark.parametrize("kind,crop", [("sn", "neither"), ("cnsn", "both")])
-def test_block(tag, nv, hw, kind, crop):
-    shape = (5, 2, *hw)
-    check_block(run_block(shape, kind, crop, "pre", True, DT[tag], 700 + nv), DT[tag], True, (tag, nv, shape, kind, crop))
+@pytest.mark.parametrize("kind,crop", [("sn", "neither"), ("cnsn", "both"), ("cnsn", "content")])
+@pytest.mark.parametrize("n", [5, 37])
+def test_block(tag, nv, hw, kind, crop, n):
+    shape = (n, 2, *hw)
+    check_block(run_block(shape, kind, crop, "pre", True, DT[tag], 700 + nv + n), DT[tag], True, (tag, nv, shape, kind, crop))
