@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "cnsn_device.h"
 #include "cnsn_host_plan.h"
 #include "cnsn_local.h"
@@ -17,15 +19,29 @@ using namespace cnsn;
 
 namespace cnsn {
 
+// channels per workgroup of the mid kernels: tiles of 8 once there are enough channels to fill the chip with tiles
+// (measured at C = 2048, N = 256: mid_fwd 115 -> see profiles/r01_small_planes.md); CNSN_MID_TILE=1 disables
+static int mid_tile(const cnsn_problem_t& p) {
+    if (const char* e = getenv("CNSN_MID_TILE"))
+        if (e[0] == '1') return 1;
+    return (p.C >= 512 && p.C % 8 == 0) ? 8 : 1;
+}
+
 void launch_mid_fwd(const Plan& pl, const double* mom, const int64_t* perm, const int64_t* chan_perm, GateDev g,
                     GateDev f, float* coef, double* saved, hipStream_t stream) {
-    mid_fwd_kernel<<<pl.pr.C, kBlock, 0, stream>>>(pl.mid, mom, perm, chan_perm, g, f, coef, saved);
+    if (mid_tile(pl.pr) == 8)
+        mid_fwd_kernel<8><<<pl.pr.C / 8, kBlock, 0, stream>>>(pl.mid, mom, perm, chan_perm, g, f, coef, saved);
+    else
+        mid_fwd_kernel<1><<<pl.pr.C, kBlock, 0, stream>>>(pl.mid, mom, perm, chan_perm, g, f, coef, saved);
 }
 
 void launch_mid_bwd(const Plan& pl, const float* sums, const double* saved, const int64_t* perm,
                     const int64_t* chan_perm, GateDev g, GateDev f, GateGradDev dg, GateGradDev df, double* tmp,
                     float* coef, hipStream_t stream) {
-    mid_bwd_a_kernel<<<pl.pr.C, kBlock, 0, stream>>>(pl.mid, sums, saved, perm, chan_perm, g, f, dg, df, tmp);
+    if (mid_tile(pl.pr) == 8)
+        mid_bwd_a_kernel<8><<<pl.pr.C / 8, kBlock, 0, stream>>>(pl.mid, sums, saved, perm, chan_perm, g, f, dg, df, tmp);
+    else
+        mid_bwd_a_kernel<1><<<pl.pr.C, kBlock, 0, stream>>>(pl.mid, sums, saved, perm, chan_perm, g, f, dg, df, tmp);
     mid_bwd_b_kernel<<<(int)((pl.P + kBlock - 1) / kBlock), kBlock, 0, stream>>>(pl.mid, saved, tmp, coef);
 }
 

@@ -8,12 +8,50 @@
 
 namespace cnsn {
 
+// Channel tiling of the mid kernels.  With one workgroup per channel (TC = 1) thread n touches plane n*C + c: every
+// access of a wave lands in a different 64-byte sector and 16 workgroups fetch the same sectors — fine while C*N is
+// small, the bound of the whole two-pass path when the planes are tiny (C = 2048, 7x7: 250 of 420 us).  With TC > 1 a
+// workgroup takes TC adjacent channels: thread t works on channel c0 + t % TC and instances t / TC, t / TC + 256/TC, ...
+// so that the TC planes of one instance form one contiguous piece of every side array.
+template <int NACC, int TC>
+__device__ __forceinline__ void tile_sum_d(double (&acc)[NACC], double* lds) {
+    if constexpr (TC == 1) {
+        block_sum_d<NACC>(acc, lds);
+    } else {  // sum over the threads that share threadIdx.x % TC; lds: (kBlock/64) * TC * NACC doubles
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) {
+            double v = acc[k];
+#pragma unroll
+            for (int o = TC; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+            acc[k] = v;
+        }
+        __syncthreads();
+        if (lane < TC) {
+#pragma unroll
+            for (int k = 0; k < NACC; ++k) lds[(wave * TC + lane) * NACC + k] = acc[k];
+        }
+        __syncthreads();
+        const int cl = threadIdx.x % TC;
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) {
+            double t = 0.0;
+            for (int w = 0; w < kBlock / 64; ++w) t += lds[(w * TC + cl) * NACC + k];
+            acc[k] = t;
+        }
+    }
+}
+
+template <int TC>
 __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double* __restrict__ mom,
                                                          const int64_t* __restrict__ perm,
                                                          const int64_t* __restrict__ chan_perm, GateDev gg, GateDev gf,
                                                          float* __restrict__ coef, double* __restrict__ saved) {
-    __shared__ double red[(kBlock / 64) * 2];
-    const int c = blockIdx.x;
+    __shared__ double red[(kBlock / 64) * 2 * TC];
+    constexpr int NSTEP = kBlock / TC;                 // instances per sweep step
+    const int n0 = threadIdx.x / TC;                   // first instance of this thread
+    const bool lead = n0 == 0;                         // the thread that writes its channel's per-channel results
+    const int c = blockIdx.x * TC + threadIdx.x % TC;  // (C is a multiple of TC)
     const size_t P = (size_t)a.N * a.C;
     const int cs = (a.cn_active && chan_perm) ? (int)chan_perm[c] : c;
 
@@ -29,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
 
     // ---- sweep 1: CrossNorm algebra per plane, SelfNorm pre-activations z, sum z over the batch
     double sz[2] = {0.0, 0.0};
-    for (int n = threadIdx.x; n < a.N; n += kBlock) {
+    for (int n = n0; n < a.N; n += NSTEP) {
         const size_t p = (size_t)n * a.C + c;
         Moments o;
         o.mu_c = mom[p];
@@ -60,22 +98,22 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
     if (a.sn_active) {
         if (a.sn_training) {
             // ---- BatchNorm1d batch statistics over N (biased variance for normalising, :138)
-            block_sum_d<2>(sz, red);
+            tile_sum_d<2, TC>(sz, red);
             mg = sz[0] / a.N;
             mf = sz[1] / a.N;
             double sv[2] = {0.0, 0.0};
-            for (int n = threadIdx.x; n < a.N; n += kBlock) {
+            for (int n = n0; n < a.N; n += NSTEP) {
                 const size_t p = (size_t)n * a.C + c;
                 const double dg = saved[sv_at(p, SV_ZH_G)] - mg;
                 const double df = saved[sv_at(p, SV_ZH_F)] - mf;
                 sv[0] += dg * dg;
                 sv[1] += df * df;
             }
-            block_sum_d<2>(sv, red);
+            tile_sum_d<2, TC>(sv, red);
             const double vg = sv[0] / a.N, vf = sv[1] / a.N;
             rg = 1.0 / sqrt(vg + (double)a.eps_bn);
             rf = 1.0 / sqrt(vf + (double)a.eps_bn);
-            if (threadIdx.x == 0) {
+            if (lead) {
                 const double mom_ = a.momentum, unb = (double)a.N / ((double)a.N - 1.0);
                 gg.run_mean[c] = (float)((1.0 - mom_) * gg.run_mean[c] + mom_ * mg);
                 gg.run_var[c] = (float)((1.0 - mom_) * gg.run_var[c] + mom_ * vg * unb);
@@ -92,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
                 rf = 1.0 / sqrt((double)gf.run_var[c] + (double)a.eps_bn);
             }
         }
-        if (threadIdx.x == 0) {
+        if (lead) {
             saved[SV_ROWS * P + c] = rg;
             saved[SV_ROWS * P + a.C + c] = rf;
         }
@@ -101,7 +139,7 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
     // ---- sweep 3: gates and the five forward coefficients of every plane of this channel
     const double gam_g = a.sn_active ? (double)gg.gamma[c] : 0.0, bet_g = a.sn_active ? (double)gg.beta[c] : 0.0;
     const double gam_f = a.sn_two ? (double)gf.gamma[c] : 0.0, bet_f = a.sn_two ? (double)gf.beta[c] : 0.0;
-    for (int n = threadIdx.x; n < a.N; n += kBlock) {
+    for (int n = n0; n < a.N; n += NSTEP) {
         const size_t p = (size_t)n * a.C + c;
         double g = 1.0, f = 1.0, zhg = 0.0, zhf = 0.0;
         if (a.sn_active) {
@@ -134,13 +172,17 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
 
 // per channel: gate / BatchNorm backward, parameter gradients, statistic gradients per plane;
 // scatters the style-statistic gradients to the planes that lent their statistics.
+template <int TC>
 __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const float* __restrict__ sums,
                                                            const double* __restrict__ saved,
                                                            const int64_t* __restrict__ perm,
                                                            const int64_t* __restrict__ chan_perm, GateDev gg, GateDev gf,
                                                            GateGradDev dg, GateGradDev df, double* __restrict__ tmp) {
-    __shared__ double red[(kBlock / 64) * 4];
-    const int c = blockIdx.x;
+    __shared__ double red[(kBlock / 64) * 4 * TC];
+    constexpr int NSTEP = kBlock / TC;
+    const int n0 = threadIdx.x / TC;
+    const bool lead = n0 == 0;
+    const int c = blockIdx.x * TC + threadIdx.x % TC;
     const size_t P = (size_t)a.N * a.C;
     const int cs = (a.cn_active && chan_perm) ? (int)chan_perm[c] : c;
 
@@ -152,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
     // ---- sweep 1: dL/dgate -> through the sigmoid; batch sums for BatchNorm backward
     double s[4] = {0, 0, 0, 0};  // sum dt_g, sum dt_g*zh_g, sum dt_f, sum dt_f*zh_f
     if (a.sn_active) {
-        for (int n = threadIdx.x; n < a.N; n += kBlock) {
+        for (int n = n0; n < a.N; n += NSTEP) {
             const size_t p = (size_t)n * a.C + c;
             double dtg, dtf;
             const CnRowsT<double> cr = load_cn_rows<double>(a, saved, p, saved[sv_at(p, SV_MU_C)]);
@@ -165,8 +207,8 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
             tmp[BT_DT_G * P + p] = dtg;
             tmp[BT_DT_F * P + p] = dtf;
         }
-        block_sum_d<4>(s, red);
-        if (threadIdx.x == 0) {
+        tile_sum_d<4, TC>(s, red);
+        if (lead) {
             dg.dgamma[c] = (float)s[1];
             dg.dbeta[c] = (float)s[0];
             if (a.sn_two) {
@@ -193,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
         }
     }
     double sw[4] = {0, 0, 0, 0};  // sum dz_g*mu_p, dz_g*sig_p, dz_f*mu_p, dz_f*sig_p
-    for (int n = threadIdx.x; n < a.N; n += kBlock) {
+    for (int n = n0; n < a.N; n += NSTEP) {
         const size_t p = (size_t)n * a.C + c;
         const double mu_p = saved[sv_at(p, SV_MU_P)], sig_p = saved[sv_at(p, SV_SIG_P)];
         const CnRowsT<double> cr = load_cn_rows<double>(a, saved, p, saved[sv_at(p, SV_MU_C)]);
@@ -216,8 +258,8 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
         }
     }
     if (a.sn_active) {
-        block_sum_d<4>(sw, red);
-        if (threadIdx.x == 0) {
+        tile_sum_d<4, TC>(sw, red);
+        if (lead) {
             dg.dw[2 * c] = (float)sw[0];
             dg.dw[2 * c + 1] = (float)sw[1];
             if (a.sn_two) {

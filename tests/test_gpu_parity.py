@@ -528,3 +528,13 @@ def test_fuzz_shapes_and_modes(strategy, case):
     i, shape, dtype, crop, kind, is_two, training, lam = case
     out = run_pair(shape, crop, kind, dtype, 1000 + i, lam=lam, is_two=is_two, training=training)
     assert_parity(out, dtype, (case, strategy))
+
+
+# many channels: the mid kernels of the two-pass path switch to tiles of 8 channels per workgroup at C >= 512
+@pytest.mark.parametrize("shape", [(5, 512, 7, 7), (6, 1024, 6, 8), (34, 512, 8, 8)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("kind,crop", [("sn", "neither"), ("cnsn", "neither"), ("cnsn", "both"), ("cn", "style")])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_many_channels(strategy, shape, kind, crop, dtype):
+    seed = seed_of(shape, kind, crop, str(dtype))
+    is_two = kind == "sn" and shape[0] == 5
+    assert_parity(run_pair(shape, crop, kind, dtype, seed, is_two=is_two), dtype, (shape, kind, crop, dtype, strategy))
