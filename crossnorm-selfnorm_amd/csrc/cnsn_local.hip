@@ -114,13 +114,14 @@ LocalPlan local_plan(const Plan& pl, int add, bool backward) {
         }
     }
     if (CG == 0) return lp;
-    // AUTO: copies of at least 4 bytes; an image over 64 KiB (a workgroup alone on its CU) only where the cluster-
-    // resident kernels cannot take the plane (fewer than 33 vectors, or no 8/16-byte vectors) — there it replaces
-    // the two-pass path ((256,2048,7,7) bf16 backward 0.115 vs 0.199 ms); where they can, they are as fast or faster
+    // AUTO: copies of at least 4 bytes; an image over 64 KiB (a workgroup alone on its CU) only where the two-pass
+    // alternative is slower (not fp32 with the channel-tiled mid kernels of C >= 512) and only where the cluster-resident kernels cannot take the plane (fewer than 33 vectors, or no 8/16-byte
+    // vectors) — (256,2048,7,7) backward: bf16 0.117 vs 0.127 ms two-pass, but fp32 0.203 vs 0.163 once the mid
+    // kernels are channel-tiled; where the resident kernels can take the plane they are as fast or faster
     if (p.strategy == CNSN_STRATEGY_AUTO) {
         const int rv = pick_vec(p.dtype, M);
         const bool resident_can = (rv * b == 16 || (b == 2 && rv == 4)) && M / rv > 32;
-        if (W < 4 || (lp.lds > 64 * 1024 && resident_can)) return lp;
+        if (W < 4 || (lp.lds > 64 * 1024 && (resident_can || (b == 4 && p.C >= 512)))) return lp;
     }
     lp.CG = CG;
     lp.W = W;

@@ -26,7 +26,7 @@ TABLE = [
     ((256, 2048, 7, 7), BF16, FC(**SN), "local", "local"),                     # resident cannot take 98-byte planes
     ((256, 2048, 7, 7), BF16, FC(**BLOCK), "local", "local"),
     ((256, 2048, 7, 7), BF16, FC(**SN, **CN), "packed", "packed"),             # CrossNorm: not channel-local
-    ((256, 2048, 7, 7), F32, FC(**SN), "local", "local"),
+    ((256, 2048, 7, 7), F32, FC(**SN), "local", "packed"),                     # fp32 backward image = 100 KiB: two-pass
     ((128, 128, 8, 8), F32, FC(**SN), "local", "local"),
     ((128, 32, 32, 32), F32, FC(**SN, **BOTH), "resident", "resident"),        # WideResNet stage 1
     ((768, 3, 224, 224), F32, FC(**CN), "streaming", "streaming"),             # image-level CrossNorm: 12544 vectors
