@@ -13,14 +13,23 @@ minibatch); with N>1 the SelfNorm parameter gradients (4C floats
 over RCCL each step like DDP would.  `value` = all ranks' algorithmic bytes (8*E*b per step:
 3 tensor passes forward, 5 backward — SURVEY.md §8d3) / wall time, in GB/s.
 
+`--gpus N` with N > 1 and no torchrun environment re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` (one process per GPU, RCCL); under the driver's own torchrun
+launch it just joins the group.  With more ranks than devices (a 1-GPU box) the ranks share a device and the
+collectives go over gloo — RCCL refuses two ranks on one device — which still exercises the launcher end to end.
+
 One JSON line is printed by rank 0; it also carries
-  roofline     — the backward launch (dominant kernel) timed with HIP events on the launch stream
+  roofline     — the backward launch (dominant kernel) timed with HIP events on the launch stream, priced on the
+                 bytes that launch HAS to move (single touch: 3*E*b) against the 8 TB/s peak; the same interval
+                 priced on SURVEY §8(d3)'s two-pass byte count and the in-process copy / triad ceilings ride along
   cpu_baseline — the CPU oracle (a port of the reference's eager PyTorch path) timed on this
-                 host's cores on a bounded slice of the same workload (rank 0, N=1 only)
+                 host's cores on a bounded slice of the same workload (rank 0, N=1 only), plus one thread
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -64,19 +73,13 @@ def conditioned(shape, device, dtype, seed):
     return x.to(dtype)
 
 
-def cpu_baseline(shape, crop, kind, budget_s):
-    """Time the CPU oracle (op-for-op restatement of the reference's eager path) on a slice."""
+def _time_oracle(sshape, crop, kind, threads, budget_s, max_iters):
     import numpy as np
     from oracle import cnsn_oracle as orc
-    n, c, h, w = shape
-    ns = max(2, min(n, 32))                          # 1/8 of the north-star batch: ~0.4 s / step on 8 cores
-    sshape = (ns, c, h, w)
-    # measured on the MI355X host (2x EPYC 9575F, 256 hw threads): eager torch peaks at 16-32 threads and
-    # collapses beyond 64 (11 s/iter at 256), so the baseline uses the fastest setting, not all threads
-    threads = min(32, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     np.random.seed(0)
+    c = sshape[1]
     x = conditioned(sshape, "cpu", torch.float32, 0).requires_grad_()
     gy = torch.randn(sshape)
     mod = orc.CNSN(orc.CrossNorm(crop, 1) if kind != "sn" else None,
@@ -84,7 +87,7 @@ def cpu_baseline(shape, crop, kind, budget_s):
     times = []
     t_end = time.perf_counter() + budget_s
     it = 0
-    while it < 2 or (time.perf_counter() < t_end and it < 40):
+    while it < 2 or (time.perf_counter() < t_end and it < max_iters):
         if mod.crossnorm is not None:
             mod.crossnorm.active = True
         x.grad = None
@@ -94,13 +97,58 @@ def cpu_baseline(shape, crop, kind, budget_s):
         times.append(time.perf_counter() - t0)
         it += 1
     times = sorted(times[1:]) if len(times) > 1 else times
-    med = times[len(times) // 2]
+    return times[len(times) // 2], len(times)
+
+
+def cpu_baseline(shape, crop, kind, budget_s):
+    """Time the CPU oracle (op-for-op restatement of the reference's eager path) on a slice: on the thread count
+    that is fastest on this host, and on ONE thread (SURVEY §8 d4 asks for both)."""
+    n, c, h, w = shape
+    ns = max(2, min(n, 32))                          # 1/8 of the north-star batch: ~0.4 s / step on 8 cores
+    sshape = (ns, c, h, w)
+    # measured on the MI355X host (2x EPYC 9575F, 256 hw threads): eager torch peaks at 16-32 threads and
+    # collapses beyond 64 (11 s/iter at 256), so the baseline uses the fastest setting, not all threads
+    threads = min(32, os.cpu_count() or 1)
+    med, iters = _time_oracle(sshape, crop, kind, threads, budget_s * 0.65, 40)
+    n1 = max(2, min(n, 4))                           # one thread: a 4-instance slice (~1 s / iteration)
+    med1, iters1 = _time_oracle((n1, c, h, w), crop, kind, 1, budget_s * 0.35, 8)
+    torch.set_num_threads(threads)
     e = ns * c * h * w
+    e1 = n1 * c * h * w
     return {"value": round(8 * e * 4 / med / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
             "sample": f"oracle CNSN fwd+bwd fp32 on ({ns},{c},{h},{w}) = {ns}/{n} of the batch, "
-                      f"median of {len(times)} iters, {med * 1e3:.1f} ms/iter, "
+                      f"median of {iters} iters, {med * 1e3:.1f} ms/iter, "
                       f"{ns / med:.1f} img/s",
-            "cpu": _cpu_model()}
+            "single_thread": {"value": round(8 * e1 * 4 / med1 / 1e9, 3), "unit": "GB/s", "cores": 1,
+                              "sample": f"({n1},{c},{h},{w}), median of {iters1} iters, {med1 * 1e3:.1f} ms/iter"},
+            "host_threads": os.cpu_count(), "cpu": _cpu_model()}
+
+
+def copy_triad_ceiling(dev, nbytes=822083584):
+    """What plain streaming kernels reach on THIS box, in this process: torch copy (read + write)
+    and triad c = a + 2b (two reads + one write) over tensors of the north-star size, HIP events."""
+    n = nbytes // 4
+    a = torch.empty(n, device=dev).normal_()
+    b = torch.empty_like(a).normal_()
+    c = torch.empty_like(a)
+
+    def timeit(fn, k=10, w=3):
+        for _ in range(w):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(k):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / k
+
+    t_copy = timeit(lambda: c.copy_(a))
+    t_triad = timeit(lambda: torch.add(a, b, alpha=2.0, out=c))
+    del a, b, c
+    return {"copy_GBps": round(2 * nbytes / t_copy / 1e6, 1), "triad_GBps": round(3 * nbytes / t_triad / 1e6, 1),
+            "note": "torch copy_ / add(alpha=2) on 822 MB fp32 tensors, same process and device"}
 
 
 def secondary_workloads(cnsn_amd, shape, dev, args):
@@ -290,8 +338,11 @@ def model_workload(args, dist, world, rank, dev):
     net.train()
     model = net
     if dist is not None:
-        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index], broadcast_buffers=True,
-                                                          bucket_cap_mb=25)
+        if dist.get_backend() == "nccl":
+            model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index], broadcast_buffers=True,
+                                                              bucket_cap_mb=25)
+        else:   # ranks share a device (gloo): same bucketing, reduction staged by gloo's own device support
+            model = torch.nn.parallel.DistributedDataParallel(net, broadcast_buffers=True, bucket_cap_mb=25)
     opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4 if hw == 224 else 5e-4,
                           nesterov=(hw != 224))
     g = torch.Generator(device=dev).manual_seed(5 + rank)
@@ -344,7 +395,9 @@ def model_workload(args, dist, world, rank, dev):
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if amp else "f32", "data": "synthetic",
             "config": {"workload": name, "per_gpu_batch": bs * views, "global_batch": bs * views * world, "image": hw,
-                       "parallelism": f"ddp{world} (RCCL gradient all-reduce, 25 MB buckets)"}}), flush=True)
+                       "parallelism": f"ddp{world} ({'RCCL' if dist is None or dist.get_backend() == 'nccl' else dist.get_backend()} gradient all-reduce, 25 MB buckets)",
+                       "world_size": world, "devices": torch.cuda.device_count(),
+                       "backend": None if dist is None else dist.get_backend()}}), flush=True)
 
 
 def _cpu_model():
@@ -357,23 +410,69 @@ def _cpu_model():
     return "unknown"
 
 
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launcher_command(n, argv, port=None):
+    """The command `bench.py --gpus n` re-executes itself as when it was started without a torchrun environment:
+    one process per GPU on this node (the reference's multi-GPU entry is the single line
+    `net = torch.nn.DataParallel(net).cuda()`, imagenet.py:533 / cifar.py:395)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or _free_port()),
+            os.path.abspath(__file__), *argv]
+
+
+def pick_backend(world, n_devices):
+    """nccl (= RCCL over xGMI) with one device per rank; when ranks have to SHARE a device (more ranks than GPUs on
+    the box) RCCL refuses ("Duplicate GPU detected") and the collectives go over gloo."""
+    forced = os.environ.get("CNSN_BENCH_BACKEND")
+    if forced:
+        return forced
+    return "nccl" if n_devices >= world else "gloo"
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as plain `python bench.py --gpus N`: become the launcher of N ranks and relay their exit code
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = launcher_command(args.gpus, sys.argv[1:])
+        if os.environ.get("CNSN_BENCH_DRY_LAUNCH") == "1":     # (tests: show the command, start nothing)
+            print(json.dumps({"launch": cmd}))
+            return
+        sys.exit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: using the launched world size", file=sys.stderr)
+    ngpu = torch.cuda.device_count()
+    backend = None
     if world > 1:
         import torch.distributed as dist
-        ngpu = torch.cuda.device_count()
-        local = local % max(ngpu, 1)          # (smoke runs may put several ranks on one GPU)
-        torch.cuda.set_device(local)
-        backend = os.environ.get("CNSN_BENCH_BACKEND", "nccl")                   # nccl == RCCL on ROCm
-        if backend == "nccl":
+        backend = pick_backend(world, ngpu)
+        local = local % max(ngpu, 1)          # (more ranks than devices: ranks share GPUs)
+        if ngpu:
+            torch.cuda.set_device(local)
+        if backend == "nccl":                                                    # nccl == RCCL on ROCm
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:                                                                    # gloo: plumbing smoke test only
+        else:                                                                    # gloo: shared device / plumbing test
             dist.init_process_group(backend)
     else:
         dist = None
+    if os.environ.get("CNSN_BENCH_PLUMBING") == "1":
+        # launcher / rendezvous check without a GPU (tests): every rank reports, rank 0 prints the world it saw
+        t = torch.tensor([float(rank)])
+        if dist is not None:
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"plumbing": True, "n_gpus": world, "backend": backend, "rank_sum": float(t.item())}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs an MI355X (use gpurun)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -449,14 +548,31 @@ def main():
     value = world * step_bytes / (dt / args.steps) / 1e9
 
     if rank == 0:
-        bwd_bytes = 5 * e * b
+        # Bytes of the dominant launch (the backward).  SURVEY §8(d3) prices the op as a two-pass algorithm: forward
+        # 3*E*b, backward 5*E*b (`value` keeps that accounting: it is the metric BASELINE.json quotes).  The roofline
+        # object prices the kernel on the bytes a launch HAS to move — single touch: read G, read x, write dx = 3*E*b
+        # (forward: read x, write y = 2*E*b) — so that `frac` is a physical fraction of the HBM peak.
+        cfg_path = cnsn_amd.FusedConfig(cn_active=args.kind != "sn", sn_active=args.kind != "cn", sn_training=True,
+                                        content_box=(1, 1, 3, 3) if args.crop in ("content", "both") else None,
+                                        style_box=(0, 0, 2, 2) if args.crop in ("style", "both") else None)
+        path_f, path_b = cnsn_amd.which_path(x, cfg_path, False), cnsn_amd.which_path(x, cfg_path, True)
+        single = {"resident", "local"}
+        moved_f = (2 if path_f in single else 3) * e * b       # what the kernels of this path read + write
+        moved_b = (3 if path_b in single else 5) * e * b
+        need_f, need_b = 2 * e * b, 3 * e * b                  # the least any implementation moves
         traffic = None
+        traffic_source = None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
             try:
                 traffic = json.load(open(tfile)).get(f"{args.dtype}_{args.crop}_{args.kind}_bwd_bytes")
+                if traffic is not None:
+                    traffic_source = ("profiles/traffic_latest.json (replayed: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                      "passes of an earlier run of this build, corrected per MI355X_MICROARCH.md; "
+                                      "counters cannot be collected inside this process)")
             except (OSError, ValueError):
                 traffic = None
+        bwd_s, fwd_s = bwd_ms * 1e-3, fwd_ms * 1e-3
         out = {
             "metric": "fused CNSN fwd+bwd GB/s vs HBM roofline",
             "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
@@ -465,18 +581,36 @@ def main():
             "config": {"workload": f"fused CrossNorm(crop={args.crop})+SelfNorm fwd+bwd, "
                                    f"NCHW ({n},{c},{h},{w}) per GPU, kind={args.kind}",
                        "shape": list(shape), "crop": args.crop, "kind": args.kind,
-                       "strategy": args.strategy, "algorithmic_bytes_per_step": step_bytes,
-                       "parallelism": f"dp{world} (independent minibatches; grads of 4C SN params all-reduced)"},
+                       "strategy": args.strategy, "paths": {"forward": path_f, "backward": path_b},
+                       "algorithmic_bytes_per_step": step_bytes,
+                       "parallelism": f"dp{world} (independent minibatches; grads of 4C SN params all-reduced)",
+                       "world_size": world, "devices": ngpu, "backend": backend},
             "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
+            "frac_of_hbm_peak_bytes_needed": round((need_f + need_b) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "fwd_ms": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4),
             "images_per_s": round(world * n / (dt / args.steps), 1),
-            "roofline": {"bound": "hbm", "kernel": "cnsn_backward launch (dominant: 5*E*b algorithmic bytes)",
-                         "achieved": round(bwd_bytes / (bwd_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(bwd_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": traffic,
-                         "forward": {"achieved": round(3 * e * b / (fwd_ms * 1e-3) / 1e9, 1),
-                                     "frac": round(3 * e * b / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
+            "roofline": {"bound": "hbm",
+                         "kernel": f"cnsn_backward launch ({path_b} path: reads G and x, writes dx)",
+                         "bytes": need_b, "bytes_moved": moved_b,
+                         "achieved": round(need_b / bwd_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(need_b / bwd_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "frac_moved": round(moved_b / bwd_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "kernel_us": round(bwd_ms * 1e3, 1),
+                         "kernel_us_source": "HIP events on the launch stream around the cnsn_backward call of every "
+                                             "timed step (includes the launch gap; rocprofv3 kernel-only averages are "
+                                             "under profiles/)",
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "survey_d3": {"bytes": 5 * e * b, "achieved": round(5 * e * b / bwd_s / 1e9, 1),
+                                       "frac": round(5 * e * b / bwd_s / 1e9 / HBM_PEAK_GBS, 4),
+                                       "note": "two-pass accounting of SURVEY §8(d3) (the basis of `value`); can "
+                                               "exceed 1 for a single-touch kernel"},
+                         "forward": {"kernel_us": round(fwd_ms * 1e3, 1), "bytes": need_f, "bytes_moved": moved_f,
+                                     "achieved": round(need_f / fwd_s / 1e9, 1),
+                                     "frac": round(need_f / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
+                                     "survey_d3_frac": round(3 * e * b / fwd_s / 1e9 / HBM_PEAK_GBS, 4)}},
         }
+        if world == 1:
+            out["roofline"]["ceiling"] = copy_triad_ceiling(dev)
         if world == 1 and not args.no_extra:
             out["extra"] = secondary_workloads(cnsn_amd, shape, dev, args)
             out["extra"]["residual_block_add_cnsn_relu"] = residual_block_workloads(cnsn_amd, shape, dev)

@@ -13,7 +13,7 @@ CNSN_F32, CNSN_BF16, CNSN_F16 = 0, 1, 2
 STRATEGY_AUTO, STRATEGY_TWO_PASS, STRATEGY_RESIDENT, STRATEGY_LOCAL = 0, 1, 2, 3
 ADD_NONE, ADD_PRE, ADD_POST = 0, 1, 2
 PATHS = {0: "streaming", 1: "packed", 2: "resident", 3: "local"}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Problem(C.Structure):
@@ -50,6 +50,8 @@ class Epilogue(C.Structure):
 SIGNATURES = {
     "cnsn_abi_version": (C.c_int, []),
     "cnsn_status_string": (C.c_char_p, [C.c_int]),
+    "cnsn_resident_timeouts": (C.c_int, []),
+    "cnsn_resident_enable": (None, [C.c_int]),
     "cnsn_saved_floats": (C.c_size_t, [C.POINTER(Problem)]),
     "cnsn_workspace_bytes": (C.c_size_t, [C.POINTER(Problem)]),
     "cnsn_forward": (C.c_int, [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -139,6 +141,24 @@ def glue():
         raise CnsnError(f"cnsn_glue.so was built against ABI {mod.abi_version()}, binding expects {ABI_VERSION}")
     _glue = mod
     return _glue
+
+
+_timeouts_reported = 0
+
+
+def check_resident_health(what: str):
+    """Poll the library's time-out counter (a plain host read).  A cluster-resident launch that gave up leaves its
+    outputs incomplete; the library has already stopped choosing that strategy (two-pass from now on) — raise ONCE
+    per event so the training loop can repeat the step instead of consuming garbage."""
+    global _timeouts_reported
+    n = lib().cnsn_resident_timeouts()
+    if n > _timeouts_reported:
+        _timeouts_reported = n
+        raise CnsnError(
+            f"{what}: an earlier cluster-resident launch timed out waiting for part of its grid ({n} so far) — the GPU "
+            "is shared with work that kept it off the device for seconds.  The outputs of the step that was in flight "
+            "are invalid: repeat it.  The library now uses the two-pass kernels (CNSN_RESIDENT=0 selects them from "
+            "the start).")
 
 
 def check(status: int, what: str):

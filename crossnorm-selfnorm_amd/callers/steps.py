@@ -32,13 +32,20 @@ def train_step_cn(net, x, target, optimizer, cn_prob):
     return loss.detach()
 
 
-def train_step_cn_consistency(net, x, target, optimizer, consist_wt, jsd=jsd_consistency):
-    """Clean view + two independently armed CrossNorm views (cifar.py:155-190).  `jsd`: the consistency term
-    (tests of the step structure on host tensors pass a host restatement)."""
-    logits_clean = net(x)
-    logits_aug1 = net(x, aug=True)
-    logits_aug2 = net(x, aug=True)
-    loss = F.cross_entropy(logits_clean, target) + consist_wt * jsd(logits_clean, logits_aug1, logits_aug2)
+def train_step_cn_consistency(net, x, target, optimizer, consist_wt, cn_prob=1.0, jsd=jsd_consistency):
+    """Consistency step (cifar.py:163-196).  Draw order of the reference: `r = np.random.rand(1)` FIRST; only when
+    `r < cn_prob` the clean view + two independently armed CrossNorm views + JSD run (:165-187), otherwise plain
+    cross-entropy on `net(x, aug=False)` (:188-190).  `jsd`: the consistency term (tests of the step structure on
+    host tensors pass a host restatement)."""
+    r = np.random.rand(1)
+    if r < cn_prob:
+        logits_clean = net(x, aug=False)
+        loss = F.cross_entropy(logits_clean, target)
+        logits_aug1 = net(x, aug=True)
+        logits_aug2 = net(x, aug=True)
+        loss = loss + consist_wt * jsd(logits_clean, logits_aug1, logits_aug2)
+    else:
+        loss = F.cross_entropy(net(x, aug=False), target)
     optimizer.zero_grad()
     loss.backward()
     optimizer.step()

@@ -149,27 +149,40 @@ class SelfNorm(nn.Module):
 
     @staticmethod
     def _gate(fc, bn) -> GateParams:
-        return GateParams(fc.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        rm, rv = bn.running_mean, bn.running_var
+        if rm is None or rv is None:      # track_running_stats=False: batch statistics always; the kernel's
+            w = fc.weight                 # running-buffer update goes to scratch that nobody reads
+            rm = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)
+            rv = torch.ones(w.shape[0], dtype=torch.float32, device=w.device)
+        return GateParams(fc.weight, bn.weight, bn.bias, rm, rv)
 
-    def _bn_training(self) -> bool:
-        bn = self.g_bn
-        return bn.training or (bn.running_mean is None and bn.running_var is None)
+    @staticmethod
+    def _bn_call_state(bn):
+        """What nn.BatchNorm1d.forward decides per call (torch/nn/modules/batchnorm.py): the counter moves only
+        under `training and track_running_stats`; `momentum=None` means the cumulative average 1/num_batches_tracked;
+        batch statistics are used in training mode or when there are no running buffers."""
+        momentum = 0.0 if bn.momentum is None else float(bn.momentum)
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+            if bn.momentum is None:
+                momentum = 1.0 / float(bn.num_batches_tracked)
+        use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
+        return use_batch, float(bn.eps), momentum
 
     def _fused_args(self):
-        """(config fields, g, f) for the fused call; does BatchNorm1d's per-call book-keeping."""
-        bn = self.g_bn
-        training = self._bn_training()
-        momentum = bn.momentum
-        bns = [bn] + ([self.f_bn] if self.f_fc is not None else [])
-        if self.training and bn.track_running_stats:
-            for b in bns:
-                b.num_batches_tracked.add_(1)           # as nn.BatchNorm1d.forward does
-            if momentum is None:                        # cumulative moving average
-                momentum = 1.0 / float(bn.num_batches_tracked)
+        """(config fields, g, f) for the fused call; does each BatchNorm1d's own per-call book-keeping."""
+        state = self._bn_call_state(self.g_bn)
         g = self._gate(self.g_fc, self.g_bn)
-        f = self._gate(self.f_fc, self.f_bn) if self.f_fc is not None else None
-        kw = dict(sn_active=True, sn_two=f is not None, sn_training=training, eps_bn=bn.eps,
-                  momentum=0.0 if momentum is None else float(momentum))
+        f = None
+        if self.f_fc is not None:
+            state_f = self._bn_call_state(self.f_bn)
+            if state_f != state:   # one kernel launch evaluates both gates with ONE BatchNorm1d configuration
+                raise _F._ffi.CnsnError(
+                    "SelfNorm(is_two=True): g_bn and f_bn must share mode, eps and momentum "
+                    f"(g_bn: training/eps/momentum = {state}, f_bn: {state_f})")
+            f = self._gate(self.f_fc, self.f_bn)
+        use_batch, eps, momentum = state
+        kw = dict(sn_active=True, sn_two=f is not None, sn_training=use_batch, eps_bn=eps, momentum=momentum)
         return kw, g, f
 
     def forward(self, x):

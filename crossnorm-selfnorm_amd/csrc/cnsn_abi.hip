@@ -51,6 +51,9 @@ extern "C" {
 
 int cnsn_abi_version(void) { return CNSN_ABI_VERSION; }
 
+int cnsn_resident_timeouts(void) { return resident_timeouts(); }
+void cnsn_resident_enable(int on) { resident_set_enabled(on != 0); }
+
 const char* cnsn_status_string(int status) {
     switch (status) {
         case CNSN_OK: return "ok";

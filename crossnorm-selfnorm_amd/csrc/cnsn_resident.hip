@@ -1,9 +1,50 @@
 // Channel-resident strategy, the op alone: host entry points (shared logic in cnsn_resident_host.h).
 #include "cnsn_resident_host.h"
 
+#include <atomic>
+#include <cstring>
 #include <mutex>
 
 namespace cnsn {
+
+namespace {
+std::mutex g_flag_mu;
+unsigned* g_host_flag = nullptr;
+std::atomic<int> g_enabled{-1};  // -1: not decided yet (environment), 0: off, 1: on
+}  // namespace
+
+unsigned* resident_host_flag() {
+    if (g_host_flag) return g_host_flag;
+    std::lock_guard<std::mutex> lock(g_flag_mu);
+    if (!g_host_flag) {
+        void* p = nullptr;
+        // 64 pinned bytes, once per process; fails harmlessly (stays NULL, retried later) inside a stream capture
+        if (hipHostMalloc(&p, 64, hipHostMallocDefault) == hipSuccess && p) {
+            memset(p, 0, 64);
+            g_host_flag = (unsigned*)p;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    return g_host_flag;
+}
+
+int resident_timeouts() {
+    const unsigned* f = g_host_flag;
+    return f ? (int)*(volatile const unsigned*)f : 0;
+}
+
+bool resident_auto_enabled() {
+    int e = g_enabled.load(std::memory_order_relaxed);
+    if (e < 0) {
+        const char* env = getenv("CNSN_RESIDENT");
+        e = (env && env[0] == '0') ? 0 : 1;
+        g_enabled.store(e, std::memory_order_relaxed);
+    }
+    return e == 1 && resident_timeouts() == 0;
+}
+
+void resident_set_enabled(bool on) { g_enabled.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 namespace {
 struct ChainState {

@@ -106,6 +106,11 @@ static inline ResArgs make_args(const cnsn_problem_t& p, Box cb, Box sb, const M
     const char* st = getenv("CNSN_STAGGER");
     ra.stagger = st ? atoi(st) : 0;
     ra.prof = nullptr;
+    ra.host_flag = resident_host_flag();
+    const char* wm = getenv("CNSN_WAIT_MS");
+    ra.wait_ticks = (wm && atoll(wm) > 0) ? atoll(wm) * 100000ll : kWaitLimitTicks;
+    const char* fi = getenv("CNSN_FAULT_INJECT");
+    ra.fault = (fi && fi[0] == '1') ? 1 : 0;
     return ra;
 }
 
@@ -131,6 +136,7 @@ int grid_for(Kern kern, size_t lds, int K, int items) {
 static inline ResPlan plan_impl(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, bool backward, bool epi) {
     ResPlan rp{false, 0, 0, 0, 0};
     if (p.strategy == CNSN_STRATEGY_TWO_PASS || p.strategy == CNSN_STRATEGY_LOCAL || has_chan_perm) return rp;
+    if (resident_timeouts() > 0) return rp;  // a launch gave up earlier in this process: never again, even when forced
     const int M = p.H * p.W;
     rp.vec = pick_vec(p.dtype, boxed ? p.W : M);
     if (!(rp.vec == 16 / elem_bytes(p.dtype) || (elem_bytes(p.dtype) == 2 && rp.vec == 4))) return rp;
@@ -155,6 +161,7 @@ static inline ResPlan plan_impl(const cnsn_problem_t& p, bool boxed, bool has_ch
     // A register bucket more than 25 % larger than the plane needs is not worth it either.
     // CNSN_STRATEGY_RESIDENT forces the resident kernels wherever they are eligible.
     if (p.strategy == CNSN_STRATEGY_AUTO) {
+        if (!resident_auto_enabled()) return rp;  // switched off, or a launch timed out earlier: degrade to two-pass
         if ((rp.nv - need) * 4 > need) return rp;
         // 16-bit (sweeps of round 1, profiles/r01_resident_tuning.md): up to 4 slots per lane (14x14 .. 44x44)
         // always; 7/8 slots (56x56, 64x64) un-boxed only (boxed: two-pass 0.689 vs 0.725 ms at the north-star

@@ -18,9 +18,13 @@
 // Deadlock freedom: the grid is persistent, G = (resident workgroups) rounded down to a multiple
 // of K, and workgroup b handles items b, b+G, ...; the K members of a cluster are therefore
 // always the same K co-resident workgroups working on the same iteration.  Kernels of other streams
-// (RCCL all-reduce, MIOpen) may delay residency but always finish, so waiting is safe; every spin is
-// nevertheless bounded (seconds): on time-out the kernel raises a word in the control block and traps,
-// which surfaces as a launch failure on the host — never as silently wrong results.
+// (RCCL all-reduce, MIOpen) may delay residency but always finish, so waiting is safe.  Partial residency is
+// not a deadlock either: workgroups are dispatched in block order (per XCD), a cluster is K consecutive blocks
+// and waits only for its own members, so the lowest incomplete cluster always receives the next free slots
+// while complete clusters run to their end.  Every spin is nevertheless bounded (seconds): on time-out the
+// kernel raises a word in the control block (every other wait drains at once), counts the event in a
+// host-visible word (cnsn_resident_timeouts(): the host learns without synchronising, stops using this
+// strategy and reports the step as invalid) and RETURNS — no trap, the HIP context stays usable.
 #pragma once
 #include "../../include/cnsn_hip.h"
 #include "cnsn_algebra.h"
@@ -32,7 +36,7 @@ namespace cnsn {
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 
-constexpr long long kWaitLimitTicks = 5ll * 100000000ll;  // 5 s of the 100 MHz wall clock (s_memrealtime)
+constexpr long long kWaitLimitTicks = 5ll * 100000000ll;  // default: 5 s of the 100 MHz wall clock (s_memrealtime)
 constexpr int kCtlBytes = 256;  // control block in front of the granule area (word 0: time-out flag)
 
 struct ResArgs {
@@ -42,6 +46,9 @@ struct ResArgs {
     int K;      // workgroups per channel
     int items;  // C * K
     int stagger;  // start-up skew between clusters, in units of s_sleep(127) (~3.4 us)
+    unsigned* host_flag;  // pinned host word counting timed-out launches (NULL: not available)
+    long long wait_ticks;  // bound of a cluster wait in 100 MHz ticks (default 5 s; CNSN_WAIT_MS)
+    int fault;             // tests only (CNSN_FAULT_INJECT=1): the last member of channel 0's cluster never publishes
     unsigned long long* prof;  // tuning builds (-DCNSN_PROF): [workgroup < 64][iteration < 16][8] time stamps
 };
 
@@ -80,7 +87,9 @@ __device__ __forceinline__ void put_granule(unsigned long long* p, float lo, flo
 }
 
 // ONE wave gathers `total` granules (2*total floats) into LDS; re-reads all of them until none is empty.
-__device__ __forceinline__ void sweep_granules(const unsigned long long* g, int total, float* vals, unsigned* ctl) {
+// Returns false when it gave up (time-out, or another workgroup already did): the caller's workgroup must leave.
+__device__ __forceinline__ bool sweep_granules(const unsigned long long* g, int total, float* vals, unsigned* ctl,
+                                               unsigned* host_flag, long long wait_ticks) {
     const int lane = threadIdx.x & 63;
     long long t_start = 0;
     for (unsigned spins = 0;; ++spins) {
@@ -91,20 +100,24 @@ __device__ __forceinline__ void sweep_granules(const unsigned long long* g, int 
             vals[2 * i] = __uint_as_float((unsigned)v);
             vals[2 * i + 1] = __uint_as_float((unsigned)(v >> 32));
         }
-        if (__all(ok)) return;
+        if (__all(ok)) return true;
         __builtin_amdgcn_s_sleep(4);
         if ((spins & 15u) == 15u) {
             const long long now = (long long)wall_clock64();
             if (t_start == 0) t_start = now;
-            const bool dead = now - t_start > kWaitLimitTicks ||
-                              __hip_atomic_load((gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kCtlIdle;
-            if (dead) {
-                // A cluster member never published: the grid was not fully resident for seconds (it
-                // shares the GPU with something that never yields) or the launch geometry is wrong.
-                // Raise the flag so every other wait drains too, then fail LOUDLY: the trap turns into a
-                // launch failure at the host's next synchronisation instead of silently wrong numbers.
-                if (lane == 0) __hip_atomic_store((gu32*)ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_trap();
+            const unsigned seen = __hip_atomic_load((gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen != kCtlIdle) return false;  // somebody gave up already: drain
+            if (now - t_start > wait_ticks) {
+                // A cluster member never published: part of the grid was kept off the device for seconds (the GPU
+                // is shared with something that never yields).  The FIRST workgroup to notice flips the control
+                // word (every other wait drains), bumps the host-visible counter, and everybody returns: the
+                // outputs of this launch are incomplete, which the host learns from cnsn_resident_timeouts().
+                if (lane == 0) {
+                    const unsigned prev = __hip_atomic_exchange((gu32*)ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (prev == kCtlIdle && host_flag)
+                        __hip_atomic_fetch_add(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                return false;
             }
         }
     }
@@ -296,6 +309,7 @@ __host__ __device__ inline size_t res_lds_bytes(int N, int NG, int OWN, int coef
            + align16((size_t)N * 4)           // perm / inverse perm [N]
            + align16((size_t)OWN * coef_rows * 4)  // coefficients of the owned planes
            + 4 * 4 * 8                        // block reduction scratch
+           + 16                               // "this workgroup gave up" flag
            + (backward ? align16((size_t)N * D_N * 8) + align16((size_t)N * F_N * 4) : 0);  // staged `saved`
 }
 
@@ -321,6 +335,7 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
     int* sperm = (int*)((char*)zbuf + align16((size_t)2 * N * 8));
     float* ocoef = (float*)((char*)sperm + align16((size_t)N * 4));
     double* red = (double*)((char*)ocoef + align16((size_t)OWN * FC_ROWS * 4));
+    int* gave_up = (int*)(red + 4 * 4);
     (void)zbuf;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: plane bases stay in SGPRs
@@ -447,7 +462,7 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
                 solo_m2[s] = pub[1];
                 continue;
             }
-            if (n < N && lane < NG / 2) {  // lane m publishes the pair (pub[2m], pub[2m+1])
+            if (n < N && lane < NG / 2 && !(ra.fault && item == ra.K - 1)) {  // lane m publishes (pub[2m], pub[2m+1])
                 float lo = pub[0], hi = pub[1];
 #pragma unroll
                 for (int m = 1; m < NG / 2; ++m) {
@@ -515,8 +530,12 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
         CNSN_STAMP(1);
         __syncthreads();  // the previous item's readers of vals/zbuf are done
         CNSN_STAMP(2);
-        if (wave == 0) sweep_granules(gran + (size_t)c * N * (NG / 2), N * (NG / 2), vals, ctl);
+        if (wave == 0) {
+            const bool got = sweep_granules(gran + (size_t)c * N * (NG / 2), N * (NG / 2), vals, ctl, ra.host_flag, ra.wait_ticks);
+            if (lane == 0) *gave_up = got ? 0 : 1;
+        }
         __syncthreads();
+        if (*gave_up) return;  // (workgroup-uniform) timed out: see sweep_granules
         CNSN_STAMP(3);
 
         using R = float;  // per-plane algebra in float, cross-batch sums / normalisation in double
@@ -678,7 +697,8 @@ __global__ __launch_bounds__(kBlock, EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV
     int* iperm = (int*)((char*)dtb + align16((size_t)2 * N * 8));
     float* ocoef = (float*)((char*)iperm + align16((size_t)N * 4));
     double* red = (double*)((char*)ocoef + align16((size_t)OWN * BC_ROWS * 4));
-    double* svd = red + 4 * 4;                                         // [N][D_N]
+    int* gave_up = (int*)(red + 4 * 4);
+    double* svd = red + 4 * 4 + 2;                                     // [N][D_N]
     float* svf = (float*)((char*)svd + align16((size_t)N * D_N * 8));  // [N][F_N]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: plane bases stay in SGPRs
@@ -818,7 +838,7 @@ __global__ __launch_bounds__(kBlock, EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV
                 }
 #pragma unroll
             for (int m = 0; m < NS; ++m) acc[m] = wave_sum(acc[m]);
-            if (n < N && lane < NS / 2) {
+            if (n < N && lane < NS / 2 && !(ra.fault && item == ra.K - 1)) {
                 float lo = acc[0], hi = acc[1];
 #pragma unroll
                 for (int m = 1; m < NS / 2; ++m) {
@@ -832,8 +852,12 @@ __global__ __launch_bounds__(kBlock, EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV
         CNSN_STAMP(1);
         __syncthreads();
         CNSN_STAMP(2);
-        if (wave == 0) sweep_granules(gran + (size_t)c * N * (NS / 2), N * (NS / 2), vals, ctl);
+        if (wave == 0) {
+            const bool got = sweep_granules(gran + (size_t)c * N * (NS / 2), N * (NS / 2), vals, ctl, ra.host_flag, ra.wait_ticks);
+            if (lane == 0) *gave_up = got ? 0 : 1;
+        }
         __syncthreads();
+        if (*gave_up) return;  // (workgroup-uniform) timed out: see sweep_granules
         CNSN_STAMP(3);
 
         using R = float;  // per-plane algebra in float; batch sums and the dz line in double
@@ -996,6 +1020,15 @@ size_t resident_workspace_bytes(const cnsn_problem_t& p, bool boxed);
 // previous one first waits (stream-side, hipStreamWaitEvent) for the previous one's completion event.  Same-stream
 // sequences — the normal case — pay one hipEventRecord.  Streams under graph capture are left alone (a captured
 // graph replays on one stream).  This is the only state the library keeps.
+// Host-visible word (pinned memory, allocated once per process on the first cluster launch) that the kernels bump
+// when a bounded wait ran out; NULL when it could not be allocated (e.g. first use inside a stream capture).
+unsigned* resident_host_flag();
+// launches that timed out so far (0: none); after the first one AUTO stops choosing this strategy
+int resident_timeouts();
+// AUTO may choose the cluster kernels: not switched off (cnsn_resident_enable(0) / CNSN_RESIDENT=0), no time-out seen
+bool resident_auto_enabled();
+void resident_set_enabled(bool on);
+
 struct ResidentChain {
     explicit ResidentChain(hipStream_t stream);
     ~ResidentChain();

@@ -7,6 +7,7 @@
 // network made of many small CNSN sites (WideResNet-40-2: 18 sites at 32x32 and below).
 #include <torch/extension.h>
 
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 
@@ -39,6 +40,14 @@ void check_status(int st, const char* what) {
         TORCH_CHECK_VALUE(false, what, ": ", cnsn_status_string(st));
     }
     TORCH_CHECK(false, what, " failed with status ", st, ": ", cnsn_status_string(st));
+}
+
+// contiguous AND 16-byte aligned: `.contiguous()` keeps a contiguous view with a storage offset (x[1:], a
+// torch.split chunk) as it is; the kernels' 16-byte vector accesses need an aligned base, so such a view is copied
+Tensor dense(const Tensor& t) {
+    Tensor d = t.contiguous();
+    if ((reinterpret_cast<uintptr_t>(d.data_ptr()) & 15u) != 0) d = d.clone(at::MemoryFormat::Contiguous);
+    return d;
 }
 
 Tensor f32c(const Tensor& t) {
@@ -182,14 +191,17 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
                     " tensor. This implementation runs on MI355X HIP device tensors only; there is no CPU path.");
         TORCH_CHECK(x_in.dim() == 4, "expected an (N, C, H, W) tensor");
         const Config c = parse_config(cfg, fcfg);
+        // the library sizes grids / orders its persistent launches for the CURRENT device and the stream below is the
+        // tensor's device's: make that device current (a model on cuda:1 must not need set_device(1))
+        const c10::DeviceGuard device_guard(x_in.device());
 
-        const Tensor x = x_in.contiguous();  // reference cnsn.py:14
+        const Tensor x = dense(x_in);  // reference cnsn.py:14
         Tensor addend;
         if (c.add_mode != CNSN_ADD_NONE) {
             TORCH_CHECK(addend_in.has_value() && addend_in->is_cuda() && addend_in->sizes() == x.sizes() &&
                             addend_in->scalar_type() == x.scalar_type(),
                         "cnsn_forward: the addend must be a device tensor of x's shape and dtype");
-            addend = addend_in->contiguous();
+            addend = dense(*addend_in);
         }
         const cnsn_problem_t prob = make_problem(x, c);
         const cnsn_epilogue_t epi = make_epilogue(c, addend);
@@ -252,9 +264,11 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
         const cnsn_problem_t prob = make_problem(x, c);
         const bool two = c.sn_active && c.sn_two;
         const at::Device dev = x.device();
+        const c10::DeviceGuard device_guard(dev);
 
-        Tensor gy = grads[0].contiguous();
+        Tensor gy = grads[0];
         if (gy.scalar_type() != x.scalar_type()) gy = gy.to(x.scalar_type());
+        gy = dense(gy);
         Tensor dx = at::empty_like(x);
         const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
         const size_t ws_bytes = cnsn_workspace_bytes(&prob);

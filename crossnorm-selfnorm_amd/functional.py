@@ -26,6 +26,12 @@ def set_strategy(name: str):
                  "resident": _ffi.STRATEGY_RESIDENT, "local": _ffi.STRATEGY_LOCAL}[name]
 
 
+def set_resident(enabled: bool):
+    """Allow (default) or forbid CNSN_STRATEGY_AUTO to choose the cluster-resident kernels (cnsn_resident_enable);
+    the environment variable CNSN_RESIDENT=0 does the same from process start."""
+    _ffi.lib().cnsn_resident_enable(int(bool(enabled)))
+
+
 def _require_device(x: torch.Tensor, what: str):
     if not isinstance(x, torch.Tensor):
         raise TypeError(f"{what}: expected a tensor")
@@ -36,6 +42,31 @@ def _require_device(x: torch.Tensor, what: str):
     if x.dtype not in _DTYPES:
         raise TypeError(f"{what}: dtype {x.dtype} not supported (float32, bfloat16, float16)")
     assert x.dim() == 4, "expected an (N, C, H, W) tensor"          # reference cnsn.py:12
+
+
+def _dense(t: torch.Tensor) -> torch.Tensor:
+    """Contiguous AND 16-byte aligned: `.contiguous()` keeps a contiguous view with a storage offset (x[1:], a
+    torch.split chunk) as it is, and the kernels' 16-byte vector accesses need an aligned base — such a view is
+    copied once (the reference simply works on it, models/cnsn.py:14)."""
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone(memory_format=torch.contiguous_format)
+    return t
+
+
+def _on_device_of(fn):
+    """Run a Function.forward/backward with the tensor's device current: the library sizes grids, orders its
+    persistent launches and sets kernel attributes for the CURRENT device, and the stream handed over belongs
+    to the tensor's device — a model on cuda:1 must not depend on the caller having called set_device(1)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(ctx, first, *rest):
+        if not (isinstance(first, torch.Tensor) and first.is_cuda):
+            return fn(ctx, first, *rest)          # (raises the "device tensors only" error itself)
+        with torch.cuda.device(first.device):
+            return fn(ctx, first, *rest)
+    return wrapped
 
 
 def _stream(x):
@@ -201,12 +232,20 @@ class FusedCNSN(torch.autograd.Function):
     def forward(ctx, x, cfg: FusedConfig, perm, chan_perm, g_w, g_gamma, g_beta, g_rm, g_rv,
                 f_w, f_gamma, f_beta, f_rm, f_rv, addend=None):
         _require_device(x, "cnsn_forward")
+        with torch.cuda.device(x.device):
+            return FusedCNSN._forward(ctx, x, cfg, perm, chan_perm, g_w, g_gamma, g_beta, g_rm, g_rv,
+                                      f_w, f_gamma, f_beta, f_rm, f_rv, addend)
+
+    @staticmethod
+    def _forward(ctx, x, cfg, perm, chan_perm, g_w, g_gamma, g_beta, g_rm, g_rv,
+                 f_w, f_gamma, f_beta, f_rm, f_rv, addend):
         lib = _ffi.lib()
-        x = x.contiguous()                                         # reference cnsn.py:14
+        _ffi.check_resident_health("cnsn_forward")
+        x = _dense(x)                                              # reference cnsn.py:14
         if cfg.add_mode != "none":
             _require_device(addend, "cnsn_forward(addend)")
             assert addend.shape == x.shape and addend.dtype == x.dtype, "addend must match x"
-            addend = addend.contiguous()
+            addend = _dense(addend)
         else:
             addend = None
         prob = _problem(x, cfg)
@@ -243,14 +282,15 @@ class FusedCNSN(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_on_device_of
     def backward(ctx, gy):
         lib = _ffi.lib()
         x, saved, perm, chan_perm, addend = ctx.saved_tensors
         cfg, prob = ctx.cfg, ctx.prob
         gate_g, gate_f = ctx.gates
-        gy = gy.contiguous()
         if gy.dtype != x.dtype:
             gy = gy.to(x.dtype)
+        gy = _dense(gy)
         dev = x.device
         dx = torch.empty_like(x)
         ws_bytes = _sizes(prob)[1]
@@ -298,6 +338,7 @@ def fused_cnsn(x, cfg: FusedConfig, perm=None, chan_perm=None, g: Optional[GateP
         return FusedCNSN.apply(x, cfg, perm, chan_perm, *ga, *fa, addend)
     # C++ glue: same C ABI calls, without the Python per-call overhead
     _require_device(x, "cnsn_forward")
+    _ffi.check_resident_health("cnsn_forward")
     if cfg.add_mode == "none":
         addend = None
     need_bwd = torch.is_grad_enabled() and (x.requires_grad or any(
@@ -322,10 +363,11 @@ class PlaneStats(torch.autograd.Function):
     """(mean, std) of every plane — cnsn_plane_stats / cnsn_plane_stats_backward."""
 
     @staticmethod
+    @_on_device_of
     def forward(ctx, x, eps, box, keep_fp32=False):
         _require_device(x, "calc_ins_mean_std")
         lib = _ffi.lib()
-        x = x.contiguous()
+        x = _dense(x)
         n, c, h, w = _dims(x)
         ms = torch.empty(2, n * c, dtype=torch.float32, device=x.device)
         st = lib.cnsn_plane_stats(_ptr(x), _DTYPES[x.dtype], n, c, h, w, _ffi.box4(box) if box else None,
@@ -339,6 +381,7 @@ class PlaneStats(torch.autograd.Function):
         return mean, std
 
     @staticmethod
+    @_on_device_of
     def backward(ctx, gmean, gstd):
         lib = _ffi.lib()
         x, ms = ctx.saved_tensors
@@ -357,10 +400,11 @@ class PlaneAffine(torch.autograd.Function):
     """y = scale[n,c]*x + shift[n,c] — cnsn_plane_affine (+ cnsn_plane_dot for the backward)."""
 
     @staticmethod
+    @_on_device_of
     def forward(ctx, x, scale, shift):
         _require_device(x, "plane_affine")
         lib = _ffi.lib()
-        x = x.contiguous()
+        x = _dense(x)
         n, c, h, w = _dims(x)
         sc, sh = _f32(scale).view(-1), _f32(shift).view(-1)
         y = torch.empty_like(x)
@@ -371,11 +415,12 @@ class PlaneAffine(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_on_device_of
     def backward(ctx, gy):
         lib = _ffi.lib()
         x, sc = ctx.saved_tensors
         n, c, h, w = _dims(x)
-        gy = gy.contiguous().to(x.dtype)
+        gy = _dense(gy.to(x.dtype))
         dt = _DTYPES[x.dtype]
         dx = dscale = dshift = None
         if ctx.needs_input_grad[0]:
@@ -398,6 +443,7 @@ class JsdConsistency(torch.autograd.Function):
     (reference imagenet.py:367-381, cifar.py:173-186)."""
 
     @staticmethod
+    @_on_device_of
     def forward(ctx, l0, l1, l2):
         lib = _ffi.lib()
         for t in (l0, l1, l2):
@@ -406,7 +452,7 @@ class JsdConsistency(torch.autograd.Function):
         assert l0.dim() == 2 and l0.shape == l1.shape == l2.shape and l0.dtype == l1.dtype == l2.dtype
         if l0.dtype not in _DTYPES:
             raise TypeError(f"jsd_consistency: dtype {l0.dtype} not supported")
-        l0, l1, l2 = l0.contiguous(), l1.contiguous(), l2.contiguous()
+        l0, l1, l2 = _dense(l0), _dense(l1), _dense(l2)
         b, k = int(l0.shape[0]), int(l0.shape[1])
         need = any(ctx.needs_input_grad)
         loss = torch.empty((), dtype=torch.float32, device=l0.device)

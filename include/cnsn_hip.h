@@ -11,8 +11,9 @@
  *   - Every pointer is a DEVICE pointer unless it says "host".  Activations are NCHW, contiguous,
  *     16-byte aligned, element type `dtype`.  All per-plane / per-channel side arrays are float32.
  *   - The caller owns every buffer (inputs, outputs, `saved`, `workspace`).  The library allocates
- *     nothing, is re-entrant, never synchronises the host, never throws; the only state it keeps is a per-device
- *     event that orders its persistent launches across streams.
+ *     nothing on the device, is re-entrant, never synchronises the host, never throws; the only state it keeps
+ *     is a per-device event that orders its persistent launches across streams and one pinned host word that
+ *     counts timed-out cluster launches (cnsn_resident_timeouts).
  *     All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream).
  *   - Randomness stays on the host: the batch permutation, channel permutation and boxes are
  *     INPUTS (the reference draws them with torch.randperm / numpy, models/cnsn.py:62,65,71,76).
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CNSN_ABI_VERSION 2
+#define CNSN_ABI_VERSION 3
 
 enum cnsn_dtype { CNSN_F32 = 0, CNSN_BF16 = 1, CNSN_F16 = 2 };
 
@@ -195,6 +196,18 @@ enum cnsn_path {
     CNSN_PATH_LOCAL = 3      /* one launch, a whole channel group per workgroup           */
 };
 int cnsn_which_path(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int has_chan_perm, int backward);
+
+/* ---- health of the cluster-resident strategy ----------------------------------------------------
+ * The resident kernels exchange per-plane scalars between co-resident workgroups with bounded spin waits.  When a
+ * wait runs out (seconds: the GPU is shared with something that keeps part of the grid off the device) the launch
+ * gives up WITHOUT trapping: its outputs are incomplete, this counter goes up, and CNSN_STRATEGY_AUTO stops choosing
+ * the resident kernels for the rest of the process (two-pass from then on).  A caller polls the counter — a plain
+ * host read, no synchronisation — and repeats the step that was in flight.  Nothing in the reference corresponds to
+ * this (eager PyTorch has no cross-workgroup exchange); it belongs to the replacement of models/cnsn.py:159-164. */
+int cnsn_resident_timeouts(void);
+/* on = 0: CNSN_STRATEGY_AUTO never chooses the resident kernels (same as the environment variable CNSN_RESIDENT=0
+ * at load time); on = 1: allowed again.  CNSN_STRATEGY_RESIDENT is not affected. */
+void cnsn_resident_enable(int on);
 
 /* ---- Jensen-Shannon consistency of three views ----------------------------------
  * imagenet.py:367-381 / cifar.py:173-186: p_i = softmax(logits_i, 1); lm = clamp(mean_i p_i, 1e-7, 1).log();

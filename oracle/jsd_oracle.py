@@ -1,10 +1,11 @@
 """TEST INFRASTRUCTURE — CPU oracle of the Jensen-Shannon consistency loss.
 
 Restates, op for op, what the reference's trainers compute between the logits and `consist_loss`
-(imagenet.py:367-381, cifar.py:173-186).  PARITY UNPINNED: those files cannot be imported in this image
-(torchvision / tensorboardX are absent and they parse arguments at import time), so no golden vector of the
-reference itself exists for this function; the restatement is five lines of documented torch ops and is checked
-by properties (>= 0, = 0 for identical views, symmetric in the views) in tests/test_callers.py.
+(imagenet.py:367-376 and :291-300, cifar.py:173-182 and :233-242).  PINNED: those files cannot be imported in this
+image (torchvision / tensorboardX are absent and they parse arguments at import time), but
+tests/golden/gen_golden_jsd.py parses them, compiles the reference's own three statements from their AST nodes and
+executes them on seeded logits; this restatement reproduces the resulting fixture (tests/golden/g8_jsd.npz: loss and
+logit gradients, fp32 and fp64) bit for bit — tests/test_oracle_golden.py::test_jsd_oracle_reproduces_reference.
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this module."""
 import torch
 import torch.nn.functional as F

@@ -1,0 +1,125 @@
+"""Worker of tests/test_gpu_ddp_concurrency.py — one rank of a 2-rank data-parallel run (launched through
+torch.distributed.run).  What BASELINE.json configs[3] will hit and round 1 never exercised: the persistent
+cluster-resident kernels running while gradient all-reduce kernels of ANOTHER stream (and the other rank's persistent
+grids) compete for the same compute units.
+
+  >= 2 GPUs : one device per rank, backend nccl (= RCCL), torch DDP with 1 MB buckets -> many all-reduces overlapping
+              the backward's resident launches
+  1 GPU     : both ranks on cuda:0 (RCCL refuses two ranks on one device -> gloo); the two processes' persistent grids
+              share the GPU, and a side stream keeps copy kernels running all the time, like a reduction stream would
+
+Every CNSN site output of the first step is compared bit-for-bit with a no-communication run of the same model /
+input in the same process; the averaged gradients are compared with a manual average of the no-comm gradients."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main(out_dir, steps=3, batch=32):
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    ngpu = torch.cuda.device_count()
+    shared = ngpu < world
+    dev = torch.device("cuda", 0 if shared else int(os.environ["LOCAL_RANK"]))
+    torch.cuda.set_device(dev)
+    backend = "gloo" if shared else "nccl"
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
+
+    import cnsn_amd
+    from cnsn_amd import _ffi, data_parallel as dp
+    from cnsn_amd.callers import ResNet50CNSN
+
+    def build():
+        torch.manual_seed(7)                       # same initial weights on both ranks and in the reference copy
+        return ResNet50CNSN(num_classes=100, cnsn_type="sn", pos="post").to(dev).train()
+
+    g = torch.Generator(device=dev).manual_seed(100 + rank)       # ranks own different data
+    xs = [torch.randn(batch, 3, 224, 224, device=dev, generator=g) for _ in range(steps)]
+    ys = [torch.randint(0, 100, (batch,), device=dev, generator=g) for _ in range(steps)]
+
+    def run(model, net, record):
+        hooks = []
+        if record is not None:      # a bottleneck's output IS its fused add + CNSN + ReLU call (callers/resnet.py)
+            for m in net.modules():
+                if type(m).__name__ == "_Bottleneck":
+                    hooks.append(m.register_forward_hook(lambda _m, _i, o: record.append(o.detach().clone())))
+        opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9)
+        grads_first = None
+        for i in range(steps):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = torch.nn.functional.cross_entropy(model(xs[i]).float(), ys[i])
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            if i == 0:
+                grads_first = [p.grad.detach().clone() for p in net.parameters()]
+                for h in hooks:
+                    h.remove()
+                hooks = []
+            opt.step()
+        torch.cuda.synchronize()
+        return grads_first, float(loss)
+
+    # ---- reference: no communication at all (plain module, nothing else on the device from this process)
+    ref_sites = []
+    ref_net = build()
+    ref_grads, _ = run(ref_net, ref_net, ref_sites)
+    # what DDP must produce for step 1: the average of the ranks' local gradients
+    ref_avg = [g_.clone() for g_ in ref_grads]
+    for t in ref_avg:
+        if backend == "gloo":
+            h = t.cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t)
+        t.div_(world)
+
+    # ---- data-parallel run with communication overlapping the backward
+    net = build()
+    ddp_sites = []
+    mode = "ddp"
+    side = torch.cuda.Stream(device=dev)
+    noise_a = torch.empty(64 << 20, device=dev)
+    noise_b = torch.empty_like(noise_a)
+    try:
+        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index] if backend == "nccl" else None,
+                                                          bucket_cap_mb=1, broadcast_buffers=False)
+    except Exception as e:                         # (gloo build without device-tensor support)
+        model, mode = net, f"manual all-reduce ({type(e).__name__})"
+    if shared:                                     # keep another stream busy the whole time (reduction-stream stand-in)
+        with torch.cuda.stream(side):
+            for _ in range(400):
+                noise_b.copy_(noise_a, non_blocking=True)
+    ddp_grads, last_loss = run(model, net, ddp_sites)
+    if mode != "ddp":
+        dp.allreduce_gradients(net.parameters())
+    torch.cuda.synchronize()
+
+    same_sites = len(ref_sites) == len(ddp_sites) == 16 and all(torch.equal(a, b) for a, b in zip(ref_sites, ddp_sites))
+    grad_err = 0.0
+    if mode == "ddp":
+        for a, b in zip(ddp_grads, ref_avg):
+            grad_err = max(grad_err, float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12)))
+    paths = sorted({cnsn_amd.which_path(s, cnsn_amd.FusedConfig(sn_active=True, add_mode="pre", relu=True), bw)
+                    for s in ref_sites for bw in (False, True)})
+    res = dict(rank=rank, world=world, backend=backend, shared_device=shared, mode=mode, sites=len(ddp_sites),
+               site_outputs_bit_identical=bool(same_sites), grad_rel_err=grad_err,
+               timeouts=int(_ffi.lib().cnsn_resident_timeouts()), paths=paths, loss=last_loss,
+               finite=bool(np.isfinite(last_loss)))
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

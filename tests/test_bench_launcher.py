@@ -1,0 +1,48 @@
+"""`python bench.py --gpus N` must launch N ranks ITSELF (round-1 verdict: `--gpus` was parsed and ignored).  No GPU
+needed: the launcher command is inspected, then two ranks are really spawned through torch.distributed.run with the
+plumbing-only switch (rendezvous on 127.0.0.1, gloo because the box has fewer devices than ranks, one all-reduce)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def test_gpus_flag_builds_a_torchrun_command():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "7", "--warmup", "2", "--workload", "resnet50_jsd"],
+                         env=_env(CNSN_BENCH_DRY_LAUNCH="1"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    cmd = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    tail = cmd[cmd.index(BENCH) + 1:]
+    assert tail == ["--gpus", "8", "--steps", "7", "--warmup", "2", "--workload", "resnet50_jsd"]   # arguments travel
+
+
+def test_gpus_2_really_spawns_two_ranks():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=_env(CNSN_BENCH_PLUMBING="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    rep = json.loads(line)
+    assert rep["n_gpus"] == 2 and rep["rank_sum"] == 1.0            # ranks 0 and 1 both contributed
+    assert rep["backend"] in ("gloo", "nccl")
+
+
+def test_single_process_stays_single():
+    from importlib import util
+    spec = util.spec_from_file_location("bench_mod", BENCH)
+    mod = util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.pick_backend(8, 8) == "nccl" and mod.pick_backend(2, 1) == "gloo"
+    cmd = mod.launcher_command(4, ["--gpus", "4"], port=29511)
+    assert cmd[cmd.index("--master-port") + 1] == "29511"

@@ -133,6 +133,36 @@ def test_jsd_properties_and_steps_on_cpu():
     assert all(not c.active for c in net.cn_modules)
 
 
+def test_consistency_step_draw_order_matches_reference():
+    """cifar.py:163-190: ONE np.random.rand(1) is drawn before anything else; r < cn_prob -> net(aug=False), then two
+    net(aug=True) views + JSD; otherwise a single net(aug=False) with plain cross-entropy."""
+    class Recorder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(12, 5)
+            self.calls = []
+
+        def forward(self, x, aug=False):
+            self.calls.append((bool(aug), float(np.random.get_state()[1][0]), np.random.get_state()[2]))
+            return self.lin(x.flatten(1))
+
+    from oracle import jsd_oracle
+    x, y = torch.randn(4, 3, 2, 2), torch.randint(0, 5, (4,))
+    for seed in range(6):
+        np.random.seed(seed)
+        r = float(np.random.rand(1)[0])
+        pos_after_one_draw = np.random.get_state()[2]
+        for cn_prob in (0.0, 0.5, 1.0):
+            net = Recorder()
+            opt = torch.optim.SGD(net.parameters(), lr=0.0)
+            np.random.seed(seed)
+            train_step_cn_consistency(net, x, y, opt, consist_wt=10.0, cn_prob=cn_prob, jsd=jsd_oracle.jsd_consistency)
+            flags = [c[0] for c in net.calls]
+            assert flags == ([False, True, True] if r < cn_prob else [False]), (seed, cn_prob, r, flags)
+            assert net.calls[0][2] == pos_after_one_draw          # exactly one draw before the first forward
+            assert np.random.get_state()[2] == pos_after_one_draw  # and none after (the stub draws nothing)
+
+
 # ------------------------------------------------------------------------------------------------
 # segmentation backbone (SURVEY §8 f4): dilated ResNet-50, SelfNorm at 'residual' + a separate CrossNorm at 'post'
 # ------------------------------------------------------------------------------------------------

@@ -54,3 +54,15 @@ def test_op(tag, nv, hw, crop, n):
 def test_block(tag, nv, hw, kind, crop, n):
     shape = (n, 2, *hw)
     check_block(run_block(shape, kind, crop, "pre", True, DT[tag], 700 + nv + n), DT[tag], True, (tag, nv, shape, kind, crop))
+
+
+# The persistent loop (`item += gridDim.x`): with C = 2 every workgroup handles ONE item.  Enough channels that the
+# grid (at most 6 workgroups x 256 CUs, a whole number of clusters) wraps around at least once per register bucket —
+# the second and later items reuse LDS, the granule area of another channel and the per-item prefetches.  Checked
+# against the oracle's eager ops on the GPU (tests/test_gpu_full_size.py), N = 37: a partial last cluster member.
+@pytest.mark.parametrize("tag,nv,hw", [c for c in CASES if c[0] in ("f32", "bf16")], ids=lambda v: str(v).replace(" ", ""))
+@pytest.mark.parametrize("kind,crop", [("sn", "neither"), ("cnsn", "both")])
+def test_persistent_loop_many_channels(tag, nv, hw, kind, crop):
+    from tests.test_gpu_full_size import check_case
+    c = 1024 if nv <= 2 else (512 if nv == 4 else 384)    # items = C * ceil(37 / (4 * planes per wave)) > 1536
+    check_case((37, c, *hw), DT[tag], kind, crop, 900 + nv)

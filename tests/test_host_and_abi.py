@@ -146,3 +146,35 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("no CPU or eager fallback", ""), f
+
+
+def test_selfnorm_batchnorm_bookkeeping_follows_each_bn_module():
+    """What nn.BatchNorm1d.forward does per call, per module (round-1 advisor finding): the counter moves only under
+    `bn.training and bn.track_running_stats`; a frozen BatchNorm inside a training SelfNorm neither counts nor uses
+    batch statistics; no running buffers -> batch statistics with scratch buffers; the two gates of is_two must agree."""
+    import cnsn_amd
+    sn = cnsn_amd.SelfNorm(4).train()
+    kw, g, f = sn._fused_args()
+    assert kw["sn_training"] is True and int(sn.g_bn.num_batches_tracked) == 1 and f is None
+    sn.g_bn.eval()                                         # frozen statistics inside a training module
+    kw, g, f = sn._fused_args()
+    assert kw["sn_training"] is False and int(sn.g_bn.num_batches_tracked) == 1
+    sn.g_bn.train()
+    sn.g_bn.momentum = None                                # cumulative moving average
+    kw, _, _ = sn._fused_args()
+    assert int(sn.g_bn.num_batches_tracked) == 2 and kw["momentum"] == pytest.approx(0.5)
+
+    nt = cnsn_amd.SelfNorm(4)
+    nt.g_bn = torch.nn.BatchNorm1d(4, track_running_stats=False)
+    for mode in (True, False):
+        nt.train(mode)
+        kw, g, _ = nt._fused_args()
+        assert kw["sn_training"] is True                   # no running buffers: batch statistics in both modes
+        assert g.running_mean.shape == (4,) and g.running_var.shape == (4,)
+
+    two = cnsn_amd.SelfNorm(4, is_two=True).train()
+    kw, g, f = two._fused_args()
+    assert f is not None and kw["sn_two"] and int(two.g_bn.num_batches_tracked) == int(two.f_bn.num_batches_tracked) == 1
+    two.f_bn.eval()
+    with pytest.raises(cnsn_amd.CnsnError):
+        two._fused_args()

@@ -163,3 +163,24 @@ def test_g5_cn_only(golden_dir):
     m.crossnorm.next_draws = orc.CNDraws(perm=t(z["cnonly_perm"]))
     exact(m(x), t(z["cnonly_y"]))
     assert bool(z["cnonly_idle_is_identity"]) and m(x) is x
+
+
+# ------------------------------------------------------------------------------------------------
+# G8: the Jensen-Shannon consistency arithmetic of the trainers (executed from the reference's own AST nodes)
+# ------------------------------------------------------------------------------------------------
+JSD_CASES = ["small", "cifar100", "imagenet", "clamped", "one_class"]
+
+
+@pytest.mark.parametrize("case", JSD_CASES)
+@pytest.mark.parametrize("tag,dtype", [("f32", torch.float32), ("f64", torch.float64)])
+def test_jsd_oracle_reproduces_reference(golden_dir, case, tag, dtype):
+    from oracle import jsd_oracle
+    g8 = np.load(os.path.join(golden_dir, "g8_jsd.npz"))
+    torch.set_num_threads(4)                      # (the generator's setting: reductions split the same way)
+    zs = [torch.from_numpy(g8[f"{case}_logits{i}"]).to(dtype).requires_grad_() for i in range(3)]
+    loss = jsd_oracle.jsd_consistency(*zs)
+    loss.backward()
+    assert np.array_equal(loss.detach().numpy(), g8[f"{case}_{tag}_loss"])
+    for i, z in enumerate(zs):
+        assert np.array_equal(z.grad.numpy(), g8[f"{case}_{tag}_grad{i}"]), (case, tag, i)
+    assert len(g8["sources"]) >= 2 and any("imagenet.py:367" in str(s_) for s_ in g8["sources"])
