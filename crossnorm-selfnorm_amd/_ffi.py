@@ -7,12 +7,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcnsn_hip.so")
+LIB_PATH = os.environ.get("CNSN_LIB_PATH") or os.path.join(_HERE, "libcnsn_hip.so")   # (override: tuning builds)
 
 CNSN_F32, CNSN_BF16, CNSN_F16 = 0, 1, 2
-STRATEGY_AUTO, STRATEGY_TWO_PASS, STRATEGY_RESIDENT, STRATEGY_LOCAL = 0, 1, 2, 3
+STRATEGY_AUTO, STRATEGY_TWO_PASS, STRATEGY_RESIDENT, STRATEGY_LOCAL, STRATEGY_MONO = 0, 1, 2, 3, 4
 ADD_NONE, ADD_PRE, ADD_POST = 0, 1, 2
-PATHS = {0: "streaming", 1: "packed", 2: "resident", 3: "local"}
+PATHS = {0: "streaming", 1: "packed", 2: "resident", 3: "local", 4: "mono"}
 ABI_VERSION = 3
 
 

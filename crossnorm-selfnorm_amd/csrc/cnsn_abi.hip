@@ -11,6 +11,7 @@
 #include "cnsn_host_plan.h"
 #include "cnsn_local.h"
 #include "cnsn_mid_kernels.h"
+#include "cnsn_mono.h"
 #include "cnsn_packed.h"
 #include "cnsn_resident_kernels.h"
 #include "cnsn_stream_kernels.h"
@@ -102,6 +103,13 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
     float* coef = (float*)(mom + 6 * pl.P + saved_doubles_of(pl));
 
     {
+        const MonoPlan mp = mono_plan(pl, 0, false);  // small planes, SelfNorm alone: the channel in one workgroup's registers
+        if (mp.ok) {
+            st = mono_forward(pl, mp, 0, 0, x, nullptr, gate_dev(g), gate_dev(f), y, saved ? saved_d : nullptr, stream);
+            if (st != CNSN_E_UNSUPPORTED) return st;
+        }
+    }
+    {
         const LocalPlan lp = local_plan(pl, 0, false);  // small planes, SelfNorm alone: no exchange, no side arrays
         if (lp.ok) {
             st = local_forward(pl, lp, 0, 0, x, nullptr, gate_dev(g), gate_dev(f), y, saved ? saved_d : nullptr, stream);
@@ -168,6 +176,14 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
     float* coef = sums + 4 * P;
     const double* saved_d = (const double*)saved;
 
+    {
+        const MonoPlan mp = mono_plan(pl, 0, true);
+        if (mp.ok) {
+            st = mono_backward(pl, mp, 0, 0, grad_y, x, nullptr, gate_dev(g), gate_dev(f), saved_d, grad_x, gate_grad_dev(dg),
+                               gate_grad_dev(df), stream);
+            if (st != CNSN_E_UNSUPPORTED) return st;
+        }
+    }
     {
         const LocalPlan lp = local_plan(pl, 0, true);
         if (lp.ok) {

@@ -7,6 +7,7 @@
 #include "cnsn_fused_stream_kernels.h"
 #include "cnsn_host_plan.h"
 #include "cnsn_local.h"
+#include "cnsn_mono.h"
 #include "cnsn_packed.h"
 #include "cnsn_resident_fused.h"
 
@@ -75,6 +76,7 @@ int cnsn_which_path(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int 
     const bool bwd = backward != 0;
     // the backward of an epilogue without ReLU and without PRE add is the plain backward
     const bool fused = bwd ? (e.relu || e.add == ADD_PRE) : (e.relu || e.add != ADD_NONE);
+    if (mono_plan(pl, fused ? e.add : 0, bwd).ok) return CNSN_PATH_MONO;
     if (local_plan(pl, fused ? e.add : 0, bwd).ok) return CNSN_PATH_LOCAL;
     if (fused ? resident_fused_plan(p, pl.boxed, chan, e.add, bwd).ok : resident_plan(p, pl.boxed, chan, bwd).ok)
         return CNSN_PATH_RESIDENT;
@@ -107,6 +109,13 @@ int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, c
     double* saved_d = saved ? (double*)saved : mom + 6 * pl.P;
     float* coef = (float*)(mom + 6 * pl.P + saved_doubles_of(pl));
 
+    {
+        const MonoPlan mp = mono_plan(pl, e.add, false);
+        if (mp.ok) {
+            st = mono_forward(pl, mp, e.add, e.relu, x, e.addend, gate_dev(g), gate_dev(f), y, saved ? saved_d : nullptr, stream);
+            if (st != CNSN_E_UNSUPPORTED) return st;
+        }
+    }
     {
         const LocalPlan lp = local_plan(pl, e.add, false);
         if (lp.ok) {
@@ -195,6 +204,14 @@ int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, 
     float* coef = sums + 4 * P;
     const double* saved_d = (const double*)saved;
 
+    {
+        const MonoPlan mp = mono_plan(pl, e.add, true);
+        if (mp.ok) {
+            st = mono_backward(pl, mp, e.add, e.relu, grad_y, x, e.addend, gate_dev(g), gate_dev(f), saved_d, grad_x,
+                               gate_grad_dev(dg), gate_grad_dev(df), stream);
+            if (st != CNSN_E_UNSUPPORTED) return st;
+        }
+    }
     {
         const LocalPlan lp = local_plan(pl, e.add, true);
         if (lp.ok) {

@@ -1,0 +1,520 @@
+// Channel-in-registers strategy ("mono") for SMALL planes without CrossNorm: ONE 1024-thread workgroup per channel,
+// every plane of the channel held in the workgroup's VGPRs, one launch per direction, single touch, and no
+// inter-workgroup exchange of any kind.
+//
+// Where it sits between the other two single-touch strategies:
+//   cluster-resident (cnsn_resident_kernels.h): a channel spread over K co-resident workgroups + an exchange through
+//       memory.  Right for planes of several KiB; for a 392-byte plane (14x14 bf16) the exchange costs more than moving
+//       the planes — (256,1024,14,14) bf16 ran at 37 % of its HBM bound in round 1.
+//   channel-local (cnsn_local_kernels.h): a channel (group) staged in ONE workgroup's LDS.  Right for 7x7 / 8x8 (planes
+//       that are not a whole number of 8-byte vectors); a 100 KiB image leaves one workgroup per CU and every phase
+//       goes through LDS twice.
+//   mono (this file): a plane of at most 64 vectors (8 or 16 bytes each) is ONE register slot of LPP = 16 or 64 lanes;
+//       a wave holds R slot rows, the 16 waves of the workgroup hold all N planes of the channel:
+//       N * M * b <= 16 waves * 64 lanes * R * vector bytes  — (256,.,14,14): R = 16 slots of 8 bytes (bf16) or 16 bytes
+//       (fp32) per lane.  Plane statistics are DPP sums inside the slot's lane group (exact two-pass from registers),
+//       SelfNorm's BatchNorm1d over N is one thread per plane + one workgroup reduction, the apply runs from registers.
+// Algebra and `saved` contract are those of the channel-local kernels (SelfNorm alone, optional residual-block
+// epilogue: PRE add and ReLU), so a forward of this strategy can be followed by a backward of any other.
+#pragma once
+#include "../../include/cnsn_hip.h"
+#include "cnsn_algebra.h"
+#include "cnsn_device.h"
+#include "cnsn_fused_stream_kernels.h"
+#include "cnsn_layout.h"
+#include "cnsn_resident_kernels.h"  // Raw / elem / pack / buf_load / buf_store / relu_open_r / add_raw
+
+namespace cnsn {
+
+#ifndef MONO_ILP
+#define MONO_ILP 2  // slot rows the scheduler may interleave in the backward's slot loops (power of two)
+#endif
+
+// waves per SIMD asked of the compiler: a 1024-thread workgroup is 4 per SIMD; 8 = TWO workgroups per CU (64 VGPRs), so
+// that one workgroup's loads and stores overlap the other's statistics / algebra — possible when a tensor's slot rows
+// take at most 32 registers (the forward of 16-bit (256,.,14,14), of fp32 up to 128 planes per channel)
+#ifndef MONO_FWD_WAVES_SMALL
+#define MONO_FWD_WAVES_SMALL 4
+#endif
+constexpr int mono_fwd_waves(int data_regs) { return data_regs <= 32 ? MONO_FWD_WAVES_SMALL : 4; }
+
+constexpr int kMonoBlock = 1024;
+constexpr int kMonoWaves = kMonoBlock / 64;
+
+struct MonoArgs {
+    MidArgs mid;
+    int nvec;  // vectors per plane (<= LPP)
+    int R;     // slot rows in use per wave (<= RMAX): N <= 16 * R * (64 / LPP)
+};
+
+__host__ __device__ inline size_t mono_lds_bytes(int N, bool backward) {
+    const size_t n = (size_t)((N + 3) & ~3);
+    return (backward ? 7 * n * 4 + 5 * n * 8 : 2 * n * 4) + (size_t)kMonoWaves * 4 * 8 + 16 * 8;
+}
+
+// sum of NACC doubles over the whole workgroup (every thread calls it); red: [kMonoWaves][NACC]
+template <int NACC>
+__device__ __forceinline__ void mono_block_sum(double (&acc)[NACC], double* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        acc[k] = v;
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) red[wave * NACC + k] = acc[k];
+    }
+    __syncthreads();
+    // the 16 partials: lane l reads the one of wave l % 16 and the four 16-lane groups of a wave each reduce to the
+    // total (4 values per lane; reading all 64 partials into every lane costs 128 VGPRs while planes sit in registers)
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+        double v = red[(lane & 15) * NACC + k];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        acc[k] = v;
+    }
+}
+
+// Tell the compiler that the packed registers of a slot "changed" (they did not): values unpacked from them before this
+// point cannot be kept alive across it, so the phases of a kernel re-unpack the 16-bit / re-read the 32-bit lanes of
+// the slot instead of holding RMAX * VEC floats per tensor next to the packed planes (which spilled to scratch).
+template <typename V>
+__device__ __forceinline__ void mono_forget(V& v) {
+    constexpr int W = (int)(sizeof(V) / 4);
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        int t = v[i];
+        asm volatile("" : "+v"(t));
+        v[i] = t;
+    }
+}
+
+// Channel order.  Workgroups are dealt to the 8 XCDs round-robin (b % 8) and every XCD has its own L2: giving each XCD
+// a CONTIGUOUS range of channels makes the workgroups that run side by side on one XCD (b, b + 8, ...) work on ADJACENT
+// channels.  Their planes share 128-byte lines at both ends (a 392-byte plane is 3.06 lines), which then meet in one
+// L2 — read once, written as whole lines — instead of travelling to two XCDs: measured +8 % at (256,1024,14,14) bf16.
+// The grid is C rounded up to a multiple of 8 workgroups; workgroup b takes channel start_x + b / 8 of its XCD's range
+// (x = b % 8), the few workgroups past the end of a range leave at once.  (A persistent walk — G8 workgroups per XCD
+// stepping through the range, LDS state in two alternating copies — was measured and dropped: the loop cost 20-70
+// spilled VGPRs and the forward got slower, 0.082 -> 0.088 ms at (256,1024,14,14) bf16, 0.095 -> 0.120 ms fp32.)
+struct MonoWalk {
+    int start, count, j;
+    __device__ __forceinline__ MonoWalk(int C) {
+        const int b = blockIdx.x, x = b & 7, per = C >> 3, rem = C & 7;
+        start = x * per + (x < rem ? x : rem);
+        count = per + (x < rem ? 1 : 0);
+        j = b >> 3;
+    }
+};
+
+template <int LPP>
+__device__ __forceinline__ float mono_group_sum(float v) {
+    if constexpr (LPP == 16)
+        return row16_sum(v);
+    else
+        return wave_sum(v);
+}
+
+// slot geometry of one lane: plane row `wave * R + r` holds planes (wave * R + r) * PPR + sub, vector vl of each
+template <typename T, int VEC, int LPP>
+struct MonoGeom {
+    static constexpr int PPR = 64 / LPP;
+    static constexpr int VB = VEC * (int)sizeof(T);
+    int sub, vl, wave, N, C, M, R;
+    bool lane_ok;
+    int voff;  // byte offset of this lane's vector inside its slot row
+    __device__ __forceinline__ MonoGeom(const MonoArgs& ma) {
+        const int lane = threadIdx.x & 63;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        sub = lane / LPP;
+        vl = lane - sub * LPP;
+        N = ma.mid.N;
+        C = ma.mid.C;
+        M = ma.mid.M;
+        R = ma.R;
+        lane_ok = vl < ma.nvec;
+        voff = (sub * C * M + vl * VEC) * (int)sizeof(T);
+    }
+    // (rows r >= R are never ok(): their loads return zeros without touching memory and their stores are dropped, so the
+    //  slot loops below run over all RMAX rows without control flow — the register arrays stay in registers)
+    __device__ __forceinline__ int plane(int r) const { return (wave * R + r) * PPR + sub; }
+    __device__ __forceinline__ bool row_ok(int r) const { return r < R && plane(r) < N; }  // a plane of THIS wave
+    __device__ __forceinline__ bool ok(int r) const { return row_ok(r) && lane_ok; }
+    // descriptor of slot row r of channel c of tensor `t`: lanes that are not ok() get an offset past its end
+    __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const T* t, int c, int r) const {
+        // the base is wave-uniform; say so explicitly (readfirstlane): when the compiler folds this address with a
+        // per-thread one it otherwise builds the descriptor in VGPRs and wraps every access in a waterfall loop
+        const unsigned long long b = (unsigned long long)(t + ((size_t)((wave * R + r) * PPR) * C + c) * M);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7ffffff0, 0x00020000);
+    }
+    __device__ __forceinline__ int off(int r) const { return ok(r) ? voff : 0x7ffffff8; }
+};
+
+// ================================================================================================
+// forward
+// ================================================================================================
+template <typename T, int VEC, int LPP, int RMAX, bool EPI>
+__global__ __launch_bounds__(kMonoBlock, mono_fwd_waves(RMAX * VEC * (int)sizeof(T) / 4)) void mono_fwd_kernel(MonoArgs ma, const T* __restrict__ x,
+                                                                  const T* __restrict__ addend, T* __restrict__ y, GateDev gg,
+                                                                  GateDev gf, double* __restrict__ saved, int add, int relu) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MidArgs a = ma.mid;
+    a.sn_two = 0;  // (the host does not send the two-gate form here)
+    const int N = a.N, C = a.C;
+    const int npad = (N + 3) & ~3;
+    const MonoWalk wk(C);
+    if (wk.j < wk.count) {
+    const int c = wk.start + wk.j;
+    char* lds = smem;
+    float* pmu = (float*)lds;  // [N] mean, later slope
+    float* pm2 = pmu + npad;    // [N] M2, later offset
+    double* red = (double*)(pm2 + npad);
+    double* par = red + kMonoWaves * 4;  // [16] per-channel parameters
+    const size_t P = (size_t)N * C;
+    const MonoGeom<T, VEC, LPP> g(ma);
+
+    if (threadIdx.x == 0) {  // per-channel parameters, fetched ahead of the bulk loads
+        par[0] = gg.w[2 * c];
+        par[1] = gg.w[2 * c + 1];
+        par[2] = gg.gamma[c];
+        par[3] = gg.beta[c];
+        par[4] = gg.run_mean[c];
+        par[5] = gg.run_var[c];
+        if (a.sn_two) {
+            par[6] = gf.w[2 * c];
+            par[7] = gf.w[2 * c + 1];
+            par[8] = gf.gamma[c];
+            par[9] = gf.beta[c];
+            par[10] = gf.run_mean[c];
+            par[11] = gf.run_var[c];
+        }
+    }
+
+    // ---- the only read of x (+ addend): every plane of the channel into registers
+    Raw<T, VEC> d[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+        d[r] = buf_load<T, VEC>(g.rsrc(x, c, r), g.off(r));
+    if constexpr (EPI) {
+        if (add == ADD_PRE) {  // the op's input is x + addend (rounded to T like `out += identity`), never written
+            constexpr int CH = (RMAX * VEC * (int)sizeof(T) > 128) ? RMAX / 2 : RMAX;  // bound the transient registers
+#pragma unroll
+            for (int r0 = 0; r0 < RMAX; r0 += CH) {
+                Raw<T, VEC> q[CH];
+#pragma unroll
+                for (int r = 0; r < CH; ++r)
+                    q[r] = buf_load<T, VEC>(g.rsrc(addend, c, r0 + r), g.off(r0 + r));
+#pragma unroll
+                for (int r = 0; r < CH; ++r)
+                    d[r0 + r] = add_raw<T, VEC>(d[r0 + r], q[r]);
+            }
+        }
+    }
+
+    // ---- exact two-pass statistics of every plane, from registers
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) s += elem<T, VEC>(d[r], q);  // lanes that are not ok() loaded zeros
+            const float mean = mono_group_sum<LPP>(s) / (float)a.M;
+            float m2 = 0.f;
+            mono_forget(d[r]);
+            if (g.ok(r)) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    const float t = elem<T, VEC>(d[r], q) - mean;
+                    m2 = fmaf(t, t, m2);
+                }
+            }
+            m2 = mono_group_sum<LPP>(m2);
+            if (g.vl == 0 && g.row_ok(r)) {  // (rows r >= R alias the planes of other waves: never written)
+                pmu[g.plane(r)] = mean;
+                pm2[g.plane(r)] = m2;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- gates: BatchNorm1d over the N planes of the channel, a thread per plane (cnsn.py:137-141)
+    using Rr = float;
+    const int n = threadIdx.x;
+    const bool act = n < N;
+    const double wg0 = par[0], wg1 = par[1], wf0 = par[6], wf1 = par[7];
+    FwdPlaneT<Rr> f{};
+    double zg = 0.0, zf = 0.0;
+    if (act) {
+        MomentsT<Rr> o;
+        o.mu_c = o.mu_s = pmu[n];
+        o.M2c = o.M2s = pm2[n];
+        o.mu_o = o.M2o = 0.f;
+        f = fwd_plane<Rr>(a, o, 0.f, 0.f);
+        zg = wg0 * (double)f.mu_p + wg1 * (double)f.sig_p;
+        zf = a.sn_two ? wf0 * (double)f.mu_p + wf1 * (double)f.sig_p : 0.0;
+    }
+    double mg = par[4], mf = par[10], rg, rf;
+    if (a.sn_training) {
+        // batch sums in double about no shift: |z| = O(10), N <= 1024 -> the variance is good to ~1e-13 absolute,
+        // eight orders below eps_bn
+        double sz[4] = {act ? zg : 0.0, act ? zg * zg : 0.0, act ? zf : 0.0, act ? zf * zf : 0.0};
+        mono_block_sum<4>(sz, red);
+        mg = sz[0] * a.inv_n;
+        mf = sz[2] * a.inv_n;
+        double vg = sz[1] * a.inv_n - mg * mg, vf = sz[3] * a.inv_n - mf * mf;
+        vg = vg > 0.0 ? vg : 0.0;
+        vf = vf > 0.0 ? vf : 0.0;
+        rg = (double)__builtin_amdgcn_rsqf((float)(vg + (double)a.eps_bn));
+        rf = (double)__builtin_amdgcn_rsqf((float)(vf + (double)a.eps_bn));
+        if (threadIdx.x == 0) {
+            const double mom_ = a.momentum, unb = a.unbias_n;
+            gg.run_mean[c] = (float)((1.0 - mom_) * par[4] + mom_ * mg);
+            gg.run_var[c] = (float)((1.0 - mom_) * par[5] + mom_ * vg * unb);
+            if (a.sn_two) {
+                gf.run_mean[c] = (float)((1.0 - mom_) * par[10] + mom_ * mf);
+                gf.run_var[c] = (float)((1.0 - mom_) * par[11] + mom_ * vf * unb);
+            }
+        }
+    } else {
+        rg = (double)__builtin_amdgcn_rsqf((float)par[5] + a.eps_bn);
+        rf = a.sn_two ? (double)__builtin_amdgcn_rsqf((float)par[11] + a.eps_bn) : 1.0;
+    }
+    if (saved && threadIdx.x == 0) {
+        saved[SV_ROWS * P + c] = rg;
+        saved[SV_ROWS * P + C + c] = rf;
+    }
+    if (act) {
+        const double zhg = (zg - mg) * rg;
+        const Rr gt = sigmoid_r<Rr>((Rr)(par[2] * zhg + par[3]));
+        double zhf = 0.0;
+        Rr ft = 1.f;
+        if (a.sn_two) {
+            zhf = (zf - mf) * rf;
+            ft = sigmoid_r<Rr>((Rr)(par[8] * zhf + par[9]));
+        }
+        const FwdCoefs cf = fwd_coefs<Rr>(a, f, gt, ft);
+        if (saved) {
+            const size_t p = (size_t)n * C + c;
+            store_fwd_plane<Rr>(saved, P, p, f, 0);
+            saved[sv_at(p, SV_G)] = gt;
+            saved[sv_at(p, SV_ZH_G)] = zhg;
+            saved[sv_at(p, SV_F)] = ft;
+            saved[sv_at(p, SV_ZH_F)] = zhf;
+            if (a.save_coefs) store_fwd_coefs(saved, p, cf);
+        }
+        pmu[n] = cf.a_in;  // SelfNorm alone: y = a_in * x + b_in  (xr = 0)
+        pm2[n] = cf.b_in;
+    }
+    __syncthreads();
+
+    // ---- apply from registers, the only write of y
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) mono_forget(d[r]);
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        {
+            const int pn = g.plane(r);
+            const float ca = pmu[pn < N ? pn : 0], cb = pm2[pn < N ? pn : 0];
+            float ov[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                ov[q] = fmaf(ca, elem<T, VEC>(d[r], q), cb);
+                if constexpr (EPI) ov[q] = relu ? fmaxf(ov[q], 0.f) : ov[q];
+            }
+            buf_store<T, VEC>(g.rsrc(y, c, r), g.off(r), pack<T, VEC>(ov));
+        }
+    }
+    }  // (a workgroup past the end of its XCD's range has nothing to do)
+}
+
+// ================================================================================================
+// backward
+// ================================================================================================
+template <typename T, int VEC, int LPP, int RMAX, bool EPI>
+__global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const T* __restrict__ gy, const T* __restrict__ x,
+                                                                  const T* __restrict__ addend, T* __restrict__ dx, GateDev gg,
+                                                                  GateDev gf, GateGradDev dgr, GateGradDev dfr,
+                                                                  const double* __restrict__ saved, int add, int relu) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MidArgs a = ma.mid;
+    a.sn_two = 0;  // (the host does not send the two-gate form here: the second gate's state would cost ~20 VGPRs)
+    const int N = a.N, C = a.C;
+    const int npad = (N + 3) & ~3;
+    const MonoWalk wk(C);
+    if (wk.j < wk.count) {
+    const int c = wk.start + wk.j;
+    char* lds = smem;
+    float* psi = (float*)lds;  // [N] float(mu_c): the shift of the second sum
+    float* pfa = psi + npad;    // [N] forward slope  (ReLU mask)   -> later xr
+    float* pfb = pfa + npad;    // [N] forward offset (ReLU mask)   -> later c0
+    float* ps1 = pfb + npad;    // [N] sum G                         -> later cG
+    float* ps2 = ps1 + npad;    // [N] sum G * (x - mu)              -> later cX
+    float* pxr = ps2 + npad;
+    float* pc0 = pxr + npad;
+    double* red = (double*)(pc0 + npad);
+    double* psv = red + kMonoWaves * 4;  // [5][N] the five rows of `saved` the algebra needs (parked in LDS: the
+                                         // registers belong to the planes until the sums are done)
+    const size_t P = (size_t)N * C;
+    const MonoGeom<T, VEC, LPP> g(ma);
+
+    // ---- what the sums and the algebra need from `saved`, a thread per plane, ahead of the bulk loads
+    const int n = threadIdx.x;
+    const bool act = n < N;
+    if (act) {
+        const size_t pme = (size_t)n * C + c;
+        const double mu = saved[sv_at(pme, SV_MU_C)];
+        psv[0 * npad + n] = mu;
+        psv[1 * npad + n] = saved[sv_at(pme, SV_MU_P)];
+        psv[2 * npad + n] = saved[sv_at(pme, SV_SIG_P)];
+        psv[3 * npad + n] = saved[sv_at(pme, SV_G)];
+        psv[4 * npad + n] = saved[sv_at(pme, SV_ZH_G)];
+        psi[n] = (float)mu;
+        if (EPI && relu) {
+            pfa[n] = (float)saved[sv_at(pme, SV_FC0 + FC_A_IN)];
+            pfb[n] = (float)saved[sv_at(pme, SV_FC0 + FC_B_IN)];
+        }
+    }
+    const float w_g0 = gg.w[2 * c], w_g1 = gg.w[2 * c + 1], gam_g = gg.gamma[c];
+    const double rs_g = saved[SV_ROWS * P + c];
+
+    // ---- the only reads of G and x (+ addend)
+    Raw<T, VEC> dg_[RMAX], dx_[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+    {
+        dg_[r] = buf_load<T, VEC>(g.rsrc(gy, c, r), g.off(r));
+        dx_[r] = buf_load<T, VEC>(g.rsrc(x, c, r), g.off(r));
+    }
+    if constexpr (EPI) {
+        if (add == ADD_PRE) {
+            constexpr int CH = (RMAX * VEC * (int)sizeof(T) > 64) ? RMAX / 2 : RMAX;
+#pragma unroll
+            for (int r0 = 0; r0 < RMAX; r0 += CH) {
+                Raw<T, VEC> q[CH];
+#pragma unroll
+                for (int r = 0; r < CH; ++r)
+                    q[r] = buf_load<T, VEC>(g.rsrc(addend, c, r0 + r), g.off(r0 + r));
+#pragma unroll
+                for (int r = 0; r < CH; ++r)
+                    dx_[r0 + r] = add_raw<T, VEC>(dx_[r0 + r], q[r]);
+            }
+        }
+    }
+    __syncthreads();  // psi / pfa / pfb are staged
+
+    // ---- ReLU mask (forward affine re-evaluated with the coefficients the forward used) and per-plane sums
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        {
+            const int pn = g.plane(r);
+            const int pi = pn < N ? pn : 0;
+            const float si = psi[pi];
+            if constexpr (EPI) {
+                if (relu) {
+                    const float fa = pfa[pi], fb = pfb[pi];
+                    float gm[VEC];
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        const float t = fmaf(fa, elem<T, VEC>(dx_[r], q) - 0.f, fb);
+                        gm[q] = relu_open_r<T>(t) ? elem<T, VEC>(dg_[r], q) : 0.f;
+                    }
+                    dg_[r] = pack<T, VEC>(gm);
+                }
+            }
+            float s1 = 0.f, s2 = 0.f;
+            if (g.ok(r)) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    const float G = elem<T, VEC>(dg_[r], q), X = elem<T, VEC>(dx_[r], q);
+                    s1 += G;
+                    s2 = fmaf(G, X - si, s2);
+                }
+            }
+            s1 = mono_group_sum<LPP>(s1);
+            s2 = mono_group_sum<LPP>(s2);
+            if (g.vl == 0 && g.row_ok(r)) {
+                ps1[pn] = s1;
+                ps2[pn] = s2;
+            }
+        }
+        if ((r & (MONO_ILP - 1)) == MONO_ILP - 1) __builtin_amdgcn_sched_barrier(0);  // bound the interleaving (registers)
+    }
+    __syncthreads();
+
+    // ---- gate / BatchNorm backward, a thread per plane; coefficients of dx
+    using Rr = float;
+    BwdSumsT<Rr> sums{};
+    Rr dtg = 0.f, dtf = 0.f;
+    double r_mu = 0, r_mup = 0, r_sigp = 0, r_g = 0, r_zhg = 0;
+    const double r_f = 1.0, r_zhf = 0.0;
+    if (act) {
+        r_mu = psv[0 * npad + n];
+        r_mup = psv[1 * npad + n];
+        r_sigp = psv[2 * npad + n];
+        r_g = psv[3 * npad + n];
+        r_zhg = psv[4 * npad + n];
+    }
+    if (act) {
+        sums = fix_sums<Rr>(a, ps1[n], ps2[n], 0.f, 0.f, r_mu, 0.0);
+        gate_dt<Rr>(a, sums, Rr(1), (Rr)r_mu, Rr(0), (Rr)r_mup, (Rr)r_g, (Rr)r_f, dtg, dtf);
+    }
+    double s4[2] = {(double)dtg, (double)dtg * r_zhg};
+    mono_block_sum<2>(s4, red);
+    BnBwd b{};
+    b.s_dt_g = s4[0];
+    b.s_dtz_g = s4[1];
+    b.wg0 = w_g0;
+    b.wg1 = w_g1;
+    b.kg = (double)gam_g * rs_g;
+    double sw[2] = {0, 0};
+    if (act) {
+        const BwdPlaneT<Rr> o = bwd_plane<Rr>(a, b, sums, (double)dtg, (double)dtf, r_zhg, r_zhf, (Rr)r_g, (Rr)r_f, Rr(1), Rr(1),
+                                              (Rr)r_mu, (Rr)r_mup, (Rr)r_sigp, Rr(1), Rr(0));
+        sw[0] = (double)o.dz_g * r_mup;
+        sw[1] = (double)o.dz_g * r_sigp;
+        const BwdCoefs k = bwd_coefs<Rr>(a, o, Rr(0), Rr(0), (Rr)r_g, Rr(1), (Rr)r_mu, (Rr)r_mup, r_mu, Rr(1), r_mu, Rr(1));
+        ps1[n] = k.cG_in;  // (every thread read its own ps1 / ps2 before the reduction above)
+        ps2[n] = k.cX_in;
+        pxr[n] = k.xr_in;
+        pc0[n] = k.c0_in;
+    }
+    mono_block_sum<2>(sw, red);
+    if (threadIdx.x == 0) {
+        dgr.dgamma[c] = (float)s4[1];
+        dgr.dbeta[c] = (float)s4[0];
+        dgr.dw[2 * c] = (float)sw[0];
+        dgr.dw[2 * c + 1] = (float)sw[1];
+    }
+    // (mono_block_sum ends with every thread past its second barrier: the coefficient rows are visible)
+
+    // ---- dx from registers, the only write
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        mono_forget(dg_[r]);
+        mono_forget(dx_[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        {
+            const int pn = g.plane(r);
+            const int pi = pn < N ? pn : 0;
+            const float cG = ps1[pi], cX = ps2[pi], xr = pxr[pi], c0 = pc0[pi];
+            float ov[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC; ++q)
+                ov[q] = fmaf(cG, elem<T, VEC>(dg_[r], q), fmaf(cX, elem<T, VEC>(dx_[r], q) - xr, c0));
+            buf_store<T, VEC>(g.rsrc(dx, c, r), g.off(r), pack<T, VEC>(ov));
+        }
+        if ((r & (MONO_ILP - 1)) == MONO_ILP - 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    }  // (a workgroup past the end of its XCD's range has nothing to do)
+}
+
+}  // namespace cnsn

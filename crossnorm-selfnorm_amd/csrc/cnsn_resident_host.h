@@ -135,7 +135,9 @@ int grid_for(Kern kern, size_t lds, int K, int items) {
 // epi: the call carries the residual-block epilogue (EPI kernels; their AUTO rule is separate)
 static inline ResPlan plan_impl(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, bool backward, bool epi) {
     ResPlan rp{false, 0, 0, 0, 0};
-    if (p.strategy == CNSN_STRATEGY_TWO_PASS || p.strategy == CNSN_STRATEGY_LOCAL || has_chan_perm) return rp;
+    if (p.strategy == CNSN_STRATEGY_TWO_PASS || p.strategy == CNSN_STRATEGY_LOCAL || p.strategy == CNSN_STRATEGY_MONO ||
+        has_chan_perm)
+        return rp;
     if (resident_timeouts() > 0) return rp;  // a launch gave up earlier in this process: never again, even when forced
     const int M = p.H * p.W;
     rp.vec = pick_vec(p.dtype, boxed ? p.W : M);

@@ -31,6 +31,10 @@
 #include "cnsn_device.h"
 #include "cnsn_layout.h"
 
+#ifndef CNSN_POLL_SLEEP
+#define CNSN_POLL_SLEEP 4  // s_sleep units (64 clocks) between two polls of the granules
+#endif
+
 namespace cnsn {
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
@@ -56,11 +60,20 @@ struct ResArgs {
 #define CNSN_STAMP(slot)                                                                        \
     do {                                                                                        \
         if (ra.prof && threadIdx.x == 0 && blockIdx.x < 64 && iter_ < 16)                       \
-            ra.prof[((size_t)blockIdx.x * 16 + iter_) * 8 + (slot)] = __builtin_readcyclecounter(); \
+            ra.prof[((size_t)blockIdx.x * 16 + iter_) * 8 + (slot)] = wall_clock64();             \
+    } while (0)
+#define CNSN_NOTE(slot, v)                                                          \
+    do {                                                                           \
+        if (ra.prof && threadIdx.x == 0 && blockIdx.x < 64 && iter_ < 16)          \
+            ra.prof[((size_t)blockIdx.x * 16 + iter_) * 8 + (slot)] = (v);        \
     } while (0)
 #else
 #define CNSN_STAMP(slot) \
     do {                 \
+    } while (0)
+#define CNSN_NOTE(slot, v) \
+    do {                   \
+        (void)(v);         \
     } while (0)
 #endif
 
@@ -89,7 +102,7 @@ __device__ __forceinline__ void put_granule(unsigned long long* p, float lo, flo
 // ONE wave gathers `total` granules (2*total floats) into LDS; re-reads all of them until none is empty.
 // Returns false when it gave up (time-out, or another workgroup already did): the caller's workgroup must leave.
 __device__ __forceinline__ bool sweep_granules(const unsigned long long* g, int total, float* vals, unsigned* ctl,
-                                               unsigned* host_flag, long long wait_ticks) {
+                                               unsigned* host_flag, long long wait_ticks, unsigned& passes) {
     const int lane = threadIdx.x & 63;
     long long t_start = 0;
     for (unsigned spins = 0;; ++spins) {
@@ -100,8 +113,9 @@ __device__ __forceinline__ bool sweep_granules(const unsigned long long* g, int 
             vals[2 * i] = __uint_as_float((unsigned)v);
             vals[2 * i + 1] = __uint_as_float((unsigned)(v >> 32));
         }
+        passes = spins + 1;
         if (__all(ok)) return true;
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(CNSN_POLL_SLEEP);
         if ((spins & 15u) == 15u) {
             const long long now = (long long)wall_clock64();
             if (t_start == 0) t_start = now;
@@ -112,6 +126,111 @@ __device__ __forceinline__ bool sweep_granules(const unsigned long long* g, int 
                 // is shared with something that never yields).  The FIRST workgroup to notice flips the control
                 // word (every other wait drains), bumps the host-visible counter, and everybody returns: the
                 // outputs of this launch are incomplete, which the host learns from cnsn_resident_timeouts().
+                if (lane == 0) {
+                    const unsigned prev = __hip_atomic_exchange((gu32*)ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (prev == kCtlIdle && host_flag)
+                        __hip_atomic_fetch_add(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                return false;
+            }
+        }
+    }
+}
+
+// ---- the same gather through the SCALAR memory path --------------------------------------------------------
+// Why: a vector load issued while the CU's other waves have ~200 KB of plane loads in flight returns only after
+// them (the vector L1 returns in order): ~9 us per poll at the north-star shape, and a cluster wait needs 2-3
+// polls (profiles/r01_resident_tuning.md).  Scalar loads take the other road — scalar data cache -> L2, out of
+// order, `glc` = never served from the scalar cache — so a poll costs an L2 round trip.  ALL FOUR waves take
+// part: wave w owns the 256-byte groups w, w+4, ... of the channel's granules, loads a group with four
+// s_load_dwordx16 into 64 SGPRs, moves them to one VGPR (v_writelane), stores that to LDS and tests it for the
+// 'empty' pattern; only groups that still had empties are read again.  A granule is an aligned 8-byte word written
+// by one store, so both of its dwords are empty or neither is: the test is per dword.
+#ifndef CNSN_SWEEP_SCALAR
+#define CNSN_SWEEP_SCALAR 0  // measured (profiles/r02_resident_phases.md): last publish -> seen 3.2 us instead of 5.5 at
+                             // the north-star shape, but no faster end to end and slower for one-item grids
+#endif
+// critical-path experiments on the exchange -> algebra -> apply section (round 2, profiles/r02_resident_phases.md).  Each
+// was measured on its own against the plain build; none pays, so all are OFF — kept because the measurements are
+// the documentation of where the time does NOT go:
+#ifndef CNSN_PRIO
+#define CNSN_PRIO 0        // wave priorities by phase (2 load/sum/publish, 0 while polling, 3 algebra/apply): +-1 % at the
+#endif                     // north-star shape, and 2x SLOWER for one-item grids ((128,32,32,32) backward 0.043 -> 0.109 ms)
+#ifndef CNSN_CHEAP_SHIFT
+#define CNSN_CHEAP_SHIFT 0 // batch sums about a shift taken from plane 0's raw moments instead of its full algebra: no change
+#endif
+#ifndef CNSN_WAVE_COEF
+#define CNSN_WAVE_COEF 0   // coefficients of a wave's planes computed by its own lanes and handed over with v_readlane
+#endif                     // (no LDS round trip, one barrier less): algebra phase 4.4 -> 2.9 us, kernel time unchanged
+                           // (fp32) to 7 % slower (bf16, two planes per wave)
+typedef unsigned su16_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ unsigned sload_glc_u32(const void* p) {
+    unsigned v;
+    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
+// lanes BASE .. BASE+15 of v <- the 16 dwords of r (v_writelane_b32; this clang has no builtin for it)
+template <int BASE>
+__device__ __forceinline__ void put16(unsigned& v, const su16_t& r) {
+#define CNSN_WL(i) asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(r[i]), "n"(BASE + (i)))
+    CNSN_WL(0); CNSN_WL(1); CNSN_WL(2); CNSN_WL(3); CNSN_WL(4); CNSN_WL(5); CNSN_WL(6); CNSN_WL(7);
+    CNSN_WL(8); CNSN_WL(9); CNSN_WL(10); CNSN_WL(11); CNSN_WL(12); CNSN_WL(13); CNSN_WL(14); CNSN_WL(15);
+#undef CNSN_WL
+}
+
+// 64 dwords at base + off (bytes) -> lane l holds dword l
+__device__ __forceinline__ unsigned sload_group(const void* base, unsigned off) {
+    su16_t a, b, c, d;
+    asm volatile(
+        "s_load_dwordx16 %0, %4, %5 glc\n\t"
+        "s_load_dwordx16 %1, %4, %6 glc\n\t"
+        "s_load_dwordx16 %2, %4, %7 glc\n\t"
+        "s_load_dwordx16 %3, %4, %8 glc\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d)
+        : "s"(base), "s"(off), "s"(off + 64u), "s"(off + 128u), "s"(off + 192u)
+        : "memory");
+    unsigned v = 0;
+    put16<0>(v, a);
+    put16<16>(v, b);
+    put16<32>(v, c);
+    put16<48>(v, d);
+    return v;
+}
+
+// Every wave of the workgroup calls this (wave-uniform arguments); returns false when this wave gave up.
+// nfloats = 2 * granules of the channel; vals must hold nfloats floats.
+__device__ __forceinline__ bool sweep_granules_scalar(const unsigned long long* g, int nfloats, float* vals, unsigned* ctl,
+                                                      unsigned* host_flag, long long wait_ticks, int wave,
+                                                      unsigned& passes) {
+    const int lane = threadIdx.x & 63;
+    const int ngroups = (nfloats + 63) >> 6;
+    const int mine = ngroups > wave ? (ngroups - wave + 3) >> 2 : 0;  // groups wave, wave+4, ...
+    unsigned long long todo = mine >= 64 ? ~0ull : ((1ull << mine) - 1ull);  // (more than 64: all re-read each pass)
+    long long t_start = 0;
+    for (unsigned spins = 0;; ++spins) {
+        bool all = true;
+        for (int k = 0; k < mine; ++k) {
+            if (k < 64 && !((todo >> k) & 1ull)) continue;
+            const int grp = wave + 4 * k;
+            const unsigned v = sload_group((const void*)g, (unsigned)grp * 256u);
+            const int idx = grp * 64 + lane;
+            const bool valid = idx < nfloats;
+            if (valid) vals[idx] = __uint_as_float(v);
+            const bool ok = __ballot(valid && v == 0xffffffffu) == 0ull;
+            if (ok && k < 64) todo &= ~(1ull << k);
+            all &= ok;
+        }
+        passes = spins + 1;
+        if (all) return true;
+        __builtin_amdgcn_s_sleep(2);
+        if ((spins & 15u) == 15u) {
+            const long long now = (long long)wall_clock64();
+            if (t_start == 0) t_start = now;
+            if (sload_glc_u32(ctl) != kCtlIdle) return false;  // somebody gave up already: drain
+            if (now - t_start > wait_ticks) {
                 if (lane == 0) {
                     const unsigned prev = __hip_atomic_exchange((gu32*)ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (prev == kCtlIdle && host_flag)
@@ -254,6 +373,11 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, int voff, co
 
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
+// value of lane `src` (a compile-time constant after unrolling) in every lane
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
 // Register budget: the planes a wave holds dominate its VGPR use, and the number of resident waves
 // per SIMD (= workgroups per CU, a workgroup being one wave per SIMD) decides how much of the sync
 // latency other workgroups can cover.  min-waves-per-SIMD handed to __launch_bounds__:
@@ -347,6 +471,9 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
     if (a.cn_active)
         for (int n = threadIdx.x; n < N; n += kBlock) sperm[n] = (int)perm[n];
     startup_skew(ra);
+#if CNSN_PRIO
+    __builtin_amdgcn_s_setprio(2);
+#endif
 
     int iter_ = -1;
     for (int item = blockIdx.x; item < ra.items; item += gridDim.x) {
@@ -527,16 +654,30 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
         }
 
         // ---- gather the whole channel's statistics
+#if CNSN_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         CNSN_STAMP(1);
+        if (threadIdx.x == 0) *gave_up = 0;
         __syncthreads();  // the previous item's readers of vals/zbuf are done
         CNSN_STAMP(2);
+        unsigned passes_ = 0;
+#if CNSN_SWEEP_SCALAR
+        if (!sweep_granules_scalar(gran + (size_t)c * N * (NG / 2), N * NG, vals, ctl, ra.host_flag, ra.wait_ticks, wave, passes_))
+            if (lane == 0) *gave_up = 1;
+#else
         if (wave == 0) {
-            const bool got = sweep_granules(gran + (size_t)c * N * (NG / 2), N * (NG / 2), vals, ctl, ra.host_flag, ra.wait_ticks);
-            if (lane == 0) *gave_up = got ? 0 : 1;
+            const bool got = sweep_granules(gran + (size_t)c * N * (NG / 2), N * (NG / 2), vals, ctl, ra.host_flag, ra.wait_ticks, passes_);
+            if (lane == 0 && !got) *gave_up = 1;
         }
+#endif
         __syncthreads();
         if (*gave_up) return;  // (workgroup-uniform) timed out: see sweep_granules
+#if CNSN_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         CNSN_STAMP(3);
+        CNSN_NOTE(6, passes_);
 
         using R = float;  // per-plane algebra in float, cross-batch sums / normalisation in double
         auto plane_of = [&](int n) {
@@ -565,9 +706,16 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
             wf0 = pw[2];
             wf1 = pw[3];
             if (a.sn_training) {
+#if CNSN_CHEAP_SHIFT
+                // any value near the batch mean of z serves as the shift: plane 0's raw content moments
+                const double sh_mu = (double)vals[0];
+                const double sh_sd = (double)sqrt_r(div_r(vals[1], (float)(a.Mc - 1)) + a.eps_sn);
+                const double zs_g = wg0 * sh_mu + wg1 * sh_sd, zs_f = wf0 * sh_mu + wf1 * sh_sd;
+#else
                 const FwdPlaneT<R> f0 = plane_of(0);
                 const double zs_g = wg0 * (double)f0.mu_p + wg1 * (double)f0.sig_p;
                 const double zs_f = wf0 * (double)f0.mu_p + wf1 * (double)f0.sig_p;
+#endif
                 double sz[4] = {0.0, 0.0, 0.0, 0.0};
                 for (int n = threadIdx.x; n < N; n += kBlock) {
                     const FwdPlaneT<R> f = plane_of(n);
@@ -611,7 +759,37 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
             }
         }
 
-        // ---- coefficients (and saved state) of the planes this workgroup owns: one thread each
+        // ---- coefficients (and saved state) of the owned planes
+#if CNSN_WAVE_COEF
+        // lane s (< PPW) of every wave takes the wave's plane s; the apply loop reads them back with v_readlane
+        FwdCoefs cfw{0.f, 0.f, 0.f, 0.f, 0.f};
+        {
+            const int n = n0 + (lane < PPW ? lane : 0);
+            if (n < N) {
+                const FwdPlaneT<R> f = plane_of(n);
+                R g = 1.f, fg = 1.f;
+                double zhg = 0.0, zhf = 0.0;
+                if (a.sn_active) {
+                    zhg = (wg0 * (double)f.mu_p + wg1 * (double)f.sig_p - mg) * rg;
+                    g = sigmoid_r<R>((R)((double)pgam[0] * zhg + (double)pbet[0]));
+                    if (a.sn_two) {
+                        zhf = (wf0 * (double)f.mu_p + wf1 * (double)f.sig_p - mf) * rf;
+                        fg = sigmoid_r<R>((R)((double)pgam[1] * zhf + (double)pbet[1]));
+                    }
+                }
+                cfw = fwd_coefs<R>(a, f, g, fg);
+                if (saved && lane < PPW) {
+                    const size_t p = (size_t)n * C + c;
+                    store_fwd_plane<R>(saved, P, p, f, a.cn_active);
+                    saved[sv_at(p, SV_G)] = g;
+                    saved[sv_at(p, SV_ZH_G)] = zhg;
+                    saved[sv_at(p, SV_F)] = fg;
+                    saved[sv_at(p, SV_ZH_F)] = zhf;
+                    if (a.save_coefs) store_fwd_coefs(saved, p, cfw);
+                }
+            }
+        }
+#else
         if (threadIdx.x < OWN) {
             const int n = k * OWN + threadIdx.x;
             if (n < N) {
@@ -645,6 +823,7 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
             }
         }
         __syncthreads();
+#endif
         CNSN_STAMP(4);
 
         // ---- apply from registers, the only write of y
@@ -652,9 +831,14 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
         for (int s = 0; s < PPW; ++s) {
             const int n = n0 + s;
             if (n < N) {
+#if CNSN_WAVE_COEF
+                const float a_in = lane_bcast(cfw.a_in, s), xr = lane_bcast(cfw.xr, s), b_in = lane_bcast(cfw.b_in, s),
+                            a_out = lane_bcast(cfw.a_out, s), b_out = lane_bcast(cfw.b_out, s);
+#else
                 const float* o = ocoef + (wave * PPW + s) * FC_ROWS;
                 const float a_in = o[FC_A_IN], xr = o[FC_XR], b_in = o[FC_B_IN], a_out = o[FC_A_OUT],
                             b_out = o[FC_B_OUT];
+#endif
                 T* yb = y + ((size_t)n * C + c) * ra.M;
                 const int pbytes = ra.M * (int)sizeof(T);
 #pragma unroll
@@ -671,6 +855,9 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
                 }
             }
         }
+#if CNSN_PRIO
+        __builtin_amdgcn_s_setprio(2);
+#endif
         CNSN_STAMP(5);
     }
 }
@@ -710,6 +897,9 @@ __global__ __launch_bounds__(kBlock, EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV
     if (a.cn_active)  // plane r receives the style-statistic gradient of the plane that borrowed from it
         for (int n = threadIdx.x; n < N; n += kBlock) iperm[(int)perm[n]] = n;
     startup_skew(ra);
+#if CNSN_PRIO
+    __builtin_amdgcn_s_setprio(2);
+#endif
 
     int iter_ = -1;
     for (int item = blockIdx.x; item < ra.items; item += gridDim.x) {
@@ -849,16 +1039,30 @@ __global__ __launch_bounds__(kBlock, EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV
             }
         }
 
+#if CNSN_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         CNSN_STAMP(1);
+        if (threadIdx.x == 0) *gave_up = 0;
         __syncthreads();
         CNSN_STAMP(2);
+        unsigned passes_ = 0;
+#if CNSN_SWEEP_SCALAR
+        if (!sweep_granules_scalar(gran + (size_t)c * N * (NS / 2), N * NS, vals, ctl, ra.host_flag, ra.wait_ticks, wave, passes_))
+            if (lane == 0) *gave_up = 1;
+#else
         if (wave == 0) {
-            const bool got = sweep_granules(gran + (size_t)c * N * (NS / 2), N * (NS / 2), vals, ctl, ra.host_flag, ra.wait_ticks);
-            if (lane == 0) *gave_up = got ? 0 : 1;
+            const bool got = sweep_granules(gran + (size_t)c * N * (NS / 2), N * (NS / 2), vals, ctl, ra.host_flag, ra.wait_ticks, passes_);
+            if (lane == 0 && !got) *gave_up = 1;
         }
+#endif
         __syncthreads();
         if (*gave_up) return;  // (workgroup-uniform) timed out: see sweep_granules
+#if CNSN_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         CNSN_STAMP(3);
+        CNSN_NOTE(6, passes_);
 
         using R = float;  // per-plane algebra in float; batch sums and the dz line in double
         auto sums_of = [&](int n) {
@@ -927,7 +1131,26 @@ __global__ __launch_bounds__(kBlock, EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV
             }
         }
 
-        // ---- coefficients of dx for the owned planes: one thread each
+        // ---- coefficients of dx for the owned planes
+#if CNSN_WAVE_COEF
+        BwdCoefs cfw{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        {
+            const int n = n0 + (lane < PPW ? lane : 0);  // lane s (< PPW) takes the wave's plane s
+            if (n < N) {
+                const float* sf = svf + n * F_N;
+                const BwdPlaneT<R> o = bwd_of(n);
+                R Emu = 0.f, Esig = 0.f;
+                if (a.cn_active) {
+                    const BwdPlaneT<R> src = bwd_of(iperm[n]);  // the plane that used (n,c) as its style
+                    Emu = src.Emu;
+                    Esig = src.Esig;
+                }
+                cfw = bwd_coefs<R>(a, o, Emu, Esig, sf[F_G], sf[F_A1], sf[F_M_IN], sf[F_MU_P], svd[n * D_N + D_MU_C],
+                                   sf[F_SIG_C], svd[n * D_N + D_MU_S], sf[F_SIG_S]);
+            }
+        }
+        __syncthreads();  // the next item's prefetch overwrites svd / svf: every wave must be done reading them
+#else
         if (threadIdx.x < OWN) {
             const int n = k * OWN + threadIdx.x;
             if (n < N) {
@@ -957,6 +1180,7 @@ __global__ __launch_bounds__(kBlock, EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV
             }
         }
         __syncthreads();
+#endif
         CNSN_STAMP(4);
 
         // ---- apply from registers, the only write of dx
@@ -964,33 +1188,47 @@ __global__ __launch_bounds__(kBlock, EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV
         for (int s = 0; s < PPW; ++s) {
             const int n = n0 + s;
             if (n < N) {
+#if CNSN_WAVE_COEF
+                const float cG_i = lane_bcast(cfw.cG_in, s), cX_i = lane_bcast(cfw.cX_in, s), xr_i = lane_bcast(cfw.xr_in, s),
+                            c0_i = lane_bcast(cfw.c0_in, s);
+                float cG_o = 0.f, cX_o = 0.f, xr_o = 0.f, c0_o = 0.f, eS = 0.f, xs = 0.f, e0 = 0.f;
+                if constexpr (BOXED) {
+                    cG_o = lane_bcast(cfw.cG_out, s), cX_o = lane_bcast(cfw.cX_out, s), xr_o = lane_bcast(cfw.xr_out, s),
+                    c0_o = lane_bcast(cfw.c0_out, s), eS = lane_bcast(cfw.eS, s), xs = lane_bcast(cfw.xs, s),
+                    e0 = lane_bcast(cfw.e0, s);
+                }
+#else
                 const float* oc = ocoef + (wave * PPW + s) * BC_ROWS;
                 const float cG_i = oc[BC_CG_IN], cX_i = oc[BC_CX_IN], xr_i = oc[BC_XR_IN], c0_i = oc[BC_C0_IN];
                 const float cG_o = oc[BC_CG_OUT], cX_o = oc[BC_CX_OUT], xr_o = oc[BC_XR_OUT], c0_o = oc[BC_C0_OUT];
                 const float eS = oc[BC_ES], xs = oc[BC_XS], e0 = oc[BC_E0];
+#endif
                 T* db = dx + ((size_t)n * C + c) * ra.M;
                 const int pbytes = ra.M * (int)sizeof(T);
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
-                        float ov[VEC];
+                    float ov[VEC];
 #pragma unroll
-                        for (int q = 0; q < VEC; ++q) {
-                            const float G = elem<T, VEC>(dg_[s][j], q), X = elem<T, VEC>(dx_[s][j], q);
-                            float v;
-                            if constexpr (!BOXED) {
-                                v = fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i));
-                            } else {
-                                const bool ic = sg.in_c(j, q), is = sg.in_s(j, q);
-                                v = ic ? fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i))
-                                       : fmaf(cG_o, G, fmaf(cX_o, X - xr_o, c0_o));
-                                v += is ? fmaf(eS, X - xs, e0) : 0.f;
-                            }
-                            ov[q] = v;
+                    for (int q = 0; q < VEC; ++q) {
+                        const float G = elem<T, VEC>(dg_[s][j], q), X = elem<T, VEC>(dx_[s][j], q);
+                        float v;
+                        if constexpr (!BOXED) {
+                            v = fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i));
+                        } else {
+                            const bool ic = sg.in_c(j, q), is = sg.in_s(j, q);
+                            v = ic ? fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i))
+                                   : fmaf(cG_o, G, fmaf(cX_o, X - xr_o, c0_o));
+                            v += is ? fmaf(eS, X - xs, e0) : 0.f;
                         }
-                        buf_store<T, VEC>(slot_rsrc<T, VEC>(db, pbytes, j), voff, pack<T, VEC>(ov));
+                        ov[q] = v;
                     }
+                    buf_store<T, VEC>(slot_rsrc<T, VEC>(db, pbytes, j), voff, pack<T, VEC>(ov));
+                }
             }
         }
+#if CNSN_PRIO
+        __builtin_amdgcn_s_setprio(2);
+#endif
         CNSN_STAMP(5);
     }
 }

@@ -20,10 +20,10 @@ _strategy = _ffi.STRATEGY_AUTO
 
 
 def set_strategy(name: str):
-    """'auto' | 'two_pass' | 'resident' | 'local' — which kernel strategy libcnsn_hip.so uses."""
+    """'auto' | 'two_pass' | 'resident' | 'local' | 'mono' — which kernel strategy libcnsn_hip.so uses."""
     global _strategy
     _strategy = {"auto": _ffi.STRATEGY_AUTO, "two_pass": _ffi.STRATEGY_TWO_PASS,
-                 "resident": _ffi.STRATEGY_RESIDENT, "local": _ffi.STRATEGY_LOCAL}[name]
+                 "resident": _ffi.STRATEGY_RESIDENT, "local": _ffi.STRATEGY_LOCAL, "mono": _ffi.STRATEGY_MONO}[name]
 
 
 def set_resident(enabled: bool):
@@ -178,7 +178,7 @@ def _epilogue(cfg: FusedConfig, addend):
 
 
 def which_path(x: torch.Tensor, cfg: FusedConfig, backward: bool = False, chan_perm: bool = False) -> str:
-    """'streaming' | 'packed' | 'resident' | 'local': the kernels a call with this tensor / configuration would run
+    """'streaming' | 'packed' | 'resident' | 'local' | 'mono': the kernels a call with this tensor / configuration would run
     under the current strategy setting (cnsn_which_path; nothing is launched)."""
     prob = _problem(x, cfg)
     epi = _epilogue(cfg, None) if cfg.has_epilogue else None

@@ -52,8 +52,10 @@ enum cnsn_strategy {
     CNSN_STRATEGY_AUTO = 0,
     CNSN_STRATEGY_TWO_PASS = 1, /* stats kernel -> mid kernel -> apply kernel (3 / 5 tensor passes) */
     CNSN_STRATEGY_RESIDENT = 2, /* one launch, channel kept on chip (2 / 3 tensor passes)            */
-    CNSN_STRATEGY_LOCAL = 3     /* small planes, SelfNorm alone: a whole channel group per workgroup; falls
+    CNSN_STRATEGY_LOCAL = 3,    /* small planes, SelfNorm alone: a whole channel group per workgroup's LDS; falls
                                    back to two-pass where that does not apply                      */
+    CNSN_STRATEGY_MONO = 4      /* small planes, SelfNorm alone: a whole channel in ONE workgroup's registers;
+                                   falls back to the others where that does not apply              */
 };
 
 /* One fused CNSN.forward call (models/cnsn.py:159-164): optional CrossNorm
@@ -193,7 +195,8 @@ enum cnsn_path {
     CNSN_PATH_STREAMING = 0, /* two-pass, 16/64/256 lanes per plane                       */
     CNSN_PATH_PACKED = 1,    /* two-pass, runs of small planes staged through LDS         */
     CNSN_PATH_RESIDENT = 2,  /* one launch, cluster of workgroups per channel             */
-    CNSN_PATH_LOCAL = 3      /* one launch, a whole channel group per workgroup           */
+    CNSN_PATH_LOCAL = 3,     /* one launch, a whole channel group per workgroup (LDS)     */
+    CNSN_PATH_MONO = 4       /* one launch, a whole channel per workgroup (registers)     */
 };
 int cnsn_which_path(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int has_chan_perm, int backward);
 

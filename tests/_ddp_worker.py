@@ -8,8 +8,10 @@ grids) compete for the same compute units.
   1 GPU     : both ranks on cuda:0 (RCCL refuses two ranks on one device -> gloo); the two processes' persistent grids
               share the GPU, and a side stream keeps copy kernels running all the time, like a reduction stream would
 
-Every CNSN site output of the first step is compared bit-for-bit with a no-communication run of the same model /
-input in the same process; the averaged gradients are compared with a manual average of the no-comm gradients."""
+The model is a tower of the 16 CNSN sites of ResNet-50 (block epilogue fused: add + SelfNorm + ReLU) joined by
+deterministic glue, so everything is reproducible bit for bit: every site output of the first step is compared with a
+no-communication run of the same model / input in the same process, and the averaged gradients with the manual average
+of the no-communication gradients."""
 import json
 import os
 import sys
@@ -36,43 +38,69 @@ def main(out_dir, steps=3, batch=32):
 
     import cnsn_amd
     from cnsn_amd import _ffi, data_parallel as dp
-    from cnsn_amd.callers import ResNet50CNSN
+
+    class Tower(torch.nn.Module):
+        """CNSN sites of ResNet-50's stages joined by DETERMINISTIC glue only (element-wise scale by a fat parameter,
+        average pooling between stages): every bit of the forward and of the gradients is reproducible, so the run
+        with communication can be compared bit for bit.  The fat parameters (one (1,C,H,W) tensor per site, 0.8-3 MB)
+        fill many 1 MB buckets whose all-reduces start while the earlier sites' backward launches are still running."""
+
+        def __init__(self):
+            super().__init__()
+            self.stem = torch.nn.Parameter(torch.randn(1, 256, 56, 56) * 0.1 + 1.0)
+            self.sites = torch.nn.ModuleList()
+            self.scales = torch.nn.ParameterList()
+            for c, hw, reps in ((256, 56, 3), (512, 28, 4), (1024, 14, 6), (2048, 7, 3)):
+                for _ in range(reps):
+                    self.sites.append(cnsn_amd.CNSN(None, cnsn_amd.SelfNorm(c)))
+                    self.scales.append(torch.nn.Parameter(torch.randn(1, c, hw, hw) * 0.1 + 1.0))
+            self.plan = [(256, 3), (512, 4), (1024, 6), (2048, 3)]
+            self.record = None                          # a list: site outputs are appended (set by the test)
+
+        def forward(self, x):
+            record = self.record
+            h = x * self.stem
+            i = 0
+            for stage, (c, reps) in enumerate(self.plan):
+                if stage:                                   # halve the plane, double the channels (deterministic ops)
+                    h = torch.nn.functional.avg_pool2d(h, 2)
+                    h = torch.cat([h, -h], 1)
+                for _ in range(reps):
+                    skip = h
+                    h = self.sites[i].forward_block(h * self.scales[i], skip, add_mode="pre", relu=True)
+                    if record is not None:
+                        record.append(h.detach().clone())
+                    i += 1
+            return h.float().mean((2, 3))
 
     def build():
         torch.manual_seed(7)                       # same initial weights on both ranks and in the reference copy
-        return ResNet50CNSN(num_classes=100, cnsn_type="sn", pos="post").to(dev).train()
+        return Tower().to(dev).train()
 
     g = torch.Generator(device=dev).manual_seed(100 + rank)       # ranks own different data
-    xs = [torch.randn(batch, 3, 224, 224, device=dev, generator=g) for _ in range(steps)]
-    ys = [torch.randint(0, 100, (batch,), device=dev, generator=g) for _ in range(steps)]
+    xs = [torch.randn(batch, 256, 56, 56, device=dev, generator=g) for _ in range(steps)]
+    ys = [torch.randint(0, 2048, (batch,), device=dev, generator=g) for _ in range(steps)]
 
     def run(model, net, record):
-        hooks = []
-        if record is not None:      # a bottleneck's output IS its fused add + CNSN + ReLU call (callers/resnet.py)
-            for m in net.modules():
-                if type(m).__name__ == "_Bottleneck":
-                    hooks.append(m.register_forward_hook(lambda _m, _i, o: record.append(o.detach().clone())))
         opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9)
         grads_first = None
         for i in range(steps):
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                loss = torch.nn.functional.cross_entropy(model(xs[i]).float(), ys[i])
+            net.record = record if i == 0 else None
+            out = model(xs[i])
+            loss = torch.nn.functional.cross_entropy(out, ys[i])
             opt.zero_grad(set_to_none=True)
             loss.backward()
             if i == 0:
                 grads_first = [p.grad.detach().clone() for p in net.parameters()]
-                for h in hooks:
-                    h.remove()
-                hooks = []
             opt.step()
         torch.cuda.synchronize()
         return grads_first, float(loss)
 
-    # ---- reference: no communication at all (plain module, nothing else on the device from this process)
+    # ---- reference: no communication at all
     ref_sites = []
     ref_net = build()
     ref_grads, _ = run(ref_net, ref_net, ref_sites)
-    # what DDP must produce for step 1: the average of the ranks' local gradients
+    # what data parallelism must produce for step 1: the average of the ranks' local gradients
     ref_avg = [g_.clone() for g_ in ref_grads]
     for t in ref_avg:
         if backend == "gloo":
@@ -81,14 +109,14 @@ def main(out_dir, steps=3, batch=32):
             t.copy_(h)
         else:
             dist.all_reduce(t)
-        t.div_(world)
+        t.div_(world)                              # (world = 2: exact in binary floating point)
 
     # ---- data-parallel run with communication overlapping the backward
     net = build()
     ddp_sites = []
     mode = "ddp"
     side = torch.cuda.Stream(device=dev)
-    noise_a = torch.empty(64 << 20, device=dev)
+    noise_a = torch.zeros(64 << 20, device=dev)
     noise_b = torch.empty_like(noise_a)
     try:
         model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index] if backend == "nccl" else None,
@@ -104,15 +132,19 @@ def main(out_dir, steps=3, batch=32):
         dp.allreduce_gradients(net.parameters())
     torch.cuda.synchronize()
 
-    same_sites = len(ref_sites) == len(ddp_sites) == 16 and all(torch.equal(a, b) for a, b in zip(ref_sites, ddp_sites))
-    grad_err = 0.0
+    n_sites = len(net.sites)
+    site_diff = [float((a.float() - b.float()).abs().max()) for a, b in zip(ref_sites, ddp_sites)]
+    same_sites = len(ref_sites) == len(ddp_sites) == n_sites and all(torch.equal(a, b) for a, b in zip(ref_sites, ddp_sites))
+    grad_err, grads_equal = 0.0, mode == "ddp"
     if mode == "ddp":
         for a, b in zip(ddp_grads, ref_avg):
-            grad_err = max(grad_err, float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12)))
+            grad_err = max(grad_err, float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-30)))
+            grads_equal = grads_equal and torch.equal(a, b)
     paths = sorted({cnsn_amd.which_path(s, cnsn_amd.FusedConfig(sn_active=True, add_mode="pre", relu=True), bw)
                     for s in ref_sites for bw in (False, True)})
     res = dict(rank=rank, world=world, backend=backend, shared_device=shared, mode=mode, sites=len(ddp_sites),
-               site_outputs_bit_identical=bool(same_sites), grad_rel_err=grad_err,
+               site_outputs_bit_identical=bool(same_sites), site_max_abs_diff=max(site_diff) if site_diff else None,
+               grad_rel_err=grad_err, grads_bit_identical=bool(grads_equal),
                timeouts=int(_ffi.lib().cnsn_resident_timeouts()), paths=paths, loss=last_loss,
                finite=bool(np.isfinite(last_loss)))
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:

@@ -21,13 +21,17 @@ TABLE = [
     ((256, 256, 56, 56), BF16, FC(**SN, **CN), "resident", "resident"),
     ((256, 256, 56, 56), BF16, FC(**SN, **BOTH), "streaming", "streaming"),    # 16-bit boxed 56x56: two-pass
     ((256, 512, 28, 28), BF16, FC(**SN, **BOTH), "resident", "resident"),      # <= 4 slots: always resident
-    ((256, 1024, 14, 14), BF16, FC(**SN), "resident", "resident"),             # image of a channel does not fit LDS
-    ((96, 1024, 14, 14), BF16, FC(**SN), "local", "resident"),                 # fwd fits (38 KiB), bwd would need 75
+    ((256, 1024, 14, 14), BF16, FC(**SN), "mono", "mono"),                     # a channel = 100 KiB: one workgroup's registers
+    ((256, 1024, 14, 14), BF16, FC(**BLOCK), "mono", "mono"),
+    ((256, 1024, 14, 14), F32, FC(**SN), "mono", "resident"),                  # fp32 backward: G and x = 128 VGPRs per lane
+    ((96, 1024, 14, 14), BF16, FC(**SN), "mono", "mono"),
+    ((256, 1024, 14, 14), BF16, FC(**SN, **CN), "resident", "resident"),       # CrossNorm: not channel-in-registers
     ((256, 2048, 7, 7), BF16, FC(**SN), "local", "local"),                     # resident cannot take 98-byte planes
     ((256, 2048, 7, 7), BF16, FC(**BLOCK), "local", "local"),
     ((256, 2048, 7, 7), BF16, FC(**SN, **CN), "packed", "packed"),             # CrossNorm: not channel-local
     ((256, 2048, 7, 7), F32, FC(**SN), "local", "packed"),                     # fp32 backward image = 100 KiB: two-pass
-    ((128, 128, 8, 8), F32, FC(**SN), "local", "local"),
+    ((128, 128, 8, 8), F32, FC(**SN), "mono", "mono"),                        # 256-byte planes, 16 lanes each
+    ((128, 64, 16, 16), F32, FC(**SN), "mono", "mono"),                        # WideResNet stage 2
     ((128, 32, 32, 32), F32, FC(**SN, **BOTH), "resident", "resident"),        # WideResNet stage 1
     ((768, 3, 224, 224), F32, FC(**CN), "streaming", "streaming"),             # image-level CrossNorm: 12544 vectors
     ((16, 256, 128, 128), F32, FC(**SN), "streaming", "streaming"),
@@ -47,7 +51,7 @@ def test_auto_resolves_as_measured(shape, dtype, cfg, fwd, bwd):
 def test_forced_strategies_fall_back():
     x = torch.empty((8, 4, 224, 224), dtype=F32, device="meta")
     try:
-        for name in ("two_pass", "resident", "local"):
+        for name in ("two_pass", "resident", "local", "mono"):
             cnsn_amd.set_strategy(name)
             assert which_path(x, FC(**SN)) == "streaming"          # too large for any single-touch strategy
         cnsn_amd.set_strategy("two_pass")

@@ -40,12 +40,12 @@ def oracle_run(x, gy, kind, crop, draws, c, dtype64):
     """the oracle's eager ops on the GPU in fp32 or fp64, on the SAME (already quantised) x / gy"""
     dt = torch.float64 if dtype64 else torch.float32
     sn = fill_sn(orc.SelfNorm(c), 4, dt).to(DEV).train() if kind != "cn" else None
-    xo = x.to(dt).requires_grad_()
+    xo = x.detach().to(dt).clone().requires_grad_()
     u = xo
     if kind != "sn":
         u = orc.cn_op_2ins_space_chan(u, crop=crop, draws=orc.CNDraws(draws.perm, draws.style_box, None, draws.content_box))
     y = sn(u) if sn is not None else u
-    y.backward(gy.to(dt))
+    y.backward(gy.detach().to(dt))
     res = {"y": y.detach(), "dx": xo.grad}
     if sn is not None:
         res["dw"] = sn.g_fc.weight.grad
@@ -62,7 +62,7 @@ def hip_run(x, gy, kind, crop, draws, c):
     if mod.crossnorm is not None:
         mod.crossnorm.active = True
         mod.crossnorm.next_draws = draws
-    xg = x.clone().requires_grad_()
+    xg = x.detach().clone().requires_grad_()
     y = mod(xg)
     y.backward(gy)
     torch.cuda.synchronize()
@@ -136,7 +136,7 @@ def test_wideresnet_sites_full_size(shape, kind, crop):
 
 # the forced strategies at the full-size small-plane sites (AUTO picks one of them per direction; the others are the
 # fall-backs a different N or a CrossNorm-armed step lands on)
-@pytest.mark.parametrize("strategy", ["two_pass", "resident", "local"])
+@pytest.mark.parametrize("strategy", ["two_pass", "resident", "local", "mono"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
 @pytest.mark.parametrize("shape", [(256, 1024, 14, 14), (256, 2048, 7, 7), (256, 512, 28, 28)], ids=ids)
 def test_small_plane_sites_every_strategy(shape, dtype, strategy):

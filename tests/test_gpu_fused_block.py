@@ -32,7 +32,7 @@ SHAPES = [
 ]
 
 
-@pytest.fixture(params=["two_pass", "resident", "local"])
+@pytest.fixture(params=["two_pass", "resident", "local", "mono"])
 def strategy(request):
     cnsn_amd.set_strategy(request.param)
     yield request.param

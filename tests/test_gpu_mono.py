@@ -1,0 +1,79 @@
+"""The channel-in-registers strategy (cnsn_mono_kernels.h): one 1024-thread workgroup per channel holds every plane of
+the channel in registers.  One case per geometry class — lanes per plane (16 / 64) x slot rows per wave (8 / 16) x
+vector width (8 / 16 bytes) x element type — through SelfNorm alone (training and inference) and the residual-block
+epilogue (PRE add, ReLU), forward and backward, against the CPU oracle in fp64; every case asserts that the mono
+kernels are what ran."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import cnsn_amd  # noqa: E402
+from tests.test_gpu_fused_block import check as check_block, run_case as run_block  # noqa: E402
+from tests.test_gpu_parity import assert_parity, run_pair  # noqa: E402
+
+F32, BF16, F16 = torch.float32, torch.bfloat16, torch.float16
+# (shape, dtype): what the geometry resolves to is noted per line (vector bytes, lanes per plane, slot rows per wave)
+CASES = [
+    ((37, 5, 14, 14), F32),     # 16 B, 49 of 64 lanes, R = 3           (ResNet-50 stage 3 plane)
+    ((256, 3, 14, 14), F32),    # 16 B, 64 lanes, R = 16: the full-size channel, forward only (backward: other paths)
+    ((256, 3, 14, 14), BF16),   # 8 B,  64 lanes, R = 16, both directions
+    ((96, 4, 14, 14), BF16),    # R = 6
+    ((128, 4, 16, 16), F32),    # 16 B, all 64 lanes, R = 8             (WideResNet stage 2)
+    ((128, 4, 16, 16), F16),    # 16 B, 32 of 64 lanes
+    ((130, 3, 8, 8), F32),      # 16 B, 16 lanes per plane, 4 planes per row, R = 3
+    ((1000, 2, 8, 8), F32),     # 16 lanes, R = 16: 1000 planes per channel
+    ((33, 4, 8, 8), BF16),      # 8 B (16-byte vectors would leave 8 per plane), 16 lanes
+    ((20, 6, 12, 12), F32),     # 36 vectors
+    ((17, 3, 6, 10), F32),      # 15 vectors of 16 B -> 16 lanes, one idle
+    ((64, 2, 10, 10), BF16),    # 25 vectors of 8 B
+    ((18, 2, 2, 6), F32),       # tiny plane (3 vectors)
+]
+ids = lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v).replace("torch.", "")  # noqa: E731
+
+
+@pytest.fixture(autouse=True)
+def mono():
+    cnsn_amd.set_strategy("mono")
+    yield
+    cnsn_amd.set_strategy("auto")
+
+
+def runs_mono(shape, dtype, backward, **cfg):
+    x = torch.empty(shape, dtype=dtype, device="cuda")
+    return cnsn_amd.which_path(x, cnsn_amd.FusedConfig(sn_active=True, **cfg), backward=backward) == "mono"
+
+
+@pytest.mark.parametrize("shape,dtype", CASES, ids=ids)
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+def test_selfnorm(shape, dtype, training):
+    assert runs_mono(shape, dtype, False, sn_training=training)
+    out = run_pair(shape, "neither", "sn", dtype, 4000 + shape[0] + shape[2], training=training)
+    assert_parity(out, dtype, ("mono", shape, dtype, training))
+
+
+@pytest.mark.parametrize("shape,dtype", CASES, ids=ids)
+@pytest.mark.parametrize("mode,relu", [("pre", True), ("pre", False), ("none", True)])
+def test_block_epilogue(shape, dtype, mode, relu):
+    assert runs_mono(shape, dtype, False, add_mode=mode, relu=relu)
+    check_block(run_block(shape, "sn", "neither", mode, relu, dtype, 4100 + shape[0] + shape[3]), dtype, relu,
+                ("mono", shape, dtype, mode, relu))
+
+
+def test_what_mono_declines():
+    FC = cnsn_amd.FusedConfig
+    x = torch.empty((8, 4, 14, 14), device="cuda")
+    assert cnsn_amd.which_path(x, FC(sn_active=True, cn_active=True)) != "mono"            # CrossNorm
+    assert cnsn_amd.which_path(x, FC(sn_active=True, sn_two=True)) != "mono"               # two-gate form
+    assert cnsn_amd.which_path(x, FC(sn_active=True, add_mode="post")) != "mono"           # POST add
+    assert cnsn_amd.which_path(torch.empty((8, 4, 7, 7), device="cuda"), FC(sn_active=True)) != "mono"     # odd plane
+    assert cnsn_amd.which_path(torch.empty((8, 4, 28, 28), device="cuda"), FC(sn_active=True)) != "mono"   # 196 vectors
+    big = torch.empty((256, 4, 14, 14), device="cuda")
+    assert cnsn_amd.which_path(big, FC(sn_active=True), backward=False) == "mono"
+    assert cnsn_amd.which_path(big, FC(sn_active=True), backward=True) != "mono"          # fp32: G and x do not fit
+    cnsn_amd.set_strategy("auto")
+    assert cnsn_amd.which_path(torch.empty((256, 1024, 14, 14), dtype=BF16, device="cuda"), FC(sn_active=True), backward=True) == "mono"
+    assert cnsn_amd.which_path(torch.empty((8, 4, 14, 14), device="cuda"), FC(sn_active=True)) != "mono"   # N < 16 under AUTO

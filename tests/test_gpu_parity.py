@@ -25,7 +25,7 @@ from oracle import cnsn_oracle as orc  # noqa: E402
 from tests.golden.gen_golden_fill import fill_sn  # noqa: E402
 
 DEV = torch.device("cuda:0")
-STRATEGIES = ["two_pass", "resident", "local"]
+STRATEGIES = ["two_pass", "resident", "local", "mono"]
 
 
 def t(a):
