@@ -25,7 +25,8 @@ class Problem(C.Structure):
         ("lam", C.c_float), ("eps_cn", C.c_float),
         ("sn_active", C.c_int32), ("sn_two", C.c_int32), ("sn_training", C.c_int32),
         ("eps_sn", C.c_float), ("eps_bn", C.c_float), ("momentum", C.c_float),
-        ("strategy", C.c_int32),
+        ("strategy", C.c_int32), ("reserved", C.c_int32),
+        ("context", C.c_void_p), ("context_bytes", C.c_uint64),
     ]
 
 
@@ -50,6 +51,8 @@ class Epilogue(C.Structure):
 SIGNATURES = {
     "cnsn_abi_version": (C.c_int, []),
     "cnsn_status_string": (C.c_char_p, [C.c_int]),
+    "cnsn_context_bytes": (C.c_size_t, [C.POINTER(Problem)]),
+    "cnsn_context_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "cnsn_resident_timeouts": (C.c_int, []),
     "cnsn_resident_enable": (None, [C.c_int]),
     "cnsn_saved_floats": (C.c_size_t, [C.POINTER(Problem)]),

@@ -13,6 +13,7 @@
 #include "cnsn_mid_kernels.h"
 #include "cnsn_mono.h"
 #include "cnsn_packed.h"
+#include "cnsn_resident_fused.h"
 #include "cnsn_resident_kernels.h"
 #include "cnsn_stream_kernels.h"
 
@@ -51,6 +52,27 @@ void launch_mid_bwd(const Plan& pl, const float* sums, const double* saved, cons
 extern "C" {
 
 int cnsn_abi_version(void) { return CNSN_ABI_VERSION; }
+
+size_t cnsn_context_bytes(const cnsn_problem_t* prob) {
+    Plan pl;
+    if (make_plan(prob, pl) != CNSN_OK) return 0;
+    const cnsn_problem_t& p = pl.pr;
+    bool any = false;
+    for (int bw = 0; bw < 2 && !any; ++bw)
+        any = resident_plan(p, pl.boxed, false, bw != 0).ok || resident_fused_plan(p, pl.boxed, false, CNSN_ADD_PRE, bw != 0).ok;
+    // control block + one tagged granule per exchanged scalar (six per plane forward with crop boxes: the most)
+    return any ? kCtlBytes + (size_t)p.N * p.C * 6 * 8 : 0;
+}
+
+int cnsn_context_init(void* context, size_t bytes, void* stream) {
+    if (!context) return CNSN_E_NULL;
+    if (((uintptr_t)context & 15u) != 0) return CNSN_E_ALIGN;
+    if (bytes < (size_t)kCtlBytes) return CNSN_E_WORKSPACE;
+    const hipError_t e = hipMemsetAsync(context, 0, bytes, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    resident_context_forget(context);
+    return CNSN_OK;
+}
 
 int cnsn_resident_timeouts(void) { return resident_timeouts(); }
 void cnsn_resident_enable(int on) { resident_set_enabled(on != 0); }

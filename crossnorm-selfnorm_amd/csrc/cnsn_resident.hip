@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 
 namespace cnsn {
 
@@ -45,6 +46,48 @@ bool resident_auto_enabled() {
 }
 
 void resident_set_enabled(bool on) { g_enabled.store(on ? 1 : 0, std::memory_order_relaxed); }
+
+namespace {
+std::mutex g_ctx_mu;
+std::unordered_map<void*, unsigned> g_ctx_epoch;  // launches counted per context (host side)
+}  // namespace
+
+void resident_context_forget(void* context) {
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    g_ctx_epoch[context] = 0;
+}
+
+ExchangeArea resident_exchange_area(const cnsn_problem_t& p, size_t tagged_bytes, void* workspace, hipStream_t stream) {
+    ExchangeArea ea{workspace, 0u};
+    if (!p.context || p.context_bytes < tagged_bytes) return ea;
+    if (const char* e = getenv("CNSN_CONTEXT"))
+        if (e[0] == '0') return ea;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return ea;  // a captured launch would replay its number: exchange through the workspace instead
+    }
+    unsigned epoch;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mu);
+        auto it = g_ctx_epoch.find(p.context);
+        if (it == g_ctx_epoch.end()) return ea;  // never initialised through cnsn_context_init: not trusted
+        if (const char* e = getenv("CNSN_EPOCH_START"))  // (tests: start close to the wrap-around)
+            if (it->second == 0) it->second = (unsigned)strtoul(e, nullptr, 0);
+        epoch = ++it->second;
+        if (epoch == 0) {  // wrapped: every tag in the context is stale-but-plausible now — clear it once, in order
+            if (hipMemsetAsync(p.context, 0, (size_t)p.context_bytes, stream) != hipSuccess) {
+                (void)hipGetLastError();
+                it->second = 0xffffffffu;  // try again next time
+                return ea;
+            }
+            epoch = it->second = 1;
+        }
+    }
+    ea.base = p.context;
+    ea.epoch = epoch;
+    return ea;
+}
 
 namespace {
 struct ChainState {

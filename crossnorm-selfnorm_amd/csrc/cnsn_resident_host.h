@@ -106,6 +106,8 @@ static inline ResArgs make_args(const cnsn_problem_t& p, Box cb, Box sb, const M
     const char* st = getenv("CNSN_STAGGER");
     ra.stagger = st ? atoi(st) : 0;
     ra.prof = nullptr;
+    ra.epoch = 0;
+    ra.ctl_idle = kCtlIdle;
     ra.host_flag = resident_host_flag();
     const char* wm = getenv("CNSN_WAIT_MS");
     ra.wait_ticks = (wm && atoll(wm) > 0) ? atoll(wm) * 100000ll : kWaitLimitTicks;
@@ -193,9 +195,13 @@ int forward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidA
     if (getenv("CNSN_PROF")) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
 #endif
     const size_t lds = res_lds_bytes(p.N, NG, 4 * rp.ppw, FC_ROWS, false);
-    unsigned* ctl = (unsigned*)workspace;
-    unsigned long long* gran = (unsigned long long*)((char*)workspace + kCtlBytes);
-    const size_t fill_bytes = kCtlBytes + (size_t)p.N * p.C * (NG / 2) * 8;  // control block + granules
+    const ExchangeArea ea = solo ? ExchangeArea{workspace, 0u}
+                                 : resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NG * 8, workspace, stream);
+    ra.epoch = ea.epoch;
+    ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
+    unsigned* ctl = (unsigned*)ea.base;
+    unsigned long long* gran = (unsigned long long*)((char*)ea.base + kCtlBytes);
+    const size_t fill_bytes = kCtlBytes + (size_t)p.N * p.C * (NG / 2) * 8;  // control block + granules (workspace form)
     int status = CNSN_E_UNSUPPORTED;
     dispatch_res<false, EPI>(p.dtype, rp.vec, rp.nv, [&](auto tt, auto vt, auto nt, auto pt) {
         using T = typename decltype(tt)::type;
@@ -209,7 +215,7 @@ int forward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidA
                                                     relu);
             } else {
                 ResidentChain chain(stream);  // cluster grids of different streams never overlap
-                e = hipMemsetAsync(workspace, 0xff, fill_bytes, stream);  // 'empty' granules, idle control word
+                if (!ea.epoch) e = hipMemsetAsync(workspace, 0xff, fill_bytes, stream);  // 'empty' granules, idle control word
                 if (e != hipSuccess) {
                     status = (int)e;
                     return;
@@ -242,8 +248,11 @@ int backward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const Mid
     if (getenv("CNSN_PROF")) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
 #endif
     const size_t lds = res_lds_bytes(p.N, NS, 4 * rp.ppw, BC_ROWS, true);
-    unsigned* ctl = (unsigned*)workspace;
-    unsigned long long* gran = (unsigned long long*)((char*)workspace + kCtlBytes);
+    const ExchangeArea ea = resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NS * 8, workspace, stream);
+    ra.epoch = ea.epoch;
+    ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
+    unsigned* ctl = (unsigned*)ea.base;
+    unsigned long long* gran = (unsigned long long*)((char*)ea.base + kCtlBytes);
     const size_t fill_bytes = kCtlBytes + (size_t)p.N * p.C * (NS / 2) * 8;
     int status = CNSN_E_UNSUPPORTED;
     dispatch_res<true, EPI>(p.dtype, rp.vec, rp.nv, [&](auto tt, auto vt, auto nt, auto pt) {
@@ -253,7 +262,7 @@ int backward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const Mid
             const int grid = grid_for(kern, lds, rp.K, ra.items);
             if (grid < rp.K) return;
             ResidentChain chain(stream);  // cluster grids of different streams never overlap
-            hipError_t e = hipMemsetAsync(workspace, 0xff, fill_bytes, stream);  // 'empty' granules, idle control word
+            hipError_t e = ea.epoch ? hipSuccess : hipMemsetAsync(workspace, 0xff, fill_bytes, stream);  // 'empty' granules
             if (e != hipSuccess) {
                 status = (int)e;
                 return;

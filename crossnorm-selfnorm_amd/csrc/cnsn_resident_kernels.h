@@ -50,6 +50,10 @@ struct ResArgs {
     int K;      // workgroups per channel
     int items;  // C * K
     int stagger;  // start-up skew between clusters, in units of s_sleep(127) (~3.4 us)
+    unsigned epoch;       // 0: granules are float PAIRS in a workspace memset to all-ones before the launch;
+                          // > 0: ONE float + this tag per granule, in a persistent context that is never cleared
+                          // (cnsn_context_init): a granule is present when its tag equals the launch's epoch
+    unsigned ctl_idle;    // value of the control word while nobody has given up (all-ones after the memset, 0 in a context)
     unsigned* host_flag;  // pinned host word counting timed-out launches (NULL: not available)
     long long wait_ticks;  // bound of a cluster wait in 100 MHz ticks (default 5 s; CNSN_WAIT_MS)
     int fault;             // tests only (CNSN_FAULT_INJECT=1): the last member of channel 0's cluster never publishes
@@ -99,19 +103,35 @@ __device__ __forceinline__ void put_granule(unsigned long long* p, float lo, flo
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// tagged form (persistent context): one float + the launch's epoch per granule
+__device__ __forceinline__ void put_tagged(unsigned long long* p, float v, unsigned epoch) {
+    __hip_atomic_store((gu64*)p, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ONE wave gathers `total` granules (2*total floats) into LDS; re-reads all of them until none is empty.
 // Returns false when it gave up (time-out, or another workgroup already did): the caller's workgroup must leave.
+// (epoch > 0: `total` granules of ONE float each, present when the tag matches — see ResArgs::epoch)
 __device__ __forceinline__ bool sweep_granules(const unsigned long long* g, int total, float* vals, unsigned* ctl,
-                                               unsigned* host_flag, long long wait_ticks, unsigned& passes) {
+                                               unsigned* host_flag, long long wait_ticks, unsigned& passes, unsigned epoch,
+                                               unsigned ctl_idle) {
     const int lane = threadIdx.x & 63;
     long long t_start = 0;
     for (unsigned spins = 0;; ++spins) {
         bool ok = true;
-        for (int i = lane; i < total; i += 64) {
-            const unsigned long long v = __hip_atomic_load((gu64*)(g + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok &= v != kGranuleEmpty;
-            vals[2 * i] = __uint_as_float((unsigned)v);
-            vals[2 * i + 1] = __uint_as_float((unsigned)(v >> 32));
+        if (epoch) {
+            for (int i = lane; i < total; i += 64) {
+                const unsigned long long v = __hip_atomic_load((gu64*)(g + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok &= (unsigned)(v >> 32) == epoch;
+                vals[i] = __uint_as_float((unsigned)v);
+            }
+        } else {
+            for (int i = lane; i < total; i += 64) {
+                const unsigned long long v = __hip_atomic_load((gu64*)(g + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok &= v != kGranuleEmpty;
+                vals[2 * i] = __uint_as_float((unsigned)v);
+                vals[2 * i + 1] = __uint_as_float((unsigned)(v >> 32));
+            }
         }
         passes = spins + 1;
         if (__all(ok)) return true;
@@ -120,7 +140,7 @@ __device__ __forceinline__ bool sweep_granules(const unsigned long long* g, int 
             const long long now = (long long)wall_clock64();
             if (t_start == 0) t_start = now;
             const unsigned seen = __hip_atomic_load((gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (seen != kCtlIdle) return false;  // somebody gave up already: drain
+            if (seen != ctl_idle) return false;  // somebody gave up already: drain
             if (now - t_start > wait_ticks) {
                 // A cluster member never published: part of the grid was kept off the device for seconds (the GPU
                 // is shared with something that never yields).  The FIRST workgroup to notice flips the control
@@ -128,7 +148,7 @@ __device__ __forceinline__ bool sweep_granules(const unsigned long long* g, int 
                 // outputs of this launch are incomplete, which the host learns from cnsn_resident_timeouts().
                 if (lane == 0) {
                     const unsigned prev = __hip_atomic_exchange((gu32*)ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (prev == kCtlIdle && host_flag)
+                    if (prev == ctl_idle && host_flag)
                         __hip_atomic_fetch_add(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
                 return false;
@@ -229,7 +249,7 @@ __device__ __forceinline__ bool sweep_granules_scalar(const unsigned long long* 
         if ((spins & 15u) == 15u) {
             const long long now = (long long)wall_clock64();
             if (t_start == 0) t_start = now;
-            if (sload_glc_u32(ctl) != kCtlIdle) return false;  // somebody gave up already: drain
+            if (sload_glc_u32(ctl) != kCtlIdle) return false;  // somebody gave up already: drain (untagged workspace only)
             if (now - t_start > wait_ticks) {
                 if (lane == 0) {
                     const unsigned prev = __hip_atomic_exchange((gu32*)ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -589,7 +609,14 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
                 solo_m2[s] = pub[1];
                 continue;
             }
-            if (n < N && lane < NG / 2 && !(ra.fault && item == ra.K - 1)) {  // lane m publishes (pub[2m], pub[2m+1])
+            if (ra.epoch) {  // persistent context: lane m publishes pub[m] with the launch's tag
+                if (n < N && lane < NG && !(ra.fault && item == ra.K - 1)) {
+                    float v = pub[0];
+#pragma unroll
+                    for (int m = 1; m < NG; ++m) v = (lane == m) ? pub[m] : v;
+                    put_tagged(gran + ((size_t)c * N + n) * NG + lane, v, ra.epoch);
+                }
+            } else if (n < N && lane < NG / 2 && !(ra.fault && item == ra.K - 1)) {  // lane m publishes (pub[2m], pub[2m+1])
                 float lo = pub[0], hi = pub[1];
 #pragma unroll
                 for (int m = 1; m < NG / 2; ++m) {
@@ -667,7 +694,10 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
             if (lane == 0) *gave_up = 1;
 #else
         if (wave == 0) {
-            const bool got = sweep_granules(gran + (size_t)c * N * (NG / 2), N * (NG / 2), vals, ctl, ra.host_flag, ra.wait_ticks, passes_);
+            const bool got = ra.epoch ? sweep_granules(gran + (size_t)c * N * NG, N * NG, vals, ctl, ra.host_flag, ra.wait_ticks,
+                                                        passes_, ra.epoch, ra.ctl_idle)
+                                      : sweep_granules(gran + (size_t)c * N * (NG / 2), N * (NG / 2), vals, ctl, ra.host_flag,
+                                                        ra.wait_ticks, passes_, 0u, ra.ctl_idle);
             if (lane == 0 && !got) *gave_up = 1;
         }
 #endif
@@ -1028,7 +1058,14 @@ __global__ __launch_bounds__(kBlock, EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV
                 }
 #pragma unroll
             for (int m = 0; m < NS; ++m) acc[m] = wave_sum(acc[m]);
-            if (n < N && lane < NS / 2 && !(ra.fault && item == ra.K - 1)) {
+            if (ra.epoch) {
+                if (n < N && lane < NS && !(ra.fault && item == ra.K - 1)) {
+                    float v = acc[0];
+#pragma unroll
+                    for (int m = 1; m < NS; ++m) v = (lane == m) ? acc[m] : v;
+                    put_tagged(gran + ((size_t)c * N + n) * NS + lane, v, ra.epoch);
+                }
+            } else if (n < N && lane < NS / 2 && !(ra.fault && item == ra.K - 1)) {
                 float lo = acc[0], hi = acc[1];
 #pragma unroll
                 for (int m = 1; m < NS / 2; ++m) {
@@ -1052,7 +1089,10 @@ __global__ __launch_bounds__(kBlock, EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV
             if (lane == 0) *gave_up = 1;
 #else
         if (wave == 0) {
-            const bool got = sweep_granules(gran + (size_t)c * N * (NS / 2), N * (NS / 2), vals, ctl, ra.host_flag, ra.wait_ticks, passes_);
+            const bool got = ra.epoch ? sweep_granules(gran + (size_t)c * N * NS, N * NS, vals, ctl, ra.host_flag, ra.wait_ticks,
+                                                        passes_, ra.epoch, ra.ctl_idle)
+                                      : sweep_granules(gran + (size_t)c * N * (NS / 2), N * (NS / 2), vals, ctl, ra.host_flag,
+                                                        ra.wait_ticks, passes_, 0u, ra.ctl_idle);
             if (lane == 0 && !got) *gave_up = 1;
         }
 #endif
@@ -1266,6 +1306,16 @@ int resident_timeouts();
 // AUTO may choose the cluster kernels: not switched off (cnsn_resident_enable(0) / CNSN_RESIDENT=0), no time-out seen
 bool resident_auto_enabled();
 void resident_set_enabled(bool on);
+
+// Exchange area of a launch: the caller's persistent context when it is usable (big enough, stream not capturing) — then
+// `epoch` is the context's next launch number (> 0) and nothing is cleared — or the workspace with epoch 0 (memset).
+// A wrap of the counter clears the context on the stream first.  Returns the area's base.
+struct ExchangeArea {
+    void* base;
+    unsigned epoch;
+};
+ExchangeArea resident_exchange_area(const cnsn_problem_t& p, size_t tagged_bytes, void* workspace, hipStream_t stream);
+void resident_context_forget(void* context);
 
 struct ResidentChain {
     explicit ResidentChain(hipStream_t stream);

@@ -147,6 +147,33 @@ cnsn_problem_t make_problem(const Tensor& x, const Config& c) {
     return p;
 }
 
+// The persistent exchange context of the cluster-resident kernels (cnsn_context_init, include/cnsn_hip.h): one buffer
+// per device, grown when a larger problem shows up; left out while the stream is being captured into a graph.
+void attach_context(cnsn_problem_t& p, const at::Device& dev, hipStream_t stream) {
+    p.context = nullptr;
+    p.context_bytes = 0;
+    const size_t need = cnsn_context_bytes(&p);
+    if (need == 0) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return;
+    }
+    static std::mutex mu;
+    static std::unordered_map<int, Tensor> ctx;
+    std::lock_guard<std::mutex> lock(mu);
+    Tensor& have = ctx[(int)dev.index()];
+    if (!have.defined() || (size_t)have.numel() < need) {
+        const size_t size = std::max(need, have.defined() ? 2 * (size_t)have.numel() : (size_t)(4u << 20));
+        Tensor buf = at::empty({(int64_t)size}, at::TensorOptions().dtype(at::kByte).device(dev));
+        check_status(cnsn_context_init(buf.data_ptr(), size, (void*)stream), "cnsn_context_init");
+        TORCH_CHECK(hipStreamSynchronize(stream) == hipSuccess, "cnsn: hipStreamSynchronize");   // once per buffer
+        have = buf;
+    }
+    p.context = have.data_ptr();
+    p.context_bytes = (uint64_t)have.numel();
+}
+
 struct GateTensors {  // float32 contiguous views/copies + where running stats must be copied back to
     Tensor w, gamma, beta, rm, rv, rm_src, rv_src;
     bool direct = true;
@@ -203,10 +230,11 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
                         "cnsn_forward: the addend must be a device tensor of x's shape and dtype");
             addend = dense(*addend_in);
         }
-        const cnsn_problem_t prob = make_problem(x, c);
+        cnsn_problem_t prob = make_problem(x, c);
         const cnsn_epilogue_t epi = make_epilogue(c, addend);
         const bool has_epi = c.add_mode != CNSN_ADD_NONE || c.relu;
         const at::Device dev = x.device();
+        attach_context(prob, dev, c10::hip::getCurrentHIPStream(dev.index()).stream());
         Tensor perm, chan;
         if (c.cn_active) {
             TORCH_CHECK(perm_in.has_value(), "cnsn_forward: CrossNorm needs the batch permutation");
@@ -261,10 +289,11 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
         const auto fcfg = ctx->saved_data["fcfg"].toDoubleVector();
         const auto pd = ctx->saved_data["pd"].toIntVector();
         const Config c = parse_config(cfg, fcfg);
-        const cnsn_problem_t prob = make_problem(x, c);
+        cnsn_problem_t prob = make_problem(x, c);
         const bool two = c.sn_active && c.sn_two;
         const at::Device dev = x.device();
         const c10::DeviceGuard device_guard(dev);
+        attach_context(prob, dev, c10::hip::getCurrentHIPStream(dev.index()).stream());
 
         Tensor gy = grads[0];
         if (gy.scalar_type() != x.scalar_type()) gy = gy.to(x.scalar_type());

@@ -93,10 +93,34 @@ def _sizes(prob):
     hit = _size_cache.get(key)
     if hit is None:
         lib = _ffi.lib()
-        hit = (lib.cnsn_saved_floats(C.byref(prob)), lib.cnsn_workspace_bytes(C.byref(prob)))
+        hit = (lib.cnsn_saved_floats(C.byref(prob)), lib.cnsn_workspace_bytes(C.byref(prob)),
+               lib.cnsn_context_bytes(C.byref(prob)))
         if hit[1] > 0:          # 0 = the library rejected the problem: let the launch report why
             _size_cache[key] = hit
     return hit
+
+
+# The persistent exchange context of the cluster-resident kernels (cnsn_context_init): ONE buffer per device, grown
+# when a larger problem shows up, allocated and initialised on first use.  With it a resident launch needs no fill
+# launch in front of it.  None while the stream is being captured into a graph (a replay would repeat the launch number).
+_contexts = {}
+
+
+def _context(prob, dev: torch.device):
+    need = _sizes(prob)[2]
+    if need == 0 or torch.cuda.is_current_stream_capturing():
+        return
+    have = _contexts.get(dev.index)
+    if have is None or have.numel() < need:
+        size = max(need, 2 * have.numel() if have is not None else (4 << 20))
+        buf = torch.empty(size, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev)
+        _ffi.check(_ffi.lib().cnsn_context_init(C.c_void_p(buf.data_ptr()), size, C.c_void_p(stream.cuda_stream)),
+                   "cnsn_context_init")
+        stream.synchronize()            # once per buffer: ordered before whichever stream uses it next
+        _contexts[dev.index] = have = buf
+    prob.context = have.data_ptr()
+    prob.context_bytes = have.numel()
 
 
 class _PinnedRing:
@@ -250,6 +274,7 @@ class FusedCNSN(torch.autograd.Function):
             addend = None
         prob = _problem(x, cfg)
         dev = x.device
+        _context(prob, dev)
         if cfg.cn_active:
             perm = _h2d.to_device(perm, dev)
             if chan_perm is not None:
@@ -258,7 +283,7 @@ class FusedCNSN(torch.autograd.Function):
         gate_f = _GateBuffers(f_w, f_gamma, f_beta, f_rm, f_rv) if (cfg.sn_active and cfg.sn_two) else None
         y = torch.empty_like(x)
         need_bwd = any(ctx.needs_input_grad)
-        saved_floats, ws_bytes = _sizes(prob)
+        saved_floats, ws_bytes = _sizes(prob)[:2]
         saved = torch.empty(saved_floats, dtype=torch.float32, device=dev) if need_bwd else None
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
         epi = _epilogue(cfg, addend) if cfg.has_epilogue else None
@@ -294,6 +319,9 @@ class FusedCNSN(torch.autograd.Function):
         dev = x.device
         dx = torch.empty_like(x)
         ws_bytes = _sizes(prob)[1]
+        _context(prob, dev)     # (the buffer may have grown since the forward; None under graph capture)
+        if torch.cuda.is_current_stream_capturing():
+            prob.context, prob.context_bytes = None, 0
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
         Cn = x.shape[1]
 

@@ -78,6 +78,12 @@ typedef struct cnsn_problem {
     float eps_bn;         /* BatchNorm1d eps, 1e-5                                           */
     float momentum;       /* BatchNorm1d momentum, 0.1                                       */
     int32_t strategy;     /* enum cnsn_strategy                                              */
+    int32_t reserved;     /* 0                                                               */
+    /* Optional persistent exchange context of the cluster-resident kernels (see cnsn_context_init): device memory
+     * the caller allocates ONCE per device and passes with every call.  NULL / too small: the kernels exchange
+     * through `workspace`, which costs one fill launch in front of every resident launch.                       */
+    void* context;
+    uint64_t context_bytes;
 } cnsn_problem_t;
 
 /* Parameters / buffers of one SelfNorm gate: g_fc + g_bn (or f_fc + f_bn), models/cnsn.py:118-126.
@@ -199,6 +205,22 @@ enum cnsn_path {
     CNSN_PATH_MONO = 4       /* one launch, a whole channel per workgroup (registers)     */
 };
 int cnsn_which_path(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int has_chan_perm, int backward);
+
+/* ---- persistent exchange context of the cluster-resident strategy --------------------------------
+ * The resident kernels hand per-plane scalars from workgroup to workgroup through device memory.  Through the
+ * per-call `workspace` (contents unknown) that memory has to be filled with an 'empty' pattern by a launch of its own
+ * before every resident launch.  A CONTEXT is memory whose contents only this library ever writes: every value in
+ * it carries the number of the launch that wrote it, so nothing is ever cleared (the library counts launches per
+ * context on the host; on wrap-around it clears the context once, stream-ordered).
+ *   cnsn_context_bytes(prob)  bytes a context must have for `prob` to use it (0: this problem never would)
+ *   cnsn_context_init(...)    zero-fills a context on `stream` and forgets its launch count; REQUIRED once for
+ *                             every buffer before it is passed as cnsn_problem_t.context; the caller orders the
+ *                             fill before the first use (same stream, or a synchronisation)
+ * One context per device, used by one stream at a time or by streams the library orders itself (its per-device
+ * launch chaining).  Not used while `stream` is being captured into a graph (a replay would repeat the launch
+ * number): such calls fall back to the workspace.  Nothing in the reference corresponds to this. */
+size_t cnsn_context_bytes(const cnsn_problem_t* prob);
+int cnsn_context_init(void* context, size_t bytes, void* stream);
 
 /* ---- health of the cluster-resident strategy ----------------------------------------------------
  * The resident kernels exchange per-plane scalars between co-resident workgroups with bounded spin waits.  When a
