@@ -222,8 +222,8 @@ int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, 
     }
     if (resident_fused_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, e.add, true).ok) {
         st = resident_fused_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, e.add, e.relu, grad_y, x, e.addend, perm,
-                                     gate_dev(g), gate_dev(f), saved_d, grad_x, gate_grad_dev(dg), gate_grad_dev(df),
-                                     workspace, stream);
+                                     gate_dev(g), gate_dev(f), saved_d, grad_x, grad_addend, gate_grad_dev(dg),
+                                     gate_grad_dev(df), workspace, stream);
         if (st != CNSN_E_UNSUPPORTED) return st;
     }
 

@@ -13,7 +13,7 @@ int resident_fused_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
                            double* saved, void* workspace, hipStream_t stream);
 int resident_fused_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, int add, int relu,
                             const void* gy, const void* x, const void* addend, const int64_t* perm, GateDev g, GateDev f,
-                            const double* saved, void* dx, GateGradDev dg, GateGradDev df, void* workspace,
+                            const double* saved, void* dx, void* d_addend, GateGradDev dg, GateGradDev df, void* workspace,
                             hipStream_t stream);
 
 }  // namespace cnsn

@@ -135,7 +135,8 @@ int grid_for(Kern kern, size_t lds, int K, int items) {
 }
 
 // epi: the call carries the residual-block epilogue (EPI kernels; their AUTO rule is separate)
-static inline ResPlan plan_impl(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, bool backward, bool epi) {
+static inline ResPlan plan_impl(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, bool backward, bool epi,
+                                bool post = false) {
     ResPlan rp{false, 0, 0, 0, 0};
     if (p.strategy == CNSN_STRATEGY_TWO_PASS || p.strategy == CNSN_STRATEGY_LOCAL || p.strategy == CNSN_STRATEGY_MONO ||
         has_chan_perm)
@@ -176,15 +177,18 @@ static inline ResPlan plan_impl(const cnsn_problem_t& p, bool boxed, bool has_ch
             if (!ok16) return rp;
         }
         if (epi && p.dtype != CNSN_F32 && rp.nv > 8) return rp;  // (those instantiations spill registers)
+        // POST forward of the 16-bit 56x56 class: two-pass 0.283 vs 0.304 ms at (256,256,56,56) (profiles/r02_post_add.md)
+        if (post && !backward && p.dtype != CNSN_F32 && rp.nv == 7 && p.sn_training) return rp;
     }
     rp.ok = true;
     return rp;
 }
 
+// post: the addend joins after the op (EPI only, un-boxed only — resident_fused_plan)
 template <bool EPI>
 int forward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* x,
                  const void* addend, int relu, const int64_t* perm, GateDev g, GateDev f, void* y, double* saved,
-                 void* workspace, hipStream_t stream) {
+                 void* workspace, hipStream_t stream, bool post = false) {
     const ResPlan rp = plan_impl(p, boxed, false, false, EPI);
     if (!rp.ok) return CNSN_E_UNSUPPORTED;
     ResArgs ra = make_args(p, cb, sb, mid, rp);
@@ -226,6 +230,15 @@ int forward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidA
             e = hipGetLastError();
             status = e == hipSuccess ? CNSN_OK : (int)e;
         };
+        if constexpr (EPI) {
+            if (post) {  // (never boxed)
+                if (solo)
+                    launch(resident_fwd_kernel<T, VEC, NV, PPW, false, true, true, true>);
+                else
+                    launch(resident_fwd_kernel<T, VEC, NV, PPW, false, true, false, true>);
+                return;
+            }
+        }
         if (boxed)
             launch(resident_fwd_kernel<T, VEC, NV, PPW, true, EPI>);
         else if (solo)
@@ -239,7 +252,8 @@ int forward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidA
 template <bool EPI>
 int backward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* gy,
                   const void* x, const void* addend, int relu, const int64_t* perm, GateDev g, GateDev f,
-                  const double* saved, void* dx, GateGradDev dg, GateGradDev df, void* workspace, hipStream_t stream) {
+                  const double* saved, void* dx, GateGradDev dg, GateGradDev df, void* workspace, hipStream_t stream,
+                  bool post = false, void* d_addend = nullptr) {
     const ResPlan rp = plan_impl(p, boxed, false, true, EPI);
     if (!rp.ok) return CNSN_E_UNSUPPORTED;
     ResArgs ra = make_args(p, cb, sb, mid, rp);
@@ -268,10 +282,16 @@ int backward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const Mid
                 return;
             }
             kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)gy, (const T*)x, (T*)dx, perm, g, f, dg, df, gran,
-                                                saved, ctl, (const T*)addend, relu);
+                                                saved, ctl, (const T*)addend, relu, (T*)d_addend);
             e = hipGetLastError();
             status = e == hipSuccess ? CNSN_OK : (int)e;
         };
+        if constexpr (EPI) {
+            if (post) {
+                launch(resident_bwd_kernel<T, VEC, NV, PPW, false, true, true>);
+                return;
+            }
+        }
         if (boxed)
             launch(resident_bwd_kernel<T, VEC, NV, PPW, true, EPI>);
         else

@@ -463,8 +463,11 @@ __host__ __device__ inline size_t res_lds_bytes(int N, int NG, int OWN, int coef
 // SOLO (un-boxed only): nothing couples the planes of a channel — SelfNorm in eval mode (running statistics), no
 // CrossNorm: the inference forward.  Every wave finishes its planes on its own: no publish, no cluster wait, no
 // workgroup barrier; 2*E*b bytes at streaming speed.
-template <typename T, int VEC, int NV, int PPW, bool BOXED, bool EPI = false, bool SOLO = false>
-__global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV) : fwd_waves(data_regs(sizeof(T), VEC, NV, PPW), (int)sizeof(T))) void resident_fwd_kernel(ResArgs ra, const T* __restrict__ x, T* __restrict__ y,
+// POST (with EPI, un-boxed): the addend joins AFTER the op — y = act(CNSN(x) + addend), the 'residual' / 'identity'
+// positions of the callers (resnet_cnsn.py:112-116).  Its planes are fetched when the exchange is over (they are in
+// flight during the algebra) and never held across the cluster wait; one workgroup per CU less than the other variants.
+template <typename T, int VEC, int NV, int PPW, bool BOXED, bool EPI = false, bool SOLO = false, bool POST = false>
+__global__ __launch_bounds__(kBlock, POST ? (data_regs(sizeof(T), VEC, NV, PPW) >= 64 ? 2 : 3) : EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV) : fwd_waves(data_regs(sizeof(T), VEC, NV, PPW), (int)sizeof(T))) void resident_fwd_kernel(ResArgs ra, const T* __restrict__ x, T* __restrict__ y,
                                                               const int64_t* __restrict__ perm, GateDev gg, GateDev gf,
                                                               unsigned long long* __restrict__ gran,
                                                               double* __restrict__ saved, unsigned* __restrict__ ctl,
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
             const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;  // past the batch end: every lane reads zeros
 #pragma unroll
             for (int j = 0; j < NV; ++j) d[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(pb, pbytes, j), voff);
-            if constexpr (EPI) {
+            if constexpr (EPI && !POST) {
                 if (addend) {  // the op's input is x + addend, formed here and never written anywhere
                     const T* ab = addend + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
 #pragma unroll
@@ -541,6 +544,20 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
                 }
             }
         }
+        Raw<T, VEC> ad[POST ? PPW : 1][POST ? NV : 1];  // POST addend planes
+        auto fetch_addend = [&]() {
+            if constexpr (POST) {
+#pragma unroll
+                for (int s = 0; s < PPW; ++s) {
+                    const int n = n0 + s;
+                    const T* ab = addend + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
+                    const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) ad[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(ab, pbytes, j), voff);
+                }
+            }
+        };
+        if constexpr (SOLO) fetch_addend();  // nothing to wait for: next to x
 
         // ---- exact two-pass statistics from registers; publish them to the cluster
         float solo_mean[SOLO ? PPW : 1], solo_m2[SOLO ? PPW : 1];
@@ -672,6 +689,7 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
                         ov[q] = fmaf(cf.a_in, elem<T, VEC>(d[s][j], q) - cf.xr, cf.b_in);
+                        if constexpr (POST) ov[q] += elem<T, VEC>(ad[s][j], q);
                         if constexpr (EPI) ov[q] = relu ? fmaxf(ov[q], 0.f) : ov[q];
                     }
                     buf_store<T, VEC>(slot_rsrc<T, VEC>(yb, pbytes, j), voff, pack<T, VEC>(ov));
@@ -708,6 +726,7 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
 #endif
         CNSN_STAMP(3);
         CNSN_NOTE(6, passes_);
+        if constexpr (!SOLO) fetch_addend();  // the exchange is over: in flight during the algebra
 
         using R = float;  // per-plane algebra in float, cross-batch sums / normalisation in double
         auto plane_of = [&](int n) {
@@ -879,6 +898,7 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
                         const float f = elem<T, VEC>(d[s][j], q);
                         const bool ic = !BOXED || (sg.in_c(j, q));
                         ov[q] = ic ? fmaf(a_in, f - xr, b_in) : fmaf(a_out, f, b_out);
+                        if constexpr (POST) ov[q] += elem<T, VEC>(ad[s][j], q);
                         if constexpr (EPI) ov[q] = relu ? fmaxf(ov[q], 0.f) : ov[q];
                     }
                     buf_store<T, VEC>(slot_rsrc<T, VEC>(yb, pbytes, j), voff, pack<T, VEC>(ov));
@@ -895,15 +915,18 @@ __global__ __launch_bounds__(kBlock, EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV
 // ================================================================================================
 // backward
 // ================================================================================================
-template <typename T, int VEC, int NV, int PPW, bool BOXED, bool EPI = false>
-__global__ __launch_bounds__(kBlock, EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV) : bwd_waves(data_regs(sizeof(T), VEC, NV, PPW))) void resident_bwd_kernel(ResArgs ra, const T* __restrict__ gy,
+// POST (with EPI and ReLU, un-boxed): the mask is that of act(CNSN(x) + addend) — the addend is read next to G and x,
+// used for the mask and dropped; the masked gradient is also the gradient of the addend and is written to d_addend.
+template <typename T, int VEC, int NV, int PPW, bool BOXED, bool EPI = false, bool POST = false>
+__global__ __launch_bounds__(kBlock, POST ? 2 : EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV) : bwd_waves(data_regs(sizeof(T), VEC, NV, PPW))) void resident_bwd_kernel(ResArgs ra, const T* __restrict__ gy,
                                                               const T* __restrict__ x, T* __restrict__ dx,
                                                               const int64_t* __restrict__ perm, GateDev gg, GateDev gf,
                                                               GateGradDev dgr, GateGradDev dfr,
                                                               unsigned long long* __restrict__ gran,
                                                               const double* __restrict__ saved,
                                                               unsigned* __restrict__ ctl,
-                                                              const T* __restrict__ addend, int relu) {
+                                                              const T* __restrict__ addend, int relu,
+                                                              T* __restrict__ d_addend) {
     constexpr int NS = BOXED ? 4 : 2;
     constexpr int OWN = 4 * PPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1004,11 +1027,18 @@ __global__ __launch_bounds__(kBlock, EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV
                 dx_[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(x + off, pbytes, j), voff);
             }
             if constexpr (EPI) {
-                if (addend) {
+                if constexpr (!POST) {
+                    if (addend) {
 #pragma unroll
-                    for (int j = 0; j < NV; ++j)
-                        dx_[s][j] =
-                            add_raw<T, VEC>(dx_[s][j], buf_load<T, VEC>(slot_rsrc<T, VEC>(addend + off, pbytes, j), voff));
+                        for (int j = 0; j < NV; ++j)
+                            dx_[s][j] = add_raw<T, VEC>(dx_[s][j],
+                                                        buf_load<T, VEC>(slot_rsrc<T, VEC>(addend + off, pbytes, j), voff));
+                    }
+                }
+                Raw<T, VEC> ad[POST ? NV : 1];
+                if constexpr (POST) {
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) ad[j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(addend + off, pbytes, j), voff);
                 }
                 if (relu) {  // shut the gradient where the forward's output was not positive: the forward affine
                              // is re-evaluated with the coefficients the forward itself used
@@ -1021,10 +1051,13 @@ __global__ __launch_bounds__(kBlock, EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV
                         for (int q = 0; q < VEC; ++q) {
                             const float X = elem<T, VEC>(dx_[s][j], q);
                             const bool ic = !BOXED || sg.in_c(j, q);
-                            const float t = ic ? fmaf(a_in, X - xr, b_in) : fmaf(a_out, X, b_out);
+                            float t = ic ? fmaf(a_in, X - xr, b_in) : fmaf(a_out, X, b_out);
+                            if constexpr (POST) t += elem<T, VEC>(ad[j], q);
                             gm[q] = relu_open_r<T>(t) ? elem<T, VEC>(dg_[s][j], q) : 0.f;
                         }
                         dg_[s][j] = pack<T, VEC>(gm);
+                        if constexpr (POST)  // the masked gradient is the addend's gradient
+                            buf_store<T, VEC>(slot_rsrc<T, VEC>(d_addend + off, pbytes, j), voff, dg_[s][j]);
                     }
                 }
             }

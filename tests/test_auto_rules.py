@@ -30,6 +30,9 @@ TABLE = [
     ((256, 2048, 7, 7), BF16, FC(**BLOCK), "local", "local"),
     ((256, 2048, 7, 7), BF16, FC(**SN, **CN), "packed", "packed"),             # CrossNorm: not channel-local
     ((256, 2048, 7, 7), F32, FC(**SN), "local", "packed"),                     # fp32 backward image = 100 KiB: two-pass
+    ((16, 512, 64, 64), F32, FC(sn_active=True, add_mode="post", relu=True), "resident", "resident"),   # segmentation: SN at 'residual'
+    ((16, 2048, 64, 64), BF16, FC(sn_active=True, add_mode="post", relu=True), "resident", "resident"),
+    ((16, 256, 128, 128), F32, FC(sn_active=True, add_mode="post", relu=True), "streaming", "streaming"),  # 4096 vectors per plane
     ((128, 128, 8, 8), F32, FC(**SN), "mono", "mono"),                        # 256-byte planes, 16 lanes each
     ((128, 64, 16, 16), F32, FC(**SN), "mono", "mono"),                        # WideResNet stage 2
     ((128, 32, 32, 32), F32, FC(**SN, **BOTH), "resident", "resident"),        # WideResNet stage 1

@@ -56,6 +56,20 @@ def test_block(tag, nv, hw, kind, crop, n):
     check_block(run_block(shape, kind, crop, "pre", True, DT[tag], 700 + nv + n), DT[tag], True, (tag, nv, shape, kind, crop))
 
 
+# POST add (`act(CNSN(x) + addend)`, the 'residual' position): the un-boxed calls run the POST instantiations of the
+# resident kernels (addend fetched after the exchange; backward: mask from the addend, masked gradient written out)
+@pytest.mark.parametrize("tag,nv,hw", CASES, ids=lambda v: str(v).replace(" ", ""))
+@pytest.mark.parametrize("kind,crop,relu", [("sn", "neither", True), ("cnsn", "neither", True), ("sn", "neither", False)])
+@pytest.mark.parametrize("n", [5, 37])
+def test_block_post(tag, nv, hw, kind, crop, relu, n):
+    shape = (n, 2, *hw)
+    x = torch.empty(shape, dtype=DT[tag], device="cuda")
+    cfg = cnsn_amd.FusedConfig(sn_active=True, cn_active=kind == "cnsn", add_mode="post", relu=relu)
+    if not (tag == "bf16v4" and nv == 1):      # (168 elements = 21 16-byte vectors: too small a plane for the cluster kernels)
+        assert cnsn_amd.which_path(x, cfg, backward=False) == "resident"
+    check_block(run_block(shape, kind, crop, "post", relu, DT[tag], 800 + nv + n), DT[tag], relu, (tag, nv, shape, kind, crop, "post"))
+
+
 # The persistent loop (`item += gridDim.x`): with C = 2 every workgroup handles ONE item.  Enough channels that the
 # grid (at most 6 workgroups x 256 CUs, a whole number of clusters) wraps around at least once per register bucket —
 # the second and later items reuse LDS, the granule area of another channel and the per-item prefetches.  Checked
