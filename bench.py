@@ -257,7 +257,7 @@ SWEEP_SHAPES = [(8, 64, 32, 32), (128, 32, 32, 32), (128, 64, 16, 16), (128, 128
 def sweep(cnsn_amd, dev):
     """`python bench.py --sweep`: every shape of SURVEY §8 d1 x dtype x mode — ms per forward+backward (HIP events),
     algorithmic GB/s (8*E*b / t) and the kernels AUTO resolved to (forward/backward) — as a markdown table
-    (profiles/r01_shape_sweep.md).  Not the one-line contract: a measurement aid."""
+    (profiles/r02_shape_sweep.md).  Not the one-line contract: a measurement aid."""
     def timeit(fn, k=20, w=5):
         for _ in range(w):
             fn()
@@ -282,7 +282,7 @@ def sweep(cnsn_amd, dev):
              ("cnsn", "neither", True), ("cnsn", "both", True)]
     print("| shape | dtype | " + " | ".join(f"{k}{'' if k == 'sn' else '/' + cr}{'' if tr else ' eval'}" for k, cr, tr in modes) + " |")
     print("|---|---|" + "---|" * len(modes))
-    short = {"streaming": "S", "packed": "P", "resident": "R", "local": "L"}
+    short = {"streaming": "S", "packed": "P", "resident": "R", "local": "L", "mono": "M"}
     for shape in SWEEP_SHAPES:
         for dt, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16)):
             x = conditioned(shape, dev, dtype, 1).requires_grad_()
@@ -481,6 +481,12 @@ def main():
     from cnsn_amd import data_parallel as dp
     cnsn_amd.lib()                                    # fail loudly now if the .so is missing
     cnsn_amd.set_strategy(args.strategy)
+    if world > ngpu:
+        # Ranks SHARE a device (a 1-GPU box running the N-rank launcher).  The cluster-resident kernels need the GPU to
+        # themselves: the persistent grids of two PROCESSES can each hold the slots the other's cluster members are
+        # waiting for, XCD by XCD (observed: a 5 s time-out -> the library degrades and reports it).  One rank per
+        # GPU — the configuration this bench is for — is not affected.
+        cnsn_amd.set_resident(False)
     import numpy as np
     if args.sweep:
         sweep(cnsn_amd, dev)

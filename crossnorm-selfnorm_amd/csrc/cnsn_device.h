@@ -156,12 +156,24 @@ __device__ __forceinline__ void block_sum_d(double (&acc)[NACC], double* lds) {
         for (int k = 0; k < NACC; ++k) lds[wave * NACC + k] = acc[k];
     }
     __syncthreads();
+#ifdef CNSN_BLOCKSUM_WIDE
 #pragma unroll
     for (int k = 0; k < NACC; ++k) {
         double s = 0.0;
         for (int w = 0; w < kBlock / 64; ++w) s += lds[w * NACC + k];
         acc[k] = s;
     }
+#else
+    // lane l reads the partial of wave l % 4 and every group of four lanes adds them up: NACC doubles live per lane
+    // instead of 4 * NACC (these sums run while whole planes sit in the caller's registers)
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+        double v = lds[(lane & 3) * NACC + k];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        acc[k] = v;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -88,7 +88,8 @@ MonoPlan mono_plan(const Plan& pl, int add, bool backward) {
     mp.lpp = lpp;
     mp.rmax = rmax;
     mp.R = R;
-    mp.lds = mono_lds_bytes(p.N, backward);
+    mp.lds = mono_lds_bytes(kMonoWaves * R * ppr, backward);
+    if (mp.lds > 64 * 1024) return mp;  // (N close to 1024 with 16 lanes per plane, backward: not worth a larger LDS grant)
     mp.ok = true;
     return mp;
 }

@@ -34,7 +34,7 @@ namespace cnsn {
 // that one workgroup's loads and stores overlap the other's statistics / algebra — possible when a tensor's slot rows
 // take at most 32 registers (the forward of 16-bit (256,.,14,14), of fp32 up to 128 planes per channel)
 #ifndef MONO_FWD_WAVES_SMALL
-#define MONO_FWD_WAVES_SMALL 4
+#define MONO_FWD_WAVES_SMALL 8   // measured: block forward (256,1024,14,14) bf16 0.096 -> 0.078 ms, plain forward unchanged
 #endif
 constexpr int mono_fwd_waves(int data_regs) { return data_regs <= 32 ? MONO_FWD_WAVES_SMALL : 4; }
 
@@ -47,8 +47,10 @@ struct MonoArgs {
     int R;     // slot rows in use per wave (<= RMAX): N <= 16 * R * (64 / LPP)
 };
 
-__host__ __device__ inline size_t mono_lds_bytes(int N, bool backward) {
-    const size_t n = (size_t)((N + 3) & ~3);
+// cap = plane slots of the workgroup = 16 waves * R rows * (64 / LPP) planes per row (>= N): the per-plane LDS arrays are
+// that long, so a slot row past the batch end indexes real (unused) LDS and needs no clamp
+__host__ __device__ inline size_t mono_lds_bytes(int cap, bool backward) {
+    const size_t n = (size_t)cap;
     return (backward ? 7 * n * 4 + 5 * n * 8 : 2 * n * 4) + (size_t)kMonoWaves * 4 * 8 + 16 * 8;
 }
 
@@ -125,34 +127,49 @@ template <typename T, int VEC, int LPP>
 struct MonoGeom {
     static constexpr int PPR = 64 / LPP;
     static constexpr int VB = VEC * (int)sizeof(T);
-    int sub, vl, wave, N, C, M, R;
-    bool lane_ok;
+    int sub, vl, wave, C, M, R;
+    long long e0;  // element offset of slot row 0 of this wave in channel c (wave-uniform, kept in SGPRs)
+    int stride;    // elements between consecutive slot rows = PPR * C * M
+    int rlim;  // this lane holds real data in slot rows r < rlim (0 for a lane past the end of the plane): ONE register
+               // decides validity of every row — r < rlim is a compare against a constant after unrolling
     int voff;  // byte offset of this lane's vector inside its slot row
     __device__ __forceinline__ MonoGeom(const MonoArgs& ma) {
         const int lane = threadIdx.x & 63;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         sub = lane / LPP;
         vl = lane - sub * LPP;
-        N = ma.mid.N;
         C = ma.mid.C;
         M = ma.mid.M;
         R = ma.R;
-        lane_ok = vl < ma.nvec;
+        // plane(r) = (wave * R + r) * PPR + sub < N  <=>  r < ceil((N - sub) / PPR) - wave * R
+        int lim = (ma.mid.N - sub + PPR - 1) / PPR - wave * R;
+        lim = lim < 0 ? 0 : (lim > R ? R : lim);
+        rlim = vl < ma.nvec ? lim : 0;
         voff = (sub * C * M + vl * VEC) * (int)sizeof(T);
+        stride = PPR * C * M;
+        e0 = 0;
+    }
+    // channel of this workgroup: fixes the (scalar) element offset of the wave's first slot row
+    __device__ __forceinline__ void set_channel(int c) {
+        const long long v = ((long long)(wave * R * PPR) * C + c) * M;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+        e0 = (long long)(((unsigned long long)hi << 32) | lo);
+    }
+    // Between the phases of a kernel: make the compiler forget what it derived from the lane geometry, so that the
+    // per-row offsets are recomputed (one compare + select each) instead of being kept — or spilled — across phases.
+    __device__ __forceinline__ void refresh() {
+        asm volatile("" : "+v"(rlim), "+v"(voff));
     }
     // (rows r >= R are never ok(): their loads return zeros without touching memory and their stores are dropped, so the
     //  slot loops below run over all RMAX rows without control flow — the register arrays stay in registers)
     __device__ __forceinline__ int plane(int r) const { return (wave * R + r) * PPR + sub; }
-    __device__ __forceinline__ bool row_ok(int r) const { return r < R && plane(r) < N; }  // a plane of THIS wave
-    __device__ __forceinline__ bool ok(int r) const { return row_ok(r) && lane_ok; }
+    __device__ __forceinline__ bool ok(int r) const { return r < rlim; }
     // descriptor of slot row r of channel c of tensor `t`: lanes that are not ok() get an offset past its end
-    __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const T* t, int c, int r) const {
-        // the base is wave-uniform; say so explicitly (readfirstlane): when the compiler folds this address with a
-        // per-thread one it otherwise builds the descriptor in VGPRs and wraps every access in a waterfall loop
-        const unsigned long long b = (unsigned long long)(t + ((size_t)((wave * R + r) * PPR) * C + c) * M);
-        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7ffffff0, 0x00020000);
+    // (the base must be wave-uniform for the compiler too — e0 went through readfirstlane —: a descriptor built in
+    //  VGPRs wraps every access in a waterfall loop)
+    __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const T* t, int /*c*/, int r) const {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(t + e0 + (long long)r * stride), 0, 0x7ffffff0, 0x00020000);
     }
     __device__ __forceinline__ int off(int r) const { return ok(r) ? voff : 0x7ffffff8; }
 };
@@ -168,7 +185,7 @@ __global__ __launch_bounds__(kMonoBlock, mono_fwd_waves(RMAX * VEC * (int)sizeof
     MidArgs a = ma.mid;
     a.sn_two = 0;  // (the host does not send the two-gate form here)
     const int N = a.N, C = a.C;
-    const int npad = (N + 3) & ~3;
+    const int npad = kMonoWaves * ma.R * (64 / LPP);
     const MonoWalk wk(C);
     if (wk.j < wk.count) {
     const int c = wk.start + wk.j;
@@ -178,7 +195,8 @@ __global__ __launch_bounds__(kMonoBlock, mono_fwd_waves(RMAX * VEC * (int)sizeof
     double* red = (double*)(pm2 + npad);
     double* par = red + kMonoWaves * 4;  // [16] per-channel parameters
     const size_t P = (size_t)N * C;
-    const MonoGeom<T, VEC, LPP> g(ma);
+    MonoGeom<T, VEC, LPP> g(ma);
+    g.set_channel(c);
 
     if (threadIdx.x == 0) {  // per-channel parameters, fetched ahead of the bulk loads
         par[0] = gg.w[2 * c];
@@ -236,7 +254,7 @@ __global__ __launch_bounds__(kMonoBlock, mono_fwd_waves(RMAX * VEC * (int)sizeof
                 }
             }
             m2 = mono_group_sum<LPP>(m2);
-            if (g.vl == 0 && g.row_ok(r)) {  // (rows r >= R alias the planes of other waves: never written)
+            if (g.vl == 0 && g.ok(r)) {  // (rows r >= R alias the planes of other waves: never written)
                 pmu[g.plane(r)] = mean;
                 pm2[g.plane(r)] = m2;
             }
@@ -315,13 +333,14 @@ __global__ __launch_bounds__(kMonoBlock, mono_fwd_waves(RMAX * VEC * (int)sizeof
     __syncthreads();
 
     // ---- apply from registers, the only write of y
+    g.refresh();
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) mono_forget(d[r]);
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
         {
             const int pn = g.plane(r);
-            const float ca = pmu[pn < N ? pn : 0], cb = pm2[pn < N ? pn : 0];
+            const float ca = pmu[pn], cb = pm2[pn];
             float ov[VEC];
 #pragma unroll
             for (int q = 0; q < VEC; ++q) {
@@ -346,7 +365,7 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
     MidArgs a = ma.mid;
     a.sn_two = 0;  // (the host does not send the two-gate form here: the second gate's state would cost ~20 VGPRs)
     const int N = a.N, C = a.C;
-    const int npad = (N + 3) & ~3;
+    const int npad = kMonoWaves * ma.R * (64 / LPP);
     const MonoWalk wk(C);
     if (wk.j < wk.count) {
     const int c = wk.start + wk.j;
@@ -362,7 +381,8 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
     double* psv = red + kMonoWaves * 4;  // [5][N] the five rows of `saved` the algebra needs (parked in LDS: the
                                          // registers belong to the planes until the sums are done)
     const size_t P = (size_t)N * C;
-    const MonoGeom<T, VEC, LPP> g(ma);
+    MonoGeom<T, VEC, LPP> g(ma);
+    g.set_channel(c);
 
     // ---- what the sums and the algebra need from `saved`, a thread per plane, ahead of the bulk loads
     const int n = threadIdx.x;
@@ -408,13 +428,14 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
         }
     }
     __syncthreads();  // psi / pfa / pfb are staged
+    g.refresh();
 
     // ---- ReLU mask (forward affine re-evaluated with the coefficients the forward used) and per-plane sums
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
         {
             const int pn = g.plane(r);
-            const int pi = pn < N ? pn : 0;
+            const int pi = pn;
             const float si = psi[pi];
             if constexpr (EPI) {
                 if (relu) {
@@ -439,7 +460,7 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
             }
             s1 = mono_group_sum<LPP>(s1);
             s2 = mono_group_sum<LPP>(s2);
-            if (g.vl == 0 && g.row_ok(r)) {
+            if (g.vl == 0 && g.ok(r)) {
                 ps1[pn] = s1;
                 ps2[pn] = s2;
             }
@@ -495,6 +516,7 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
     // (mono_block_sum ends with every thread past its second barrier: the coefficient rows are visible)
 
     // ---- dx from registers, the only write
+    g.refresh();
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
         mono_forget(dg_[r]);
@@ -504,7 +526,7 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
     for (int r = 0; r < RMAX; ++r) {
         {
             const int pn = g.plane(r);
-            const int pi = pn < N ? pn : 0;
+            const int pi = pn;
             const float cG = ps1[pi], cX = ps2[pi], xr = pxr[pi], c0 = pc0[pi];
             float ov[VEC];
 #pragma unroll

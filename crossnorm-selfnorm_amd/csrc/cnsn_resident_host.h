@@ -48,9 +48,15 @@ constexpr int kBucketNv[] = {1, 2, 4, 7, 8, 13, 16};
 #ifndef CNSN_PPW78_EPI16_FWD
 #define CNSN_PPW78_EPI16_FWD 1
 #endif
+#ifndef CNSN_PPW2_FWD
+#define CNSN_PPW2_FWD 4
+#endif
+#ifndef CNSN_PPW2_BWD
+#define CNSN_PPW2_BWD 4
+#endif
 constexpr int ppw_of(int nv, bool backward, bool epi, int elem_bytes) {
     return nv == 1 ? CNSN_PPW1
-           : nv == 2 ? 4
+           : nv == 2 ? (backward ? CNSN_PPW2_BWD : CNSN_PPW2_FWD)
            : nv == 4 ? (epi ? CNSN_PPW4_EPI : CNSN_PPW4)
            : (nv == 7 || nv == 8) ? ((backward && !epi) ? (elem_bytes == 4 ? CNSN_PPW78_F32 : (nv == 8 ? CNSN_PPW8_BWD16 : 2))
                                                      : (elem_bytes == 2 ? (epi ? (backward ? CNSN_PPW78_EPI16_BWD : CNSN_PPW78_EPI16_FWD)

@@ -38,6 +38,12 @@ def main(out_dir, steps=3, batch=32):
 
     import cnsn_amd
     from cnsn_amd import _ffi, data_parallel as dp
+    if shared:
+        # two PROCESSES on one GPU: their persistent cluster grids could each hold what the other waits for (observed
+        # once as a 5 s time-out that the library survived by degrading).  The cluster kernels are for a GPU a process
+        # has to itself — here they are switched off and the other single-touch strategies carry the run; the
+        # resident-vs-other-streams case on one GPU is test_resident_kernels_next_to_a_busy_side_stream (one process).
+        cnsn_amd.set_resident(False)
 
     class Tower(torch.nn.Module):
         """CNSN sites of ResNet-50's stages joined by DETERMINISTIC glue only (element-wise scale by a fat parameter,

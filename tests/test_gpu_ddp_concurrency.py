@@ -37,9 +37,52 @@ def test_resident_kernels_under_data_parallel_communication(tmp_path):
         json.dump(reps, open(os.path.join(keep, "ddp_concurrency.json"), "w"), indent=1)
     for rep in reps:
         assert rep["world"] == 2 and rep["sites"] == 16
-        assert "resident" in rep["paths"], rep                 # the cluster kernels really were in play
+        if not rep["shared_device"]:
+            assert "resident" in rep["paths"], rep             # one rank per GPU: the cluster kernels were in play
         assert rep["timeouts"] == 0, rep                       # no bounded wait ran out
         assert rep["site_outputs_bit_identical"], rep          # communication changes nothing in the op's results
         assert rep["finite"]
         if rep["mode"] == "ddp":
             assert rep["grads_bit_identical"], rep             # (a + b) / 2 either way: exact
+
+
+def test_resident_kernels_next_to_a_busy_side_stream():
+    """One process, one GPU: the cluster-resident kernels on the main stream while a second stream keeps the memory system
+    and some compute units busy the whole time (what a gradient-reduction stream does).  Bit-identical results, no
+    bounded wait running out."""
+    import cnsn_amd
+    from cnsn_amd import _ffi
+    from tests.golden.gen_golden_fill import fill_sn
+    dev = torch.device("cuda:0")
+    shape = (64, 128, 56, 56)
+    torch.manual_seed(5)
+    x = torch.randn(shape, device=dev)
+    gy = torch.randn(shape, device=dev)
+    assert cnsn_amd.which_path(x, cnsn_amd.FusedConfig(sn_active=True, cn_active=True)) == "resident"
+
+    def step():
+        torch.manual_seed(6)
+        mod = cnsn_amd.CNSN(cnsn_amd.CrossNorm("neither", 1), fill_sn(cnsn_amd.SelfNorm(shape[1]), 3, torch.float32)).to(dev).train()
+        outs = []
+        for _ in range(6):
+            mod.crossnorm.active = True
+            mod.crossnorm.next_draws = cnsn_amd.CNDraws(torch.arange(shape[0]).flip(0))
+            xi = x.clone().requires_grad_()
+            y = mod(xi)
+            y.backward(gy)
+            outs += [y.detach().clone(), xi.grad.clone()]
+        torch.cuda.synchronize()
+        return outs
+
+    quiet = step()
+    side = torch.cuda.Stream(device=dev)
+    a = torch.zeros(32 << 20, device=dev)
+    b = torch.empty_like(a)
+    with torch.cuda.stream(side):
+        for _ in range(300):
+            b.copy_(a, non_blocking=True)
+            b.mul_(1.0001)
+    busy = step()
+    side.synchronize()
+    assert all(torch.equal(u, v) for u, v in zip(quiet, busy))
+    assert _ffi.lib().cnsn_resident_timeouts() == 0
