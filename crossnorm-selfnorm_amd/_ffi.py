@@ -84,6 +84,10 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cnsn_plane_dot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_void_p, C.c_void_p]),
+    "cnsn_plane_dot_shifted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cnsn_plane_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

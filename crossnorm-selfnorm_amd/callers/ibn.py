@@ -3,8 +3,9 @@ kernels of this library: `nn.InstanceNorm2d(C, affine=True)` and `IBN` (models/i
 :63) with the same attribute names and `state_dict` keys (`IN.weight`, `IN.bias`, `BN.*`).
 
 InstanceNorm2d here = one plane-statistics launch (cnsn_plane_stats) + one per-plane affine launch
-(cnsn_plane_affine); the gradient flows through both custom functions (cnsn_plane_stats_backward,
-cnsn_plane_dot) and a handful of (N, C)-sized torch ops.  HIP device tensors only."""
+(cnsn_plane_affine) forward, and a dedicated backward (functional.InstanceNorm): per-plane sums of G and G*(x - mean)
+(cnsn_plane_dot_shifted) + ONE apply launch (cnsn_plane_combine) — 3 + 5 tensor passes; (N, C)-sized torch ops in
+between.  HIP device tensors only."""
 import torch
 import torch.nn as nn
 
@@ -27,17 +28,7 @@ class InstanceNorm2d(nn.Module):
 
     def forward(self, x):
         assert x.dim() == 4 and x.size(1) == self.num_features
-        m = x.size(2) * x.size(3)
-        assert m > 1, "InstanceNorm2d needs more than one value per plane"
-        # the kernel returns sqrt(unbiased var + e): with e = eps*M/(M-1),  biased var + eps = std_u^2 * (M-1)/M
-        mean, std_u = _F.PlaneStats.apply(x, self.eps * m / (m - 1.0), None, True)
-        scale = 1.0 / (std_u * ((m - 1.0) / m) ** 0.5)
-        if self.affine:
-            scale = scale * self.weight.float().view(1, -1, 1, 1)
-            shift = self.bias.float().view(1, -1, 1, 1) - mean * scale
-        else:
-            shift = -mean * scale
-        return _F.PlaneAffine.apply(x, scale, shift)
+        return _F.InstanceNorm.apply(x, self.weight if self.affine else None, self.bias if self.affine else None, self.eps)
 
 
 class IBN(nn.Module):

@@ -349,4 +349,46 @@ int cnsn_plane_dot(const void* gr, const void* x, int dtype, int N, int C, int H
     return launch_status();
 }
 
+int cnsn_plane_dot_shifted(const void* gr, const void* x, int dtype, int N, int C, int H, int W, const double* shift,
+                           float* sum_g, void* stream_) {
+    int st = check_tensor(x, dtype, N, C, H, W);
+    if (st) return st;
+    st = check_tensor(gr, dtype, N, C, H, W);
+    if (st) return st;
+    if (!sum_g || !shift) return CNSN_E_NULL;
+    const Shape s = pick_shape(dtype, H * W, W, false);
+    const Box whole{0, 0, H, W};
+    const Geom g = make_geom(N, C, H, W, s.vec, whole, whole);
+    const int blocks = blocks_for(g.P, s.lpp);
+    hipStream_t stream = (hipStream_t)stream_;
+    dispatch(dtype, s, [&](auto tt, auto vt, auto lt) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value, LPP = decltype(lt)::value;
+        bwd_reduce_kernel<T, VEC, LPP, false><<<blocks, kBlock, 0, stream>>>((const T*)gr, (const T*)x, g, shift, nullptr, 1,
+                                                                            sum_g);
+    });
+    return launch_status();
+}
+
+int cnsn_plane_combine(const void* gr, const void* x, int dtype, int N, int C, int H, int W, const float* coef, void* out,
+                       void* stream_) {
+    int st = check_tensor(x, dtype, N, C, H, W);
+    if (st) return st;
+    st = check_tensor(gr, dtype, N, C, H, W);
+    if (st) return st;
+    if (!coef || !out) return CNSN_E_NULL;
+    if (((uintptr_t)out & 15u) != 0) return CNSN_E_ALIGN;
+    const Shape s = pick_shape(dtype, H * W, W, false);
+    const Box whole{0, 0, H, W};
+    const Geom g = make_geom(N, C, H, W, s.vec, whole, whole);
+    const int blocks = blocks_for(g.P, s.lpp);
+    hipStream_t stream = (hipStream_t)stream_;
+    dispatch(dtype, s, [&](auto tt, auto vt, auto lt) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value, LPP = decltype(lt)::value;
+        apply_bwd_kernel<T, VEC, LPP, false><<<blocks, kBlock, 0, stream>>>((const T*)gr, (const T*)x, (T*)out, g, coef);
+    });
+    return launch_status();
+}
+
 }  // extern "C"

@@ -31,12 +31,17 @@ bool dispatch_m(int dtype, int vec, int lpp, int rmax, F&& f) {
     if (dtype == CNSN_F32) {
         if (vec == 4) return by_l(TypeTag<float>{}, IntTag<4>{});
         if (vec == 2) return by_l(TypeTag<float>{}, IntTag<2>{});
+        if (vec == 1) return by_l(TypeTag<float>{}, IntTag<1>{});
     } else if (dtype == CNSN_BF16) {
         if (vec == 8) return by_l(TypeTag<bf16_t>{}, IntTag<8>{});
         if (vec == 4) return by_l(TypeTag<bf16_t>{}, IntTag<4>{});
+        if (vec == 2) return by_l(TypeTag<bf16_t>{}, IntTag<2>{});
+        if (vec == 1) return by_l(TypeTag<bf16_t>{}, IntTag<1>{});
     } else if (dtype == CNSN_F16) {
         if (vec == 8) return by_l(TypeTag<_Float16>{}, IntTag<8>{});
         if (vec == 4) return by_l(TypeTag<_Float16>{}, IntTag<4>{});
+        if (vec == 2) return by_l(TypeTag<_Float16>{}, IntTag<2>{});
+        if (vec == 1) return by_l(TypeTag<_Float16>{}, IntTag<1>{});
     }
     return false;
 }
@@ -62,11 +67,10 @@ MonoPlan mono_plan(const Plan& pl, int add, bool backward) {
     if (const char* e = getenv("CNSN_MONO"))
         if (e[0] == '0' && p.strategy == CNSN_STRATEGY_AUTO) return mp;
     const int b = elem_bytes(p.dtype), M = p.H * p.W;
-    // widest vector (16 or 8 bytes) that divides the plane; a 16-byte vector that would leave fewer than 16 vectors
+    // widest vector (16 .. 2 bytes) that divides the plane; a 16-byte vector that would leave fewer than 16 vectors
     // per plane is halved once (more lanes of the slot row busy)
     int vec = 16 / b;
-    while (vec * b > 8 && M % vec) vec >>= 1;
-    if (M % vec) return mp;
+    while (vec > 1 && M % vec) vec >>= 1;
     if (vec * b == 16 && M / vec < 16 && (M / (vec / 2)) <= 64) vec >>= 1;
     const int nvec = M / vec;
     if (nvec > 64 || nvec < 2) return mp;
@@ -81,7 +85,11 @@ MonoPlan mono_plan(const Plan& pl, int add, bool backward) {
     if ((long long)ppr * p.C * M * b >= 0x7ffffff0ll) return mp;   // 31-bit lane offsets inside a slot row
     if (p.strategy == CNSN_STRATEGY_AUTO) {
         // a plane of a few dozen bytes is better served by the channel-local kernels (several channels per workgroup)
-        if ((long long)M * b < 128) return mp;
+        if ((long long)M * b < 64) return mp;
+        // one 16-bit element per lane (7x7 bf16: 25 KB per workgroup) does not amortise a 1024-thread workgroup: the
+        // channel-local kernels with several channels per workgroup are as fast or faster there (measured: forward 0.074
+        // vs 0.075, backward 0.127 vs 0.116 ms at (256,2048,7,7); fp32 0.088 / 0.165 vs 0.112 / 0.177: mono)
+        if (vec * b < 4) return mp;
         if (p.N < 16) return mp;  // hardly any planes per channel: the two-pass kernels have more parallelism
     }
     mp.vec = vec;

@@ -26,6 +26,97 @@
 
 namespace cnsn {
 
+// A slot of the mono kernels is VEC elements = 16, 8, 4 or 2 bytes per lane.  The two narrow forms serve planes that are
+// not a whole number of 8-byte vectors — 7x7: one element per lane, 49 of 64 lanes, a wave-wide access is the plane's 98
+// (bf16) or 196 (fp32) contiguous bytes; neighbouring channels, contiguous in memory, are neighbouring workgroups on one XCD.
+template <int BYTES>
+struct MRawOf;
+template <>
+struct MRawOf<16> {
+    using type = v4i_t;
+};
+template <>
+struct MRawOf<8> {
+    using type = v2i_t;
+};
+template <>
+struct MRawOf<4> {
+    using type = int;
+};
+template <>
+struct MRawOf<2> {
+    using type = unsigned short;
+};
+template <typename T, int VEC>
+using MRaw = typename MRawOf<(int)sizeof(T) * VEC>::type;
+
+template <typename T, int VEC>
+__device__ __forceinline__ float melem(const MRaw<T, VEC>& r, int q) {
+    constexpr int B = (int)sizeof(T) * VEC;
+    if constexpr (B >= 8) {
+        return elem<T, VEC>(r, q);
+    } else if constexpr (sizeof(T) == 4) {  // one float
+        return __int_as_float(r);
+    } else {
+        unsigned short h;
+        if constexpr (B == 4)
+            h = (q & 1) ? (unsigned short)((unsigned)r >> 16) : (unsigned short)((unsigned)r & 0xffffu);
+        else
+            h = r;
+        if constexpr (__is_same(T, bf16_t))
+            return __uint_as_float((unsigned)h << 16);
+        else
+            return (float)__builtin_bit_cast(_Float16, h);
+    }
+}
+template <typename T>
+__device__ __forceinline__ unsigned short mhalf_bits(float f) {
+    if constexpr (__is_same(T, bf16_t))
+        return from_float<bf16_t>(f).bits;
+    else
+        return __builtin_bit_cast(unsigned short, from_float<_Float16>(f));
+}
+template <typename T, int VEC>
+__device__ __forceinline__ MRaw<T, VEC> mpack(const float (&f)[VEC]) {
+    constexpr int B = (int)sizeof(T) * VEC;
+    if constexpr (B >= 8) {
+        return pack<T, VEC>(f);
+    } else if constexpr (sizeof(T) == 4) {
+        return __float_as_int(f[0]);
+    } else if constexpr (B == 4) {
+        return (int)(((unsigned)mhalf_bits<T>(f[1]) << 16) | (unsigned)mhalf_bits<T>(f[0]));
+    } else {
+        return mhalf_bits<T>(f[0]);
+    }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ MRaw<T, VEC> mload(__amdgpu_buffer_rsrc_t r, int voff) {
+    constexpr int B = (int)sizeof(T) * VEC;
+    if constexpr (B >= 8)
+        return buf_load<T, VEC>(r, voff);
+    else if constexpr (B == 4)
+        return __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, CNSN_RES_LOAD_AUX);
+    else
+        return __builtin_amdgcn_raw_buffer_load_b16(r, voff, 0, CNSN_RES_LOAD_AUX);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void mstore(__amdgpu_buffer_rsrc_t r, int voff, const MRaw<T, VEC>& v) {
+    constexpr int B = (int)sizeof(T) * VEC;
+    if constexpr (B >= 8)
+        buf_store<T, VEC>(r, voff, v);
+    else if constexpr (B == 4)
+        __builtin_amdgcn_raw_buffer_store_b32(v, r, voff, 0, CNSN_RES_STORE_AUX);
+    else
+        __builtin_amdgcn_raw_buffer_store_b16(v, r, voff, 0, CNSN_RES_STORE_AUX);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ MRaw<T, VEC> madd(const MRaw<T, VEC>& a, const MRaw<T, VEC>& b) {
+    float f[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) f[q] = melem<T, VEC>(a, q) + melem<T, VEC>(b, q);
+    return mpack<T, VEC>(f);
+}
+
 #ifndef MONO_ILP
 #define MONO_ILP 2  // slot rows the scheduler may interleave in the backward's slot loops (power of two)
 #endif
@@ -87,12 +178,18 @@ __device__ __forceinline__ void mono_block_sum(double (&acc)[NACC], double* red)
 // the slot instead of holding RMAX * VEC floats per tensor next to the packed planes (which spilled to scratch).
 template <typename V>
 __device__ __forceinline__ void mono_forget(V& v) {
-    constexpr int W = (int)(sizeof(V) / 4);
+    if constexpr (sizeof(V) >= 8) {
+        constexpr int W = (int)(sizeof(V) / 4);
 #pragma unroll
-    for (int i = 0; i < W; ++i) {
-        int t = v[i];
+        for (int i = 0; i < W; ++i) {
+            int t = v[i];
+            asm volatile("" : "+v"(t));
+            v[i] = t;
+        }
+    } else {
+        int t = (int)v;
         asm volatile("" : "+v"(t));
-        v[i] = t;
+        v = (V)t;
     }
 }
 
@@ -216,22 +313,22 @@ __global__ __launch_bounds__(kMonoBlock, mono_fwd_waves(RMAX * VEC * (int)sizeof
     }
 
     // ---- the only read of x (+ addend): every plane of the channel into registers
-    Raw<T, VEC> d[RMAX];
+    MRaw<T, VEC> d[RMAX];
 #pragma unroll
     for (int r = 0; r < RMAX; ++r)
-        d[r] = buf_load<T, VEC>(g.rsrc(x, c, r), g.off(r));
+        d[r] = mload<T, VEC>(g.rsrc(x, c, r), g.off(r));
     if constexpr (EPI) {
         if (add == ADD_PRE) {  // the op's input is x + addend (rounded to T like `out += identity`), never written
             constexpr int CH = (RMAX * VEC * (int)sizeof(T) > 128) ? RMAX / 2 : RMAX;  // bound the transient registers
 #pragma unroll
             for (int r0 = 0; r0 < RMAX; r0 += CH) {
-                Raw<T, VEC> q[CH];
+                MRaw<T, VEC> q[CH];
 #pragma unroll
                 for (int r = 0; r < CH; ++r)
-                    q[r] = buf_load<T, VEC>(g.rsrc(addend, c, r0 + r), g.off(r0 + r));
+                    q[r] = mload<T, VEC>(g.rsrc(addend, c, r0 + r), g.off(r0 + r));
 #pragma unroll
                 for (int r = 0; r < CH; ++r)
-                    d[r0 + r] = add_raw<T, VEC>(d[r0 + r], q[r]);
+                    d[r0 + r] = madd<T, VEC>(d[r0 + r], q[r]);
             }
         }
     }
@@ -242,14 +339,14 @@ __global__ __launch_bounds__(kMonoBlock, mono_fwd_waves(RMAX * VEC * (int)sizeof
         {
             float s = 0.f;
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) s += elem<T, VEC>(d[r], q);  // lanes that are not ok() loaded zeros
+            for (int q = 0; q < VEC; ++q) s += melem<T, VEC>(d[r], q);  // lanes that are not ok() loaded zeros
             const float mean = mono_group_sum<LPP>(s) / (float)a.M;
             float m2 = 0.f;
             mono_forget(d[r]);
             if (g.ok(r)) {
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) {
-                    const float t = elem<T, VEC>(d[r], q) - mean;
+                    const float t = melem<T, VEC>(d[r], q) - mean;
                     m2 = fmaf(t, t, m2);
                 }
             }
@@ -344,10 +441,10 @@ __global__ __launch_bounds__(kMonoBlock, mono_fwd_waves(RMAX * VEC * (int)sizeof
             float ov[VEC];
 #pragma unroll
             for (int q = 0; q < VEC; ++q) {
-                ov[q] = fmaf(ca, elem<T, VEC>(d[r], q), cb);
+                ov[q] = fmaf(ca, melem<T, VEC>(d[r], q), cb);
                 if constexpr (EPI) ov[q] = relu ? fmaxf(ov[q], 0.f) : ov[q];
             }
-            buf_store<T, VEC>(g.rsrc(y, c, r), g.off(r), pack<T, VEC>(ov));
+            mstore<T, VEC>(g.rsrc(y, c, r), g.off(r), mpack<T, VEC>(ov));
         }
     }
     }  // (a workgroup past the end of its XCD's range has nothing to do)
@@ -405,25 +502,25 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
     const double rs_g = saved[SV_ROWS * P + c];
 
     // ---- the only reads of G and x (+ addend)
-    Raw<T, VEC> dg_[RMAX], dx_[RMAX];
+    MRaw<T, VEC> dg_[RMAX], dx_[RMAX];
 #pragma unroll
     for (int r = 0; r < RMAX; ++r)
     {
-        dg_[r] = buf_load<T, VEC>(g.rsrc(gy, c, r), g.off(r));
-        dx_[r] = buf_load<T, VEC>(g.rsrc(x, c, r), g.off(r));
+        dg_[r] = mload<T, VEC>(g.rsrc(gy, c, r), g.off(r));
+        dx_[r] = mload<T, VEC>(g.rsrc(x, c, r), g.off(r));
     }
     if constexpr (EPI) {
         if (add == ADD_PRE) {
             constexpr int CH = (RMAX * VEC * (int)sizeof(T) > 64) ? RMAX / 2 : RMAX;
 #pragma unroll
             for (int r0 = 0; r0 < RMAX; r0 += CH) {
-                Raw<T, VEC> q[CH];
+                MRaw<T, VEC> q[CH];
 #pragma unroll
                 for (int r = 0; r < CH; ++r)
-                    q[r] = buf_load<T, VEC>(g.rsrc(addend, c, r0 + r), g.off(r0 + r));
+                    q[r] = mload<T, VEC>(g.rsrc(addend, c, r0 + r), g.off(r0 + r));
 #pragma unroll
                 for (int r = 0; r < CH; ++r)
-                    dx_[r0 + r] = add_raw<T, VEC>(dx_[r0 + r], q[r]);
+                    dx_[r0 + r] = madd<T, VEC>(dx_[r0 + r], q[r]);
             }
         }
     }
@@ -443,17 +540,17 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
                     float gm[VEC];
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
-                        const float t = fmaf(fa, elem<T, VEC>(dx_[r], q) - 0.f, fb);
-                        gm[q] = relu_open_r<T>(t) ? elem<T, VEC>(dg_[r], q) : 0.f;
+                        const float t = fmaf(fa, melem<T, VEC>(dx_[r], q) - 0.f, fb);
+                        gm[q] = relu_open_r<T>(t) ? melem<T, VEC>(dg_[r], q) : 0.f;
                     }
-                    dg_[r] = pack<T, VEC>(gm);
+                    dg_[r] = mpack<T, VEC>(gm);
                 }
             }
             float s1 = 0.f, s2 = 0.f;
             if (g.ok(r)) {
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) {
-                    const float G = elem<T, VEC>(dg_[r], q), X = elem<T, VEC>(dx_[r], q);
+                    const float G = melem<T, VEC>(dg_[r], q), X = melem<T, VEC>(dx_[r], q);
                     s1 += G;
                     s2 = fmaf(G, X - si, s2);
                 }
@@ -531,8 +628,8 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
             float ov[VEC];
 #pragma unroll
             for (int q = 0; q < VEC; ++q)
-                ov[q] = fmaf(cG, elem<T, VEC>(dg_[r], q), fmaf(cX, elem<T, VEC>(dx_[r], q) - xr, c0));
-            buf_store<T, VEC>(g.rsrc(dx, c, r), g.off(r), pack<T, VEC>(ov));
+                ov[q] = fmaf(cG, melem<T, VEC>(dg_[r], q), fmaf(cX, melem<T, VEC>(dx_[r], q) - xr, c0));
+            mstore<T, VEC>(g.rsrc(dx, c, r), g.off(r), mpack<T, VEC>(ov));
         }
         if ((r & (MONO_ILP - 1)) == MONO_ILP - 1) __builtin_amdgcn_sched_barrier(0);
     }

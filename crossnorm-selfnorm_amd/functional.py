@@ -466,6 +466,71 @@ class PlaneAffine(torch.autograd.Function):
         return dx, dscale, dshift
 
 
+class InstanceNorm(torch.autograd.Function):
+    """nn.InstanceNorm2d (biased variance + eps, optional affine) with a dedicated backward: forward = plane statistics
+    + per-plane affine (3 tensor passes), backward = per-plane sums of G and G*(x - mean) + ONE apply launch
+    dx = r*w*(G - mean(G) - xhat*mean(G*xhat)) (5 passes; composing PlaneStats / PlaneAffine needs 9).
+    Reference: models/imagenet/resnet_ibn_cnsn.py:24-44 instantiates nn.InstanceNorm2d(half, affine=True)."""
+
+    @staticmethod
+    @_on_device_of
+    def forward(ctx, x, weight, bias, eps):
+        _require_device(x, "instance_norm")
+        lib = _ffi.lib()
+        x = _dense(x)
+        n, c, h, w = _dims(x)
+        m = h * w
+        assert m > 1, "InstanceNorm2d needs more than one value per plane"
+        dt = _DTYPES[x.dtype]
+        ms = torch.empty(2, n * c, dtype=torch.float32, device=x.device)
+        # the kernel returns sqrt(unbiased var + e): with e = eps*M/(M-1),  biased var + eps = std_u^2 * (M-1)/M
+        st = lib.cnsn_plane_stats(_ptr(x), dt, n, c, h, w, None, float(eps) * m / (m - 1.0), _ptr(ms), _stream(x))
+        _ffi.check(st, "cnsn_plane_stats")
+        mean = ms[0].view(n, c)
+        rstd = 1.0 / (ms[1].view(n, c) * ((m - 1.0) / m) ** 0.5)          # 1 / sqrt(biased var + eps), (N, C)
+        wf = weight.detach().float().view(1, c) if weight is not None else None
+        scale = rstd * wf if wf is not None else rstd
+        shift = -mean * scale
+        if bias is not None:
+            shift = shift + bias.detach().float().view(1, c)
+        scale, shift = scale.contiguous().view(-1), shift.contiguous().view(-1)
+        y = torch.empty_like(x)
+        st = lib.cnsn_plane_affine(_ptr(x), dt, n, c, h, w, _ptr(scale), _ptr(shift), _ptr(y), _stream(x))
+        _ffi.check(st, "cnsn_plane_affine")
+        ctx.save_for_backward(x, mean, rstd, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @_on_device_of
+    def backward(ctx, gy):
+        lib = _ffi.lib()
+        x, mean, rstd, weight = ctx.saved_tensors
+        n, c, h, w = _dims(x)
+        m = float(h * w)
+        dt = _DTYPES[x.dtype]
+        gy = _dense(gy.to(x.dtype))
+        mean64 = mean.double().contiguous().view(-1)
+        sums = torch.empty(2, n * c, dtype=torch.float32, device=x.device)
+        st = lib.cnsn_plane_dot_shifted(_ptr(gy), _ptr(x), dt, n, c, h, w, _ptr(mean64), _ptr(sums), _stream(x))
+        _ffi.check(st, "cnsn_plane_dot_shifted")
+        s1 = sums[0].view(n, c).double()
+        # the kernel shifts by float(mean): sum G*(x - mean) = s2 + (float(mean) - mean) * s1 — mean IS a float here
+        sgx = sums[1].view(n, c).double() * rstd.double()                 # sum G * xhat
+        wd = weight.detach().double().view(1, c) if weight is not None else torch.ones(1, c, dtype=torch.float64, device=x.device)
+        rw = rstd.double() * wd
+        coef = torch.stack([rw, -rw * rstd.double() * sgx / m, mean.double(), -rw * s1 / m]).float().contiguous()
+        dx = torch.empty_like(x)
+        st = lib.cnsn_plane_combine(_ptr(gy), _ptr(x), dt, n, c, h, w, _ptr(coef), _ptr(dx), _stream(x))
+        _ffi.check(st, "cnsn_plane_combine")
+        dweight = dbias = None
+        if weight is not None and ctx.needs_input_grad[1]:
+            dweight = sgx.sum(0).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dbias = s1.sum(0).to(weight.dtype if weight is not None else torch.float32)
+        return dx, dweight, dbias, None
+
+
 class JsdConsistency(torch.autograd.Function):
     """Jensen-Shannon consistency of three (B, K) logit tensors — cnsn_jsd: loss and gradient in one launch
     (reference imagenet.py:367-381, cifar.py:173-186)."""

@@ -195,6 +195,16 @@ int cnsn_plane_affine(const void* x, int dtype, int N, int C, int H, int W, cons
 int cnsn_plane_dot(const void* g, const void* x, int dtype, int N, int C, int H, int W,
                    float* sums, void* stream);
 
+/* The two launches of a dedicated InstanceNorm2d backward (models/imagenet/resnet_ibn_cnsn.py:24-44 — what autograd
+ * derives for nn.InstanceNorm2d): 5 tensor passes instead of the 9 of composing the two functions above.
+ *   cnsn_plane_dot_shifted : sums (2, N*C) — row 0 sum(g), row 1 sum(g * (x - float(shift[p]))) — `shift` float64 (N*C)
+ *                            (the plane means: the second sum is formed about the mean, no cancellation afterwards)
+ *   cnsn_plane_combine     : out = cG[p]*g + cX[p]*(x - xr[p]) + c0[p];  coef float32 (4, N*C): rows cG, cX, xr, c0 */
+int cnsn_plane_dot_shifted(const void* g, const void* x, int dtype, int N, int C, int H, int W,
+                           const double* shift, float* sums, void* stream);
+int cnsn_plane_combine(const void* g, const void* x, int dtype, int N, int C, int H, int W, const float* coef,
+                       void* out, void* stream);
+
 /* Which kernels a call would run (pure function of the problem; nothing is launched): lets a caller, a test or a
  * benchmark see what CNSN_STRATEGY_AUTO — or a forced strategy with its fall-backs — resolves to. */
 enum cnsn_path {

@@ -29,7 +29,7 @@ TABLE = [
     ((256, 2048, 7, 7), BF16, FC(**SN), "local", "local"),                     # resident cannot take 98-byte planes
     ((256, 2048, 7, 7), BF16, FC(**BLOCK), "local", "local"),
     ((256, 2048, 7, 7), BF16, FC(**SN, **CN), "packed", "packed"),             # CrossNorm: not channel-local
-    ((256, 2048, 7, 7), F32, FC(**SN), "local", "packed"),                     # fp32 backward image = 100 KiB: two-pass
+    ((256, 2048, 7, 7), F32, FC(**SN), "mono", "mono"),                        # fp32 7x7: one element (4 B) per lane
     ((16, 512, 64, 64), F32, FC(sn_active=True, add_mode="post", relu=True), "resident", "resident"),   # segmentation: SN at 'residual'
     ((16, 2048, 64, 64), BF16, FC(sn_active=True, add_mode="post", relu=True), "resident", "resident"),
     ((16, 256, 128, 128), F32, FC(sn_active=True, add_mode="post", relu=True), "streaming", "streaming"),  # 4096 vectors per plane

@@ -31,6 +31,12 @@ CASES = [
     ((17, 3, 6, 10), F32),      # 15 vectors of 16 B -> 16 lanes, one idle
     ((64, 2, 10, 10), BF16),    # 25 vectors of 8 B
     ((18, 2, 2, 6), F32),       # tiny plane (3 vectors)
+    ((40, 6, 7, 7), BF16),      # 2 B per lane, 49 of 64 lanes      (ResNet-50 stage 4 plane)
+    ((256, 3, 7, 7), BF16),     # R = 16
+    ((256, 3, 7, 7), F32),      # 4 B per lane
+    ((33, 4, 7, 7), F16),
+    ((50, 3, 6, 6), BF16),      # 36 elements: 18 vectors of 4 B
+    ((21, 3, 5, 9), F32),       # 45 elements, one per lane
 ]
 ids = lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v).replace("torch.", "")  # noqa: E731
 
@@ -69,7 +75,9 @@ def test_what_mono_declines():
     assert cnsn_amd.which_path(x, FC(sn_active=True, cn_active=True)) != "mono"            # CrossNorm
     assert cnsn_amd.which_path(x, FC(sn_active=True, sn_two=True)) != "mono"               # two-gate form
     assert cnsn_amd.which_path(x, FC(sn_active=True, add_mode="post")) != "mono"           # POST add
-    assert cnsn_amd.which_path(torch.empty((8, 4, 7, 7), device="cuda"), FC(sn_active=True)) != "mono"     # odd plane
+    assert cnsn_amd.which_path(torch.empty((8, 4, 7, 7), device="cuda"), FC(sn_active=True)) == "mono"     # odd plane: one element per lane
+    assert cnsn_amd.which_path(torch.empty((8, 4, 9, 9), device="cuda"), FC(sn_active=True)) != "mono"     # 81 single elements
+    seven = torch.empty((256, 2048, 7, 7), device="cuda")
     assert cnsn_amd.which_path(torch.empty((8, 4, 28, 28), device="cuda"), FC(sn_active=True)) != "mono"   # 196 vectors
     big = torch.empty((256, 4, 14, 14), device="cuda")
     assert cnsn_amd.which_path(big, FC(sn_active=True), backward=False) == "mono"
@@ -77,3 +85,5 @@ def test_what_mono_declines():
     cnsn_amd.set_strategy("auto")
     assert cnsn_amd.which_path(torch.empty((256, 1024, 14, 14), dtype=BF16, device="cuda"), FC(sn_active=True), backward=True) == "mono"
     assert cnsn_amd.which_path(torch.empty((8, 4, 14, 14), device="cuda"), FC(sn_active=True)) != "mono"   # N < 16 under AUTO
+    assert cnsn_amd.which_path(seven, FC(sn_active=True)) == "mono"                                        # 7x7 fp32: 4 B per lane
+    assert cnsn_amd.which_path(seven.bfloat16(), FC(sn_active=True)) == "local"                            # 7x7 bf16: channel-local
