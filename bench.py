@@ -59,6 +59,8 @@ def parse():
                          "training steps of the caller backbones (images/s)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch of the model workloads (0 = config default)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="wrn40: run the steps whose CrossNorm sites are idle eagerly instead of replaying them from a HIP graph")
     ap.add_argument("--sweep", action="store_true", help="print the SURVEY d1 shape sweep as a markdown table and exit")
     return ap.parse_args()
 
@@ -370,6 +372,17 @@ def model_workload(args, dist, world, rank, dev):
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
+
+    graphed = None
+    if args.workload == "wrn40" and dist is None and not args.no_graph:
+        # launch-bound network: the steps with idle CrossNorm sites (half of them at cn_prob 0.5) replay a captured
+        # step — forward, loss, backward, SGD — instead of ~700 eager launches; armed steps stay eager
+        from cnsn_amd.callers import GraphedIdleStep
+        graphed = GraphedIdleStep(net, opt, x, y)
+        name += "; idle-site steps replayed from a HIP graph"
+
+        def step():                                                                              # noqa: F811
+            graphed.step(x, y, 0.5)
 
     for _ in range(args.warmup):
         step()

@@ -65,3 +65,37 @@ def test_training_step_of_selfnorm_replays_from_a_graph():
     for a, b in zip(grads, want):
         assert torch.equal(a, b)
     assert torch.equal(mod.selfnorm.g_bn.running_var, ref.selfnorm.g_bn.running_var)
+
+
+def test_graphed_idle_step_matches_eager_steps():
+    """callers.GraphedIdleStep: steps whose CrossNorm sites are idle are replayed from one captured graph; the sequence of
+    parameters equals the eager sequence under the same seeds (armed steps are eager in both)."""
+    import numpy as np
+    from cnsn_amd.callers import GraphedIdleStep, WideResNetCNSN, train_step_cn
+
+    def run(graphed):
+        torch.manual_seed(11)
+        np.random.seed(11)
+        net = WideResNetCNSN(10, 10, 1, active_num=1, pos="post", beta=1, crop="both", cnsn_type="cnsn").to(DEV).train()
+        opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9)
+        g = torch.Generator(device=DEV).manual_seed(3)
+        x = torch.randn(16, 3, 32, 32, device=DEV, generator=g)
+        y = torch.randint(0, 10, (16,), device=DEV, generator=g)
+        for _ in range(2):                      # (both variants: two eager steps first — MIOpen picks its kernels outside a capture)
+            train_step_cn(net, x, y, opt, 0.5)
+        stepper = GraphedIdleStep(net, opt, x, y, warmup=0) if graphed else None
+        np.random.seed(12)
+        torch.manual_seed(12)
+        for _ in range(6):
+            if graphed:
+                stepper.step(x, y, 0.5)
+            else:
+                train_step_cn(net, x, y, opt, 0.5)
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in net.parameters()], net.state_dict()["block1.layer.0.cnsn.selfnorm.g_bn.num_batches_tracked"].item()
+
+    eager, n_e = run(False)
+    graph, n_g = run(True)
+    assert n_g == n_e                          # capturing records the step, it does not run it
+    worst = max(float((a - b).abs().max() / (b.abs().max() + 1e-12)) for a, b in zip(graph, eager))
+    assert worst < 5e-3, worst                 # same arithmetic; MIOpen's convolutions are not bit-reproducible run to run
