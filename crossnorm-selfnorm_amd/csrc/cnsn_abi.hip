@@ -132,6 +132,13 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
         }
     }
     {
+        const MonoPlan mp = mono_cn_plan(pl, chan_perm != nullptr, 0, false);  // small planes WITH CrossNorm, the same frame
+        if (mp.ok) {
+            st = mono_cn_forward(pl, mp, 0, 0, x, nullptr, perm, gate_dev(g), y, saved ? saved_d : nullptr, stream);
+            if (st != CNSN_E_UNSUPPORTED) return st;
+        }
+    }
+    {
         const LocalPlan lp = local_plan(pl, 0, false);  // small planes, SelfNorm alone: no exchange, no side arrays
         if (lp.ok) {
             st = local_forward(pl, lp, 0, 0, x, nullptr, gate_dev(g), gate_dev(f), y, saved ? saved_d : nullptr, stream);
@@ -203,6 +210,13 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
         if (mp.ok) {
             st = mono_backward(pl, mp, 0, 0, grad_y, x, nullptr, gate_dev(g), gate_dev(f), saved_d, grad_x, gate_grad_dev(dg),
                                gate_grad_dev(df), stream);
+            if (st != CNSN_E_UNSUPPORTED) return st;
+        }
+    }
+    {
+        const MonoPlan mp = mono_cn_plan(pl, chan_perm != nullptr, 0, true);
+        if (mp.ok) {
+            st = mono_cn_backward(pl, mp, 0, 0, grad_y, x, nullptr, perm, gate_dev(g), saved_d, grad_x, gate_grad_dev(dg), stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
     }

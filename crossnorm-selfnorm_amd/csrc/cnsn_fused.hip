@@ -77,6 +77,7 @@ int cnsn_which_path(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int 
     // the backward of an epilogue without ReLU and without PRE add is the plain backward
     const bool fused = bwd ? (e.relu || e.add == ADD_PRE) : (e.relu || e.add != ADD_NONE);
     if (mono_plan(pl, fused ? e.add : 0, bwd).ok) return CNSN_PATH_MONO;
+    if (mono_cn_plan(pl, chan, fused ? e.add : 0, bwd).ok) return CNSN_PATH_MONO;
     if (local_plan(pl, fused ? e.add : 0, bwd).ok) return CNSN_PATH_LOCAL;
     if (fused ? resident_fused_plan(p, pl.boxed, chan, e.add, bwd).ok : resident_plan(p, pl.boxed, chan, bwd).ok)
         return CNSN_PATH_RESIDENT;
@@ -113,6 +114,13 @@ int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, c
         const MonoPlan mp = mono_plan(pl, e.add, false);
         if (mp.ok) {
             st = mono_forward(pl, mp, e.add, e.relu, x, e.addend, gate_dev(g), gate_dev(f), y, saved ? saved_d : nullptr, stream);
+            if (st != CNSN_E_UNSUPPORTED) return st;
+        }
+    }
+    {
+        const MonoPlan mp = mono_cn_plan(pl, chan_perm != nullptr, e.add, false);
+        if (mp.ok) {
+            st = mono_cn_forward(pl, mp, e.add, e.relu, x, e.addend, perm, gate_dev(g), y, saved ? saved_d : nullptr, stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
     }
@@ -209,6 +217,14 @@ int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, 
         if (mp.ok) {
             st = mono_backward(pl, mp, e.add, e.relu, grad_y, x, e.addend, gate_dev(g), gate_dev(f), saved_d, grad_x,
                                gate_grad_dev(dg), gate_grad_dev(df), stream);
+            if (st != CNSN_E_UNSUPPORTED) return st;
+        }
+    }
+    {
+        const MonoPlan mp = mono_cn_plan(pl, chan_perm != nullptr, e.add, true);
+        if (mp.ok) {
+            st = mono_cn_backward(pl, mp, e.add, e.relu, grad_y, x, e.addend, perm, gate_dev(g), saved_d, grad_x,
+                                  gate_grad_dev(dg), stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
     }

@@ -1,0 +1,139 @@
+// Channel-in-registers strategy with CrossNorm: eligibility, geometry, launches (kernels: cnsn_mono_cn_kernels.h).
+#include <cstdlib>
+
+#include "cnsn_mono.h"
+#include "cnsn_mono_cn_kernels.h"
+
+namespace cnsn {
+
+namespace {
+
+// f(TypeTag<T>, IntTag<VEC>, IntTag<LPP>, IntTag<RMAX>)
+template <typename F>
+bool dispatch_mc(int dtype, int vec, int lpp, int rmax, F&& f) {
+    auto by_r = [&](auto tt, auto vt, auto lt) -> bool {
+        if (rmax == 8) {
+            f(tt, vt, lt, IntTag<8>{});
+            return true;
+        }
+        if (rmax == 16) {
+            f(tt, vt, lt, IntTag<16>{});
+            return true;
+        }
+        return false;
+    };
+    auto by_l = [&](auto tt, auto vt) -> bool {
+        if (lpp == 16) return by_r(tt, vt, IntTag<16>{});
+        if (lpp == 64) return by_r(tt, vt, IntTag<64>{});
+        return false;
+    };
+    if (dtype == CNSN_F32) {
+        if (vec == 4) return by_l(TypeTag<float>{}, IntTag<4>{});
+        if (vec == 2) return by_l(TypeTag<float>{}, IntTag<2>{});
+        if (vec == 1) return by_l(TypeTag<float>{}, IntTag<1>{});
+    } else if (dtype == CNSN_BF16) {
+        if (vec == 8) return by_l(TypeTag<bf16_t>{}, IntTag<8>{});
+        if (vec == 4) return by_l(TypeTag<bf16_t>{}, IntTag<4>{});
+        if (vec == 2) return by_l(TypeTag<bf16_t>{}, IntTag<2>{});
+        if (vec == 1) return by_l(TypeTag<bf16_t>{}, IntTag<1>{});
+    } else if (dtype == CNSN_F16) {
+        if (vec == 8) return by_l(TypeTag<_Float16>{}, IntTag<8>{});
+        if (vec == 4) return by_l(TypeTag<_Float16>{}, IntTag<4>{});
+    }
+    return false;
+}
+
+MonoCnArgs make_cn_args(const Plan& pl, const MonoPlan& mp) {
+    MonoCnArgs ca;
+    ca.m.mid = pl.mid;
+    ca.m.nvec = pl.mid.M / mp.vec;
+    ca.m.R = mp.R;
+    ca.Wd = pl.pr.W;
+    ca.cb = pl.cb;
+    ca.sb = pl.sb;
+    return ca;
+}
+
+inline int mono_grid(int C) { return ((C + 7) / 8) * 8; }
+
+}  // namespace
+
+MonoPlan mono_cn_plan(const Plan& pl, bool has_chan_perm, int add, bool backward) {
+    MonoPlan mp{false, 0, 0, 0, 0, 0};
+    const cnsn_problem_t& p = pl.pr;
+    if (p.strategy != CNSN_STRATEGY_AUTO && p.strategy != CNSN_STRATEGY_MONO) return mp;
+    if (!p.cn_active || has_chan_perm || (p.sn_active && p.sn_two) || add == ADD_POST) return mp;
+    if (const char* e = getenv("CNSN_MONO"))
+        if (e[0] == '0' && p.strategy == CNSN_STRATEGY_AUTO) return mp;
+    const int b = elem_bytes(p.dtype), M = p.H * p.W;
+    int vec = 16 / b;  // masks are per element: a vector may straddle rows of the plane
+    while (vec > 1 && M % vec) vec >>= 1;
+    if (vec * b == 16 && M / vec < 16 && (M / (vec / 2)) <= 64) vec >>= 1;
+    if (p.dtype == CNSN_F16 && vec < 4) return mp;  // (not instantiated)
+    const int nvec = M / vec;
+    if (nvec > 64 || nvec < 2 || M < 2) return mp;
+    const int lpp = nvec <= 16 ? 16 : 64, ppr = 64 / lpp;
+    const int rows = (p.N + ppr - 1) / ppr;
+    const int R = (rows + kMonoWaves - 1) / kMonoWaves;
+    if (R > 16 || p.N > kMonoBlock) return mp;
+    const int rmax = R <= 8 ? 8 : 16;
+    const int data_regs = rmax * (vec * b < 4 ? 4 : vec * b) / 4 * (backward ? 2 : 1);
+    if (data_regs > 72) return mp;
+    if ((long long)ppr * p.C * M * b >= 0x7ffffff0ll) return mp;
+    mp.lds = mono_cn_lds_bytes(kMonoWaves * R * ppr, backward);
+    if (mp.lds > 64 * 1024) return mp;
+    if (p.strategy == CNSN_STRATEGY_AUTO) {
+        if ((long long)M * b < 64 || p.N < 16) return mp;
+        // one 16-bit element per lane (7x7 bf16) only pays with crop boxes — measured at (256,2048,7,7), fwd+bwd:
+        // boxed 0.305 vs 0.361 ms packed two-pass, un-boxed 0.286 vs 0.258
+        if (vec * b < 4 && !pl.boxed) return mp;
+    }
+    mp.vec = vec;
+    mp.lpp = lpp;
+    mp.rmax = rmax;
+    mp.R = R;
+    mp.ok = true;
+    return mp;
+}
+
+int mono_cn_forward(const Plan& pl, const MonoPlan& mp, int add, int relu, const void* x, const void* addend,
+                    const int64_t* perm, GateDev g, void* y, double* saved, hipStream_t stream) {
+    const MonoCnArgs ca = make_cn_args(pl, mp);
+    const bool epi = add == ADD_PRE || relu;
+    int status = CNSN_E_UNSUPPORTED;
+    dispatch_mc(pl.pr.dtype, mp.vec, mp.lpp, mp.rmax, [&](auto tt, auto vt, auto lt, auto rt) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value, LPP = decltype(lt)::value, RMAX = decltype(rt)::value;
+        if (epi)
+            mono_cn_fwd_kernel<T, VEC, LPP, RMAX, true><<<mono_grid(pl.pr.C), kMonoBlock, mp.lds, stream>>>(
+                ca, (const T*)x, (const T*)(add == ADD_PRE ? addend : nullptr), (T*)y, perm, g, saved, add, relu);
+        else
+            mono_cn_fwd_kernel<T, VEC, LPP, RMAX, false><<<mono_grid(pl.pr.C), kMonoBlock, mp.lds, stream>>>(
+                ca, (const T*)x, nullptr, (T*)y, perm, g, saved, ADD_NONE, 0);
+        const hipError_t e = hipGetLastError();
+        status = e == hipSuccess ? CNSN_OK : (int)e;
+    });
+    return status;
+}
+
+int mono_cn_backward(const Plan& pl, const MonoPlan& mp, int add, int relu, const void* gy, const void* x, const void* addend,
+                     const int64_t* perm, GateDev g, const double* saved, void* dx, GateGradDev dg, hipStream_t stream) {
+    const MonoCnArgs ca = make_cn_args(pl, mp);
+    const bool epi = add == ADD_PRE || relu;
+    int status = CNSN_E_UNSUPPORTED;
+    dispatch_mc(pl.pr.dtype, mp.vec, mp.lpp, mp.rmax, [&](auto tt, auto vt, auto lt, auto rt) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value, LPP = decltype(lt)::value, RMAX = decltype(rt)::value;
+        if (epi)
+            mono_cn_bwd_kernel<T, VEC, LPP, RMAX, true><<<mono_grid(pl.pr.C), kMonoBlock, mp.lds, stream>>>(
+                ca, (const T*)gy, (const T*)x, (const T*)(add == ADD_PRE ? addend : nullptr), (T*)dx, perm, g, dg, saved, add, relu);
+        else
+            mono_cn_bwd_kernel<T, VEC, LPP, RMAX, false><<<mono_grid(pl.pr.C), kMonoBlock, mp.lds, stream>>>(
+                ca, (const T*)gy, (const T*)x, nullptr, (T*)dx, perm, g, dg, saved, ADD_NONE, 0);
+        const hipError_t e = hipGetLastError();
+        status = e == hipSuccess ? CNSN_OK : (int)e;
+    });
+    return status;
+}
+
+}  // namespace cnsn

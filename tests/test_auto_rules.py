@@ -25,7 +25,10 @@ TABLE = [
     ((256, 1024, 14, 14), BF16, FC(**BLOCK), "mono", "mono"),
     ((256, 1024, 14, 14), F32, FC(**SN), "mono", "resident"),                  # fp32 backward: G and x = 128 VGPRs per lane
     ((96, 1024, 14, 14), BF16, FC(**SN), "mono", "mono"),
-    ((256, 1024, 14, 14), BF16, FC(**SN, **CN), "resident", "resident"),       # CrossNorm: not channel-in-registers
+    ((256, 1024, 14, 14), BF16, FC(**SN, **CN), "mono", "mono"),               # CrossNorm inside the channel's workgroup
+    ((256, 1024, 14, 14), BF16, FC(**SN, **BOTH), "mono", "mono"),             # (was packed two-pass: vectors straddle rows)
+    ((128, 128, 8, 8), F32, FC(**SN, **BOTH), "mono", "mono"),                 # WideResNet stage 3, armed site
+    ((256, 2048, 7, 7), BF16, FC(**SN, **BOTH), "mono", "mono"),               # 7x7 bf16 with boxes: one element per lane
     ((256, 2048, 7, 7), BF16, FC(**SN), "local", "local"),                     # resident cannot take 98-byte planes
     ((256, 2048, 7, 7), BF16, FC(**BLOCK), "local", "local"),
     ((256, 2048, 7, 7), BF16, FC(**SN, **CN), "packed", "packed"),             # CrossNorm: not channel-local

@@ -72,7 +72,8 @@ def test_block_epilogue(shape, dtype, mode, relu):
 def test_what_mono_declines():
     FC = cnsn_amd.FusedConfig
     x = torch.empty((8, 4, 14, 14), device="cuda")
-    assert cnsn_amd.which_path(x, FC(sn_active=True, cn_active=True)) != "mono"            # CrossNorm
+    assert cnsn_amd.which_path(x, FC(sn_active=True, cn_active=True)) == "mono"            # CrossNorm: the mono-cn kernels
+    assert cnsn_amd.which_path(x, FC(sn_active=True, cn_active=True), chan_perm=True) != "mono"     # channel permutation
     assert cnsn_amd.which_path(x, FC(sn_active=True, sn_two=True)) != "mono"               # two-gate form
     assert cnsn_amd.which_path(x, FC(sn_active=True, add_mode="post")) != "mono"           # POST add
     assert cnsn_amd.which_path(torch.empty((8, 4, 7, 7), device="cuda"), FC(sn_active=True)) == "mono"     # odd plane: one element per lane
@@ -87,3 +88,44 @@ def test_what_mono_declines():
     assert cnsn_amd.which_path(torch.empty((8, 4, 14, 14), device="cuda"), FC(sn_active=True)) != "mono"   # N < 16 under AUTO
     assert cnsn_amd.which_path(seven, FC(sn_active=True)) == "mono"                                        # 7x7 fp32: 4 B per lane
     assert cnsn_amd.which_path(seven.bfloat16(), FC(sn_active=True)) == "local"                            # 7x7 bf16: channel-local
+
+
+# ------------------------------------------------------------------------------------------------
+# the same frame WITH CrossNorm (cnsn_mono_cn_kernels.h): crop boxes, lam, with and without SelfNorm
+# ------------------------------------------------------------------------------------------------
+CN_CASES = [
+    ((37, 5, 14, 14), F32), ((256, 3, 14, 14), BF16), ((128, 4, 16, 16), F32), ((130, 3, 8, 8), F32), ((33, 4, 8, 8), BF16),
+    ((40, 6, 7, 7), BF16), ((64, 3, 7, 7), F32), ((20, 6, 12, 12), F16), ((17, 3, 6, 10), F32), ((300, 2, 8, 8), F32),
+]
+
+
+def runs_mono_cn(shape, dtype, backward, crop, sn, **cfg):
+    x = torch.empty(shape, dtype=dtype, device="cuda")
+    boxes = dict(content_box=(1, 1, 3, 3) if crop in ("content", "both") else None,
+                 style_box=(0, 0, 2, 2) if crop in ("style", "both") else None)
+    return cnsn_amd.which_path(x, cnsn_amd.FusedConfig(cn_active=True, sn_active=sn, **boxes, **cfg), backward=backward) == "mono"
+
+
+@pytest.mark.parametrize("shape,dtype", CN_CASES, ids=ids)
+@pytest.mark.parametrize("crop", ["neither", "style", "content", "both"])
+@pytest.mark.parametrize("kind", ["cn", "cnsn"])
+def test_crossnorm(shape, dtype, crop, kind):
+    assert runs_mono_cn(shape, dtype, False, crop, kind == "cnsn") and runs_mono_cn(shape, dtype, True, crop, kind == "cnsn")
+    out = run_pair(shape, crop, kind, dtype, 4200 + shape[0] + shape[3], training=True)
+    assert_parity(out, dtype, ("mono-cn", shape, dtype, crop, kind))
+
+
+@pytest.mark.parametrize("shape,dtype", CN_CASES[:6], ids=ids)
+def test_crossnorm_options(shape, dtype):
+    out = run_pair(shape, "both", "cnsn", dtype, 4300 + shape[0], lam=0.3, training=True)      # lam blend (cnsn.py:86-89)
+    assert_parity(out, dtype, ("mono-cn lam", shape, dtype))
+    out = run_pair(shape, "style", "cnsn", dtype, 4310 + shape[0], training=False)             # SelfNorm on running statistics
+    assert_parity(out, dtype, ("mono-cn eval-sn", shape, dtype))
+
+
+@pytest.mark.parametrize("shape,dtype", CN_CASES[:6], ids=ids)
+@pytest.mark.parametrize("mode,relu", [("pre", True), ("pre", False), ("none", True)])
+@pytest.mark.parametrize("kind,crop", [("cnsn", "both"), ("cn", "content")])
+def test_crossnorm_block_epilogue(shape, dtype, mode, relu, kind, crop):
+    check_block(run_block(shape, kind, crop, mode, relu, dtype, 4400 + shape[0] + shape[3]), dtype, relu,
+                ("mono-cn", shape, dtype, kind, crop, mode, relu))
