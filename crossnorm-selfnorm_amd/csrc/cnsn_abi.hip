@@ -59,7 +59,8 @@ size_t cnsn_context_bytes(const cnsn_problem_t* prob) {
     const cnsn_problem_t& p = pl.pr;
     bool any = false;
     for (int bw = 0; bw < 2 && !any; ++bw)
-        any = resident_plan(p, pl.boxed, false, bw != 0).ok || resident_fused_plan(p, pl.boxed, false, CNSN_ADD_PRE, bw != 0).ok;
+        any = resident_plan(p, pl.boxed, false, bw != 0).ok || resident_fused_plan(p, pl.boxed, false, CNSN_ADD_PRE, bw != 0).ok ||
+              resident_split_plan(p, pl.boxed, false, CNSN_ADD_NONE, 0, bw != 0).ok;
     // control block + one tagged granule per exchanged scalar (six per plane forward with crop boxes: the most)
     return any ? kCtlBytes + (size_t)p.N * p.C * 6 * 8 : 0;
 }
@@ -150,6 +151,11 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
                               saved ? saved_d : nullptr, workspace, stream);
         if (st != CNSN_E_UNSUPPORTED) return st;  // otherwise: fall through to the two-pass strategy
     }
+    if (resident_split_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, CNSN_ADD_NONE, 0, false).ok) {  // large planes
+        st = resident_split_forward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, CNSN_ADD_NONE, 0, x, nullptr, perm, gate_dev(g),
+                                    gate_dev(f), y, saved ? saved_d : nullptr, workspace, stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
+    }
 
     PackedGeom pg;
     if (packed_plan(pl, pg)) {  // small planes: runs of planes staged through LDS (cnsn_packed_kernels.h)
@@ -231,6 +237,12 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
     if (resident_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, true).ok) {
         st = resident_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, grad_y, x, perm, gate_dev(g), gate_dev(f),
                                saved_d, grad_x, gate_grad_dev(dg), gate_grad_dev(df), workspace, stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
+    }
+    if (resident_split_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, CNSN_ADD_NONE, 0, true).ok) {
+        st = resident_split_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, CNSN_ADD_NONE, 0, grad_y, x, nullptr, perm,
+                                     gate_dev(g), gate_dev(f), saved_d, grad_x, nullptr, gate_grad_dev(dg), gate_grad_dev(df),
+                                     workspace, stream);
         if (st != CNSN_E_UNSUPPORTED) return st;
     }
 

@@ -81,6 +81,7 @@ int cnsn_which_path(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int 
     if (local_plan(pl, fused ? e.add : 0, bwd).ok) return CNSN_PATH_LOCAL;
     if (fused ? resident_fused_plan(p, pl.boxed, chan, e.add, bwd).ok : resident_plan(p, pl.boxed, chan, bwd).ok)
         return CNSN_PATH_RESIDENT;
+    if (resident_split_plan(p, pl.boxed, chan, fused ? e.add : ADD_NONE, fused ? e.relu : 0, bwd).ok) return CNSN_PATH_RESIDENT;
     PackedGeom pg;
     return packed_plan(pl, pg) ? CNSN_PATH_PACKED : CNSN_PATH_STREAMING;
 }
@@ -134,6 +135,11 @@ int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, c
     }
     if (resident_fused_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, e.add, false).ok) {
         st = resident_fused_forward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, e.add, e.relu, x, e.addend, perm, gate_dev(g),
+                                    gate_dev(f), y, saved ? saved_d : nullptr, workspace, stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
+    }
+    if (resident_split_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, e.add, e.relu, false).ok) {  // large planes
+        st = resident_split_forward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, e.add, e.relu, x, e.addend, perm, gate_dev(g),
                                     gate_dev(f), y, saved ? saved_d : nullptr, workspace, stream);
         if (st != CNSN_E_UNSUPPORTED) return st;
     }
@@ -238,6 +244,12 @@ int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, 
     }
     if (resident_fused_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, e.add, true).ok) {
         st = resident_fused_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, e.add, e.relu, grad_y, x, e.addend, perm,
+                                     gate_dev(g), gate_dev(f), saved_d, grad_x, grad_addend, gate_grad_dev(dg),
+                                     gate_grad_dev(df), workspace, stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
+    }
+    if (resident_split_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, e.add, e.relu, true).ok) {
+        st = resident_split_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, e.add, e.relu, grad_y, x, e.addend, perm,
                                      gate_dev(g), gate_dev(f), saved_d, grad_x, grad_addend, gate_grad_dev(dg),
                                      gate_grad_dev(df), workspace, stream);
         if (st != CNSN_E_UNSUPPORTED) return st;

@@ -268,7 +268,7 @@ __device__ __forceinline__ bool sweep_granules_scalar(const unsigned long long* 
 template <int VEC, int NV, bool BOXED>
 struct SlotGeom {
     static constexpr int WORDS = BOXED ? (NV * VEC + 31) / 32 : 1;
-    int lane, nvec;
+    int lane, nvec;  // (SPLIT kernels: lane carries the wave's slot offset, lane + 64 * first slot of the wave)
     unsigned cbits[WORDS];  // bit j*VEC+q: element q of slot j is inside the content box
     unsigned sbits[WORDS];  // ... inside the style box
     __device__ __forceinline__ SlotGeom(const ResArgs& ra, int lane_) : lane(lane_), nvec(ra.nvec) {
@@ -442,6 +442,19 @@ __device__ __forceinline__ Raw<T, VEC> add_raw(const Raw<T, VEC>& a, const Raw<T
     return pack<T, VEC>(f);
 }
 
+// SPLIT kernels (a plane spread over the four waves of its workgroup): add wave-uniform partials across the waves.
+// xch: [4][8] floats.  Every wave calls it; one workgroup barrier.
+template <int NVAL>
+__device__ __forceinline__ void split_merge(float (&v)[NVAL], float* xch, int wave, int lane) {
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NVAL; ++i) xch[wave * 8 + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NVAL; ++i) v[i] = (xch[i] + xch[8 + i]) + (xch[16 + i] + xch[24 + i]);
+}
+
 // dynamic LDS carve (bytes); NG = granules per plane, OWN = planes per workgroup
 // rows of `saved` the backward algebra needs, staged in LDS per item (floats / doubles per instance)
 enum StageF { F_A1 = 0, F_M_IN, F_MU_O, F_MU_P, F_G, F_F, F_A, F_SIG_P, F_SIG_C, F_M2C, F_SIG_S, F_N };
@@ -454,6 +467,7 @@ __host__ __device__ inline size_t res_lds_bytes(int N, int NG, int OWN, int coef
            + align16((size_t)OWN * coef_rows * 4)  // coefficients of the owned planes
            + 4 * 4 * 8                        // block reduction scratch
            + 16                               // "this workgroup gave up" flag
+           + 2 * 4 * 8 * 4                    // SPLIT kernels: per-wave partial statistics, two alternating copies
            + (backward ? align16((size_t)N * D_N * 8) + align16((size_t)N * F_N * 4) : 0);  // staged `saved`
 }
 
@@ -466,14 +480,19 @@ __host__ __device__ inline size_t res_lds_bytes(int N, int NG, int OWN, int coef
 // POST (with EPI, un-boxed): the addend joins AFTER the op — y = act(CNSN(x) + addend), the 'residual' / 'identity'
 // positions of the callers (resnet_cnsn.py:112-116).  Its planes are fetched when the exchange is over (they are in
 // flight during the algebra) and never held across the cluster wait; one workgroup per CU less than the other variants.
-template <typename T, int VEC, int NV, int PPW, bool BOXED, bool EPI = false, bool SOLO = false, bool POST = false>
-__global__ __launch_bounds__(kBlock, POST ? (data_regs(sizeof(T), VEC, NV, PPW) >= 64 ? 2 : 3) : EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV) : fwd_waves(data_regs(sizeof(T), VEC, NV, PPW), (int)sizeof(T))) void resident_fwd_kernel(ResArgs ra, const T* __restrict__ x, T* __restrict__ y,
+// SPLIT: ONE plane per workgroup, a quarter per wave (slots wave*NV .. wave*NV+NV-1): planes of 1025..4096 vectors
+// (128x128 fp32).  The waves' partial sums meet in LDS (exact two-pass kept: the second pass runs about the merged
+// means), wave 0 publishes; everything after the exchange is the same code with one plane per workgroup.
+template <typename T, int VEC, int NV, int PPW, bool BOXED, bool EPI = false, bool SOLO = false, bool POST = false,
+          bool SPLIT = false>
+__global__ __launch_bounds__(kBlock, SPLIT ? (POST ? 2 : 3) : POST ? (data_regs(sizeof(T), VEC, NV, PPW) >= 64 ? 2 : 3) : EPI ? fwd_waves_epi((int)sizeof(T), VEC, NV) : fwd_waves(data_regs(sizeof(T), VEC, NV, PPW), (int)sizeof(T))) void resident_fwd_kernel(ResArgs ra, const T* __restrict__ x, T* __restrict__ y,
                                                               const int64_t* __restrict__ perm, GateDev gg, GateDev gf,
                                                               unsigned long long* __restrict__ gran,
                                                               double* __restrict__ saved, unsigned* __restrict__ ctl,
                                                               const T* __restrict__ addend, int relu) {
     constexpr int NG = BOXED ? 6 : 2;
-    constexpr int OWN = 4 * PPW;
+    constexpr int OWN = SPLIT ? 1 : 4 * PPW;
+    static_assert(!SPLIT || (PPW == 1 && !CNSN_WAVE_COEF), "a split plane is the workgroup's only plane");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const MidArgs a = ra.mid;
     const int N = a.N, C = a.C;
@@ -483,11 +502,14 @@ __global__ __launch_bounds__(kBlock, POST ? (data_regs(sizeof(T), VEC, NV, PPW) 
     float* ocoef = (float*)((char*)sperm + align16((size_t)N * 4));
     double* red = (double*)((char*)ocoef + align16((size_t)OWN * FC_ROWS * 4));
     int* gave_up = (int*)(red + 4 * 4);
+    float* xch = (float*)(gave_up + 4);  // [2][4][8] (SPLIT)
     (void)zbuf;
+    (void)xch;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: plane bases stay in SGPRs
     const size_t P = (size_t)N * C;
-    const SlotGeom<VEC, NV, BOXED> sg(ra, lane);
+    const int j0 = SPLIT ? wave * NV : 0;  // first slot of this wave within its plane
+    const SlotGeom<VEC, NV, BOXED> sg(ra, lane + 64 * j0);
     constexpr int VB = VEC * (int)sizeof(T);  // bytes per vector
     const int voff = lane * VB;
 
@@ -501,7 +523,7 @@ __global__ __launch_bounds__(kBlock, POST ? (data_regs(sizeof(T), VEC, NV, PPW) 
     int iter_ = -1;
     for (int item = blockIdx.x; item < ra.items; item += gridDim.x) {
         const int c = item / ra.K, k = item - c * ra.K;
-        const int n0 = (k * 4 + wave) * PPW;
+        const int n0 = SPLIT ? k : (k * 4 + wave) * PPW;
         ++iter_;
         CNSN_STAMP(0);
 
@@ -534,13 +556,13 @@ __global__ __launch_bounds__(kBlock, POST ? (data_regs(sizeof(T), VEC, NV, PPW) 
             const T* pb = x + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
             const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;  // past the batch end: every lane reads zeros
 #pragma unroll
-            for (int j = 0; j < NV; ++j) d[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(pb, pbytes, j), voff);
+            for (int j = 0; j < NV; ++j) d[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(pb, pbytes, j0 + j), voff);
             if constexpr (EPI && !POST) {
                 if (addend) {  // the op's input is x + addend, formed here and never written anywhere
                     const T* ab = addend + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
 #pragma unroll
                     for (int j = 0; j < NV; ++j)
-                        d[s][j] = add_raw<T, VEC>(d[s][j], buf_load<T, VEC>(slot_rsrc<T, VEC>(ab, pbytes, j), voff));
+                        d[s][j] = add_raw<T, VEC>(d[s][j], buf_load<T, VEC>(slot_rsrc<T, VEC>(ab, pbytes, j0 + j), voff));
                 }
             }
         }
@@ -553,7 +575,7 @@ __global__ __launch_bounds__(kBlock, POST ? (data_regs(sizeof(T), VEC, NV, PPW) 
                     const T* ab = addend + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
                     const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;
 #pragma unroll
-                    for (int j = 0; j < NV; ++j) ad[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(ab, pbytes, j), voff);
+                    for (int j = 0; j < NV; ++j) ad[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(ab, pbytes, j0 + j), voff);
                 }
             }
         };
@@ -571,7 +593,9 @@ __global__ __launch_bounds__(kBlock, POST ? (data_regs(sizeof(T), VEC, NV, PPW) 
                 for (int j = 0; j < NV; ++j)
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) sum += elem<T, VEC>(d[s][j], q);
-                const float mean = wave_sum(sum) / (float)ra.M;
+                float tot[1] = {wave_sum(sum)};
+                if constexpr (SPLIT) split_merge<1>(tot, xch, wave, lane);
+                const float mean = tot[0] / (float)ra.M;
                 float m2 = 0.f;
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
@@ -582,8 +606,10 @@ __global__ __launch_bounds__(kBlock, POST ? (data_regs(sizeof(T), VEC, NV, PPW) 
                             m2 = fmaf(t, t, m2);
                         }
                     }
+                float tq[1] = {wave_sum(m2)};
+                if constexpr (SPLIT) split_merge<1>(tq, xch + 32, wave, lane);
                 pub[0] = mean;
-                pub[1] = wave_sum(m2);
+                pub[1] = tq[0];
             } else {
                 float sc = 0.f, so = 0.f, ss = 0.f;
 #pragma unroll
@@ -597,9 +623,11 @@ __global__ __launch_bounds__(kBlock, POST ? (data_regs(sizeof(T), VEC, NV, PPW) 
                         ss += is ? f : 0.f;
                     }
                 const int Mo = a.M - a.Mc;
-                const float mc = wave_sum(sc) / (float)a.Mc;
-                const float mo = Mo > 0 ? wave_sum(so) / (float)Mo : 0.f;
-                const float ms = wave_sum(ss) / (float)a.Ms;
+                float tot[3] = {wave_sum(sc), wave_sum(so), wave_sum(ss)};
+                if constexpr (SPLIT) split_merge<3>(tot, xch, wave, lane);
+                const float mc = tot[0] / (float)a.Mc;
+                const float mo = Mo > 0 ? tot[1] / (float)Mo : 0.f;
+                const float ms = tot[2] / (float)a.Ms;
                 float qc = 0.f, qo = 0.f, qs = 0.f;
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
@@ -614,12 +642,14 @@ __global__ __launch_bounds__(kBlock, POST ? (data_regs(sizeof(T), VEC, NV, PPW) 
                             qs += is ? ts * ts : 0.f;
                         }
                     }
+                float tq[3] = {wave_sum(qc), wave_sum(qo), wave_sum(qs)};
+                if constexpr (SPLIT) split_merge<3>(tq, xch + 32, wave, lane);
                 pub[0] = mc;
-                pub[1] = wave_sum(qc);
+                pub[1] = tq[0];
                 pub[2] = mo;
-                pub[3] = wave_sum(qo);
+                pub[3] = tq[1];
                 pub[4] = ms;
-                pub[5] = wave_sum(qs);
+                pub[5] = tq[2];
             }
             if constexpr (SOLO) {
                 solo_mean[s] = pub[0];
@@ -627,13 +657,13 @@ __global__ __launch_bounds__(kBlock, POST ? (data_regs(sizeof(T), VEC, NV, PPW) 
                 continue;
             }
             if (ra.epoch) {  // persistent context: lane m publishes pub[m] with the launch's tag
-                if (n < N && lane < NG && !(ra.fault && item == ra.K - 1)) {
+                if (n < N && lane < NG && (!SPLIT || wave == 0) && !(ra.fault && item == ra.K - 1)) {
                     float v = pub[0];
 #pragma unroll
                     for (int m = 1; m < NG; ++m) v = (lane == m) ? pub[m] : v;
                     put_tagged(gran + ((size_t)c * N + n) * NG + lane, v, ra.epoch);
                 }
-            } else if (n < N && lane < NG / 2 && !(ra.fault && item == ra.K - 1)) {  // lane m publishes (pub[2m], pub[2m+1])
+            } else if (n < N && lane < NG / 2 && (!SPLIT || wave == 0) && !(ra.fault && item == ra.K - 1)) {  // lane m: (pub[2m], pub[2m+1])
                 float lo = pub[0], hi = pub[1];
 #pragma unroll
                 for (int m = 1; m < NG / 2; ++m) {
@@ -672,7 +702,7 @@ __global__ __launch_bounds__(kBlock, POST ? (data_regs(sizeof(T), VEC, NV, PPW) 
                     }
                 }
                 const FwdCoefs cf = fwd_coefs<float>(a, f, g, fg);
-                if (saved && lane == 0) {
+                if (saved && lane == 0 && (!SPLIT || wave == 0)) {
                     const size_t p = (size_t)n * C + c;
                     store_fwd_plane<float>(saved, P, p, f, a.cn_active);
                     saved[sv_at(p, SV_G)] = g;
@@ -692,7 +722,7 @@ __global__ __launch_bounds__(kBlock, POST ? (data_regs(sizeof(T), VEC, NV, PPW) 
                         if constexpr (POST) ov[q] += elem<T, VEC>(ad[s][j], q);
                         if constexpr (EPI) ov[q] = relu ? fmaxf(ov[q], 0.f) : ov[q];
                     }
-                    buf_store<T, VEC>(slot_rsrc<T, VEC>(yb, pbytes, j), voff, pack<T, VEC>(ov));
+                    buf_store<T, VEC>(slot_rsrc<T, VEC>(yb, pbytes, j0 + j), voff, pack<T, VEC>(ov));
                 }
             }
             continue;
@@ -884,7 +914,7 @@ __global__ __launch_bounds__(kBlock, POST ? (data_regs(sizeof(T), VEC, NV, PPW) 
                 const float a_in = lane_bcast(cfw.a_in, s), xr = lane_bcast(cfw.xr, s), b_in = lane_bcast(cfw.b_in, s),
                             a_out = lane_bcast(cfw.a_out, s), b_out = lane_bcast(cfw.b_out, s);
 #else
-                const float* o = ocoef + (wave * PPW + s) * FC_ROWS;
+                const float* o = ocoef + (SPLIT ? 0 : wave * PPW + s) * FC_ROWS;
                 const float a_in = o[FC_A_IN], xr = o[FC_XR], b_in = o[FC_B_IN], a_out = o[FC_A_OUT],
                             b_out = o[FC_B_OUT];
 #endif
@@ -901,7 +931,7 @@ __global__ __launch_bounds__(kBlock, POST ? (data_regs(sizeof(T), VEC, NV, PPW) 
                         if constexpr (POST) ov[q] += elem<T, VEC>(ad[s][j], q);
                         if constexpr (EPI) ov[q] = relu ? fmaxf(ov[q], 0.f) : ov[q];
                     }
-                    buf_store<T, VEC>(slot_rsrc<T, VEC>(yb, pbytes, j), voff, pack<T, VEC>(ov));
+                    buf_store<T, VEC>(slot_rsrc<T, VEC>(yb, pbytes, j0 + j), voff, pack<T, VEC>(ov));
                 }
             }
         }
@@ -917,8 +947,8 @@ __global__ __launch_bounds__(kBlock, POST ? (data_regs(sizeof(T), VEC, NV, PPW) 
 // ================================================================================================
 // POST (with EPI and ReLU, un-boxed): the mask is that of act(CNSN(x) + addend) — the addend is read next to G and x,
 // used for the mask and dropped; the masked gradient is also the gradient of the addend and is written to d_addend.
-template <typename T, int VEC, int NV, int PPW, bool BOXED, bool EPI = false, bool POST = false>
-__global__ __launch_bounds__(kBlock, POST ? 2 : EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV) : bwd_waves(data_regs(sizeof(T), VEC, NV, PPW))) void resident_bwd_kernel(ResArgs ra, const T* __restrict__ gy,
+template <typename T, int VEC, int NV, int PPW, bool BOXED, bool EPI = false, bool POST = false, bool SPLIT = false>
+__global__ __launch_bounds__(kBlock, SPLIT ? 2 : POST ? 2 : EPI ? bwd_waves_epi((int)sizeof(T), VEC, NV) : bwd_waves(data_regs(sizeof(T), VEC, NV, PPW))) void resident_bwd_kernel(ResArgs ra, const T* __restrict__ gy,
                                                               const T* __restrict__ x, T* __restrict__ dx,
                                                               const int64_t* __restrict__ perm, GateDev gg, GateDev gf,
                                                               GateGradDev dgr, GateGradDev dfr,
@@ -928,7 +958,8 @@ __global__ __launch_bounds__(kBlock, POST ? 2 : EPI ? bwd_waves_epi((int)sizeof(
                                                               const T* __restrict__ addend, int relu,
                                                               T* __restrict__ d_addend) {
     constexpr int NS = BOXED ? 4 : 2;
-    constexpr int OWN = 4 * PPW;
+    constexpr int OWN = SPLIT ? 1 : 4 * PPW;
+    static_assert(!SPLIT || (PPW == 1 && !CNSN_WAVE_COEF), "a split plane is the workgroup's only plane");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const MidArgs a = ra.mid;
     const int N = a.N, C = a.C;
@@ -938,12 +969,15 @@ __global__ __launch_bounds__(kBlock, POST ? 2 : EPI ? bwd_waves_epi((int)sizeof(
     float* ocoef = (float*)((char*)iperm + align16((size_t)N * 4));
     double* red = (double*)((char*)ocoef + align16((size_t)OWN * BC_ROWS * 4));
     int* gave_up = (int*)(red + 4 * 4);
-    double* svd = red + 4 * 4 + 2;                                     // [N][D_N]
+    float* xch = (float*)(gave_up + 4);                                // [2][4][8] (SPLIT)
+    (void)xch;
+    double* svd = red + 4 * 4 + 2 + 32;                                // [N][D_N]
     float* svf = (float*)((char*)svd + align16((size_t)N * D_N * 8));  // [N][F_N]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: plane bases stay in SGPRs
     const size_t P = (size_t)N * C;
-    const SlotGeom<VEC, NV, BOXED> sg(ra, lane);
+    const int j0 = SPLIT ? wave * NV : 0;  // first slot of this wave within its plane
+    const SlotGeom<VEC, NV, BOXED> sg(ra, lane + 64 * j0);
     constexpr int VB = VEC * (int)sizeof(T);  // bytes per vector
     const int voff = lane * VB;
 
@@ -957,7 +991,7 @@ __global__ __launch_bounds__(kBlock, POST ? 2 : EPI ? bwd_waves_epi((int)sizeof(
     int iter_ = -1;
     for (int item = blockIdx.x; item < ra.items; item += gridDim.x) {
         const int c = item / ra.K, k = item - c * ra.K;
-        const int n0 = (k * 4 + wave) * PPW;
+        const int n0 = SPLIT ? k : (k * 4 + wave) * PPW;
         ++iter_;
         CNSN_STAMP(0);
 
@@ -1023,8 +1057,8 @@ __global__ __launch_bounds__(kBlock, POST ? 2 : EPI ? bwd_waves_epi((int)sizeof(
             const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                dg_[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(gy + off, pbytes, j), voff);
-                dx_[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(x + off, pbytes, j), voff);
+                dg_[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(gy + off, pbytes, j0 + j), voff);
+                dx_[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(x + off, pbytes, j0 + j), voff);
             }
             if constexpr (EPI) {
                 if constexpr (!POST) {
@@ -1032,13 +1066,13 @@ __global__ __launch_bounds__(kBlock, POST ? 2 : EPI ? bwd_waves_epi((int)sizeof(
 #pragma unroll
                         for (int j = 0; j < NV; ++j)
                             dx_[s][j] = add_raw<T, VEC>(dx_[s][j],
-                                                        buf_load<T, VEC>(slot_rsrc<T, VEC>(addend + off, pbytes, j), voff));
+                                                        buf_load<T, VEC>(slot_rsrc<T, VEC>(addend + off, pbytes, j0 + j), voff));
                     }
                 }
                 Raw<T, VEC> ad[POST ? NV : 1];
                 if constexpr (POST) {
 #pragma unroll
-                    for (int j = 0; j < NV; ++j) ad[j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(addend + off, pbytes, j), voff);
+                    for (int j = 0; j < NV; ++j) ad[j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(addend + off, pbytes, j0 + j), voff);
                 }
                 if (relu) {  // shut the gradient where the forward's output was not positive: the forward affine
                              // is re-evaluated with the coefficients the forward itself used
@@ -1057,7 +1091,7 @@ __global__ __launch_bounds__(kBlock, POST ? 2 : EPI ? bwd_waves_epi((int)sizeof(
                         }
                         dg_[s][j] = pack<T, VEC>(gm);
                         if constexpr (POST)  // the masked gradient is the addend's gradient
-                            buf_store<T, VEC>(slot_rsrc<T, VEC>(d_addend + off, pbytes, j), voff, dg_[s][j]);
+                            buf_store<T, VEC>(slot_rsrc<T, VEC>(d_addend + off, pbytes, j0 + j), voff, dg_[s][j]);
                     }
                 }
             }
@@ -1091,14 +1125,15 @@ __global__ __launch_bounds__(kBlock, POST ? 2 : EPI ? bwd_waves_epi((int)sizeof(
                 }
 #pragma unroll
             for (int m = 0; m < NS; ++m) acc[m] = wave_sum(acc[m]);
+            if constexpr (SPLIT) split_merge<NS>(acc, xch, wave, lane);
             if (ra.epoch) {
-                if (n < N && lane < NS && !(ra.fault && item == ra.K - 1)) {
+                if (n < N && lane < NS && (!SPLIT || wave == 0) && !(ra.fault && item == ra.K - 1)) {
                     float v = acc[0];
 #pragma unroll
                     for (int m = 1; m < NS; ++m) v = (lane == m) ? acc[m] : v;
                     put_tagged(gran + ((size_t)c * N + n) * NS + lane, v, ra.epoch);
                 }
-            } else if (n < N && lane < NS / 2 && !(ra.fault && item == ra.K - 1)) {
+            } else if (n < N && lane < NS / 2 && (!SPLIT || wave == 0) && !(ra.fault && item == ra.K - 1)) {
                 float lo = acc[0], hi = acc[1];
 #pragma unroll
                 for (int m = 1; m < NS / 2; ++m) {
@@ -1271,7 +1306,7 @@ __global__ __launch_bounds__(kBlock, POST ? 2 : EPI ? bwd_waves_epi((int)sizeof(
                     e0 = lane_bcast(cfw.e0, s);
                 }
 #else
-                const float* oc = ocoef + (wave * PPW + s) * BC_ROWS;
+                const float* oc = ocoef + (SPLIT ? 0 : wave * PPW + s) * BC_ROWS;
                 const float cG_i = oc[BC_CG_IN], cX_i = oc[BC_CX_IN], xr_i = oc[BC_XR_IN], c0_i = oc[BC_C0_IN];
                 const float cG_o = oc[BC_CG_OUT], cX_o = oc[BC_CX_OUT], xr_o = oc[BC_XR_OUT], c0_o = oc[BC_C0_OUT];
                 const float eS = oc[BC_ES], xs = oc[BC_XS], e0 = oc[BC_E0];
@@ -1295,7 +1330,7 @@ __global__ __launch_bounds__(kBlock, POST ? 2 : EPI ? bwd_waves_epi((int)sizeof(
                         }
                         ov[q] = v;
                     }
-                    buf_store<T, VEC>(slot_rsrc<T, VEC>(db, pbytes, j), voff, pack<T, VEC>(ov));
+                    buf_store<T, VEC>(slot_rsrc<T, VEC>(db, pbytes, j0 + j), voff, pack<T, VEC>(ov));
                 }
             }
         }
@@ -1315,6 +1350,16 @@ struct ResPlan {
 };
 // can the resident strategy run this problem?  (auto = apply the profitability heuristics too)
 ResPlan resident_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, bool backward);
+// planes of 1025..4096 vectors: one plane per workgroup, split over its four waves (cnsn_resident_split.hip);
+// add: ADD_NONE or ADD_POST (un-boxed), with or without ReLU
+ResPlan resident_split_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, int add, int relu, bool backward);
+int resident_split_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, int add, int relu,
+                           const void* x, const void* addend, const int64_t* perm, GateDev g, GateDev f, void* y,
+                           double* saved, void* workspace, hipStream_t stream);
+int resident_split_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, int add, int relu,
+                            const void* gy, const void* x, const void* addend, const int64_t* perm, GateDev g, GateDev f,
+                            const double* saved, void* dx, void* d_addend, GateGradDev dg, GateGradDev df, void* workspace,
+                            hipStream_t stream);
 
 // both return CNSN_OK, a hipError_t, or CNSN_E_UNSUPPORTED (caller falls back to two-pass)
 int resident_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* x,

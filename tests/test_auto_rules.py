@@ -35,12 +35,14 @@ TABLE = [
     ((256, 2048, 7, 7), F32, FC(**SN), "mono", "mono"),                        # fp32 7x7: one element (4 B) per lane
     ((16, 512, 64, 64), F32, FC(sn_active=True, add_mode="post", relu=True), "resident", "resident"),   # segmentation: SN at 'residual'
     ((16, 2048, 64, 64), BF16, FC(sn_active=True, add_mode="post", relu=True), "resident", "resident"),
-    ((16, 256, 128, 128), F32, FC(sn_active=True, add_mode="post", relu=True), "streaming", "streaming"),  # 4096 vectors per plane
+    ((16, 256, 128, 128), F32, FC(sn_active=True, add_mode="post", relu=True), "resident", "resident"),  # a plane per workgroup (split)
+    ((16, 256, 128, 128), BF16, FC(**CN, style_box=(0, 0, 64, 64)), "resident", "resident"),            # segmentation's separate CrossNorm
     ((128, 128, 8, 8), F32, FC(**SN), "mono", "mono"),                        # 256-byte planes, 16 lanes each
     ((128, 64, 16, 16), F32, FC(**SN), "mono", "mono"),                        # WideResNet stage 2
     ((128, 32, 32, 32), F32, FC(**SN, **BOTH), "resident", "resident"),        # WideResNet stage 1
     ((768, 3, 224, 224), F32, FC(**CN), "streaming", "streaming"),             # image-level CrossNorm: 12544 vectors
-    ((16, 256, 128, 128), F32, FC(**SN), "streaming", "streaming"),
+    ((16, 256, 128, 128), F32, FC(**SN), "resident", "resident"),              # 4096 vectors: split over the workgroup's waves
+    ((16, 256, 72, 64), F32, FC(**SN), "streaming", "streaming"),              # 5 of 8 slots per wave used: not worth it
     ((256, 256, 56, 56), F32, FC(sn_active=True, sn_training=False), "resident", "resident"),   # inference (SOLO)
     ((64, 128, 88, 88), BF16, FC(**SN, **CN), "streaming", "resident"),        # 16 slots, 16-bit: un-boxed backward only
 ]

@@ -80,3 +80,32 @@ def test_persistent_loop_many_channels(tag, nv, hw, kind, crop):
     from tests.test_gpu_full_size import check_case
     c = 1024 if nv <= 2 else (512 if nv == 4 else 384)    # items = C * ceil(37 / (4 * planes per wave)) > 1536
     check_case((37, c, *hw), DT[tag], kind, crop, 900 + nv)
+
+
+# Large planes (1025..4096 vectors): ONE plane per workgroup, a quarter per wave (cnsn_resident_split.hip) — segmentation
+# layer 1's 128x128 sites.  Buckets of 8 / 16 slots per wave, fp32 / bf16 / fp16, boxed and not, inference, the POST
+# epilogue; N = 3 and 9 members per cluster.
+SPLIT_CASES = [("f32", (128, 64)), ("f32", (128, 128)), ("f32", (72, 64)), ("bf16", (128, 128)), ("bf16", (128, 192)),
+               ("f16", (96, 96))]
+
+
+@pytest.mark.parametrize("tag,hw", SPLIT_CASES, ids=lambda v: str(v).replace(" ", ""))
+@pytest.mark.parametrize("kind,crop", [("cnsn", "neither"), ("cnsn", "both"), ("cn", "style"), ("sn", "neither")])
+@pytest.mark.parametrize("n", [3, 9])
+def test_split_plane_op(tag, hw, kind, crop, n):
+    shape = (n, 2, *hw)
+    x = torch.empty(shape, dtype=DT[tag], device="cuda")
+    cfg = cnsn_amd.FusedConfig(sn_active=kind != "cn", cn_active=kind != "sn")
+    assert cnsn_amd.which_path(x, cfg, backward=False) == "resident" and cnsn_amd.which_path(x, cfg, backward=True) == "resident"
+    out = run_pair(shape, crop, kind, DT[tag], 950 + n + hw[0], training=True)
+    assert_parity(out, DT[tag], ("split", tag, shape, kind, crop))
+
+
+@pytest.mark.parametrize("tag,hw", SPLIT_CASES[:4], ids=lambda v: str(v).replace(" ", ""))
+def test_split_plane_inference_and_post(tag, hw):
+    shape = (5, 2, *hw)
+    out = run_pair(shape, "neither", "sn", DT[tag], 970 + hw[1], training=False)                 # SOLO variant
+    assert_parity(out, DT[tag], ("split eval", tag, shape))
+    for mode, relu in (("post", True), ("post", False), ("none", True)):
+        check_block(run_block(shape, "sn", "neither", mode, relu, DT[tag], 980 + hw[1]), DT[tag], relu, ("split", tag, shape, mode, relu))
+    check_block(run_block(shape, "cnsn", "both", "none", True, DT[tag], 990 + hw[1]), DT[tag], True, ("split boxed relu", tag, shape))
