@@ -62,7 +62,8 @@ size_t cnsn_context_bytes(const cnsn_problem_t* prob) {
         any = resident_plan(p, pl.boxed, false, bw != 0).ok || resident_fused_plan(p, pl.boxed, false, CNSN_ADD_PRE, bw != 0).ok ||
               resident_split_plan(p, pl.boxed, false, CNSN_ADD_NONE, 0, bw != 0).ok;
     // control block + one tagged granule per exchanged scalar (six per plane forward with crop boxes: the most)
-    return any ? kCtlBytes + (size_t)p.N * p.C * 6 * 8 : 0;
+    // (+ 256: the scalar-path gather reads whole 256-byte groups)
+    return any ? kCtlBytes + (size_t)p.N * p.C * 6 * 8 + 256 : 0;
 }
 
 int cnsn_context_init(void* context, size_t bytes, void* stream) {
@@ -147,6 +148,9 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
         }
     }
     if (resident_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, false).ok) {
+        st = resident_pipe_forward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, x, perm, gate_dev(g), gate_dev(f), y,
+                                   saved ? saved_d : nullptr, workspace, stream);  // large items: loads under the exchange
+        if (st != CNSN_E_UNSUPPORTED) return st;
         st = resident_forward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, x, perm, gate_dev(g), gate_dev(f), y,
                               saved ? saved_d : nullptr, workspace, stream);
         if (st != CNSN_E_UNSUPPORTED) return st;  // otherwise: fall through to the two-pass strategy

@@ -143,7 +143,7 @@ int resident_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const
 }
 
 size_t resident_workspace_bytes(const cnsn_problem_t& p, bool boxed) {
-    return kCtlBytes + (size_t)p.N * p.C * (boxed ? 6 : 2) * 8;
+    return kCtlBytes + (size_t)p.N * p.C * (boxed ? 6 : 2) * 8 + 256;  // (+ 256: whole 256-byte groups are read)
 }
 
 }  // namespace cnsn

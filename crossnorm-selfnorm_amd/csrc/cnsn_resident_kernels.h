@@ -1350,6 +1350,12 @@ struct ResPlan {
 };
 // can the resident strategy run this problem?  (auto = apply the profitability heuristics too)
 ResPlan resident_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, bool backward);
+// pipelined forward (cnsn_resident_pipe.hip): the next item's loads are in flight across the exchange of the current one;
+// ok only where resident_plan(forward) is ok too.  *npark: slots of an item parked in LDS.
+ResPlan resident_pipe_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, int* npark);
+int resident_pipe_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* x,
+                          const int64_t* perm, GateDev g, GateDev f, void* y, double* saved, void* workspace,
+                          hipStream_t stream);
 // planes of 1025..4096 vectors: one plane per workgroup, split over its four waves (cnsn_resident_split.hip);
 // add: ADD_NONE or ADD_POST (un-boxed), with or without ReLU
 ResPlan resident_split_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, int add, int relu, bool backward);

@@ -1,0 +1,121 @@
+// Host side of the pipelined cluster-resident forward (cnsn_resident_pipe_kernels.h): eligibility, how many slots of
+// an item are parked in LDS, launch.  Offered for the op alone (no epilogue), training or CrossNorm-coupled calls, planes
+// of 7+ register slots (40x40 fp32 / 56x56 16-bit and larger) — the classes whose items are large enough (>= 25 KB per
+// workgroup) for the exposed cluster wait to be the bottleneck.
+#include "cnsn_resident_host.h"
+#include "cnsn_resident_pipe_kernels.h"
+
+namespace cnsn {
+
+namespace {
+
+constexpr size_t kLdsPerCu = 160 * 1024;
+constexpr int kPipeWgPerCu = 3;
+
+// f(TypeTag<T>, IntTag<VEC>, IntTag<NV>, IntTag<PPW>)
+template <typename F>
+bool dispatch_pipe(int dtype, int vec, int nv, F&& f) {
+    auto by_nv = [&](auto tt, auto vt) -> bool {
+        using T = typename decltype(tt)::type;
+        switch (nv) {
+            case 7: f(tt, vt, IntTag<7>{}, IntTag<reshost::ppw_of(7, false, false, (int)sizeof(T))>{}); return true;
+            case 8: f(tt, vt, IntTag<8>{}, IntTag<reshost::ppw_of(8, false, false, (int)sizeof(T))>{}); return true;
+            case 13: f(tt, vt, IntTag<13>{}, IntTag<1>{}); return true;
+            case 16: f(tt, vt, IntTag<16>{}, IntTag<1>{}); return true;
+            default: return false;
+        }
+    };
+    if (dtype == CNSN_F32 && vec == 4) return by_nv(TypeTag<float>{}, IntTag<4>{});
+    if (dtype == CNSN_BF16 && vec == 8) return by_nv(TypeTag<bf16_t>{}, IntTag<8>{});
+    if (dtype == CNSN_F16 && vec == 8) return by_nv(TypeTag<_Float16>{}, IntTag<8>{});
+    return false;
+}
+
+// CNSN_PIPE=0: never; CNSN_PIPE=2: also for grids with fewer than three items per workgroup (tests)
+int pipe_mode() {
+    const char* e = getenv("CNSN_PIPE");
+    return e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : 1;
+}
+
+}  // namespace
+
+// rp.ok: the pipelined forward takes the call; *npark = slots of an item that go to LDS
+ResPlan resident_pipe_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, int* npark) {
+    ResPlan none{false, 0, 0, 0, 0};
+    const int mode = pipe_mode();
+    if (mode == 0) return none;
+    ResPlan rp = reshost::plan_impl(p, boxed, has_chan_perm, false, false);
+    if (!rp.ok) return none;
+    if (!boxed && !p.cn_active && !(p.sn_active && p.sn_training)) return none;  // inference: nothing to wait for
+    const int vb = rp.vec * elem_bytes(p.dtype);
+    if (vb != 16 || rp.nv < 7) return none;
+    const int slots = rp.ppw * rp.nv, nvec = p.H * p.W / rp.vec;
+    const int grid_max = (kPipeWgPerCu * reshost::cu_count() / rp.K) * rp.K;
+    if (grid_max < rp.K || (mode != 2 && (long)p.C * rp.K < 3l * grid_max)) return none;  // fewer than three items per workgroup: no pipeline to fill
+    // slots worth parking: the full ones of every plane held (a last, partly filled slot may as well stay in registers)
+    const int keep_max = slots < kPipeKeep ? slots : kPipeKeep;
+    const size_t budget = (kLdsPerCu / kPipeWgPerCu) & ~(size_t)511;
+    int np = slots;
+    if (rp.ppw == 1 && nvec % 64 != 0 && nvec % 64 <= 32) np = slots - 1;
+    while (np >= slots - keep_max && pipe_lds_bytes(p.N, boxed ? 6 : 2, 4 * rp.ppw, np, vb, p.cn_active != 0) > budget) --np;
+    if (np < slots - keep_max) return none;
+    // AUTO / forced-resident without CNSN_PIPE=2: where it measured faster than the plain kernel on MI355X
+    // (profiles/r02_pipelined_forward.md): un-boxed calls of the 7- and 13-slot classes.  With crop boxes the gather is
+    // three times as long and the kernel is VALU-bound (0.53 vs 0.46 ms at the north-star shape); the 16-slot class spills.
+    if (mode != 2) {
+        if (boxed) return none;
+        if (!(rp.nv == 7 || rp.nv == 13)) return none;
+    }
+    if (npark) *npark = np;
+    return rp;
+}
+
+int resident_pipe_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* x,
+                          const int64_t* perm, GateDev g, GateDev f, void* y, double* saved, void* workspace,
+                          hipStream_t stream) {
+    int npark = 0;
+    const ResPlan rp = resident_pipe_plan(p, boxed, false, &npark);
+    if (!rp.ok) return CNSN_E_UNSUPPORTED;
+    ResArgs ra = reshost::make_args(p, cb, sb, mid, rp);
+    const int NG = boxed ? 6 : 2;
+#ifdef CNSN_PROF
+    if (getenv("CNSN_PROF")) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
+#endif
+    const size_t lds = pipe_lds_bytes(p.N, NG, 4 * rp.ppw, npark, rp.vec * elem_bytes(p.dtype), p.cn_active != 0);
+    const ExchangeArea ea = resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NG * 8 + 256, workspace, stream);
+    ra.epoch = ea.epoch;
+    ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
+    unsigned* ctl = (unsigned*)ea.base;
+    unsigned long long* gran = (unsigned long long*)((char*)ea.base + kCtlBytes);
+    const size_t fill_bytes = kCtlBytes + (size_t)p.N * p.C * (NG / 2) * 8;
+    int status = CNSN_E_UNSUPPORTED;
+    dispatch_pipe(p.dtype, rp.vec, rp.nv, [&](auto tt, auto vt, auto nt, auto pt) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value, NV = decltype(nt)::value, PPW = decltype(pt)::value;
+        auto launch = [&](auto kern) {
+            if (lds > 64 * 1024 &&
+                hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                (void)hipGetLastError();
+                return;
+            }
+            const int grid = reshost::grid_for(kern, lds, rp.K, ra.items);
+            if (grid < rp.K) return;
+            ResidentChain chain(stream);
+            hipError_t e = ea.epoch ? hipSuccess : hipMemsetAsync(workspace, 0xff, fill_bytes, stream);
+            if (e != hipSuccess) {
+                status = (int)e;
+                return;
+            }
+            kern<<<grid, kBlock, lds, stream>>>(ra, npark, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl);
+            e = hipGetLastError();
+            status = e == hipSuccess ? CNSN_OK : (int)e;
+        };
+        if (boxed)
+            launch(resident_fwd_pipe_kernel<T, VEC, NV, PPW, true>);
+        else
+            launch(resident_fwd_pipe_kernel<T, VEC, NV, PPW, false>);
+    });
+    return status;
+}
+
+}  // namespace cnsn

@@ -1,0 +1,422 @@
+// Pipelined forward of the cluster-resident strategy (round 2).
+//
+// The plain resident forward (cnsn_resident_kernels.h) runs load -> statistics -> publish -> cluster wait -> algebra ->
+// apply -> store as ONE dependent chain per item: 18.9 us at the north-star shape, half of it the wait, with the
+// memory system idle for this workgroup from its last load to its first store (profiles/r02_resident_phases.md).
+// Here a workgroup works on TWO items: item t sits in LDS ("parked": its statistics are published), item t+1 is
+// being loaded into registers.  Per iteration
+//     issue the loads of t+1  ->  gather t's channel (SCALAR memory path: a vector load would return behind the
+//     bulk loads this wave has just issued)  ->  algebra of t  ->  statistics of t+1 from registers, publish  ->
+//     apply t from LDS, store  ->  park t+1
+// so the loads of t+1 are in flight during the whole exchange and algebra of t, the publish of t+1 travels while t is
+// being stored, and the chain from one publish to the next is gather + algebra + statistics alone.  Cost: the parked item (49 KB at 56x56 fp32) bounds residency at 3 workgroups per CU
+// where the plain kernel has 4; the host side declines when LDS would not take 3.
+// Same arithmetic, same published numbers, same `saved` rows as the plain kernel: results are bit-identical.
+#pragma once
+#include "cnsn_resident_kernels.h"
+
+namespace cnsn {
+
+// ---- gather of TAGGED granules ({float, epoch} per 8 bytes) through the scalar path.  Every wave calls it
+// (wave-uniform arguments); wave w owns the 256-byte groups w, w+4, ...; lane l of a group holds dword l: even lanes
+// the value, odd lanes the tag.  The area is readable one group past the channel's end (context sizing).
+__device__ __forceinline__ bool sweep_tagged_scalar(const unsigned long long* g, int ngran, float* vals, unsigned* ctl,
+                                                    unsigned* host_flag, long long wait_ticks, int wave, unsigned epoch,
+                                                    unsigned& passes) {
+    const int lane = threadIdx.x & 63;
+    const int ndw = 2 * ngran;
+    const int ngroups = (ndw + 63) >> 6;
+    const int mine = ngroups > wave ? (ngroups - wave + 3) >> 2 : 0;
+    unsigned long long todo = mine >= 64 ? ~0ull : ((1ull << mine) - 1ull);
+    long long t_start = 0;
+    for (unsigned spins = 0;; ++spins) {
+        bool all = true;
+        for (int k = 0; k < mine; ++k) {
+            if (k < 64 && !((todo >> k) & 1ull)) continue;
+            const int grp = wave + 4 * k;
+            const unsigned v = sload_group((const void*)g, (unsigned)grp * 256u);
+            const int idx = grp * 64 + lane;
+            const bool valid = idx < ndw;
+            if (valid && !(lane & 1)) vals[idx >> 1] = __uint_as_float(v);
+            const bool ok = __ballot(valid && (lane & 1) && v != epoch) == 0ull;
+            if (ok && k < 64) todo &= ~(1ull << k);
+            all &= ok;
+        }
+        passes = spins + 1;
+        if (all) return true;
+        __builtin_amdgcn_s_sleep(2);
+        if ((spins & 15u) == 15u) {
+            const long long now = (long long)wall_clock64();
+            if (t_start == 0) t_start = now;
+            if (sload_glc_u32(ctl) != 0u) return false;  // somebody gave up already (context: idle word is 0)
+            if (now - t_start > wait_ticks) {
+                if (lane == 0) {
+                    const unsigned prev = __hip_atomic_exchange((gu32*)ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (prev == 0u && host_flag)
+                        __hip_atomic_fetch_add(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                return false;
+            }
+        }
+    }
+}
+
+// LDS of the pipelined forward: the parked item first (16-byte aligned), then the exchange arrays
+__host__ __device__ inline size_t pipe_lds_bytes(int N, int NG, int own, int parked_slots, int vec_bytes, bool cn) {
+    return (size_t)4 * 64 * parked_slots * vec_bytes  // parked item: [wave][slot][lane]
+           + align16((size_t)N * NG * 4)              // vals[N][NG]
+           + (cn ? align16((size_t)N * 4) : 0)        // style permutation
+           + align16((size_t)own * FC_ROWS * 4)       // coefficients of the owned planes
+           + 4 * 4 * 8                                // block reduction scratch
+           + 16;                                      // "this workgroup gave up" flag
+}
+
+// Not every slot of the item has to go to LDS: the last `SLOTS - npark` (at most kPipeKeep) stay in registers.  npark is
+// a launch argument — the host parks as many slots as let three workgroups share a CU's 160 KB (at 56x56 fp32 the 13th
+// slot, a quarter full, stays: 12 slots = 48 KB).
+constexpr int kPipeKeep = 6;
+template <typename T, int VEC, int NV, int PPW, bool BOXED>
+__global__ __launch_bounds__(kBlock, 3) void resident_fwd_pipe_kernel(ResArgs ra, int npark, const T* __restrict__ x,
+                                                                      T* __restrict__ y, const int64_t* __restrict__ perm,
+                                                                      GateDev gg, GateDev gf,
+                                                                      unsigned long long* __restrict__ gran,
+                                                                      double* __restrict__ saved, unsigned* __restrict__ ctl) {
+    constexpr int NG = BOXED ? 6 : 2;
+    constexpr int OWN = 4 * PPW;
+    constexpr int SLOTS = PPW * NV;
+    constexpr int KEEP = SLOTS < kPipeKeep ? SLOTS : kPipeKeep, FIRST_KEEP = SLOTS - KEEP;  // slots below FIRST_KEEP: always parked
+    constexpr int VB = VEC * (int)sizeof(T);
+    const int NPARK = __builtin_amdgcn_readfirstlane(npark);  // FIRST_KEEP <= NPARK <= SLOTS
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const MidArgs a = ra.mid;
+    const int N = a.N, C = a.C;
+    Raw<T, VEC>* park = (Raw<T, VEC>*)smem;
+    float* vals = (float*)(smem + (size_t)4 * 64 * NPARK * VB);
+    int* sperm = (int*)((char*)vals + align16((size_t)N * NG * 4));
+    float* ocoef = (float*)((char*)sperm + (a.cn_active ? align16((size_t)N * 4) : 0));
+    double* red = (double*)((char*)ocoef + align16((size_t)OWN * FC_ROWS * 4));
+    int* gave_up = (int*)(red + 4 * 4);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t P = (size_t)N * C;
+    const SlotGeom<VEC, NV, BOXED> sg(ra, lane);
+    const int voff = lane * VB;
+    Raw<T, VEC>* mypark = park + (size_t)wave * NPARK * 64 + lane;  // slot i of this lane: mypark[i * 64]
+
+    if (a.cn_active)
+        for (int n = threadIdx.x; n < N; n += kBlock) sperm[n] = (int)perm[n];
+    if (threadIdx.x == 0) *gave_up = 0;
+    __syncthreads();
+    startup_skew(ra);
+
+    Raw<T, VEC> d[PPW][NV];                        // the item being loaded / whose statistics are being taken
+    Raw<T, VEC> keep[KEEP];                        // slots of the parked item that did not go to LDS
+
+    auto load_item = [&](int item) {
+        const int c = item / ra.K, k = item - c * ra.K;
+#pragma unroll
+        for (int s = 0; s < PPW; ++s) {
+            const int n = (k * 4 + wave) * PPW + s;
+            const T* pb = x + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
+            const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;  // past the batch end: every lane reads zeros
+#pragma unroll
+            for (int j = 0; j < NV; ++j) d[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(pb, pbytes, j), voff);
+        }
+    };
+
+    // exact two-pass statistics of the planes in d, published to the cluster
+    auto stats_publish = [&](int item) {
+        const int c = item / ra.K, k = item - c * ra.K;
+#pragma unroll
+        for (int s = 0; s < PPW; ++s) {
+            const int n = (k * 4 + wave) * PPW + s;
+            float pub[NG];
+            if constexpr (!BOXED) {
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) sum += elem<T, VEC>(d[s][j], q);
+                const float mean = wave_sum(sum) / (float)ra.M;
+                float m2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+                    if (sg.valid(j)) {
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) {
+                            const float t = elem<T, VEC>(d[s][j], q) - mean;
+                            m2 = fmaf(t, t, m2);
+                        }
+                    }
+                pub[0] = mean;
+                pub[1] = wave_sum(m2);
+            } else {
+                float sc = 0.f, so = 0.f, ss = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        const float f = elem<T, VEC>(d[s][j], q);  // invalid slots hold 0 and no box bit
+                        const bool ic = sg.in_c(j, q), is = sg.in_s(j, q);
+                        sc += ic ? f : 0.f;
+                        so += ic ? 0.f : f;
+                        ss += is ? f : 0.f;
+                    }
+                const int Mo = a.M - a.Mc;
+                const float mc = wave_sum(sc) / (float)a.Mc;
+                const float so_t = wave_sum(so);
+                const float mo = Mo > 0 ? so_t / (float)Mo : 0.f;
+                const float ms = wave_sum(ss) / (float)a.Ms;
+                float qc = 0.f, qo = 0.f, qs = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+                    if (sg.valid(j)) {
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) {
+                            const float f = elem<T, VEC>(d[s][j], q);
+                            const bool ic = sg.in_c(j, q), is = sg.in_s(j, q);
+                            const float tc = f - mc, to = f - mo, ts = f - ms;
+                            qc += ic ? tc * tc : 0.f;
+                            qo += ic ? 0.f : to * to;
+                            qs += is ? ts * ts : 0.f;
+                        }
+                    }
+                pub[0] = mc;
+                pub[1] = wave_sum(qc);
+                pub[2] = mo;
+                pub[3] = wave_sum(qo);
+                pub[4] = ms;
+                pub[5] = wave_sum(qs);
+            }
+            if (ra.epoch) {  // persistent context: lane m publishes pub[m] with the launch's tag
+                if (n < N && lane < NG && !(ra.fault && item == ra.K - 1)) {
+                    float v = pub[0];
+#pragma unroll
+                    for (int m = 1; m < NG; ++m) v = (lane == m) ? pub[m] : v;
+                    put_tagged(gran + ((size_t)c * N + n) * NG + lane, v, ra.epoch);
+                }
+            } else if (n < N && lane < NG / 2 && !(ra.fault && item == ra.K - 1)) {  // lane m: (pub[2m], pub[2m+1])
+                float lo = pub[0], hi = pub[1];
+#pragma unroll
+                for (int m = 1; m < NG / 2; ++m) {
+                    lo = (lane == m) ? pub[2 * m] : lo;
+                    hi = (lane == m) ? pub[2 * m + 1] : hi;
+                }
+                put_granule(gran + ((size_t)c * N + n) * (NG / 2) + lane, lo, hi);
+            }
+        }
+    };
+    // d -> LDS (+ keep): every lane writes (and later reads back) its own slots only — no barrier involved
+    auto park_item = [&]() {
+#pragma unroll
+        for (int s = 0; s < PPW; ++s)
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = s * NV + j;
+                if (i < FIRST_KEEP || i < NPARK)  // (wave-uniform)
+                    mypark[i * 64] = d[s][j];
+                else
+                    keep[i - FIRST_KEEP] = d[s][j];
+            }
+    };
+
+    int item = blockIdx.x;
+    if (item >= ra.items) return;  // (the grid never exceeds the items)
+    int iter_ = 0;
+    (void)iter_;
+    CNSN_STAMP(0);
+    load_item(item);
+    stats_publish(item);
+    park_item();
+
+    for (;;) {
+        const int c = item / ra.K, k = item - c * ra.K;
+        const int next = item + (int)gridDim.x;
+        const bool more = next < ra.items;  // workgroup-uniform
+        CNSN_STAMP(1);
+
+        // ---- per-channel parameters of item t (scalar loads: in flight during the gather)
+        float pw[4] = {0.f, 0.f, 0.f, 0.f}, pgam[2] = {0.f, 0.f}, pbet[2] = {0.f, 0.f}, prm[2] = {0.f, 0.f},
+              prv[2] = {1.f, 1.f};
+        if (a.sn_active) {
+            pw[0] = gg.w[2 * c];
+            pw[1] = gg.w[2 * c + 1];
+            pgam[0] = gg.gamma[c];
+            pbet[0] = gg.beta[c];
+            prm[0] = gg.run_mean[c];
+            prv[0] = gg.run_var[c];
+            if (a.sn_two) {
+                pw[2] = gf.w[2 * c];
+                pw[3] = gf.w[2 * c + 1];
+                pgam[1] = gf.gamma[c];
+                pbet[1] = gf.beta[c];
+                prm[1] = gf.run_mean[c];
+                prv[1] = gf.run_var[c];
+            }
+        }
+
+        // ---- the NEXT item's planes start their way into registers: the only read of x
+        if (more) load_item(next);
+
+        // ---- gather item t's channel
+        unsigned passes_ = 0;
+        {
+            const bool got = ra.epoch ? sweep_tagged_scalar(gran + (size_t)c * N * NG, N * NG, vals, ctl, ra.host_flag,
+                                                            ra.wait_ticks, wave, ra.epoch, passes_)
+                                      : sweep_granules_scalar(gran + (size_t)c * N * (NG / 2), N * NG, vals, ctl, ra.host_flag,
+                                                              ra.wait_ticks, wave, passes_);
+            if (lane == 0 && !got) *gave_up = 1;
+        }
+        __syncthreads();
+        if (*gave_up) return;  // (workgroup-uniform) timed out: see sweep_granules
+        CNSN_STAMP(2);
+        CNSN_NOTE(6, passes_);
+
+        using R = float;  // per-plane algebra in float, cross-batch sums / normalisation in double
+        auto plane_of = [&](int n) {
+            MomentsT<R> o;
+            o.mu_c = vals[n * NG];
+            o.M2c = vals[n * NG + 1];
+            o.mu_o = BOXED ? vals[n * NG + 2] : 0.f;
+            o.M2o = BOXED ? vals[n * NG + 3] : 0.f;
+            o.mu_s = BOXED ? vals[n * NG + 4] : o.mu_c;
+            o.M2s = BOXED ? vals[n * NG + 5] : o.M2c;
+            R mu_sq = 0.f, M2_sq = 0.f;
+            if (a.cn_active) {
+                const int q = sperm[n];  // style source instance, same channel (cnsn.py:66,68)
+                mu_sq = vals[q * NG + (BOXED ? 4 : 0)];
+                M2_sq = vals[q * NG + (BOXED ? 5 : 1)];
+            }
+            return fwd_plane<R>(a, o, mu_sq, M2_sq);
+        };
+
+        // ---- SelfNorm gate statistics over the batch (every member computes them redundantly)
+        double mg = 0, mf = 0, rg = 1, rf = 1, wg0 = 0, wg1 = 0, wf0 = 0, wf1 = 0;
+        if (a.sn_active) {
+            wg0 = pw[0];
+            wg1 = pw[1];
+            wf0 = pw[2];
+            wf1 = pw[3];
+            if (a.sn_training) {
+                const FwdPlaneT<R> f0 = plane_of(0);
+                const double zs_g = wg0 * (double)f0.mu_p + wg1 * (double)f0.sig_p;
+                const double zs_f = wf0 * (double)f0.mu_p + wf1 * (double)f0.sig_p;
+                double sz[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int n = threadIdx.x; n < N; n += kBlock) {
+                    const FwdPlaneT<R> f = plane_of(n);
+                    const double dg = wg0 * (double)f.mu_p + wg1 * (double)f.sig_p - zs_g;
+                    const double df = wf0 * (double)f.mu_p + wf1 * (double)f.sig_p - zs_f;
+                    sz[0] += dg;
+                    sz[1] += dg * dg;
+                    sz[2] += df;
+                    sz[3] += df * df;
+                }
+                block_sum_d<4>(sz, red);
+                mg = zs_g + sz[0] * a.inv_n;
+                mf = zs_f + sz[2] * a.inv_n;
+                double vg = (sz[1] - sz[0] * sz[0] * a.inv_n) * a.inv_n, vf = (sz[3] - sz[2] * sz[2] * a.inv_n) * a.inv_n;
+                vg = vg > 0.0 ? vg : 0.0;
+                vf = vf > 0.0 ? vf : 0.0;
+                rg = (double)__builtin_amdgcn_rsqf((float)(vg + (double)a.eps_bn));
+                rf = (double)__builtin_amdgcn_rsqf((float)(vf + (double)a.eps_bn));
+                if (k == 0 && threadIdx.x == 0) {
+                    const double mom_ = a.momentum, unb = a.unbias_n;
+                    gg.run_mean[c] = (float)((1.0 - mom_) * (double)prm[0] + mom_ * mg);
+                    gg.run_var[c] = (float)((1.0 - mom_) * (double)prv[0] + mom_ * vg * unb);
+                    if (a.sn_two) {
+                        gf.run_mean[c] = (float)((1.0 - mom_) * (double)prm[1] + mom_ * mf);
+                        gf.run_var[c] = (float)((1.0 - mom_) * (double)prv[1] + mom_ * vf * unb);
+                    }
+                }
+            } else {
+                mg = prm[0];
+                rg = (double)__builtin_amdgcn_rsqf(prv[0] + a.eps_bn);
+                if (a.sn_two) {
+                    mf = prm[1];
+                    rf = (double)__builtin_amdgcn_rsqf(prv[1] + a.eps_bn);
+                }
+            }
+            if (saved && k == 0 && threadIdx.x == 0) {
+                saved[SV_ROWS * P + c] = rg;
+                saved[SV_ROWS * P + C + c] = rf;
+            }
+        }
+
+        // ---- coefficients (and saved state) of the owned planes
+        if (threadIdx.x < OWN) {
+            const int n = k * OWN + threadIdx.x;
+            if (n < N) {
+                const FwdPlaneT<R> f = plane_of(n);
+                R g = 1.f, fg = 1.f;
+                double zhg = 0.0, zhf = 0.0;
+                if (a.sn_active) {
+                    zhg = (wg0 * (double)f.mu_p + wg1 * (double)f.sig_p - mg) * rg;
+                    g = sigmoid_r<R>((R)((double)pgam[0] * zhg + (double)pbet[0]));
+                    if (a.sn_two) {
+                        zhf = (wf0 * (double)f.mu_p + wf1 * (double)f.sig_p - mf) * rf;
+                        fg = sigmoid_r<R>((R)((double)pgam[1] * zhf + (double)pbet[1]));
+                    }
+                }
+                const FwdCoefs cf = fwd_coefs<R>(a, f, g, fg);
+                float* o = ocoef + threadIdx.x * FC_ROWS;
+                o[FC_A_IN] = cf.a_in;
+                o[FC_XR] = cf.xr;
+                o[FC_B_IN] = cf.b_in;
+                o[FC_A_OUT] = cf.a_out;
+                o[FC_B_OUT] = cf.b_out;
+                if (saved) {
+                    const size_t p = (size_t)n * C + c;
+                    store_fwd_plane<R>(saved, P, p, f, a.cn_active);
+                    saved[sv_at(p, SV_G)] = g;
+                    saved[sv_at(p, SV_ZH_G)] = zhg;
+                    saved[sv_at(p, SV_F)] = fg;
+                    saved[sv_at(p, SV_ZH_F)] = zhf;
+                    if (a.save_coefs) store_fwd_coefs(saved, p, cf);
+                }
+            }
+        }
+        __syncthreads();
+        CNSN_STAMP(3);
+
+        // ---- item t+1 has arrived long ago: its statistics go out BEFORE item t is applied — the cluster's next
+        //      exchange travels while this workgroup stores
+        if (more) stats_publish(next);
+        CNSN_STAMP(4);
+
+        // ---- apply item t from LDS, the only write of y
+#pragma unroll
+        for (int s = 0; s < PPW; ++s) {
+            const int n = (k * 4 + wave) * PPW + s;
+            if (n < N) {
+                const float* o = ocoef + (wave * PPW + s) * FC_ROWS;
+                const float a_in = o[FC_A_IN], xr = o[FC_XR], b_in = o[FC_B_IN], a_out = o[FC_A_OUT], b_out = o[FC_B_OUT];
+                T* yb = y + ((size_t)n * C + c) * ra.M;
+                const int pbytes = ra.M * (int)sizeof(T);
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int i = s * NV + j;
+                    Raw<T, VEC> v;
+                    if (i < FIRST_KEEP || i < NPARK)
+                        v = mypark[i * 64];
+                    else
+                        v = keep[i - FIRST_KEEP];
+                    float ov[VEC];
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        const float f = elem<T, VEC>(v, q);
+                        const bool ic = !BOXED || (sg.in_c(j, q));
+                        ov[q] = ic ? fmaf(a_in, f - xr, b_in) : fmaf(a_out, f, b_out);
+                    }
+                    buf_store<T, VEC>(slot_rsrc<T, VEC>(yb, pbytes, j), voff, pack<T, VEC>(ov));
+                }
+            }
+        }
+        if (!more) break;
+        park_item();
+        CNSN_STAMP(5);
+        item = next;
+        ++iter_;
+    }
+}
+
+}  // namespace cnsn

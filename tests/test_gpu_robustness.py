@@ -110,8 +110,9 @@ print("TIMEOUT-PATH-OK")
 
 def test_resident_timeout_degrades_instead_of_trapping():
     env = dict(os.environ, CNSN_WAIT_MS="200")
-    for glue in ("0", "1"):
+    for glue, pipe in (("0", "1"), ("1", "1"), ("0", "2")):   # CNSN_PIPE=2: the pipelined forward gives up the same way
         env["CNSN_NO_GLUE"] = glue
+        env["CNSN_PIPE"] = pipe
         r = subprocess.run([sys.executable, "-c", _TIMEOUT_SCRIPT % ROOT], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0 and "TIMEOUT-PATH-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
