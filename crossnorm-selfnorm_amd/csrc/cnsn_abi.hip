@@ -239,6 +239,9 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
         }
     }
     if (resident_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, true).ok) {
+        st = resident_pipe_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, grad_y, x, perm, gate_dev(g), gate_dev(f),
+                                    saved_d, grad_x, gate_grad_dev(dg), gate_grad_dev(df), workspace, stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
         st = resident_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, grad_y, x, perm, gate_dev(g), gate_dev(f),
                                saved_d, grad_x, gate_grad_dev(dg), gate_grad_dev(df), workspace, stream);
         if (st != CNSN_E_UNSUPPORTED) return st;
@@ -265,10 +268,10 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
         constexpr int VEC = decltype(vt)::value, LPP = decltype(lt)::value;
         if (pl.boxed)
             bwd_reduce_kernel<T, VEC, LPP, true><<<blocks, kBlock, 0, stream>>>(
-                (const T*)grad_y, (const T*)x, pl.geom, saved_d + SV_MU_C, saved_d + SV_MU_O, SV_ROWS, sums);
+                (const T*)grad_y, (const T*)x, pl.geom, saved_d + (size_t)SV_MU_C * p.N, saved_d + (size_t)SV_MU_O * p.N, 0, sums);
         else
             bwd_reduce_kernel<T, VEC, LPP, false><<<blocks, kBlock, 0, stream>>>(
-                (const T*)grad_y, (const T*)x, pl.geom, saved_d + SV_MU_C, nullptr, SV_ROWS, sums);
+                (const T*)grad_y, (const T*)x, pl.geom, saved_d + (size_t)SV_MU_C * p.N, nullptr, 0, sums);
     });
     launch_mid_bwd(pl, sums, saved_d, perm, chan_perm, gate_dev(g), gate_dev(f), gate_grad_dev(dg), gate_grad_dev(df), tmp,
                    coef, stream);

@@ -189,6 +189,7 @@ struct Box {
 
 struct Geom {
     int P;     // planes = N*C
+    int N, C;  // (plane p = n*C + c; the `saved` records are channel-major: cnsn_layout.h)
     int M;     // elements per plane = H*W
     int Wd;    // width (dim 3)
     int nvec;  // M / VEC

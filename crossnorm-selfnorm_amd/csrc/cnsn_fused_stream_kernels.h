@@ -45,7 +45,7 @@ __device__ __forceinline__ void stream3(const T* __restrict__ a, const T* __rest
 // the forward's apply coefficients of one plane, as the forward kept them
 struct FwdAffine {
     float a_in, xr, b_in, a_out, b_out;
-    __device__ __forceinline__ FwdAffine(const double* __restrict__ saved, size_t p) {
+    __device__ __forceinline__ FwdAffine(const double* __restrict__ saved, SvRec p) {
         a_in = (float)saved[sv_at(p, SV_FC0 + FC_A_IN)];
         xr = (float)saved[sv_at(p, SV_FC0 + FC_XR)];
         b_in = (float)saved[sv_at(p, SV_FC0 + FC_B_IN)];
@@ -215,9 +215,10 @@ __global__ __launch_bounds__(kBlock) void fused_bwd_reduce_kernel(const T* __res
     __shared__ float lds[4 * NACC];
     const PlaneId<LPP> id(g.P);
     const size_t off = (size_t)id.p * g.M;
-    const float si = (float)saved[sv_at(id.p, SV_MU_C)];
-    const float so = BOXED ? (float)saved[sv_at(id.p, SV_MU_O)] : 0.f;
-    const FwdAffine fa(saved, id.p);  // rows hold garbage without ReLU; never used then
+    const SvRec ps = sv_rec_of_plane((size_t)id.p, g.N, g.C);
+    const float si = (float)saved[sv_at(ps, SV_MU_C)];
+    const float so = BOXED ? (float)saved[sv_at(ps, SV_MU_O)] : 0.f;
+    const FwdAffine fa(saved, ps);  // rows hold garbage without ReLU; never used then
     float part[NACC][VEC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k)
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void fused_apply_bwd_kernel(const T* __rest
         xs = coef[9 * P + id.p];
         e0 = coef[10 * P + id.p];
     }
-    const FwdAffine fa(saved, id.p);
+    const FwdAffine fa(saved, sv_rec_of_plane((size_t)id.p, g.N, g.C));
     T* db = dx + off;
     auto emit = [&](const Vec<T, VEC>& vg, const Vec<T, VEC>& vx, const Vec<T, VEC>& vb, int i) {
         Vec<T, VEC> o, om;

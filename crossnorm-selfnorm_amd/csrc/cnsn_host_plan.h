@@ -81,6 +81,8 @@ inline int parse_box(const int32_t* in, int H, int W, Box& b, bool& present) {
 inline Geom make_geom(int N, int C, int H, int W, int vec, Box cb, Box sb) {
     Geom g;
     g.P = N * C;
+    g.N = N;
+    g.C = C;
     g.M = H * W;
     g.Wd = W;
     g.nvec = g.M / vec;

@@ -5,9 +5,14 @@
 
 namespace cnsn {
 
-// `saved`: one record of SV_ROWS doubles per plane p = n*C + c (array of structs: every reader and writer
-// touches all fields of a plane, so one base address + constant offsets), followed by two rows of C
-// (BatchNorm rstd of g and f) at SV_ROWS*P.
+// `saved`: SV_ROWS doubles per plane, stored CHANNEL BY CHANNEL and, within a channel, ROW BY ROW over the batch: value
+// `row` of plane (n, c) is element (c*SV_ROWS + row)*N + n; two rows of C (BatchNorm rstd of g and f) follow at
+// SV_ROWS*P.  Why: every consumer that needs more than its own plane walks ONE channel over the batch (the BatchNorm1d
+// over N of cnsn.py:121,138; the style permutation of cnsn.py:62) with one thread per instance — in this layout every
+// such load or store is 64 consecutive doubles.  In tensor order with one record per plane (round 1) the same walk
+// touched one 128-byte line per 8-byte field: at the north-star shape four times as many memory requests as the planes
+// themselves (round 2: the backward of the resident kernels lost 40 us to it).  SvRec keeps record positions and plane
+// numbers (p = n*C + c, the order of every other side array) apart at compile time.
 enum SavedRow {
     // ---- rows every mode needs, first and contiguous: a SelfNorm-only forward writes just these seven (one or
     //      two 64-byte sectors per plane instead of scattered 8-byte writes over a 160-byte record — for planes of
@@ -35,7 +40,17 @@ enum SavedRow {
     SV_ROWS = SV_FC0 + 5
 };
 
-__host__ __device__ inline size_t sv_at(size_t p, int row) { return p * SV_ROWS + row; }
+struct SvRec {
+    size_t base;  // position of row 0 of the plane: c*SV_ROWS*N + n
+    int N;        // distance between two rows of the plane
+};
+__host__ __device__ inline SvRec sv_rec(int n, int c, int N) { return SvRec{(size_t)c * SV_ROWS * (size_t)N + (size_t)n, N}; }
+// from a plane number in tensor order (p = n*C + c)
+__host__ __device__ inline SvRec sv_rec_of_plane(size_t p, int N, int C) {
+    const size_t n = p / (size_t)C;
+    return sv_rec((int)n, (int)(p - n * (size_t)C), N);
+}
+__host__ __device__ inline size_t sv_at(SvRec r, int row) { return r.base + (size_t)row * (size_t)r.N; }
 
 // rows of the forward coefficient block handed to apply_fwd_kernel
 enum FwdCoefRow { FC_A_IN = 0, FC_XR, FC_B_IN, FC_A_OUT, FC_B_OUT, FC_ROWS };
@@ -50,7 +65,7 @@ enum BwdCoefRow {
 };
 
 template <typename R>
-__device__ __forceinline__ void store_fwd_plane(double* __restrict__ saved, size_t P, size_t p,
+__device__ __forceinline__ void store_fwd_plane(double* __restrict__ saved, size_t P, SvRec p,
                                                 const FwdPlaneT<R>& f, int cn_active) {
     saved[sv_at(p, SV_MU_C)] = f.mu_c;
     saved[sv_at(p, SV_MU_P)] = f.mu_p;
@@ -74,7 +89,7 @@ struct CnRowsT {
     double mu_s;
 };
 template <typename R>
-__device__ __forceinline__ CnRowsT<R> load_cn_rows(const MidArgs& a, const double* __restrict__ saved, size_t p,
+__device__ __forceinline__ CnRowsT<R> load_cn_rows(const MidArgs& a, const double* __restrict__ saved, SvRec p,
                                                    double mu_c) {
     CnRowsT<R> r;
     if (a.cn_active) {
@@ -99,7 +114,7 @@ __device__ __forceinline__ CnRowsT<R> load_cn_rows(const MidArgs& a, const doubl
     return r;
 }
 
-__device__ __forceinline__ void store_fwd_coefs(double* __restrict__ saved, size_t p, const FwdCoefs& k) {
+__device__ __forceinline__ void store_fwd_coefs(double* __restrict__ saved, SvRec p, const FwdCoefs& k) {
     saved[sv_at(p, SV_FC0 + FC_A_IN)] = k.a_in;
     saved[sv_at(p, SV_FC0 + FC_XR)] = k.xr;
     saved[sv_at(p, SV_FC0 + FC_B_IN)] = k.b_in;

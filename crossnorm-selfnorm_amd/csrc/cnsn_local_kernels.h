@@ -343,7 +343,7 @@ __global__ __launch_bounds__(LB) void local_fwd_kernel(LocalArgs la, const T* __
             }
             const FwdCoefs cf = fwd_coefs<R>(a, f, g, fg);
             if (saved) {
-                const size_t p = (size_t)n * C + c;
+                const SvRec p = sv_rec(n, c, N);
                 store_fwd_plane<R>(saved, P, p, f, 0);
                 saved[sv_at(p, SV_G)] = g;
                 saved[sv_at(p, SV_ZH_G)] = zhg;
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(LB) void local_bwd_kernel(LocalArgs la, const T* __
         const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
         for (int pl = grp; pl < planes; pl += LB / 16) {
             const int n = pl / CG, cc = pl - n * CG;
-            const size_t p = (size_t)n * C + c0 + cc;
+            const SvRec p = sv_rec(n, c0 + cc, N);
             const float si = (float)saved[sv_at(p, SV_MU_C)];
             float fa = 0.f, fb = 0.f;
             if (EPI && relu) {
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(LB) void local_bwd_kernel(LocalArgs la, const T* __
         const bool act = cc0 + gidx < CG;
         const int cc = act ? cc0 + gidx : 0;
         const int c = c0 + cc;
-        auto rec = [&](int n, int row) { return saved[sv_at((size_t)n * C + c, row)]; };
+        auto rec = [&](int n, int row) { return saved[sv_at(sv_rec(n, c, N), row)]; };
         auto sums_of = [&](int n) {
             const int pl = n * CG + cc;
             return fix_sums<R>(a, ps1[pl], ps2[pl], 0.f, 0.f, rec(n, SV_MU_C), 0.0);

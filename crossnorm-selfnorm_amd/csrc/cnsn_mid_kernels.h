@@ -69,6 +69,7 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
     double sz[2] = {0.0, 0.0};
     for (int n = n0; n < a.N; n += NSTEP) {
         const size_t p = (size_t)n * a.C + c;
+        const SvRec ps = sv_rec(n, c, a.N);
         Moments o;
         o.mu_c = mom[p];
         o.M2c = mom[P + p];
@@ -83,12 +84,12 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
             M2_sq = a.boxed ? mom[5 * P + q] : mom[P + q];
         }
         const FwdPlane f = fwd_plane<double>(a, o, mu_sq, M2_sq);
-        store_fwd_plane(saved, P, p, f, a.cn_active);
+        store_fwd_plane(saved, P, ps, f, a.cn_active);
         if (a.sn_active) {
             const double zg = wg0 * f.mu_p + wg1 * f.sig_p;  // Conv1d k=2 groups=C (cnsn.py:137)
             const double zf = wf0 * f.mu_p + wf1 * f.sig_p;
-            saved[sv_at(p, SV_ZH_G)] = zg;  // parked here until normalised in sweep 3
-            saved[sv_at(p, SV_ZH_F)] = zf;
+            saved[sv_at(ps, SV_ZH_G)] = zg;  // parked here until normalised in sweep 3
+            saved[sv_at(ps, SV_ZH_F)] = zf;
             sz[0] += zg;
             sz[1] += zf;
         }
@@ -104,8 +105,9 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
             double sv[2] = {0.0, 0.0};
             for (int n = n0; n < a.N; n += NSTEP) {
                 const size_t p = (size_t)n * a.C + c;
-                const double dg = saved[sv_at(p, SV_ZH_G)] - mg;
-                const double df = saved[sv_at(p, SV_ZH_F)] - mf;
+                const SvRec ps = sv_rec(n, c, a.N);
+                const double dg = saved[sv_at(ps, SV_ZH_G)] - mg;
+                const double df = saved[sv_at(ps, SV_ZH_F)] - mf;
                 sv[0] += dg * dg;
                 sv[1] += df * df;
             }
@@ -141,32 +143,33 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
     const double gam_f = a.sn_two ? (double)gf.gamma[c] : 0.0, bet_f = a.sn_two ? (double)gf.beta[c] : 0.0;
     for (int n = n0; n < a.N; n += NSTEP) {
         const size_t p = (size_t)n * a.C + c;
+        const SvRec ps = sv_rec(n, c, a.N);
         double g = 1.0, f = 1.0, zhg = 0.0, zhf = 0.0;
         if (a.sn_active) {
-            zhg = (saved[sv_at(p, SV_ZH_G)] - mg) * rg;
+            zhg = (saved[sv_at(ps, SV_ZH_G)] - mg) * rg;
             g = sigmoid_d(gam_g * zhg + bet_g);
             if (a.sn_two) {
-                zhf = (saved[sv_at(p, SV_ZH_F)] - mf) * rf;
+                zhf = (saved[sv_at(ps, SV_ZH_F)] - mf) * rf;
                 f = sigmoid_d(gam_f * zhf + bet_f);
             }
         }
-        saved[sv_at(p, SV_G)] = g;
-        saved[sv_at(p, SV_ZH_G)] = zhg;
-        saved[sv_at(p, SV_F)] = f;
-        saved[sv_at(p, SV_ZH_F)] = zhf;
+        saved[sv_at(ps, SV_G)] = g;
+        saved[sv_at(ps, SV_ZH_G)] = zhg;
+        saved[sv_at(ps, SV_F)] = f;
+        saved[sv_at(ps, SV_ZH_F)] = zhf;
         FwdPlane fp;
-        fp.mu_c = saved[sv_at(p, SV_MU_C)];
-        const CnRowsT<double> cr = load_cn_rows<double>(a, saved, p, fp.mu_c);
+        fp.mu_c = saved[sv_at(ps, SV_MU_C)];
+        const CnRowsT<double> cr = load_cn_rows<double>(a, saved, ps, fp.mu_c);
         fp.a1 = cr.a1;
         fp.m_in = cr.m_in;
-        fp.mu_p = saved[sv_at(p, SV_MU_P)];
+        fp.mu_p = saved[sv_at(ps, SV_MU_P)];
         const FwdCoefs k = fwd_coefs<double>(a, fp, g, f);
         coef[FC_A_IN * P + p] = k.a_in;
         coef[FC_XR * P + p] = k.xr;
         coef[FC_B_IN * P + p] = k.b_in;
         coef[FC_A_OUT * P + p] = k.a_out;
         coef[FC_B_OUT * P + p] = k.b_out;
-        if (a.save_coefs) store_fwd_coefs(saved, p, k);
+        if (a.save_coefs) store_fwd_coefs(saved, ps, k);
     }
 }
 
@@ -186,9 +189,9 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
     const size_t P = (size_t)a.N * a.C;
     const int cs = (a.cn_active && chan_perm) ? (int)chan_perm[c] : c;
 
-    auto sums_of = [&](size_t p) {
+    auto sums_of = [&](size_t p, SvRec ps) {
         return fix_sums<double>(a, sums[p], sums[P + p], a.boxed ? sums[2 * P + p] : 0.f, a.boxed ? sums[3 * P + p] : 0.f,
-                        saved[sv_at(p, SV_MU_C)], a.boxed ? saved[sv_at(p, SV_MU_O)] : 0.0);
+                        saved[sv_at(ps, SV_MU_C)], a.boxed ? saved[sv_at(ps, SV_MU_O)] : 0.0);
     };
 
     // ---- sweep 1: dL/dgate -> through the sigmoid; batch sums for BatchNorm backward
@@ -196,14 +199,15 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
     if (a.sn_active) {
         for (int n = n0; n < a.N; n += NSTEP) {
             const size_t p = (size_t)n * a.C + c;
+            const SvRec ps = sv_rec(n, c, a.N);
             double dtg, dtf;
-            const CnRowsT<double> cr = load_cn_rows<double>(a, saved, p, saved[sv_at(p, SV_MU_C)]);
-            gate_dt<double>(a, sums_of(p), cr.a1, cr.m_in, cr.mu_o, saved[sv_at(p, SV_MU_P)], saved[sv_at(p, SV_G)],
-                            saved[sv_at(p, SV_F)], dtg, dtf);
+            const CnRowsT<double> cr = load_cn_rows<double>(a, saved, ps, saved[sv_at(ps, SV_MU_C)]);
+            gate_dt<double>(a, sums_of(p, ps), cr.a1, cr.m_in, cr.mu_o, saved[sv_at(ps, SV_MU_P)], saved[sv_at(ps, SV_G)],
+                            saved[sv_at(ps, SV_F)], dtg, dtf);
             s[0] += dtg;
-            s[1] += dtg * saved[sv_at(p, SV_ZH_G)];
+            s[1] += dtg * saved[sv_at(ps, SV_ZH_G)];
             s[2] += dtf;
-            s[3] += dtf * saved[sv_at(p, SV_ZH_F)];
+            s[3] += dtf * saved[sv_at(ps, SV_ZH_F)];
             tmp[BT_DT_G * P + p] = dtg;
             tmp[BT_DT_F * P + p] = dtf;
         }
@@ -237,11 +241,12 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
     double sw[4] = {0, 0, 0, 0};  // sum dz_g*mu_p, dz_g*sig_p, dz_f*mu_p, dz_f*sig_p
     for (int n = n0; n < a.N; n += NSTEP) {
         const size_t p = (size_t)n * a.C + c;
-        const double mu_p = saved[sv_at(p, SV_MU_P)], sig_p = saved[sv_at(p, SV_SIG_P)];
-        const CnRowsT<double> cr = load_cn_rows<double>(a, saved, p, saved[sv_at(p, SV_MU_C)]);
+        const SvRec ps = sv_rec(n, c, a.N);
+        const double mu_p = saved[sv_at(ps, SV_MU_P)], sig_p = saved[sv_at(ps, SV_SIG_P)];
+        const CnRowsT<double> cr = load_cn_rows<double>(a, saved, ps, saved[sv_at(ps, SV_MU_C)]);
         const BwdPlane o =
-            bwd_plane<double>(a, b, sums_of(p), a.sn_active ? tmp[BT_DT_G * P + p] : 0.0, a.sn_active ? tmp[BT_DT_F * P + p] : 0.0,
-                      saved[sv_at(p, SV_ZH_G)], saved[sv_at(p, SV_ZH_F)], saved[sv_at(p, SV_G)], saved[sv_at(p, SV_F)],
+            bwd_plane<double>(a, b, sums_of(p, ps), a.sn_active ? tmp[BT_DT_G * P + p] : 0.0, a.sn_active ? tmp[BT_DT_F * P + p] : 0.0,
+                      saved[sv_at(ps, SV_ZH_G)], saved[sv_at(ps, SV_ZH_F)], saved[sv_at(ps, SV_G)], saved[sv_at(ps, SV_F)],
                       cr.aa, cr.a1, cr.m_in, mu_p, sig_p, cr.sig_c, cr.M2c);
         sw[0] += o.dz_g * mu_p;
         sw[1] += o.dz_g * sig_p;
@@ -275,6 +280,7 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_b_kernel(MidArgs a, const doub
                                                            const double* __restrict__ tmp, float* __restrict__ coef) {
     const size_t P = (size_t)a.N * a.C;
     const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const SvRec ps = sv_rec_of_plane(p, a.N, a.C);
     if (p >= P) return;
     BwdPlane o{};
     o.dmu_p = tmp[BT_DMU_P * P + p];
@@ -286,9 +292,9 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_b_kernel(MidArgs a, const doub
         Emu = tmp[BT_E_MU * P + p];
         Esig = tmp[BT_E_SIG * P + p];
     }
-    const CnRowsT<double> cr = load_cn_rows<double>(a, saved, p, saved[sv_at(p, SV_MU_C)]);
-    const BwdCoefs k = bwd_coefs<double>(a, o, Emu, Esig, saved[sv_at(p, SV_G)], cr.a1, cr.m_in, saved[sv_at(p, SV_MU_P)],
-                                         saved[sv_at(p, SV_MU_C)], cr.sig_c, cr.mu_s, cr.sig_s);
+    const CnRowsT<double> cr = load_cn_rows<double>(a, saved, ps, saved[sv_at(ps, SV_MU_C)]);
+    const BwdCoefs k = bwd_coefs<double>(a, o, Emu, Esig, saved[sv_at(ps, SV_G)], cr.a1, cr.m_in, saved[sv_at(ps, SV_MU_P)],
+                                         saved[sv_at(ps, SV_MU_C)], cr.sig_c, cr.mu_s, cr.sig_s);
     coef[BC_CG_IN * P + p] = k.cG_in;
     coef[BC_CX_IN * P + p] = k.cX_in;
     coef[BC_XR_IN * P + p] = k.xr_in;

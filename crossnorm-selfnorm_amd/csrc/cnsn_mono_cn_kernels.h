@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kMonoBlock) void mono_cn_fwd_kernel(MonoCnArgs ca, 
             }
             const FwdCoefs cf = fwd_coefs<Rr>(a, f, gt, Rr(1));
             if (saved) {
-                const size_t p = (size_t)n * C + c;
+                const SvRec p = sv_rec(n, c, N);
                 store_fwd_plane<Rr>(saved, P, p, f, 1);
                 saved[sv_at(p, SV_G)] = gt;
                 saved[sv_at(p, SV_ZH_G)] = zhg;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kMonoBlock) void mono_cn_bwd_kernel(MonoCnArgs ca, 
         // ---- what the sums need from `saved`, a thread per plane, ahead of the bulk loads
         const int n = threadIdx.x;
         const bool act = n < N;
-        const size_t pme = (size_t)(act ? n : 0) * C + c;
+        const SvRec pme = sv_rec(act ? n : 0, c, N);
         if (act) {
             iperm[(int)perm[n]] = n;  // plane perm[n] lent its statistics to plane n
             st[MB_SI * cap + n] = (float)saved[sv_at(pme, SV_MU_C)];

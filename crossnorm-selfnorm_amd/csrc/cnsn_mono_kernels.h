@@ -416,7 +416,7 @@ __global__ __launch_bounds__(kMonoBlock, mono_fwd_waves(RMAX * VEC * (int)sizeof
         }
         const FwdCoefs cf = fwd_coefs<Rr>(a, f, gt, ft);
         if (saved) {
-            const size_t p = (size_t)n * C + c;
+            const SvRec p = sv_rec(n, c, N);
             store_fwd_plane<Rr>(saved, P, p, f, 0);
             saved[sv_at(p, SV_G)] = gt;
             saved[sv_at(p, SV_ZH_G)] = zhg;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
     const int n = threadIdx.x;
     const bool act = n < N;
     if (act) {
-        const size_t pme = (size_t)n * C + c;
+        const SvRec pme = sv_rec(n, c, N);
         const double mu = saved[sv_at(pme, SV_MU_C)];
         psv[0 * npad + n] = mu;
         psv[1 * npad + n] = saved[sv_at(pme, SV_MU_P)];

@@ -131,7 +131,7 @@ void packed_reduce(const Plan& pl, const PackedGeom& g, int add, int relu, const
         using T = typename decltype(tt)::type;
         constexpr bool BOXED = decltype(bt)::value != 0;
         constexpr int ADD = decltype(at)::value;
-        PackedReduceOp<T, BOXED, ADD> op{saved, sums, g.P, relu};
+        PackedReduceOp<T, BOXED, ADD> op{saved, sums, g.P, relu, pl.pr.N, pl.pr.C};
         launch<T, BOXED>(g, gy, x, addend, nullptr, nullptr, op, stream);
     });
 }
@@ -143,7 +143,7 @@ void packed_apply_bwd(const Plan& pl, const PackedGeom& g, int add, int relu, co
         using T = typename decltype(tt)::type;
         constexpr bool BOXED = decltype(bt)::value != 0;
         constexpr int ADD = decltype(at)::value;
-        PackedApplyBwdOp<T, BOXED, ADD> op{coef, saved, g.P, relu};
+        PackedApplyBwdOp<T, BOXED, ADD> op{coef, saved, g.P, relu, pl.pr.N, pl.pr.C};
         launch<T, BOXED>(g, gy, x, addend, dx, d_addend, op, stream);
     });
 }

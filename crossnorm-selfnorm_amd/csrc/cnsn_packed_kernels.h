@@ -267,16 +267,17 @@ struct PackedReduceOp {
     static constexpr int NIN = ADD == ADD_NONE ? 2 : 3, NOUT = 0, NSC = kBwdScFwd;
     const double* saved;
     float* out;
-    int P, relu;
+    int P, relu, N, C;
     struct Acc {
         float a[BOXED ? 4 : 2];
     };
     __device__ __forceinline__ void fetch(int p, float* sc) const {
-        sc[0] = (float)saved[sv_at(p, SV_MU_C)];
-        sc[1] = BOXED ? (float)saved[sv_at(p, SV_MU_O)] : 0.f;
+        const SvRec ps = sv_rec_of_plane((size_t)p, N, C);
+        sc[0] = (float)saved[sv_at(ps, SV_MU_C)];
+        sc[1] = BOXED ? (float)saved[sv_at(ps, SV_MU_O)] : 0.f;
         if (relu) {
 #pragma unroll
-            for (int r = 0; r < FC_ROWS; ++r) sc[kBwdScShift + r] = (float)saved[sv_at(p, SV_FC0 + r)];
+            for (int r = 0; r < FC_ROWS; ++r) sc[kBwdScShift + r] = (float)saved[sv_at(ps, SV_FC0 + r)];
         }
     }
     __device__ __forceinline__ Acc begin(const float*, const float*) const {
@@ -316,14 +317,15 @@ struct PackedApplyBwdOp {
     static constexpr int NIN = ADD == ADD_NONE ? 2 : 3, NOUT = ADD == ADD_POST ? 2 : 1, NSC = BC_ROWS + 5;
     const float* coef;  // BC_ROWS rows of stride P
     const double* saved;
-    int P, relu;
+    int P, relu, N, C;
     struct Acc {};
     __device__ __forceinline__ void fetch(int p, float* sc) const {
 #pragma unroll
         for (int r = 0; r < (BOXED ? (int)BC_ROWS : 4); ++r) sc[r] = coef[(size_t)r * P + p];
         if (relu) {
+            const SvRec ps = sv_rec_of_plane((size_t)p, N, C);
 #pragma unroll
-            for (int r = 0; r < FC_ROWS; ++r) sc[BC_ROWS + r] = (float)saved[sv_at(p, SV_FC0 + r)];
+            for (int r = 0; r < FC_ROWS; ++r) sc[BC_ROWS + r] = (float)saved[sv_at(ps, SV_FC0 + r)];
         }
     }
     __device__ __forceinline__ Acc begin(const float*, const float*) const { return Acc{}; }

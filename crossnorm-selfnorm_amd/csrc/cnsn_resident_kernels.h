@@ -26,6 +26,8 @@
 // host-visible word (cnsn_resident_timeouts(): the host learns without synchronising, stops using this
 // strategy and reports the step as invalid) and RETURNS — no trap, the HIP context stays usable.
 #pragma once
+#include <type_traits>
+
 #include "../../include/cnsn_hip.h"
 #include "cnsn_algebra.h"
 #include "cnsn_device.h"
@@ -61,15 +63,21 @@ struct ResArgs {
 };
 
 #ifdef CNSN_PROF
+#ifndef CNSN_PROF_SKIP
+#define CNSN_PROF_SKIP 0  // first iteration recorded
+#endif
+#ifndef CNSN_PROF_WG0
+#define CNSN_PROF_WG0 0   // first workgroup recorded
+#endif
 #define CNSN_STAMP(slot)                                                                        \
     do {                                                                                        \
-        if (ra.prof && threadIdx.x == 0 && blockIdx.x < 64 && iter_ < 16)                       \
-            ra.prof[((size_t)blockIdx.x * 16 + iter_) * 8 + (slot)] = wall_clock64();             \
+        if (ra.prof && threadIdx.x == 0 && blockIdx.x >= CNSN_PROF_WG0 && blockIdx.x < CNSN_PROF_WG0 + 64 && iter_ >= CNSN_PROF_SKIP && iter_ < CNSN_PROF_SKIP + 16) \
+            ra.prof[((size_t)(blockIdx.x - CNSN_PROF_WG0) * 16 + iter_ - CNSN_PROF_SKIP) * 8 + (slot)] = wall_clock64(); \
     } while (0)
 #define CNSN_NOTE(slot, v)                                                          \
     do {                                                                           \
-        if (ra.prof && threadIdx.x == 0 && blockIdx.x < 64 && iter_ < 16)          \
-            ra.prof[((size_t)blockIdx.x * 16 + iter_) * 8 + (slot)] = (v);        \
+        if (ra.prof && threadIdx.x == 0 && blockIdx.x >= CNSN_PROF_WG0 && blockIdx.x < CNSN_PROF_WG0 + 64 && iter_ >= CNSN_PROF_SKIP && iter_ < CNSN_PROF_SKIP + 16) \
+            ra.prof[((size_t)(blockIdx.x - CNSN_PROF_WG0) * 16 + iter_ - CNSN_PROF_SKIP) * 8 + (slot)] = (v);        \
     } while (0)
 #else
 #define CNSN_STAMP(slot) \
@@ -703,7 +711,7 @@ __global__ __launch_bounds__(kBlock, SPLIT ? (POST ? 2 : 3) : POST ? (data_regs(
                 }
                 const FwdCoefs cf = fwd_coefs<float>(a, f, g, fg);
                 if (saved && lane == 0 && (!SPLIT || wave == 0)) {
-                    const size_t p = (size_t)n * C + c;
+                    const SvRec p = sv_rec(n, c, N);
                     store_fwd_plane<float>(saved, P, p, f, a.cn_active);
                     saved[sv_at(p, SV_G)] = g;
                     saved[sv_at(p, SV_ZH_G)] = zhg;
@@ -758,7 +766,8 @@ __global__ __launch_bounds__(kBlock, SPLIT ? (POST ? 2 : 3) : POST ? (data_regs(
         CNSN_NOTE(6, passes_);
         if constexpr (!SOLO) fetch_addend();  // the exchange is over: in flight during the algebra
 
-        using R = float;  // per-plane algebra in float, cross-batch sums / normalisation in double
+        // per-plane algebra in float, cross-batch sums / normalisation in double (SPLIT: double throughout, see the backward)
+        using R = typename std::conditional<SPLIT, double, float>::type;
         auto plane_of = [&](int n) {
             MomentsT<R> o;
             o.mu_c = vals[n * NG];
@@ -858,7 +867,7 @@ __global__ __launch_bounds__(kBlock, SPLIT ? (POST ? 2 : 3) : POST ? (data_regs(
                 }
                 cfw = fwd_coefs<R>(a, f, g, fg);
                 if (saved && lane < PPW) {
-                    const size_t p = (size_t)n * C + c;
+                    const SvRec p = sv_rec(n, c, N);
                     store_fwd_plane<R>(saved, P, p, f, a.cn_active);
                     saved[sv_at(p, SV_G)] = g;
                     saved[sv_at(p, SV_ZH_G)] = zhg;
@@ -891,7 +900,7 @@ __global__ __launch_bounds__(kBlock, SPLIT ? (POST ? 2 : 3) : POST ? (data_regs(
                 o[FC_A_OUT] = cf.a_out;
                 o[FC_B_OUT] = cf.b_out;
                 if (saved) {
-                    const size_t p = (size_t)n * C + c;
+                    const SvRec p = sv_rec(n, c, N);
                     store_fwd_plane<R>(saved, P, p, f, a.cn_active);
                     saved[sv_at(p, SV_G)] = g;
                     saved[sv_at(p, SV_ZH_G)] = zhg;
@@ -1016,7 +1025,7 @@ __global__ __launch_bounds__(kBlock, SPLIT ? 2 : POST ? 2 : EPI ? bwd_waves_epi(
         float own_fc[EPI ? PPW : 1][FC_ROWS];  // the forward's apply coefficients of the owned planes (ReLU mask)
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
-            const size_t p = (size_t)(n0 + s < N ? n0 + s : 0) * C + c;
+            const SvRec p = sv_rec((n0 + s < N ? n0 + s : 0), c, N);
             own_si[s] = (float)saved[sv_at(p, SV_MU_C)];
             own_so[s] = BOXED ? (float)saved[sv_at(p, SV_MU_O)] : 0.f;
             if constexpr (EPI) {
@@ -1027,7 +1036,7 @@ __global__ __launch_bounds__(kBlock, SPLIT ? 2 : POST ? 2 : EPI ? bwd_waves_epi(
             }
         }
         for (int n = threadIdx.x; n < N; n += kBlock) {
-            const size_t p = (size_t)n * C + c;
+            const SvRec p = sv_rec(n, c, N);
             float* sf = svf + n * F_N;
             double* sd = svd + n * D_N;
             sd[D_MU_C] = saved[sv_at(p, SV_MU_C)];
@@ -1172,7 +1181,10 @@ __global__ __launch_bounds__(kBlock, SPLIT ? 2 : POST ? 2 : EPI ? bwd_waves_epi(
         CNSN_STAMP(3);
         CNSN_NOTE(6, passes_);
 
-        using R = float;  // per-plane algebra in float; batch sums and the dz line in double
+        // per-plane algebra in float (batch sums and the dz line in double); SPLIT planes are 4-16x larger, their sums
+        // carry 4-16x the absolute rounding into the BatchNorm-backward cancellation, and one workgroup has ONE plane's
+        // algebra to do: double there (tests/test_gpu_parity.py, (2,4,128,96): grad of g_fc.weight 1.4e-2 -> within 2x of the fp32 oracle)
+        using R = typename std::conditional<SPLIT, double, float>::type;
         auto sums_of = [&](int n) {
             return fix_sums<R>(a, vals[n * NS], vals[n * NS + 1], BOXED ? vals[n * NS + 2] : 0.f,
                                BOXED ? vals[n * NS + 3] : 0.f, svd[n * D_N + D_MU_C], (double)svf[n * F_N + F_MU_O]);
@@ -1356,6 +1368,10 @@ ResPlan resident_pipe_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_pe
 int resident_pipe_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* x,
                           const int64_t* perm, GateDev g, GateDev f, void* y, double* saved, void* workspace,
                           hipStream_t stream);
+ResPlan resident_pipe_bwd_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, int* npark);
+int resident_pipe_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* gy,
+                           const void* x, const int64_t* perm, GateDev g, GateDev f, const double* saved, void* dx,
+                           GateGradDev dg, GateGradDev df, void* workspace, hipStream_t stream);
 // planes of 1025..4096 vectors: one plane per workgroup, split over its four waves (cnsn_resident_split.hip);
 // add: ADD_NONE or ADD_POST (un-boxed), with or without ReLU
 ResPlan resident_split_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, int add, int relu, bool backward);

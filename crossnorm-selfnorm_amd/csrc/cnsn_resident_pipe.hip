@@ -118,4 +118,90 @@ int resident_pipe_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, c
     return status;
 }
 
+
+// ---- backward ----------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kPipeBwdWgPerCu = 2;
+
+// f(TypeTag<T>, IntTag<VEC>): the 13-slot class, one plane per wave
+template <typename F>
+bool dispatch_pipe_bwd(int dtype, int vec, F&& f) {
+    if (dtype == CNSN_F32 && vec == 4) { f(TypeTag<float>{}, IntTag<4>{}); return true; }
+    if (dtype == CNSN_BF16 && vec == 8) { f(TypeTag<bf16_t>{}, IntTag<8>{}); return true; }
+    if (dtype == CNSN_F16 && vec == 8) { f(TypeTag<_Float16>{}, IntTag<8>{}); return true; }
+    return false;
+}
+}  // namespace
+
+ResPlan resident_pipe_bwd_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm, int* npark) {
+    ResPlan none{false, 0, 0, 0, 0};
+    const int mode = pipe_mode();
+    if (mode == 0) return none;
+    ResPlan rp = reshost::plan_impl(p, boxed, has_chan_perm, true, false);
+    if (!rp.ok) return none;
+    const int vb = rp.vec * elem_bytes(p.dtype);
+    if (vb != 16 || rp.nv != 13 || rp.ppw != 1) return none;
+    const int slots = 2 * rp.nv;
+    const int grid_max = (kPipeBwdWgPerCu * reshost::cu_count() / rp.K) * rp.K;
+    if (grid_max < rp.K || (mode != 2 && (long)p.C * rp.K < 3l * grid_max)) return none;
+    const size_t budget = (kLdsPerCu / kPipeBwdWgPerCu) & ~(size_t)511;
+    int np = slots;
+    while (np >= kPipeBwdFirstKeep && pipe_bwd_lds_bytes(p.N, boxed ? 4 : 2, 4, np, vb) > budget) --np;
+    if (np < kPipeBwdFirstKeep) return none;
+    if (mode != 2) {
+        if (boxed) return none;  // (as the forward: not measured faster with crop boxes)
+    }
+    if (npark) *npark = np;
+    return rp;
+}
+
+int resident_pipe_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* gy,
+                           const void* x, const int64_t* perm, GateDev g, GateDev f, const double* saved, void* dx,
+                           GateGradDev dg, GateGradDev df, void* workspace, hipStream_t stream) {
+    int npark = 0;
+    const ResPlan rp = resident_pipe_bwd_plan(p, boxed, false, &npark);
+    if (!rp.ok) return CNSN_E_UNSUPPORTED;
+    ResArgs ra = reshost::make_args(p, cb, sb, mid, rp);
+    const int NS = boxed ? 4 : 2;
+#ifdef CNSN_PROF
+    if (getenv("CNSN_PROF")) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
+#endif
+    const size_t lds = pipe_bwd_lds_bytes(p.N, NS, 4, npark, rp.vec * elem_bytes(p.dtype));
+    const ExchangeArea ea = resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NS * 8 + 256, workspace, stream);
+    ra.epoch = ea.epoch;
+    ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
+    unsigned* ctl = (unsigned*)ea.base;
+    unsigned long long* gran = (unsigned long long*)((char*)ea.base + kCtlBytes);
+    const size_t fill_bytes = kCtlBytes + (size_t)p.N * p.C * (NS / 2) * 8;
+    int status = CNSN_E_UNSUPPORTED;
+    dispatch_pipe_bwd(p.dtype, rp.vec, [&](auto tt, auto vt) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value;
+        auto launch = [&](auto kern) {
+            if (lds > 64 * 1024 &&
+                hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                (void)hipGetLastError();
+                return;
+            }
+            const int grid = reshost::grid_for(kern, lds, rp.K, ra.items);
+            if (grid < rp.K) return;
+            ResidentChain chain(stream);
+            hipError_t e = ea.epoch ? hipSuccess : hipMemsetAsync(workspace, 0xff, fill_bytes, stream);
+            if (e != hipSuccess) {
+                status = (int)e;
+                return;
+            }
+            kern<<<grid, kBlock, lds, stream>>>(ra, npark, (const T*)gy, (const T*)x, (T*)dx, perm, g, f, dg, df, gran, saved,
+                                                ctl);
+            e = hipGetLastError();
+            status = e == hipSuccess ? CNSN_OK : (int)e;
+        };
+        if (boxed)
+            launch(resident_bwd_pipe_kernel<T, VEC, 13, 1, true>);
+        else
+            launch(resident_bwd_pipe_kernel<T, VEC, 13, 1, false>);
+    });
+    return status;
+}
+
 }  // namespace cnsn

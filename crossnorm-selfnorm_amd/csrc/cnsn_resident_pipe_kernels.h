@@ -5,11 +5,12 @@
 // memory system idle for this workgroup from its last load to its first store (profiles/r02_resident_phases.md).
 // Here a workgroup works on TWO items: item t sits in LDS ("parked": its statistics are published), item t+1 is
 // being loaded into registers.  Per iteration
-//     issue the loads of t+1  ->  gather t's channel (SCALAR memory path: a vector load would return behind the
-//     bulk loads this wave has just issued)  ->  algebra of t  ->  statistics of t+1 from registers, publish  ->
-//     apply t from LDS, store  ->  park t+1
-// so the loads of t+1 are in flight during the whole exchange and algebra of t, the publish of t+1 travels while t is
-// being stored, and the chain from one publish to the next is gather + algebra + statistics alone.  Cost: the parked item (49 KB at 56x56 fp32) bounds residency at 3 workgroups per CU
+//     gather t's channel (SCALAR memory path: a vector load would return behind the bulk loads this wave has in
+//     flight)  ->  algebra of t  ->  statistics of t+1 from registers, publish  ->  slot by slot: apply t from LDS and
+//     store, park t+1's slot in its place, issue the load of t+2's slot
+// so the loads of an item are in flight during the whole exchange and algebra of its predecessor, the publish of t+1
+// travels while t is being stored, loads and stores reach the memory system interleaved, and the chain from one publish
+// to the next is gather + algebra + statistics alone.  Cost: the parked item (49 KB at 56x56 fp32) bounds residency at 3 workgroups per CU
 // where the plain kernel has 4; the host side declines when LDS would not take 3.
 // Same arithmetic, same published numbers, same `saved` rows as the plain kernel: results are bit-identical.
 #pragma once
@@ -228,11 +229,12 @@ __global__ __launch_bounds__(kBlock, 3) void resident_fwd_pipe_kernel(ResArgs ra
     load_item(item);
     stats_publish(item);
     park_item();
+    if (item + (int)gridDim.x < ra.items) load_item(item + (int)gridDim.x);
 
     for (;;) {
         const int c = item / ra.K, k = item - c * ra.K;
-        const int next = item + (int)gridDim.x;
-        const bool more = next < ra.items;  // workgroup-uniform
+        const int next = item + (int)gridDim.x, next2 = next + (int)gridDim.x;
+        const bool more = next < ra.items, more2 = next2 < ra.items;  // workgroup-uniform
         CNSN_STAMP(1);
 
         // ---- per-channel parameters of item t (scalar loads: in flight during the gather)
@@ -254,9 +256,6 @@ __global__ __launch_bounds__(kBlock, 3) void resident_fwd_pipe_kernel(ResArgs ra
                 prv[1] = gf.run_var[c];
             }
         }
-
-        // ---- the NEXT item's planes start their way into registers: the only read of x
-        if (more) load_item(next);
 
         // ---- gather item t's channel
         unsigned passes_ = 0;
@@ -365,7 +364,7 @@ __global__ __launch_bounds__(kBlock, 3) void resident_fwd_pipe_kernel(ResArgs ra
                 o[FC_A_OUT] = cf.a_out;
                 o[FC_B_OUT] = cf.b_out;
                 if (saved) {
-                    const size_t p = (size_t)n * C + c;
+                    const SvRec p = sv_rec(n, c, N);
                     store_fwd_plane<R>(saved, P, p, f, a.cn_active);
                     saved[sv_at(p, SV_G)] = g;
                     saved[sv_at(p, SV_ZH_G)] = zhg;
@@ -383,15 +382,22 @@ __global__ __launch_bounds__(kBlock, 3) void resident_fwd_pipe_kernel(ResArgs ra
         if (more) stats_publish(next);
         CNSN_STAMP(4);
 
-        // ---- apply item t from LDS, the only write of y
+        // ---- slot by slot: apply item t from LDS (the only write of y), park item t+1's slot in its place, send the
+        //      load of item t+2's slot (the only read of x) after it: item t's stores and item t+2's loads reach the
+        //      memory system interleaved, and the loads are under way a whole apply phase earlier
+        {
+            const int c2 = next2 / ra.K, k2 = next2 - c2 * ra.K;
 #pragma unroll
-        for (int s = 0; s < PPW; ++s) {
-            const int n = (k * 4 + wave) * PPW + s;
-            if (n < N) {
+            for (int s = 0; s < PPW; ++s) {
+                const int n = (k * 4 + wave) * PPW + s;
                 const float* o = ocoef + (wave * PPW + s) * FC_ROWS;
                 const float a_in = o[FC_A_IN], xr = o[FC_XR], b_in = o[FC_B_IN], a_out = o[FC_A_OUT], b_out = o[FC_B_OUT];
-                T* yb = y + ((size_t)n * C + c) * ra.M;
-                const int pbytes = ra.M * (int)sizeof(T);
+                T* yb = y + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
+                const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;  // (a plane past the batch end drops its stores)
+                const int n2 = (k2 * 4 + wave) * PPW + s;
+                const bool live2 = more2 && n2 < N;
+                const T* xb2 = x + ((size_t)(live2 ? n2 : 0) * C + (more2 ? c2 : 0)) * ra.M;
+                const int pbytes2 = live2 ? ra.M * (int)sizeof(T) : 0;  // nothing to load: zeros, no traffic
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
                     const int i = s * NV + j;
@@ -408,11 +414,436 @@ __global__ __launch_bounds__(kBlock, 3) void resident_fwd_pipe_kernel(ResArgs ra
                         ov[q] = ic ? fmaf(a_in, f - xr, b_in) : fmaf(a_out, f, b_out);
                     }
                     buf_store<T, VEC>(slot_rsrc<T, VEC>(yb, pbytes, j), voff, pack<T, VEC>(ov));
+                    if (i < FIRST_KEEP || i < NPARK)  // park slot i of item t+1 (garbage after the last item: never read)
+                        mypark[i * 64] = d[s][j];
+                    else
+                        keep[i - FIRST_KEEP] = d[s][j];
+                    d[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(xb2, pbytes2, j), voff);
                 }
             }
         }
         if (!more) break;
-        park_item();
+        CNSN_STAMP(5);
+        item = next;
+        ++iter_;
+    }
+}
+
+// ================================================================================================
+// pipelined backward
+// ================================================================================================
+// The same schedule for the backward: item t (its G and x planes, 2 * NV slots per plane) waits parked while item t+1
+// loads.  An item is twice the forward's, so residency is TWO workgroups per CU (256 VGPRs per lane): the first `npark`
+// slots of the parked item go to LDS (80 KB per workgroup less the staged `saved` rows: 13 slots at N = 256), the rest
+// stays in registers next to the item being loaded.  Slot order: G slots first (s * 2 * NV + j), then x slots
+// (s * 2 * NV + NV + j).
+__host__ __device__ inline size_t pipe_bwd_lds_bytes(int N, int NS, int own, int parked_slots, int vec_bytes) {
+    return (size_t)4 * 64 * parked_slots * vec_bytes  // parked slots: [wave][slot][lane]
+           + align16((size_t)N * NS * 4)              // vals[N][NS]
+           + align16((size_t)2 * N * 8)               // dt [2][N]
+           + align16((size_t)N * 4)                   // inverse permutation
+           + align16((size_t)own * BC_ROWS * 4)       // coefficients of the owned planes
+           + 4 * 4 * 8 + 16                           // block reduction scratch, "gave up" flag
+           + align16((size_t)N * D_N * 8) + align16((size_t)N * F_N * 4);  // staged `saved` rows
+}
+
+constexpr int kPipeBwdFirstKeep = 12;  // slots below this index always go to LDS
+template <typename T, int VEC, int NV, int PPW, bool BOXED>
+__global__ __launch_bounds__(kBlock, 2) void resident_bwd_pipe_kernel(ResArgs ra, int npark, const T* __restrict__ gy,
+                                                                      const T* __restrict__ x, T* __restrict__ dx,
+                                                                      const int64_t* __restrict__ perm, GateDev gg, GateDev gf,
+                                                                      GateGradDev dgr, GateGradDev dfr,
+                                                                      unsigned long long* __restrict__ gran,
+                                                                      const double* __restrict__ saved,
+                                                                      unsigned* __restrict__ ctl) {
+    constexpr int NS = BOXED ? 4 : 2;
+    constexpr int OWN = 4 * PPW;
+    constexpr int SLOTS = 2 * PPW * NV;
+    constexpr int FIRST_KEEP = SLOTS < kPipeBwdFirstKeep ? SLOTS : kPipeBwdFirstKeep, KEEP = SLOTS - FIRST_KEEP;
+    constexpr int VB = VEC * (int)sizeof(T);
+    const int NPARK = __builtin_amdgcn_readfirstlane(npark);  // FIRST_KEEP <= NPARK <= SLOTS
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const MidArgs a = ra.mid;
+    const int N = a.N, C = a.C;
+    Raw<T, VEC>* park = (Raw<T, VEC>*)smem;
+    float* vals = (float*)(smem + (size_t)4 * 64 * NPARK * VB);
+    double* dtb = (double*)((char*)vals + align16((size_t)N * NS * 4));
+    int* iperm = (int*)((char*)dtb + align16((size_t)2 * N * 8));
+    float* ocoef = (float*)((char*)iperm + align16((size_t)N * 4));
+    double* red = (double*)((char*)ocoef + align16((size_t)OWN * BC_ROWS * 4));
+    int* gave_up = (int*)(red + 4 * 4);
+    double* svd = red + 4 * 4 + 2;                                      // [N][D_N]
+    float* svf = (float*)((char*)svd + align16((size_t)N * D_N * 8));  // [N][F_N]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t P = (size_t)N * C;
+    const SlotGeom<VEC, NV, BOXED> sg(ra, lane);
+    const int voff = lane * VB;
+    Raw<T, VEC>* mypark = park + (size_t)wave * NPARK * 64 + lane;  // slot i of this lane: mypark[i * 64]
+
+    if (a.cn_active)  // plane r receives the style-statistic gradient of the plane that borrowed from it
+        for (int n = threadIdx.x; n < N; n += kBlock) iperm[(int)perm[n]] = n;
+    if (threadIdx.x == 0) *gave_up = 0;
+    __syncthreads();
+    startup_skew(ra);
+
+    Raw<T, VEC> dg_[PPW][NV], dx_[PPW][NV];  // the item being loaded / whose sums are being taken
+    Raw<T, VEC> keep[KEEP > 0 ? KEEP : 1];   // slots of the parked item that did not go to LDS
+    float own_si[PPW], own_so[PPW];          // saved means of the planes in dg_/dx_ (the shift of their sums)
+
+    auto load_item = [&](int item) {
+        const int c = item / ra.K, k = item - c * ra.K;
+#pragma unroll
+        for (int s = 0; s < PPW; ++s) {
+            const int n = (k * 4 + wave) * PPW + s;
+            const SvRec p = sv_rec((n < N ? n : 0), c, N);
+            own_si[s] = (float)saved[sv_at(p, SV_MU_C)];
+            own_so[s] = BOXED ? (float)saved[sv_at(p, SV_MU_O)] : 0.f;
+            const size_t off = ((size_t)(n < N ? n : 0) * C + c) * ra.M;
+            const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) dg_[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(gy + off, pbytes, j), voff);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) dx_[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(x + off, pbytes, j), voff);
+        }
+    };
+
+    // per-plane sums of G against x (shifted by the saved means, as pass A' does), published to the cluster
+    auto sums_publish = [&](int item) {
+        const int c = item / ra.K, k = item - c * ra.K;
+#pragma unroll
+        for (int s = 0; s < PPW; ++s) {
+            const int n = (k * 4 + wave) * PPW + s;
+            const float si = own_si[s], so = own_so[s];
+            float acc[NS];
+#pragma unroll
+            for (int m = 0; m < NS; ++m) acc[m] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                if (sg.valid(j)) {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        const float G = elem<T, VEC>(dg_[s][j], q), X = elem<T, VEC>(dx_[s][j], q);
+                        if constexpr (!BOXED) {
+                            acc[0] += G;
+                            acc[1] = fmaf(G, X - si, acc[1]);
+                        } else {
+                            const bool ic = sg.in_c(j, q);
+                            acc[0] += ic ? G : 0.f;
+                            acc[1] += ic ? G * (X - si) : 0.f;
+                            acc[2] += ic ? 0.f : G;
+                            acc[3] += ic ? 0.f : G * (X - so);
+                        }
+                    }
+                }
+#pragma unroll
+            for (int m = 0; m < NS; ++m) acc[m] = wave_sum(acc[m]);
+            if (ra.epoch) {
+                if (n < N && lane < NS && !(ra.fault && item == ra.K - 1)) {
+                    float v = acc[0];
+#pragma unroll
+                    for (int m = 1; m < NS; ++m) v = (lane == m) ? acc[m] : v;
+                    put_tagged(gran + ((size_t)c * N + n) * NS + lane, v, ra.epoch);
+                }
+            } else if (n < N && lane < NS / 2 && !(ra.fault && item == ra.K - 1)) {
+                float lo = acc[0], hi = acc[1];
+#pragma unroll
+                for (int m = 1; m < NS / 2; ++m) {
+                    lo = (lane == m) ? acc[2 * m] : lo;
+                    hi = (lane == m) ? acc[2 * m + 1] : hi;
+                }
+                put_granule(gran + ((size_t)c * N + n) * (NS / 2) + lane, lo, hi);
+            }
+        }
+    };
+    // registers -> LDS (+ keep): every lane writes (and later reads back) its own slots only
+    auto park_item = [&]() {
+#pragma unroll
+        for (int s = 0; s < PPW; ++s)
+#pragma unroll
+            for (int j = 0; j < 2 * NV; ++j) {
+                const int i = s * 2 * NV + j;
+                const Raw<T, VEC> v = j < NV ? dg_[s][j] : dx_[s][j - NV];
+                if (i < FIRST_KEEP || i < NPARK)  // (wave-uniform)
+                    mypark[i * 64] = v;
+                else
+                    keep[i - FIRST_KEEP] = v;
+            }
+    };
+    auto parked = [&](int i) -> Raw<T, VEC> {
+        if (i < FIRST_KEEP || i < NPARK) return mypark[i * 64];
+        return keep[i - FIRST_KEEP];
+    };
+
+    // `saved` rows of a whole channel for the algebra, in two halves: fetch (global -> registers, instance threadIdx.x)
+    // and stage (registers -> LDS).  The fetch of item t+1 is issued before item t's stores and staged after them, so
+    // its latency is nobody's wait.  Instances past the first 256 (N > 256) are fetched and staged in one go.
+    struct Rows {
+        double mu_c, zh_g, zh_f, mu_s;
+        float a1, m_in, mu_o, mu_p, g, f, aa, sig_p, sig_c, M2c, sig_s;
+    };
+    auto rows_of = [&](int c, int n) {
+        const SvRec p = sv_rec(n, c, N);
+        Rows r;
+        r.mu_c = saved[sv_at(p, SV_MU_C)];
+        r.zh_g = saved[sv_at(p, SV_ZH_G)];
+        r.zh_f = saved[sv_at(p, SV_ZH_F)];
+        const CnRowsT<float> cr = load_cn_rows<float>(a, saved, p, r.mu_c);
+        r.mu_s = cr.mu_s;
+        r.a1 = cr.a1;
+        r.m_in = cr.m_in;
+        r.mu_o = cr.mu_o;
+        r.mu_p = (float)saved[sv_at(p, SV_MU_P)];
+        r.g = (float)saved[sv_at(p, SV_G)];
+        r.f = (float)saved[sv_at(p, SV_F)];
+        r.aa = cr.aa;
+        r.sig_p = (float)saved[sv_at(p, SV_SIG_P)];
+        r.sig_c = cr.sig_c;
+        r.M2c = cr.M2c;
+        r.sig_s = cr.sig_s;
+        return r;
+    };
+    auto stage_row = [&](int n, const Rows& r) {
+        float* sf = svf + n * F_N;
+        double* sd = svd + n * D_N;
+        sd[D_MU_C] = r.mu_c;
+        sd[D_ZH_G] = r.zh_g;
+        sd[D_ZH_F] = r.zh_f;
+        sd[D_MU_S] = r.mu_s;
+        sf[F_A1] = r.a1;
+        sf[F_M_IN] = r.m_in;
+        sf[F_MU_O] = r.mu_o;
+        sf[F_MU_P] = r.mu_p;
+        sf[F_G] = r.g;
+        sf[F_F] = r.f;
+        sf[F_A] = r.aa;
+        sf[F_SIG_P] = r.sig_p;
+        sf[F_SIG_C] = r.sig_c;
+        sf[F_M2C] = r.M2c;
+        sf[F_SIG_S] = r.sig_s;
+    };
+    auto stage_rows = [&](int c, const Rows& mine) {
+        if ((int)threadIdx.x < N) stage_row(threadIdx.x, mine);
+        for (int n = threadIdx.x + kBlock; n < N; n += kBlock) stage_row(n, rows_of(c, n));
+    };
+
+    int item = blockIdx.x;
+    if (item >= ra.items) return;
+    int iter_ = 0;
+    (void)iter_;
+    CNSN_STAMP(0);
+    load_item(item);
+    {
+        const int c0 = item / ra.K;
+        stage_rows(c0, rows_of(c0, (int)threadIdx.x < N ? threadIdx.x : 0));
+    }
+    sums_publish(item);
+    park_item();
+    if (item + (int)gridDim.x < ra.items) load_item(item + (int)gridDim.x);
+
+    for (;;) {
+        const int c = item / ra.K, k = item - c * ra.K;
+        const int next = item + (int)gridDim.x, next2 = next + (int)gridDim.x;
+        const bool more = next < ra.items, more2 = next2 < ra.items;  // workgroup-uniform
+        CNSN_STAMP(1);
+
+        // ---- per-channel parameters of item t (scalar loads; its `saved` rows were staged at the end of the previous
+        //      iteration; item t+1's planes have been on their way into registers since then, too)
+        float pw[4] = {0.f, 0.f, 0.f, 0.f}, pgam[2] = {0.f, 0.f};
+        double prs[2] = {1.0, 1.0};
+        if (a.sn_active) {
+            pw[0] = gg.w[2 * c];
+            pw[1] = gg.w[2 * c + 1];
+            pgam[0] = gg.gamma[c];
+            prs[0] = saved[SV_ROWS * P + c];
+            if (a.sn_two) {
+                pw[2] = gf.w[2 * c];
+                pw[3] = gf.w[2 * c + 1];
+                pgam[1] = gf.gamma[c];
+                prs[1] = saved[SV_ROWS * P + C + c];
+            }
+        }
+
+        // ---- gather item t's channel (scalar path)
+        unsigned passes_ = 0;
+        {
+            const bool got = ra.epoch ? sweep_tagged_scalar(gran + (size_t)c * N * NS, N * NS, vals, ctl, ra.host_flag,
+                                                            ra.wait_ticks, wave, ra.epoch, passes_)
+                                      : sweep_granules_scalar(gran + (size_t)c * N * (NS / 2), N * NS, vals, ctl, ra.host_flag,
+                                                              ra.wait_ticks, wave, passes_);
+            if (lane == 0 && !got) *gave_up = 1;
+        }
+        __syncthreads();
+        if (*gave_up) return;  // (workgroup-uniform) timed out: see sweep_granules
+        CNSN_STAMP(2);
+        CNSN_NOTE(6, passes_);
+
+        using R = float;  // per-plane algebra in float; batch sums and the dz line in double
+        auto sums_of = [&](int n) {
+            return fix_sums<R>(a, vals[n * NS], vals[n * NS + 1], BOXED ? vals[n * NS + 2] : 0.f,
+                               BOXED ? vals[n * NS + 3] : 0.f, svd[n * D_N + D_MU_C], (double)svf[n * F_N + F_MU_O]);
+        };
+
+        // ---- gate backward: dt for every instance of the channel, batch sums (all members)
+        double s4[4] = {0, 0, 0, 0};
+        BnBwd b{};
+        if (a.sn_active) {
+            for (int n = threadIdx.x; n < N; n += kBlock) {
+                const float* sf = svf + n * F_N;
+                R dtg, dtf;
+                gate_dt<R>(a, sums_of(n), sf[F_A1], sf[F_M_IN], sf[F_MU_O], sf[F_MU_P], sf[F_G], sf[F_F], dtg, dtf);
+                s4[0] += (double)dtg;
+                s4[1] += (double)dtg * svd[n * D_N + D_ZH_G];
+                s4[2] += (double)dtf;
+                s4[3] += (double)dtf * svd[n * D_N + D_ZH_F];
+                dtb[n] = dtg;
+                dtb[N + n] = dtf;
+            }
+            block_sum_d<4>(s4, red);
+            b.s_dt_g = s4[0];
+            b.s_dtz_g = s4[1];
+            b.s_dt_f = s4[2];
+            b.s_dtz_f = s4[3];
+            b.wg0 = pw[0];
+            b.wg1 = pw[1];
+            b.kg = (double)pgam[0] * prs[0];
+            b.wf0 = pw[2];
+            b.wf1 = pw[3];
+            b.kf = (double)pgam[1] * prs[1];
+        }
+
+        auto bwd_of = [&](int n) {
+            const float* sf = svf + n * F_N;
+            return bwd_plane<R>(a, b, sums_of(n), a.sn_active ? dtb[n] : 0.0, a.sn_active ? dtb[N + n] : 0.0,
+                                svd[n * D_N + D_ZH_G], svd[n * D_N + D_ZH_F], sf[F_G], sf[F_F], sf[F_A], sf[F_A1],
+                                sf[F_M_IN], sf[F_MU_P], sf[F_SIG_P], sf[F_SIG_C], sf[F_M2C]);
+        };
+
+        // ---- parameter gradients of the channel: one member per channel (rotating) does the sums
+        if (a.sn_active && k == c % ra.K) {
+            double sw[4] = {0, 0, 0, 0};
+            for (int n = threadIdx.x; n < N; n += kBlock) {
+                const BwdPlaneT<R> o = bwd_of(n);
+                const double mu_p = svf[n * F_N + F_MU_P], sig_p = svf[n * F_N + F_SIG_P];
+                sw[0] += (double)o.dz_g * mu_p;
+                sw[1] += (double)o.dz_g * sig_p;
+                sw[2] += (double)o.dz_f * mu_p;
+                sw[3] += (double)o.dz_f * sig_p;
+            }
+            block_sum_d<4>(sw, red);
+            if (threadIdx.x == 0) {
+                dgr.dgamma[c] = (float)s4[1];
+                dgr.dbeta[c] = (float)s4[0];
+                dgr.dw[2 * c] = (float)sw[0];
+                dgr.dw[2 * c + 1] = (float)sw[1];
+                if (a.sn_two) {
+                    dfr.dgamma[c] = (float)s4[3];
+                    dfr.dbeta[c] = (float)s4[2];
+                    dfr.dw[2 * c] = (float)sw[2];
+                    dfr.dw[2 * c + 1] = (float)sw[3];
+                }
+            }
+        }
+
+        // ---- coefficients of dx for the owned planes
+        if (threadIdx.x < OWN) {
+            const int n = k * OWN + threadIdx.x;
+            if (n < N) {
+                const float* sf = svf + n * F_N;
+                const BwdPlaneT<R> o = bwd_of(n);
+                R Emu = 0.f, Esig = 0.f;
+                if (a.cn_active) {
+                    const BwdPlaneT<R> src = bwd_of(iperm[n]);  // the plane that used (n,c) as its style
+                    Emu = src.Emu;
+                    Esig = src.Esig;
+                }
+                const BwdCoefs cf =
+                    bwd_coefs<R>(a, o, Emu, Esig, sf[F_G], sf[F_A1], sf[F_M_IN], sf[F_MU_P], svd[n * D_N + D_MU_C],
+                                 sf[F_SIG_C], svd[n * D_N + D_MU_S], sf[F_SIG_S]);
+                float* oc = ocoef + threadIdx.x * BC_ROWS;
+                oc[BC_CG_IN] = cf.cG_in;
+                oc[BC_CX_IN] = cf.cX_in;
+                oc[BC_XR_IN] = cf.xr_in;
+                oc[BC_C0_IN] = cf.c0_in;
+                oc[BC_CG_OUT] = cf.cG_out;
+                oc[BC_CX_OUT] = cf.cX_out;
+                oc[BC_XR_OUT] = cf.xr_out;
+                oc[BC_C0_OUT] = cf.c0_out;
+                oc[BC_ES] = cf.eS;
+                oc[BC_XS] = cf.xs;
+                oc[BC_E0] = cf.e0;
+            }
+        }
+        __syncthreads();  // (also: every wave is done reading svd / svf before the next iteration restages them)
+        CNSN_STAMP(3);
+
+        // ---- item t+1 has arrived long ago: its sums go out BEFORE item t is applied; the fetch of its channel's
+        //      `saved` rows is issued ahead of item t's stores
+        const int cn_ = next / ra.K;
+        Rows nrow{};
+        if (more) {
+            sums_publish(next);
+            nrow = rows_of(cn_, (int)threadIdx.x < N ? threadIdx.x : 0);
+        }
+        CNSN_STAMP(4);
+
+        // ---- slot by slot: apply item t from LDS / the kept registers (the only write of dx), park item t+1's slot in
+        //      its place, and send the load of item t+2's slot after it — item t's stores and item t+2's loads reach
+        //      the memory system interleaved, and the loads are under way a whole apply phase earlier than they would
+        //      be after it
+        static_assert(PPW == 1, "the slot pipeline below walks one plane per wave");
+        {
+            const int n = k * 4 + wave;
+            const float* oc = ocoef + wave * BC_ROWS;
+            const float cG_i = oc[BC_CG_IN], cX_i = oc[BC_CX_IN], xr_i = oc[BC_XR_IN], c0_i = oc[BC_C0_IN];
+            const float cG_o = oc[BC_CG_OUT], cX_o = oc[BC_CX_OUT], xr_o = oc[BC_XR_OUT], c0_o = oc[BC_C0_OUT];
+            const float eS = oc[BC_ES], xs = oc[BC_XS], e0 = oc[BC_E0];
+            T* db = dx + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
+            const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;  // (a plane past the batch end drops its stores)
+            // item t+2 (this wave's plane of it)
+            const int c2 = next2 / ra.K, k2 = next2 - c2 * ra.K;
+            const int n2 = k2 * 4 + wave;
+            const bool live2 = more2 && n2 < N;
+            const SvRec p2 = sv_rec(live2 ? n2 : 0, more2 ? c2 : 0, N);
+            const float si2 = (float)saved[sv_at(p2, SV_MU_C)];
+            const float so2 = BOXED ? (float)saved[sv_at(p2, SV_MU_O)] : 0.f;
+            const size_t off2 = ((size_t)(live2 ? n2 : 0) * C + (more2 ? c2 : 0)) * ra.M;
+            const int pbytes2 = live2 ? ra.M * (int)sizeof(T) : 0;  // nothing to load: every lane reads zeros, no traffic
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const Raw<T, VEC> rg = parked(j), rx = parked(NV + j);
+                float ov[VEC];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    const float G = elem<T, VEC>(rg, q), X = elem<T, VEC>(rx, q);
+                    float v;
+                    if constexpr (!BOXED) {
+                        v = fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i));
+                    } else {
+                        const bool ic = sg.in_c(j, q), is = sg.in_s(j, q);
+                        v = ic ? fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i)) : fmaf(cG_o, G, fmaf(cX_o, X - xr_o, c0_o));
+                        v += is ? fmaf(eS, X - xs, e0) : 0.f;
+                    }
+                    ov[q] = v;
+                }
+                buf_store<T, VEC>(slot_rsrc<T, VEC>(db, pbytes, j), voff, pack<T, VEC>(ov));
+                // park slot j of item t+1 (garbage after the last item: never read)
+                if (j < FIRST_KEEP || j < NPARK)
+                    mypark[j * 64] = dg_[0][j];
+                else
+                    keep[j - FIRST_KEEP] = dg_[0][j];
+                if (NV + j < FIRST_KEEP || NV + j < NPARK)
+                    mypark[(NV + j) * 64] = dx_[0][j];
+                else
+                    keep[NV + j - FIRST_KEEP] = dx_[0][j];
+                dg_[0][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(gy + off2, pbytes2, j), voff);
+                dx_[0][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(x + off2, pbytes2, j), voff);
+            }
+            own_si[0] = si2;
+            own_so[0] = so2;
+        }
+        if (!more) break;
+        stage_rows(cn_, nrow);  // (every wave left the algebra of item t at the barrier above)
         CNSN_STAMP(5);
         item = next;
         ++iter_;

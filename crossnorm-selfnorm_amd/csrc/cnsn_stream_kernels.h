@@ -270,9 +270,11 @@ __global__ __launch_bounds__(kBlock) void bwd_reduce_kernel(const T* __restrict_
     __shared__ float lds[4 * NACC];
     const PlaneId<LPP> id(g.P);
     const size_t off = (size_t)id.p * g.M;
-    // shifts live in the per-plane records of `saved` (stride = record length); mid_bwd_a undoes the rounding
-    const float si = shift_in ? (float)shift_in[(size_t)id.p * shift_stride] : 0.f;
-    const float so = (BOXED && shift_out) ? (float)shift_out[(size_t)id.p * shift_stride] : 0.f;
+    // shifts: a plain array over the planes (shift_stride 1), or rows of `saved` (shift_stride 0: the pointers are the
+    // rows' starts, cnsn_layout.h); mid_bwd_a undoes the rounding
+    const size_t srec = shift_stride == 1 ? (size_t)id.p : sv_rec_of_plane((size_t)id.p, g.N, g.C).base;
+    const float si = shift_in ? (float)shift_in[srec] : 0.f;
+    const float so = (BOXED && shift_out) ? (float)shift_out[srec] : 0.f;
     float part[NACC][VEC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k)
