@@ -149,8 +149,29 @@ def copy_triad_ceiling(dev, nbytes=822083584):
     t_copy = timeit(lambda: c.copy_(a))
     t_triad = timeit(lambda: torch.add(a, b, alpha=2.0, out=c))
     del a, b, c
-    return {"copy_GBps": round(2 * nbytes / t_copy / 1e6, 1), "triad_GBps": round(3 * nbytes / t_triad / 1e6, 1),
-            "note": "torch copy_ / add(alpha=2) on 822 MB fp32 tensors, same process and device"}
+    out = {"copy_GBps": round(2 * nbytes / t_copy / 1e6, 1), "triad_GBps": round(3 * nbytes / t_triad / 1e6, 1),
+           "note": "torch copy_ / add(alpha=2) on 822 MB fp32 tensors, same process and device"}
+    out.update(access_pattern_ceiling())
+    return out
+
+
+def access_pattern_ceiling():
+    """What the single-touch ACCESS PATTERN allows on this box: tools/pattern_bench (built by __graft_entry__.build)
+    copies 56x56 fp32 planes in the item order of the cluster-resident kernels — a channel's 256 planes are 3.2 MB
+    apart — with no exchange and no arithmetic; forward shape (one plane in, one out) and backward shape (two in, one
+    out).  profiles/r02_access_pattern.md has the full table (linear order reaches 10 % more)."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "pattern_bench")
+    if not os.path.exists(exe):
+        return {}
+    try:
+        r = subprocess.run([exe, "256", "256", "brief"], capture_output=True, text=True, timeout=120)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"resident_order_copy_GBps": d["column_copy_GBps"], "resident_order_triad_GBps": d["column_triad_GBps"],
+                "resident_order_note": "tools/pattern_bench: plane copy / two-in-one-out in the resident kernels' item order, "
+                                       "no exchange, no arithmetic — the ceiling of the forward / backward launch on this box"}
+    except Exception as e:  # the tool is an aid: never fail the bench over it
+        return {"resident_order_error": str(e)[:200]}
 
 
 def secondary_workloads(cnsn_amd, shape, dev, args):
@@ -258,7 +279,7 @@ SWEEP_SHAPES = [(8, 64, 32, 32), (128, 32, 32, 32), (128, 64, 16, 16), (128, 128
 
 def sweep(cnsn_amd, dev):
     """`python bench.py --sweep`: every shape of SURVEY §8 d1 x dtype x mode — ms per forward+backward (HIP events),
-    algorithmic GB/s (8*E*b / t) and the kernels AUTO resolved to (forward/backward) — as a markdown table
+    (best of 3 x 20 calls), algorithmic GB/s (8*E*b / t) and the kernels AUTO resolved to (forward/backward) — as a markdown table
     (profiles/r02_shape_sweep.md).  Not the one-line contract: a measurement aid."""
     def timeit(fn, k=20, w=5):
         for _ in range(w):
@@ -309,7 +330,9 @@ def sweep(cnsn_amd, dev):
                                            content_box=(1, 1, 3, 3) if crop == "both" else None,
                                            style_box=(0, 0, 2, 2) if crop == "both" else None)
                 path = short[cnsn_amd.which_path(x, cfg, False)] + short[cnsn_amd.which_path(x, cfg, True)]
-                t = timeit(run)
+                # best of three timings: calls of a few tens of microseconds leave the GPU mostly idle, and its clocks
+                # then wander between power states from one timing to the next (0.055 vs 0.09 ms for the same call)
+                t = min(timeit(run) for _ in range(3))
                 cells.append(f"{t:.3f} ms {8 * eb / t / 1e6:.0f} {path}")
             print(f"| {shape} | {dt} | " + " | ".join(cells) + " |", flush=True)
 
@@ -629,7 +652,14 @@ def main():
                                      "survey_d3_frac": round(3 * e * b / fwd_s / 1e9 / HBM_PEAK_GBS, 4)}},
         }
         if world == 1:
-            out["roofline"]["ceiling"] = copy_triad_ceiling(dev)
+            ceil = copy_triad_ceiling(dev)
+            out["roofline"]["ceiling"] = ceil
+            if "resident_order_triad_GBps" in ceil and list(shape) == [256, 256, 56, 56] and b == 4:
+                # how close the two launches are to what their access pattern allows on THIS box
+                out["roofline"]["frac_of_resident_order_ceiling"] = round(
+                    out["roofline"]["achieved"] / ceil["resident_order_triad_GBps"], 4)
+                out["roofline"]["forward"]["frac_of_resident_order_ceiling"] = round(
+                    out["roofline"]["forward"]["achieved"] / ceil["resident_order_copy_GBps"], 4)
         if world == 1 and not args.no_extra:
             out["extra"] = secondary_workloads(cnsn_amd, shape, dev, args)
             out["extra"]["residual_block_add_cnsn_relu"] = residual_block_workloads(cnsn_amd, shape, dev)
