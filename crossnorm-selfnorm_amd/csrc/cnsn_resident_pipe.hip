@@ -18,6 +18,8 @@ bool dispatch_pipe(int dtype, int vec, int nv, F&& f) {
     auto by_nv = [&](auto tt, auto vt) -> bool {
         using T = typename decltype(tt)::type;
         switch (nv) {
+            case 2: f(tt, vt, IntTag<2>{}, IntTag<reshost::ppw_of(2, false, false, (int)sizeof(T))>{}); return true;
+            case 4: f(tt, vt, IntTag<4>{}, IntTag<reshost::ppw_of(4, false, false, (int)sizeof(T))>{}); return true;
             case 7: f(tt, vt, IntTag<7>{}, IntTag<reshost::ppw_of(7, false, false, (int)sizeof(T))>{}); return true;
             case 8: f(tt, vt, IntTag<8>{}, IntTag<reshost::ppw_of(8, false, false, (int)sizeof(T))>{}); return true;
             case 13: f(tt, vt, IntTag<13>{}, IntTag<1>{}); return true;
@@ -48,23 +50,25 @@ ResPlan resident_pipe_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_pe
     if (!rp.ok) return none;
     if (!boxed && !p.cn_active && !(p.sn_active && p.sn_training)) return none;  // inference: nothing to wait for
     const int vb = rp.vec * elem_bytes(p.dtype);
-    if (vb != 16 || rp.nv < 7) return none;
+    if (vb != 16 || rp.nv < 2) return none;
     const int slots = rp.ppw * rp.nv, nvec = p.H * p.W / rp.vec;
-    const int grid_max = (kPipeWgPerCu * reshost::cu_count() / rp.K) * rp.K;
+    const int wg_per_cu = pipe_fwd_waves(slots);
+    const int grid_max = (wg_per_cu * reshost::cu_count() / rp.K) * rp.K;
     if (grid_max < rp.K || (mode != 2 && (long)p.C * rp.K < 3l * grid_max)) return none;  // fewer than three items per workgroup: no pipeline to fill
     // slots worth parking: the full ones of every plane held (a last, partly filled slot may as well stay in registers)
     const int keep_max = slots < kPipeKeep ? slots : kPipeKeep;
-    const size_t budget = (kLdsPerCu / kPipeWgPerCu) & ~(size_t)511;
+    const size_t budget = (kLdsPerCu / wg_per_cu) & ~(size_t)511;
     int np = slots;
     if (rp.ppw == 1 && nvec % 64 != 0 && nvec % 64 <= 32) np = slots - 1;
     while (np >= slots - keep_max && pipe_lds_bytes(p.N, boxed ? 6 : 2, 4 * rp.ppw, np, vb, p.cn_active != 0) > budget) --np;
     if (np < slots - keep_max) return none;
     // AUTO / forced-resident without CNSN_PIPE=2: where it measured faster than the plain kernel on MI355X
-    // (profiles/r02_pipelined_forward.md): un-boxed calls of the 7- and 13-slot classes.  With crop boxes the gather is
-    // three times as long and the kernel is VALU-bound (0.53 vs 0.46 ms at the north-star shape); the 16-slot class spills.
+    // (profiles/r02_pipelined_resident.md): un-boxed calls of the 2-, 4-, 7- and 13-slot classes (28x28: 2-8 %, 40x40
+    // 16-bit: 20 %, 56x56: 9 %).  With crop boxes the gather is three times as long and the kernel is VALU-bound (0.53 vs
+    // 0.46 ms at the north-star shape); the 8-slot class measured 4 % slower, the 16-slot class spills.
     if (mode != 2) {
         if (boxed) return none;
-        if (!(rp.nv == 7 || rp.nv == 13)) return none;
+        if (!(rp.nv == 2 || rp.nv == 4 || rp.nv == 7 || rp.nv == 13)) return none;
     }
     if (npark) *npark = np;
     return rp;
@@ -121,14 +125,25 @@ int resident_pipe_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, c
 
 // ---- backward ----------------------------------------------------------------------------------------------------
 namespace {
-constexpr int kPipeBwdWgPerCu = 2;
 
-// f(TypeTag<T>, IntTag<VEC>): the 13-slot class, one plane per wave
+// planes per wave of the pipelined backward (its own choice: G and x of an item are both on chip twice over)
+constexpr int pipe_bwd_ppw(int nv) { return nv == 2 ? 4 : (nv == 4 ? 2 : 1); }
+
+// f(TypeTag<T>, IntTag<VEC>, IntTag<NV>, IntTag<PPW>)
 template <typename F>
-bool dispatch_pipe_bwd(int dtype, int vec, F&& f) {
-    if (dtype == CNSN_F32 && vec == 4) { f(TypeTag<float>{}, IntTag<4>{}); return true; }
-    if (dtype == CNSN_BF16 && vec == 8) { f(TypeTag<bf16_t>{}, IntTag<8>{}); return true; }
-    if (dtype == CNSN_F16 && vec == 8) { f(TypeTag<_Float16>{}, IntTag<8>{}); return true; }
+bool dispatch_pipe_bwd(int dtype, int vec, int nv, F&& f) {
+    auto by_nv = [&](auto tt, auto vt) -> bool {
+        // Only the 13-slot class is built.  The kernel is generic in (NV, PPW); the 16-slot items of the smaller
+        // classes — (2,4), (4,2), (7,1), (8,1) — were tried at three workgroups per CU: 50-60 spilled VGPRs at the
+        // 168-register budget and 5-30 % slower than the plain kernels (profiles/r02_pipelined_resident.md).
+        switch (nv) {
+            case 13: f(tt, vt, IntTag<13>{}, IntTag<pipe_bwd_ppw(13)>{}); return true;
+            default: return false;
+        }
+    };
+    if (dtype == CNSN_F32 && vec == 4) return by_nv(TypeTag<float>{}, IntTag<4>{});
+    if (dtype == CNSN_BF16 && vec == 8) return by_nv(TypeTag<bf16_t>{}, IntTag<8>{});
+    if (dtype == CNSN_F16 && vec == 8) return by_nv(TypeTag<_Float16>{}, IntTag<8>{});
     return false;
 }
 }  // namespace
@@ -140,14 +155,18 @@ ResPlan resident_pipe_bwd_plan(const cnsn_problem_t& p, bool boxed, bool has_cha
     ResPlan rp = reshost::plan_impl(p, boxed, has_chan_perm, true, false);
     if (!rp.ok) return none;
     const int vb = rp.vec * elem_bytes(p.dtype);
-    if (vb != 16 || rp.nv != 13 || rp.ppw != 1) return none;
-    const int slots = 2 * rp.nv;
-    const int grid_max = (kPipeBwdWgPerCu * reshost::cu_count() / rp.K) * rp.K;
+    if (vb != 16 || rp.nv != 13) return none;
+    rp.ppw = pipe_bwd_ppw(rp.nv);
+    rp.K = (p.N + 4 * rp.ppw - 1) / (4 * rp.ppw);
+    if (rp.K > 2 * reshost::cu_count()) return none;
+    const int slots = 2 * rp.ppw * rp.nv;
+    const int wg_per_cu = pipe_bwd_waves(slots);
+    const int grid_max = (wg_per_cu * reshost::cu_count() / rp.K) * rp.K;
     if (grid_max < rp.K || (mode != 2 && (long)p.C * rp.K < 3l * grid_max)) return none;
-    const size_t budget = (kLdsPerCu / kPipeBwdWgPerCu) & ~(size_t)511;
+    const size_t budget = (kLdsPerCu / wg_per_cu) & ~(size_t)511;
     int np = slots;
-    while (np >= kPipeBwdFirstKeep && pipe_bwd_lds_bytes(p.N, boxed ? 4 : 2, 4, np, vb) > budget) --np;
-    if (np < kPipeBwdFirstKeep) return none;
+    while (np >= pipe_bwd_first_keep(slots) && pipe_bwd_lds_bytes(p.N, boxed ? 4 : 2, 4 * rp.ppw, np, vb) > budget) --np;
+    if (np < pipe_bwd_first_keep(slots)) return none;
     if (mode != 2) {
         if (boxed) return none;  // (as the forward: not measured faster with crop boxes)
     }
@@ -166,7 +185,7 @@ int resident_pipe_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
 #ifdef CNSN_PROF
     if (getenv("CNSN_PROF")) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
 #endif
-    const size_t lds = pipe_bwd_lds_bytes(p.N, NS, 4, npark, rp.vec * elem_bytes(p.dtype));
+    const size_t lds = pipe_bwd_lds_bytes(p.N, NS, 4 * rp.ppw, npark, rp.vec * elem_bytes(p.dtype));
     const ExchangeArea ea = resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NS * 8 + 256, workspace, stream);
     ra.epoch = ea.epoch;
     ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
@@ -174,9 +193,9 @@ int resident_pipe_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
     unsigned long long* gran = (unsigned long long*)((char*)ea.base + kCtlBytes);
     const size_t fill_bytes = kCtlBytes + (size_t)p.N * p.C * (NS / 2) * 8;
     int status = CNSN_E_UNSUPPORTED;
-    dispatch_pipe_bwd(p.dtype, rp.vec, [&](auto tt, auto vt) {
+    dispatch_pipe_bwd(p.dtype, rp.vec, rp.nv, [&](auto tt, auto vt, auto nt, auto pt) {
         using T = typename decltype(tt)::type;
-        constexpr int VEC = decltype(vt)::value;
+        constexpr int VEC = decltype(vt)::value, NV = decltype(nt)::value, PPW = decltype(pt)::value;
         auto launch = [&](auto kern) {
             if (lds > 64 * 1024 &&
                 hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -197,9 +216,9 @@ int resident_pipe_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
             status = e == hipSuccess ? CNSN_OK : (int)e;
         };
         if (boxed)
-            launch(resident_bwd_pipe_kernel<T, VEC, 13, 1, true>);
+            launch(resident_bwd_pipe_kernel<T, VEC, NV, PPW, true>);
         else
-            launch(resident_bwd_pipe_kernel<T, VEC, 13, 1, false>);
+            launch(resident_bwd_pipe_kernel<T, VEC, NV, PPW, false>);
     });
     return status;
 }

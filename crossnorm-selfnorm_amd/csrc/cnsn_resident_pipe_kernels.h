@@ -76,8 +76,10 @@ __host__ __device__ inline size_t pipe_lds_bytes(int N, int NG, int own, int par
 // a launch argument — the host parks as many slots as let three workgroups share a CU's 160 KB (at 56x56 fp32 the 13th
 // slot, a quarter full, stays: 12 slots = 48 KB).
 constexpr int kPipeKeep = 6;
+// workgroups per CU the forward is compiled for: small items (8 slots = 32 data registers) want more neighbours
+constexpr int pipe_fwd_waves(int slots) { return slots <= 8 ? 4 : 3; }
 template <typename T, int VEC, int NV, int PPW, bool BOXED>
-__global__ __launch_bounds__(kBlock, 3) void resident_fwd_pipe_kernel(ResArgs ra, int npark, const T* __restrict__ x,
+__global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd_pipe_kernel(ResArgs ra, int npark, const T* __restrict__ x,
                                                                       T* __restrict__ y, const int64_t* __restrict__ perm,
                                                                       GateDev gg, GateDev gf,
                                                                       unsigned long long* __restrict__ gran,
@@ -447,9 +449,12 @@ __host__ __device__ inline size_t pipe_bwd_lds_bytes(int N, int NS, int own, int
            + align16((size_t)N * D_N * 8) + align16((size_t)N * F_N * 4);  // staged `saved` rows
 }
 
-constexpr int kPipeBwdFirstKeep = 12;  // slots below this index always go to LDS
+// slots below this index always go to LDS; workgroups per CU the backward is compiled for (items of up to 16 slots:
+// three, with fewer slots in LDS and more in registers)
+constexpr int pipe_bwd_first_keep(int slots) { return slots <= 16 ? 6 : 12; }
+constexpr int pipe_bwd_waves(int slots) { return slots <= 16 ? 3 : 2; }
 template <typename T, int VEC, int NV, int PPW, bool BOXED>
-__global__ __launch_bounds__(kBlock, 2) void resident_bwd_pipe_kernel(ResArgs ra, int npark, const T* __restrict__ gy,
+__global__ __launch_bounds__(kBlock, pipe_bwd_waves(2 * PPW * NV)) void resident_bwd_pipe_kernel(ResArgs ra, int npark, const T* __restrict__ gy,
                                                                       const T* __restrict__ x, T* __restrict__ dx,
                                                                       const int64_t* __restrict__ perm, GateDev gg, GateDev gf,
                                                                       GateGradDev dgr, GateGradDev dfr,
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(kBlock, 2) void resident_bwd_pipe_kernel(ResArgs ra
     constexpr int NS = BOXED ? 4 : 2;
     constexpr int OWN = 4 * PPW;
     constexpr int SLOTS = 2 * PPW * NV;
-    constexpr int FIRST_KEEP = SLOTS < kPipeBwdFirstKeep ? SLOTS : kPipeBwdFirstKeep, KEEP = SLOTS - FIRST_KEEP;
+    constexpr int FIRST_KEEP = pipe_bwd_first_keep(SLOTS), KEEP = SLOTS - FIRST_KEEP;
     constexpr int VB = VEC * (int)sizeof(T);
     const int NPARK = __builtin_amdgcn_readfirstlane(npark);  // FIRST_KEEP <= NPARK <= SLOTS
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -791,56 +796,60 @@ __global__ __launch_bounds__(kBlock, 2) void resident_bwd_pipe_kernel(ResArgs ra
         //      its place, and send the load of item t+2's slot after it — item t's stores and item t+2's loads reach
         //      the memory system interleaved, and the loads are under way a whole apply phase earlier than they would
         //      be after it
-        static_assert(PPW == 1, "the slot pipeline below walks one plane per wave");
         {
-            const int n = k * 4 + wave;
-            const float* oc = ocoef + wave * BC_ROWS;
-            const float cG_i = oc[BC_CG_IN], cX_i = oc[BC_CX_IN], xr_i = oc[BC_XR_IN], c0_i = oc[BC_C0_IN];
-            const float cG_o = oc[BC_CG_OUT], cX_o = oc[BC_CX_OUT], xr_o = oc[BC_XR_OUT], c0_o = oc[BC_C0_OUT];
-            const float eS = oc[BC_ES], xs = oc[BC_XS], e0 = oc[BC_E0];
-            T* db = dx + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
-            const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;  // (a plane past the batch end drops its stores)
-            // item t+2 (this wave's plane of it)
             const int c2 = next2 / ra.K, k2 = next2 - c2 * ra.K;
-            const int n2 = k2 * 4 + wave;
-            const bool live2 = more2 && n2 < N;
-            const SvRec p2 = sv_rec(live2 ? n2 : 0, more2 ? c2 : 0, N);
-            const float si2 = (float)saved[sv_at(p2, SV_MU_C)];
-            const float so2 = BOXED ? (float)saved[sv_at(p2, SV_MU_O)] : 0.f;
-            const size_t off2 = ((size_t)(live2 ? n2 : 0) * C + (more2 ? c2 : 0)) * ra.M;
-            const int pbytes2 = live2 ? ra.M * (int)sizeof(T) : 0;  // nothing to load: every lane reads zeros, no traffic
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const Raw<T, VEC> rg = parked(j), rx = parked(NV + j);
-                float ov[VEC];
+            for (int s = 0; s < PPW; ++s) {
+                const int n = (k * 4 + wave) * PPW + s;
+                const float* oc = ocoef + (wave * PPW + s) * BC_ROWS;
+                const float cG_i = oc[BC_CG_IN], cX_i = oc[BC_CX_IN], xr_i = oc[BC_XR_IN], c0_i = oc[BC_C0_IN];
+                const float cG_o = oc[BC_CG_OUT], cX_o = oc[BC_CX_OUT], xr_o = oc[BC_XR_OUT], c0_o = oc[BC_C0_OUT];
+                const float eS = oc[BC_ES], xs = oc[BC_XS], e0 = oc[BC_E0];
+                T* db = dx + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
+                const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;  // (a plane past the batch end drops its stores)
+                // item t+2 (this wave's plane s of it)
+                const int n2 = (k2 * 4 + wave) * PPW + s;
+                const bool live2 = more2 && n2 < N;
+                const SvRec p2 = sv_rec(live2 ? n2 : 0, more2 ? c2 : 0, N);
+                const float si2 = (float)saved[sv_at(p2, SV_MU_C)];
+                const float so2 = BOXED ? (float)saved[sv_at(p2, SV_MU_O)] : 0.f;
+                const size_t off2 = ((size_t)(live2 ? n2 : 0) * C + (more2 ? c2 : 0)) * ra.M;
+                const int pbytes2 = live2 ? ra.M * (int)sizeof(T) : 0;  // nothing to load: every lane reads zeros, no traffic
+                const int base = s * 2 * NV;
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) {
-                    const float G = elem<T, VEC>(rg, q), X = elem<T, VEC>(rx, q);
-                    float v;
-                    if constexpr (!BOXED) {
-                        v = fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i));
-                    } else {
-                        const bool ic = sg.in_c(j, q), is = sg.in_s(j, q);
-                        v = ic ? fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i)) : fmaf(cG_o, G, fmaf(cX_o, X - xr_o, c0_o));
-                        v += is ? fmaf(eS, X - xs, e0) : 0.f;
+                for (int j = 0; j < NV; ++j) {
+                    const int ig = base + j, ix = base + NV + j;
+                    const Raw<T, VEC> rg = parked(ig), rx = parked(ix);
+                    float ov[VEC];
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        const float G = elem<T, VEC>(rg, q), X = elem<T, VEC>(rx, q);
+                        float v;
+                        if constexpr (!BOXED) {
+                            v = fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i));
+                        } else {
+                            const bool ic = sg.in_c(j, q), is = sg.in_s(j, q);
+                            v = ic ? fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i)) : fmaf(cG_o, G, fmaf(cX_o, X - xr_o, c0_o));
+                            v += is ? fmaf(eS, X - xs, e0) : 0.f;
+                        }
+                        ov[q] = v;
                     }
-                    ov[q] = v;
+                    buf_store<T, VEC>(slot_rsrc<T, VEC>(db, pbytes, j), voff, pack<T, VEC>(ov));
+                    // park slot j of item t+1 (garbage after the last item: never read)
+                    if (ig < FIRST_KEEP || ig < NPARK)
+                        mypark[ig * 64] = dg_[s][j];
+                    else
+                        keep[ig - FIRST_KEEP] = dg_[s][j];
+                    if (ix < FIRST_KEEP || ix < NPARK)
+                        mypark[ix * 64] = dx_[s][j];
+                    else
+                        keep[ix - FIRST_KEEP] = dx_[s][j];
+                    dg_[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(gy + off2, pbytes2, j), voff);
+                    dx_[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(x + off2, pbytes2, j), voff);
                 }
-                buf_store<T, VEC>(slot_rsrc<T, VEC>(db, pbytes, j), voff, pack<T, VEC>(ov));
-                // park slot j of item t+1 (garbage after the last item: never read)
-                if (j < FIRST_KEEP || j < NPARK)
-                    mypark[j * 64] = dg_[0][j];
-                else
-                    keep[j - FIRST_KEEP] = dg_[0][j];
-                if (NV + j < FIRST_KEEP || NV + j < NPARK)
-                    mypark[(NV + j) * 64] = dx_[0][j];
-                else
-                    keep[NV + j - FIRST_KEEP] = dx_[0][j];
-                dg_[0][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(gy + off2, pbytes2, j), voff);
-                dx_[0][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(x + off2, pbytes2, j), voff);
+                own_si[s] = si2;
+                own_so[s] = so2;
             }
-            own_si[0] = si2;
-            own_so[0] = so2;
         }
         if (!more) break;
         stage_rows(cn_, nrow);  // (every wave left the algebra of item t at the barrier above)

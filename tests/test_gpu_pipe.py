@@ -16,8 +16,8 @@ if not torch.cuda.is_available():
 import cnsn_amd  # noqa: E402
 
 DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
-# (tag, H, W): register buckets 7, 8, 13, 16 of 16-byte vectors
-PLANES = [("f32", 40, 40), ("f32", 60, 32), ("f32", 56, 56), ("f32", 60, 64), ("bf16", 56, 56), ("bf16", 60, 64),
+# (tag, H, W): register buckets 2, 4, 7, 8, 13, 16 of 16-byte vectors (2 and 4: four planes per wave in the forward)
+PLANES = [("f32", 12, 32), ("f32", 28, 32), ("bf16", 12, 64), ("bf16", 28, 64), ("f16", 28, 64), ("f32", 40, 40), ("f32", 60, 32), ("f32", 56, 56), ("f32", 60, 64), ("bf16", 56, 56), ("bf16", 60, 64),
           ("bf16", 96, 64), ("bf16", 120, 64), ("f16", 56, 56), ("f16", 96, 64)]
 
 
