@@ -12,6 +12,7 @@
 #include "cnsn_local.h"
 #include "cnsn_mid_kernels.h"
 #include "cnsn_mono.h"
+#include "cnsn_wide.h"
 #include "cnsn_packed.h"
 #include "cnsn_resident_fused.h"
 #include "cnsn_resident_kernels.h"
@@ -127,6 +128,13 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
     float* coef = (float*)(mom + 6 * pl.P + saved_doubles_of(pl));
 
     {
+        const WidePlan wp = wide_plan(pl, 0, false);  // planes that are no whole number of vectors (7x7): channel groups in registers
+        if (wp.ok) {
+            st = wide_forward(pl, wp, 0, 0, x, nullptr, gate_dev(g), y, saved ? saved_d : nullptr, stream);
+            if (st != CNSN_E_UNSUPPORTED) return st;
+        }
+    }
+    {
         const MonoPlan mp = mono_plan(pl, 0, false);  // small planes, SelfNorm alone: the channel in one workgroup's registers
         if (mp.ok) {
             st = mono_forward(pl, mp, 0, 0, x, nullptr, gate_dev(g), gate_dev(f), y, saved ? saved_d : nullptr, stream);
@@ -215,6 +223,13 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
     float* coef = sums + 4 * P;
     const double* saved_d = (const double*)saved;
 
+    {
+        const WidePlan wp = wide_plan(pl, 0, true);
+        if (wp.ok) {
+            st = wide_backward(pl, wp, 0, 0, grad_y, x, nullptr, gate_dev(g), saved_d, grad_x, gate_grad_dev(dg), stream);
+            if (st != CNSN_E_UNSUPPORTED) return st;
+        }
+    }
     {
         const MonoPlan mp = mono_plan(pl, 0, true);
         if (mp.ok) {

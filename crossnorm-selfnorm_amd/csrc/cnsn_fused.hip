@@ -8,6 +8,7 @@
 #include "cnsn_host_plan.h"
 #include "cnsn_local.h"
 #include "cnsn_mono.h"
+#include "cnsn_wide.h"
 #include "cnsn_packed.h"
 #include "cnsn_resident_fused.h"
 
@@ -76,6 +77,7 @@ int cnsn_which_path(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int 
     const bool bwd = backward != 0;
     // the backward of an epilogue without ReLU and without PRE add is the plain backward
     const bool fused = bwd ? (e.relu || e.add == ADD_PRE) : (e.relu || e.add != ADD_NONE);
+    if (wide_plan(pl, fused ? e.add : 0, bwd).ok) return CNSN_PATH_MONO;  // (channel GROUPS in registers: reported as mono)
     if (mono_plan(pl, fused ? e.add : 0, bwd).ok) return CNSN_PATH_MONO;
     if (mono_cn_plan(pl, chan, fused ? e.add : 0, bwd).ok) return CNSN_PATH_MONO;
     if (local_plan(pl, fused ? e.add : 0, bwd).ok) return CNSN_PATH_LOCAL;
@@ -111,6 +113,13 @@ int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, c
     double* saved_d = saved ? (double*)saved : mom + 6 * pl.P;
     float* coef = (float*)(mom + 6 * pl.P + saved_doubles_of(pl));
 
+    {
+        const WidePlan wp = wide_plan(pl, e.add, false);
+        if (wp.ok) {
+            st = wide_forward(pl, wp, e.add, e.relu, x, e.addend, gate_dev(g), y, saved ? saved_d : nullptr, stream);
+            if (st != CNSN_E_UNSUPPORTED) return st;
+        }
+    }
     {
         const MonoPlan mp = mono_plan(pl, e.add, false);
         if (mp.ok) {
@@ -218,6 +227,13 @@ int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, 
     float* coef = sums + 4 * P;
     const double* saved_d = (const double*)saved;
 
+    {
+        const WidePlan wp = wide_plan(pl, e.add, true);
+        if (wp.ok) {
+            st = wide_backward(pl, wp, e.add, e.relu, grad_y, x, e.addend, gate_dev(g), saved_d, grad_x, gate_grad_dev(dg), stream);
+            if (st != CNSN_E_UNSUPPORTED) return st;
+        }
+    }
     {
         const MonoPlan mp = mono_plan(pl, e.add, true);
         if (mp.ok) {

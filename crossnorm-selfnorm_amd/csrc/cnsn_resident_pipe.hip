@@ -135,7 +135,8 @@ bool dispatch_pipe_bwd(int dtype, int vec, int nv, F&& f) {
     auto by_nv = [&](auto tt, auto vt) -> bool {
         // Only the 13-slot class is built.  The kernel is generic in (NV, PPW); the 16-slot items of the smaller
         // classes — (2,4), (4,2), (7,1), (8,1) — were tried at three workgroups per CU: 50-60 spilled VGPRs at the
-        // 168-register budget and 5-30 % slower than the plain kernels (profiles/r02_pipelined_resident.md).
+        // 168-register budget and 5-30 % slower than the plain kernels; the 7-slot class with two planes per wave (28 slots, two workgroups per CU): +5 % in 16
+        // bits, -1 % in fp32 (profiles/r02_pipelined_resident.md).
         switch (nv) {
             case 13: f(tt, vt, IntTag<13>{}, IntTag<pipe_bwd_ppw(13)>{}); return true;
             default: return false;

@@ -16,6 +16,10 @@
 #pragma once
 #include "cnsn_resident_kernels.h"
 
+#ifndef CNSN_PIPE_PRIO
+#define CNSN_PIPE_PRIO 0
+#endif
+
 namespace cnsn {
 
 // ---- gather of TAGGED granules ({float, epoch} per 8 bytes) through the scalar path.  Every wave calls it
@@ -271,6 +275,9 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
         __syncthreads();
         if (*gave_up) return;  // (workgroup-uniform) timed out: see sweep_granules
         CNSN_STAMP(2);
+#if CNSN_PIPE_PRIO
+        __builtin_amdgcn_s_setprio(3);  // the algebra is the short serial section of the cycle: ahead of the neighbours' bulk loops
+#endif
         CNSN_NOTE(6, passes_);
 
         using R = float;  // per-plane algebra in float, cross-batch sums / normalisation in double
@@ -377,6 +384,9 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
             }
         }
         __syncthreads();
+#if CNSN_PIPE_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         CNSN_STAMP(3);
 
         // ---- item t+1 has arrived long ago: its statistics go out BEFORE item t is applied — the cluster's next
@@ -681,6 +691,9 @@ __global__ __launch_bounds__(kBlock, pipe_bwd_waves(2 * PPW * NV)) void resident
         __syncthreads();
         if (*gave_up) return;  // (workgroup-uniform) timed out: see sweep_granules
         CNSN_STAMP(2);
+#if CNSN_PIPE_PRIO
+        __builtin_amdgcn_s_setprio(3);  // the algebra is the short serial section of the cycle: ahead of the neighbours' bulk loops
+#endif
         CNSN_NOTE(6, passes_);
 
         using R = float;  // per-plane algebra in float; batch sums and the dz line in double
@@ -780,6 +793,9 @@ __global__ __launch_bounds__(kBlock, pipe_bwd_waves(2 * PPW * NV)) void resident
             }
         }
         __syncthreads();  // (also: every wave is done reading svd / svf before the next iteration restages them)
+#if CNSN_PIPE_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         CNSN_STAMP(3);
 
         // ---- item t+1 has arrived long ago: its sums go out BEFORE item t is applied; the fetch of its channel's

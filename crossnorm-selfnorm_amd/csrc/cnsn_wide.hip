@@ -1,0 +1,114 @@
+// Channel-group-in-registers strategy: eligibility, geometry, launches.
+#include "cnsn_wide.h"
+
+#include <cstdlib>
+
+#include "cnsn_wide_kernels.h"
+
+namespace cnsn {
+
+namespace {
+
+// f(TypeTag<T>, IntTag<VEC>): VEC elements = VB bytes per lane (16 forward, 8 backward)
+template <int VB, typename F>
+bool dispatch_w(int dtype, F&& f) {
+    if (dtype == CNSN_F32) { f(TypeTag<float>{}, IntTag<VB / 4>{}); return true; }
+    if (dtype == CNSN_BF16) { f(TypeTag<bf16_t>{}, IntTag<VB / 2>{}); return true; }
+    if (dtype == CNSN_F16) { f(TypeTag<_Float16>{}, IntTag<VB / 2>{}); return true; }
+    return false;
+}
+
+inline int wide_grid(int groups) { return ((groups + 7) / 8) * 8; }
+
+template <typename K>
+bool grant_lds(K kern, size_t lds) {
+    if (lds <= 64 * 1024) return true;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+WidePlan wide_plan(const Plan& pl, int add, bool backward) {
+    WidePlan wp{false, 0, 0, 0};
+    const cnsn_problem_t& p = pl.pr;
+    if (p.strategy != CNSN_STRATEGY_AUTO && p.strategy != CNSN_STRATEGY_MONO) return wp;
+    if (p.cn_active || !p.sn_active || p.sn_two || add == ADD_POST) return wp;
+    int mode = 1;  // CNSN_WIDE=0: never; CNSN_WIDE=2: wherever eligible (tests: fp32 and small batches too)
+    if (const char* e = getenv("CNSN_WIDE")) mode = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);
+    if (mode == 0) return wp;
+    const int b = elem_bytes(p.dtype), M = p.H * p.W;
+    if (M > 64 || (M * b) % 8 == 0) return wp;  // whole 8-byte vectors: the mono / cluster kernels' ground
+    // forward: 16-byte vectors (x alone is held); backward: 8-byte vectors (G and x are held: 2 * 16 rows * 2 registers)
+    const int vec = (backward ? 8 : 16) / b;
+    if (M < vec) return wp;                        // a lane may straddle at most two channels
+    const int vec_all = 16 / b;
+    if (p.C % vec_all) return wp;                  // (the same channel count serves both directions)
+    if (p.N > 16 * kWideRows || p.N < 16) return wp;
+    if (mode != 2) {
+        // measured on MI355X at (N,2048,7,7) (profiles/r02_wide_7x7.md): 16-bit N = 256 forward 51 vs 75 us, backward 97 vs
+        // 116 us (channel-local kernels); N = 96 / 128: equal; fp32: the mono kernels' 4-byte accesses are as fast forward
+        // (0.079 vs 0.074 ms) and faster backward (0.146 vs 0.21: two channels per workgroup do not fill it)
+        if (b != 2 || p.N < 128) return wp;
+    }
+    wp.vec = vec;
+    wp.R = (p.N + kWideWaves - 1) / kWideWaves;
+    wp.lds = backward ? wide_lds_bytes(p.N, vec, 4, 2, 7, kWideParkBwd * 8) : wide_lds_bytes(p.N, vec, 8, 1, 2, kWideParkFwd * 16);
+    if (wp.lds > 160 * 1024) return wp;
+    wp.ok = true;
+    return wp;
+}
+
+int wide_forward(const Plan& pl, const WidePlan& wp, int add, int relu, const void* x, const void* addend, GateDev g, void* y,
+                 double* saved, hipStream_t stream) {
+    WideArgs wa{pl.mid, wp.R};
+    const bool epi = add == ADD_PRE || relu;
+    const int grid = wide_grid(pl.pr.C / wp.vec);
+    int status = CNSN_E_UNSUPPORTED;
+    dispatch_w<16>(pl.pr.dtype, [&](auto tt, auto vt) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value;
+        auto launch = [&](auto kern) {
+            if (!grant_lds(kern, wp.lds)) return;
+            kern<<<grid, kWideBlock, wp.lds, stream>>>(wa, (const T*)x, (const T*)(add == ADD_PRE ? addend : nullptr), (T*)y, g,
+                                                       saved, epi ? add : ADD_NONE, epi ? relu : 0);
+            const hipError_t e = hipGetLastError();
+            status = e == hipSuccess ? CNSN_OK : (int)e;
+        };
+        if (epi)
+            launch(wide_fwd_kernel<T, VEC, true>);
+        else
+            launch(wide_fwd_kernel<T, VEC, false>);
+    });
+    return status;
+}
+
+int wide_backward(const Plan& pl, const WidePlan& wp, int add, int relu, const void* gy, const void* x, const void* addend,
+                  GateDev g, const double* saved, void* dx, GateGradDev dg, hipStream_t stream) {
+    WideArgs wa{pl.mid, wp.R};
+    const bool epi = add == ADD_PRE || relu;
+    const int grid = wide_grid(pl.pr.C / wp.vec);
+    int status = CNSN_E_UNSUPPORTED;
+    dispatch_w<8>(pl.pr.dtype, [&](auto tt, auto vt) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value;
+        auto launch = [&](auto kern) {
+            if (!grant_lds(kern, wp.lds)) return;
+            kern<<<grid, kWideBlock, wp.lds, stream>>>(wa, (const T*)gy, (const T*)x,
+                                                       (const T*)(add == ADD_PRE ? addend : nullptr), (T*)dx, g, dg, saved,
+                                                       epi ? add : ADD_NONE, epi ? relu : 0);
+            const hipError_t e = hipGetLastError();
+            status = e == hipSuccess ? CNSN_OK : (int)e;
+        };
+        if (epi)
+            launch(wide_bwd_kernel<T, VEC, true>);
+        else
+            launch(wide_bwd_kernel<T, VEC, false>);
+    });
+    return status;
+}
+
+}  // namespace cnsn

@@ -1,0 +1,488 @@
+// Channel-GROUP-in-registers strategy ("wide") for planes that are NOT a whole number of 8- or 16-byte vectors — 7x7:
+// 98 bytes in 16 bits, 196 in fp32 (ResNet-50 stage 4, WideResNet's last sites are 8x8 and do not need it).
+//
+// The mono kernels reach such planes one element per lane (2- or 4-byte accesses, 49 of 64 lanes) and the channel-local
+// kernels through LDS: (256,2048,7,7) bf16 ran at 27 % of its HBM bound.  Here ONE 1024-thread workgroup takes CH
+// ADJACENT channels: the CH planes of an instance are contiguous in NCHW — CH*M elements — and CH = VEC (the elements
+// of one 16- or 8-byte vector) makes that super-plane exactly M vectors: lane l < M holds elements l*VEC .. l*VEC+VEC-1,
+// which belong to channel (l*VEC)/M and, past a per-lane split point, to the next one.  A wave holds R instances
+// (16 waves: N <= 16*R), so every access is a full-width vector and the whole channel group sits in registers:
+// one launch per direction, single touch, no exchange.
+//   per-(instance, channel) sums: every lane forms the two partial sums of its two channels, the partials of a batch of
+//   rows go to a per-wave LDS scratch, and one lane per (row, channel) adds the 7-14 partials of its segment in a fixed
+//   order (no atomics: results are reproducible); exact two-pass statistics as everywhere else;
+//   SelfNorm's BatchNorm1d over N: one thread per (instance, channel), channel = thread index mod CH, so a channel's sum
+//   is a butterfly over lanes CH apart + 16 wave partials.
+// Algebra and `saved` contract are the mono / channel-local kernels' (SelfNorm alone, one gate, optional PRE add and
+// ReLU), so a forward of this strategy can be followed by a backward of any other.
+#pragma once
+#include "cnsn_mono_kernels.h"
+
+namespace cnsn {
+
+constexpr int kWideBlock = 1024, kWideWaves = 16, kWideRows = 16;
+
+struct WideArgs {
+    MidArgs mid;
+    int R;  // instances per wave (<= 16): N <= 16 * R
+};
+
+// LDS: scratch of one batch of rows [16 waves][BATCH][64 lanes][NACC pairs], then NARR arrays over the (instance,
+// channel) pairs, then the reduction scratch [16][8][4] doubles
+// (the scratch doubles as the place where `parked_bytes` per thread of plane rows wait during the algebra)
+__host__ __device__ inline size_t wide_lds_bytes(int N, int ch, int batch, int nacc, int narr, int parked_bytes) {
+    const size_t scratch = (size_t)kWideWaves * batch * 64 * nacc * 8, park = (size_t)kWideBlock * parked_bytes;
+    return (scratch > park ? scratch : park) + (size_t)narr * (((size_t)N * ch + 63) & ~(size_t)63) * 4 +
+           (size_t)kWideWaves * 8 * 4 * 8;
+}
+constexpr int kWideParkFwd = 8, kWideParkBwd = 12;  // rows parked during the algebra (forward: of x; backward: of x)
+
+// per-lane geometry of the super-plane
+template <int VEC>
+struct WideLane {
+    int a;     // channel (within the group) of this lane's first element
+    int qs;    // elements 0 .. qs-1 belong to channel a, the rest to a + 1
+    bool live;  // lane < M
+    __device__ __forceinline__ WideLane(int lane, int M) {
+        a = (lane * VEC) / M;
+        const int left = (a + 1) * M - lane * VEC;
+        qs = left < VEC ? left : VEC;
+        live = lane < M;
+        if (!live) {
+            a = 0;
+            qs = VEC;
+        }
+    }
+};
+
+// sum of v over the threads of the workgroup whose index is congruent to this thread's modulo CH (CH a power of two
+// <= 8): butterfly over lanes CH, 2CH, .. 32 apart, then the 16 waves' partials through `red` ([16][8][NACC] doubles)
+template <int NACC, int CH>
+__device__ __forceinline__ void wide_chan_sum(double (&v)[NACC], double* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int m = CH; m < 64; m <<= 1)
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) v[i] += __shfl_xor(v[i], m);
+    __syncthreads();  // (the previous use of `red` is over)
+    if (lane < CH) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) red[(wave * 8 + lane) * NACC + i] = v[i];
+    }
+    __syncthreads();
+    const int k = lane & (CH - 1);
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWideWaves; ++w) s += red[(w * 8 + k) * NACC + i];
+        v[i] = s;
+    }
+}
+
+// One batch of rows: every lane has written its NACC (pa, pb) pairs per row to sc[(wave*BATCH + rr)*64 + lane][i];
+// lane p < BATCH*CH takes (rr, k) = (p / CH, p % CH) and returns the segment sums of channel k in row rr.
+template <int VEC, int NACC, int BATCH>
+__device__ __forceinline__ void wide_segment(const float2* sc, int wave, int p, int M, float (&out)[NACC]) {
+    constexpr int CH = VEC;
+    const int rr = p / CH, k = p - rr * CH;
+    const int lo = (k * M) / VEC, hi = (k * M + M - 1) / VEC;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) out[i] = 0.f;
+    const float2* row = sc + ((size_t)(wave * BATCH + rr) * 64) * NACC;
+    for (int l = lo; l <= hi; ++l) {
+        const bool first = (l * VEC) / M == k;  // the lane's first channel is k: its pa; otherwise (only l == lo) its pb
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) {
+            const float2 v = row[l * NACC + i];
+            out[i] += first ? v.x : v.y;
+        }
+    }
+}
+
+// ================================================================================================
+// forward
+// ================================================================================================
+template <typename T, int VEC, bool EPI>
+__global__ __launch_bounds__(kWideBlock) void wide_fwd_kernel(WideArgs wa, const T* __restrict__ x, const T* __restrict__ addend,
+                                                              T* __restrict__ y, GateDev gg, double* __restrict__ saved,
+                                                              int add, int relu) {
+    constexpr int CH = VEC, VB = VEC * (int)sizeof(T), BATCH = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const MidArgs a = wa.mid;
+    const int N = a.N, C = a.C, M = a.M, R = wa.R;
+    const int npad = (N * CH + 63) & ~63;
+    float2* sc = (float2*)smem;                                              // [16][BATCH][64]
+    constexpr size_t kScratch = (size_t)kWideWaves * BATCH * 64 * 8, kPark = (size_t)kWideBlock * kWideParkFwd * VB;
+    float* smu = (float*)(smem + (kScratch > kPark ? kScratch : kPark));     // [N][CH] mean   -> later a_in
+    float* sm2 = smu + npad;                                                 // [N][CH] M2     -> later b_in
+    double* red = (double*)(sm2 + npad);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const MonoWalk wk(C / CH);  // neighbouring channel groups (they share 128-byte lines) on one XCD
+    if (wk.j >= wk.count) return;  // (workgroup-uniform: the grid is rounded up to whole rounds of the 8 XCDs)
+    const int c0 = (wk.start + wk.j) * CH;
+    const size_t P = (size_t)N * C;
+    const WideLane<VEC> wl(lane, M);
+    const int voff = lane * VB;
+    const int gbytes = CH * M * (int)sizeof(T);  // a super-plane
+
+    // ---- the only read of x (+ addend)
+    MRaw<T, VEC> d[kWideRows];
+#pragma unroll
+    for (int r = 0; r < kWideRows; ++r) {
+        const int n = wave * R + r;
+        const bool ok = r < R && n < N;  // wave-uniform
+        const size_t off = ((size_t)(ok ? n : 0) * C + c0) * M;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + off), 0, ok ? gbytes : 0, 0x00020000);
+        d[r] = mload<T, VEC>(rs, voff);
+        if constexpr (EPI) {
+            if (add == ADD_PRE) {
+                const __amdgpu_buffer_rsrc_t ra =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(addend + off), 0, ok ? gbytes : 0, 0x00020000);
+                d[r] = madd<T, VEC>(d[r], mload<T, VEC>(ra, voff));
+            }
+        }
+    }
+
+    // ---- exact two-pass statistics of every (instance, channel) plane
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int h = 0; h < kWideRows / BATCH; ++h) {
+            if (h * BATCH >= R) break;  // (workgroup-uniform: no rows in this batch)
+#pragma unroll
+            for (int rr = 0; rr < BATCH; ++rr) {
+                const int r = h * BATCH + rr;
+                const int n = wave * R + r;
+                float ma = 0.f, mb = 0.f;
+                if (pass == 1 && r < R && n < N) {
+                    ma = smu[n * CH + wl.a];
+                    mb = smu[n * CH + (wl.a + 1 < CH ? wl.a + 1 : wl.a)];
+                }
+                float pa = 0.f, pb = 0.f;
+                mono_forget(d[r]);  // (keeps the unpacked floats of other rows / passes out of the registers)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    const float f = melem<T, VEC>(d[r], q);  // dead lanes and dead rows loaded zeros
+                    const bool first = q < wl.qs;
+                    const float t = pass == 0 ? f : (first ? f - ma : f - mb);
+                    const float u = pass == 0 ? t : t * t;
+                    pa += (first && wl.live) ? u : 0.f;
+                    pb += (!first && wl.live) ? u : 0.f;
+                }
+                sc[(size_t)(wave * BATCH + rr) * 64 + lane] = make_float2(pa, pb);
+                if (rr & 1) __builtin_amdgcn_sched_barrier(0);  // bound the interleaving of rows (registers)
+            }
+            __syncthreads();
+            for (int p = lane; p < BATCH * CH; p += 64) {
+                float s[1];
+                wide_segment<VEC, 1, BATCH>(sc, wave, p, M, s);
+                const int r = h * BATCH + p / CH, k = p % CH;
+                const int n = wave * R + r;
+                if (r < R && n < N) {
+                    if (pass == 0)
+                        smu[n * CH + k] = s[0] / (float)M;
+                    else
+                        sm2[n * CH + k] = s[0];
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- the algebra wants registers: the last rows of the planes wait in the (now idle) scratch
+    constexpr int NPARKED = kWideParkFwd;
+    MRaw<T, VEC>* parked = (MRaw<T, VEC>*)sc;
+#pragma unroll
+    for (int i = 0; i < NPARKED; ++i) parked[(size_t)i * kWideBlock + threadIdx.x] = d[kWideRows - NPARKED + i];
+
+    // ---- gates: BatchNorm1d over the N planes of each channel, a thread per (instance, channel)  (cnsn.py:137-141)
+    using Rr = float;
+    constexpr int PP = 2;  // pairs per thread: N * CH <= 2048
+    const int k = threadIdx.x & (CH - 1), c = c0 + k;
+    const double wg0 = gg.w[2 * c], wg1 = gg.w[2 * c + 1], gam = gg.gamma[c], bet = gg.beta[c];
+    const double rm0 = gg.run_mean[c], rv0 = gg.run_var[c];
+    auto plane_of = [&](int p) {  // (cheap: recomputed after the reduction instead of kept across it)
+        MomentsT<Rr> o;
+        o.mu_c = o.mu_s = smu[p];
+        o.M2c = o.M2s = sm2[p];
+        o.mu_o = o.M2o = 0.f;
+        return fwd_plane<Rr>(a, o, 0.f, 0.f);
+    };
+    double sz[2] = {0.0, 0.0};
+#pragma unroll 1  // (one pair's algebra at a time: the planes keep their registers)
+    for (int i = 0; i < PP; ++i) {
+        const int p = threadIdx.x + i * kWideBlock;
+        if (p / CH < N) {
+            const FwdPlaneT<Rr> f = plane_of(p);
+            const double z = wg0 * (double)f.mu_p + wg1 * (double)f.sig_p;
+            sz[0] += z;
+            sz[1] += z * z;
+        }
+    }
+    double mg = rm0, rg;
+    if (a.sn_training) {
+        wide_chan_sum<2, CH>(sz, red);
+        mg = sz[0] * a.inv_n;
+        double vg = sz[1] * a.inv_n - mg * mg;
+        vg = vg > 0.0 ? vg : 0.0;
+        rg = (double)__builtin_amdgcn_rsqf((float)(vg + (double)a.eps_bn));
+        if (threadIdx.x < CH) {
+            const double mom_ = a.momentum, unb = a.unbias_n;
+            gg.run_mean[c] = (float)((1.0 - mom_) * rm0 + mom_ * mg);
+            gg.run_var[c] = (float)((1.0 - mom_) * rv0 + mom_ * vg * unb);
+        }
+    } else {
+        rg = (double)__builtin_amdgcn_rsqf((float)rv0 + a.eps_bn);
+    }
+    if (saved && threadIdx.x < CH) {
+        saved[SV_ROWS * P + c] = rg;
+        saved[SV_ROWS * P + C + c] = 1.0;
+    }
+#pragma unroll 1
+    for (int i = 0; i < PP; ++i) {
+        const int p = threadIdx.x + i * kWideBlock;
+        if (p / CH < N) {
+            const int n = p / CH;
+            const FwdPlaneT<Rr> f = plane_of(p);
+            const double z = wg0 * (double)f.mu_p + wg1 * (double)f.sig_p;
+            const double zhg = (z - mg) * rg;
+            const Rr gt = sigmoid_r<Rr>((Rr)(gam * zhg + bet));
+            const FwdCoefs cf = fwd_coefs<Rr>(a, f, gt, 1.f);
+            if (saved) {
+                const SvRec ps = sv_rec(n, c, N);
+                store_fwd_plane<Rr>(saved, P, ps, f, 0);
+                saved[sv_at(ps, SV_G)] = gt;
+                saved[sv_at(ps, SV_ZH_G)] = zhg;
+                saved[sv_at(ps, SV_F)] = 1.0;
+                saved[sv_at(ps, SV_ZH_F)] = 0.0;
+                if (a.save_coefs) store_fwd_coefs(saved, ps, cf);
+            }
+            smu[p] = cf.a_in;  // SelfNorm alone: y = a_in * x + b_in  (xr = 0)
+            sm2[p] = cf.b_in;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NPARKED; ++i) d[kWideRows - NPARKED + i] = parked[(size_t)i * kWideBlock + threadIdx.x];
+
+    // ---- apply from registers, the only write of y
+#pragma unroll
+    for (int r = 0; r < kWideRows; ++r) {
+        const int n = wave * R + r;
+        const bool ok = r < R && n < N;
+        if (!ok) continue;  // wave-uniform
+        const int ia = n * CH + wl.a, ib = n * CH + (wl.a + 1 < CH ? wl.a + 1 : wl.a);
+        const float ca = smu[ia], cb = sm2[ia], ca2 = smu[ib], cb2 = sm2[ib];
+        mono_forget(d[r]);
+        float ov[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const bool first = q < wl.qs;
+            ov[q] = fmaf(first ? ca : ca2, melem<T, VEC>(d[r], q), first ? cb : cb2);
+            if constexpr (EPI) ov[q] = relu ? fmaxf(ov[q], 0.f) : ov[q];
+        }
+        const size_t off = ((size_t)n * C + c0) * M;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(y + off), 0, gbytes, 0x00020000);
+        mstore<T, VEC>(rs, voff, mpack<T, VEC>(ov));
+        if (r & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ================================================================================================
+// backward  (N * CH <= 1024: ONE (instance, channel) pair per thread)
+// ================================================================================================
+template <typename T, int VEC, bool EPI>
+__global__ __launch_bounds__(kWideBlock) void wide_bwd_kernel(WideArgs wa, const T* __restrict__ gy, const T* __restrict__ x,
+                                                              const T* __restrict__ addend, T* __restrict__ dx, GateDev gg,
+                                                              GateGradDev dgr, const double* __restrict__ saved, int add,
+                                                              int relu) {
+    constexpr int CH = VEC, VB = VEC * (int)sizeof(T), BATCH = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MidArgs a = wa.mid;
+    a.sn_two = 0;
+    const int N = a.N, C = a.C, M = a.M, R = wa.R;
+    const int npad = (N * CH + 63) & ~63;
+    float2* sc = (float2*)smem;                                               // [16][BATCH][64][2]
+    constexpr size_t kScratch = (size_t)kWideWaves * BATCH * 64 * 2 * 8, kPark = (size_t)kWideBlock * kWideParkBwd * VB;
+    float* psi = (float*)(smem + (kScratch > kPark ? kScratch : kPark));      // [N][CH] float(mu_c): shift of the second sum
+    float* pfa = psi + npad;                                                  // forward slope  (ReLU mask)
+    float* pfb = pfa + npad;                                                  // forward offset (ReLU mask)
+    float* ps1 = pfb + npad;                                                  // sum G            -> later cG
+    float* ps2 = ps1 + npad;                                                  // sum G*(x - mu)   -> later cX
+    float* pxr = ps2 + npad;
+    float* pc0 = pxr + npad;
+    double* red = (double*)(pc0 + npad);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const MonoWalk wk(C / CH);
+    if (wk.j >= wk.count) return;
+    const int c0 = (wk.start + wk.j) * CH;
+    const size_t P = (size_t)N * C;
+    const WideLane<VEC> wl(lane, M);
+    const int voff = lane * VB;
+    const int gbytes = CH * M * (int)sizeof(T);
+
+    // ---- what the sums and the algebra need from `saved`, a thread per (instance, channel), ahead of the bulk loads
+    const int p = threadIdx.x, np = p / CH, k = p & (CH - 1), c = c0 + k;
+    const bool act = np < N;
+    double r_mu = 0, r_mup = 0, r_sigp = 0, r_g = 0, r_zhg = 0;
+    if (act) {
+        const SvRec ps = sv_rec(np, c, N);
+        r_mu = saved[sv_at(ps, SV_MU_C)];
+        r_mup = saved[sv_at(ps, SV_MU_P)];
+        r_sigp = saved[sv_at(ps, SV_SIG_P)];
+        r_g = saved[sv_at(ps, SV_G)];
+        r_zhg = saved[sv_at(ps, SV_ZH_G)];
+        psi[p] = (float)r_mu;
+        if (EPI && relu) {
+            pfa[p] = (float)saved[sv_at(ps, SV_FC0 + FC_A_IN)];
+            pfb[p] = (float)saved[sv_at(ps, SV_FC0 + FC_B_IN)];
+        }
+    }
+    const float w_g0 = gg.w[2 * c], w_g1 = gg.w[2 * c + 1], gam_g = gg.gamma[c];
+    const double rs_g = saved[SV_ROWS * P + c];
+
+    // ---- the only reads of G and x (+ addend)
+    MRaw<T, VEC> dg_[kWideRows], dx_[kWideRows];
+#pragma unroll
+    for (int r = 0; r < kWideRows; ++r) {
+        const int n = wave * R + r;
+        const bool ok = r < R && n < N;
+        const size_t off = ((size_t)(ok ? n : 0) * C + c0) * M;
+        const int bytes = ok ? gbytes : 0;
+        dg_[r] = mload<T, VEC>(__builtin_amdgcn_make_buffer_rsrc((void*)(gy + off), 0, bytes, 0x00020000), voff);
+        dx_[r] = mload<T, VEC>(__builtin_amdgcn_make_buffer_rsrc((void*)(x + off), 0, bytes, 0x00020000), voff);
+        if constexpr (EPI) {
+            if (add == ADD_PRE)
+                dx_[r] = madd<T, VEC>(dx_[r], mload<T, VEC>(__builtin_amdgcn_make_buffer_rsrc((void*)(addend + off), 0, bytes, 0x00020000), voff));
+        }
+    }
+    __syncthreads();  // psi / pfa / pfb are staged
+
+    // ---- ReLU mask (forward affine re-evaluated with the coefficients the forward used) and per-plane sums
+#pragma unroll
+    for (int h = 0; h < kWideRows / BATCH; ++h) {
+        if (h * BATCH >= R) break;  // (workgroup-uniform: no rows in this batch)
+#pragma unroll
+        for (int rr = 0; rr < BATCH; ++rr) {
+            const int r = h * BATCH + rr;
+            const int n = wave * R + r;
+            const bool ok = r < R && n < N;
+            const int ia = (ok ? n : 0) * CH + wl.a, ib = (ok ? n : 0) * CH + (wl.a + 1 < CH ? wl.a + 1 : wl.a);
+            const float sia = psi[ia], sib = psi[ib];
+            mono_forget(dg_[r]);
+            mono_forget(dx_[r]);
+            if constexpr (EPI) {
+                if (relu) {
+                    const float fa = pfa[ia], fb = pfb[ia], fa2 = pfa[ib], fb2 = pfb[ib];
+                    float gm[VEC];
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        const bool first = q < wl.qs;
+                        const float t = fmaf(first ? fa : fa2, melem<T, VEC>(dx_[r], q), first ? fb : fb2);
+                        gm[q] = relu_open_r<T>(t) ? melem<T, VEC>(dg_[r], q) : 0.f;
+                    }
+                    dg_[r] = mpack<T, VEC>(gm);
+                }
+            }
+            float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const bool first = q < wl.qs;
+                const float G = melem<T, VEC>(dg_[r], q), X = melem<T, VEC>(dx_[r], q);
+                const float t = G * (X - (first ? sia : sib));
+                const bool fa_ = first && wl.live && ok, fb_ = !first && wl.live && ok;
+                a1 += fa_ ? G : 0.f;
+                b1 += fb_ ? G : 0.f;
+                a2 += fa_ ? t : 0.f;
+                b2 += fb_ ? t : 0.f;
+            }
+            sc[((size_t)(wave * BATCH + rr) * 64 + lane) * 2 + 0] = make_float2(a1, b1);
+            sc[((size_t)(wave * BATCH + rr) * 64 + lane) * 2 + 1] = make_float2(a2, b2);
+            __builtin_amdgcn_sched_barrier(0);  // bound the interleaving of rows (registers)
+        }
+        __syncthreads();
+        for (int q = lane; q < BATCH * CH; q += 64) {
+            float s[2];
+            wide_segment<VEC, 2, BATCH>(sc, wave, q, M, s);
+            const int r = h * BATCH + q / CH, kk = q % CH;
+            const int n = wave * R + r;
+            if (r < R && n < N) {
+                ps1[n * CH + kk] = s[0];
+                ps2[n * CH + kk] = s[1];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- the algebra wants registers: half of the x rows wait in the (now idle) scratch
+    constexpr int NPARKED = kWideParkBwd;
+    MRaw<T, VEC>* parked = (MRaw<T, VEC>*)sc;
+#pragma unroll
+    for (int i = 0; i < NPARKED; ++i) parked[(size_t)i * kWideBlock + threadIdx.x] = dx_[kWideRows - NPARKED + i];
+
+    // ---- gate / BatchNorm backward, a thread per (instance, channel); coefficients of dx
+    using Rr = float;
+    BwdSumsT<Rr> sums{};
+    Rr dtg = 0.f, dtf = 0.f;
+    const double r_f = 1.0, r_zhf = 0.0;
+    if (act) {
+        sums = fix_sums<Rr>(a, ps1[p], ps2[p], 0.f, 0.f, r_mu, 0.0);
+        gate_dt<Rr>(a, sums, Rr(1), (Rr)r_mu, Rr(0), (Rr)r_mup, (Rr)r_g, (Rr)r_f, dtg, dtf);
+    }
+    double s4[2] = {(double)dtg, (double)dtg * r_zhg};
+    wide_chan_sum<2, CH>(s4, red);
+    BnBwd b{};
+    b.s_dt_g = s4[0];
+    b.s_dtz_g = s4[1];
+    b.wg0 = w_g0;
+    b.wg1 = w_g1;
+    b.kg = (double)gam_g * rs_g;
+    double sw[2] = {0, 0};
+    if (act) {
+        const BwdPlaneT<Rr> o = bwd_plane<Rr>(a, b, sums, (double)dtg, (double)dtf, r_zhg, r_zhf, (Rr)r_g, (Rr)r_f, Rr(1), Rr(1),
+                                              (Rr)r_mu, (Rr)r_mup, (Rr)r_sigp, Rr(1), Rr(0));
+        sw[0] = (double)o.dz_g * r_mup;
+        sw[1] = (double)o.dz_g * r_sigp;
+        const BwdCoefs kf = bwd_coefs<Rr>(a, o, Rr(0), Rr(0), (Rr)r_g, Rr(1), (Rr)r_mu, (Rr)r_mup, r_mu, Rr(1), r_mu, Rr(1));
+        ps1[p] = kf.cG_in;  // (every thread read its own ps1 / ps2 before the reduction above)
+        ps2[p] = kf.cX_in;
+        pxr[p] = kf.xr_in;
+        pc0[p] = kf.c0_in;
+    }
+    wide_chan_sum<2, CH>(sw, red);
+    if (threadIdx.x < CH) {
+        dgr.dgamma[c] = (float)s4[1];
+        dgr.dbeta[c] = (float)s4[0];
+        dgr.dw[2 * c] = (float)sw[0];
+        dgr.dw[2 * c + 1] = (float)sw[1];
+    }
+    __syncthreads();  // the coefficient rows are visible
+#pragma unroll
+    for (int i = 0; i < NPARKED; ++i) dx_[kWideRows - NPARKED + i] = parked[(size_t)i * kWideBlock + threadIdx.x];
+
+    // ---- dx from registers, the only write
+#pragma unroll
+    for (int r = 0; r < kWideRows; ++r) {
+        const int n = wave * R + r;
+        const bool ok = r < R && n < N;
+        if (!ok) continue;
+        const int ia = n * CH + wl.a, ib = n * CH + (wl.a + 1 < CH ? wl.a + 1 : wl.a);
+        const float cG = ps1[ia], cX = ps2[ia], xr = pxr[ia], c0_ = pc0[ia];
+        const float cG2 = ps1[ib], cX2 = ps2[ib], xr2 = pxr[ib], c02 = pc0[ib];
+        mono_forget(dg_[r]);
+        mono_forget(dx_[r]);
+        float ov[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const bool first = q < wl.qs;
+            ov[q] = fmaf(first ? cG : cG2, melem<T, VEC>(dg_[r], q),
+                         fmaf(first ? cX : cX2, melem<T, VEC>(dx_[r], q) - (first ? xr : xr2), first ? c0_ : c02));
+        }
+        const size_t off = ((size_t)n * C + c0) * M;
+        mstore<T, VEC>(__builtin_amdgcn_make_buffer_rsrc((void*)(dx + off), 0, gbytes, 0x00020000), voff, mpack<T, VEC>(ov));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+}  // namespace cnsn

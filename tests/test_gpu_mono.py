@@ -87,7 +87,8 @@ def test_what_mono_declines():
     assert cnsn_amd.which_path(torch.empty((256, 1024, 14, 14), dtype=BF16, device="cuda"), FC(sn_active=True), backward=True) == "mono"
     assert cnsn_amd.which_path(torch.empty((8, 4, 14, 14), device="cuda"), FC(sn_active=True)) != "mono"   # N < 16 under AUTO
     assert cnsn_amd.which_path(seven, FC(sn_active=True)) == "mono"                                        # 7x7 fp32: 4 B per lane
-    assert cnsn_amd.which_path(seven.bfloat16(), FC(sn_active=True)) == "local"                            # 7x7 bf16: channel-local
+    assert cnsn_amd.which_path(seven.bfloat16(), FC(sn_active=True)) == "mono"                             # 7x7 bf16, N = 256: channel groups ("wide")
+    assert cnsn_amd.which_path(seven.bfloat16()[:96], FC(sn_active=True)) == "local"                       # small batch: channel-local
 
 
 # ------------------------------------------------------------------------------------------------
