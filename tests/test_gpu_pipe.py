@@ -103,3 +103,38 @@ def test_default_rule_takes_the_headline_shape():
     for a, b in zip(ref, out):
         assert torch.equal(a, b)
     assert cnsn_amd.lib().cnsn_resident_timeouts() == 0
+
+
+def test_pipelined_kernels_replay_from_a_graph():
+    """Under stream capture the launch-tagged exchange context is not used (a captured launch would replay its tag): the
+    pipelined kernels then gather UNTAGGED granules through the scalar path.  A captured forward+backward of the
+    13-slot class (both directions pipelined under CNSN_PIPE=2) replays bit-identically to the eager plain kernels."""
+    from tests.golden.gen_golden_fill import fill_sn
+    os.environ["CNSN_PIPE"] = "2"
+    cnsn_amd.set_strategy("resident")
+    shape = (37, 6, 56, 56)
+    mod = cnsn_amd.CNSN(None, fill_sn(cnsn_amd.SelfNorm(6), 5, torch.float32)).cuda().train()
+    ref = cnsn_amd.CNSN(None, fill_sn(cnsn_amd.SelfNorm(6), 5, torch.float32)).cuda().train()
+    x = torch.randn(shape, device="cuda", requires_grad=True)
+    gy = torch.randn(shape, device="cuda")
+    params = list(mod.parameters())
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            torch.autograd.grad(mod(x), [x] + params, gy)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        grads = torch.autograd.grad(mod(x), [x] + params, gy)
+    os.environ["CNSN_PIPE"] = "0"
+    for _ in range(2):                                   # the reference module caught up on the two warm-up steps
+        torch.autograd.grad(ref(x), [x] + list(ref.parameters()), gy)
+    for _ in range(3):
+        g.replay()
+        want = torch.autograd.grad(ref(x), [x] + list(ref.parameters()), gy)
+    torch.cuda.synchronize()
+    for a, b in zip(grads, want):
+        assert torch.equal(a, b)
+    assert torch.equal(mod.selfnorm.g_bn.running_var, ref.selfnorm.g_bn.running_var)
+    assert cnsn_amd.lib().cnsn_resident_timeouts() == 0
