@@ -42,21 +42,19 @@ WidePlan wide_plan(const Plan& pl, int add, bool backward) {
     if (mode == 0) return wp;
     const int b = elem_bytes(p.dtype), M = p.H * p.W;
     if (M > 64 || (M * b) % 8 == 0) return wp;  // whole 8-byte vectors: the mono / cluster kernels' ground
-    // forward: 16-byte vectors (x alone is held); backward: 8-byte vectors (G and x are held: 2 * 16 rows * 2 registers)
-    const int vec = (backward ? 8 : 16) / b;
+    const int vec = 16 / b;  // = channels per workgroup, both directions
     if (M < vec) return wp;                        // a lane may straddle at most two channels
     const int vec_all = 16 / b;
     if (p.C % vec_all) return wp;                  // (the same channel count serves both directions)
     if (p.N > 16 * kWideRows || p.N < 16) return wp;
     if (mode != 2) {
-        // measured on MI355X at (N,2048,7,7) (profiles/r02_wide_7x7.md): 16-bit N = 256 forward 51 vs 75 us, backward 97 vs
-        // 116 us (channel-local kernels); N = 96 / 128: equal; fp32: the mono kernels' 4-byte accesses are as fast forward
-        // (0.079 vs 0.074 ms) and faster backward (0.146 vs 0.21: two channels per workgroup do not fill it)
-        if (b != 2 || p.N < 128) return wp;
+        // measured on MI355X at (N,2048,7,7) (profiles/r02_wide_7x7.md): N = 256 bf16 0.108 vs 0.185 ms per step (channel-
+        // local kernels), fp32 0.189 vs 0.224 (mono, 4-byte accesses); N <= 96: the step is host-bound either way
+        if (p.N < 128) return wp;
     }
     wp.vec = vec;
     wp.R = (p.N + kWideWaves - 1) / kWideWaves;
-    wp.lds = backward ? wide_lds_bytes(p.N, vec, 4, 2, 7, kWideParkBwd * 8) : wide_lds_bytes(p.N, vec, 8, 1, 2, kWideParkFwd * 16);
+    wp.lds = backward ? wide_lds_bytes(p.N, vec, 4, 2, 7, 0) : wide_lds_bytes(p.N, vec, 8, 1, 2, kWideParkFwd * 16);
     if (wp.lds > 160 * 1024) return wp;
     wp.ok = true;
     return wp;
@@ -92,7 +90,7 @@ int wide_backward(const Plan& pl, const WidePlan& wp, int add, int relu, const v
     const bool epi = add == ADD_PRE || relu;
     const int grid = wide_grid(pl.pr.C / wp.vec);
     int status = CNSN_E_UNSUPPORTED;
-    dispatch_w<8>(pl.pr.dtype, [&](auto tt, auto vt) {
+    dispatch_w<16>(pl.pr.dtype, [&](auto tt, auto vt) {
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value;
         auto launch = [&](auto kern) {

@@ -6,8 +6,10 @@
 // ADJACENT channels: the CH planes of an instance are contiguous in NCHW — CH*M elements — and CH = VEC (the elements
 // of one 16- or 8-byte vector) makes that super-plane exactly M vectors: lane l < M holds elements l*VEC .. l*VEC+VEC-1,
 // which belong to channel (l*VEC)/M and, past a per-lane split point, to the next one.  A wave holds R instances
-// (16 waves: N <= 16*R), so every access is a full-width vector and the whole channel group sits in registers:
-// one launch per direction, single touch, no exchange.
+// (16 waves: N <= 16*R), so every access is a full 16-byte vector: 8 channels per workgroup in 16 bits, 4 in fp32.
+// Forward: the whole channel group sits in registers — one launch, single touch, no exchange.  Backward: G and x of a
+// group do not fit the registers of one workgroup (128 VGPRs per lane), so it reads them twice, the second time from
+// cache (see wide_bwd_kernel).
 //   per-(instance, channel) sums: every lane forms the two partial sums of its two channels, the partials of a batch of
 //   rows go to a per-wave LDS scratch, and one lane per (row, channel) adds the 7-14 partials of its segment in a fixed
 //   order (no atomics: results are reproducible); exact two-pass statistics as everywhere else;
@@ -35,7 +37,7 @@ __host__ __device__ inline size_t wide_lds_bytes(int N, int ch, int batch, int n
     return (scratch > park ? scratch : park) + (size_t)narr * (((size_t)N * ch + 63) & ~(size_t)63) * 4 +
            (size_t)kWideWaves * 8 * 4 * 8;
 }
-constexpr int kWideParkFwd = 8, kWideParkBwd = 12;  // rows parked during the algebra (forward: of x; backward: of x)
+constexpr int kWideParkFwd = 8;  // rows of x parked during the forward's algebra
 
 // per-lane geometry of the super-plane
 template <int VEC>
@@ -290,22 +292,28 @@ __global__ __launch_bounds__(kWideBlock) void wide_fwd_kernel(WideArgs wa, const
 }
 
 // ================================================================================================
-// backward  (N * CH <= 1024: ONE (instance, channel) pair per thread)
+// backward, two-phase ("reload"): 16-byte vectors = as many channels per workgroup as the forward
 // ================================================================================================
+// Holding G and x of a group at once would limit the backward to 8-byte vectors = half the channels per workgroup =
+// TWO rounds of the chip (built first: 95 us at (256,2048,7,7) bf16 against 60 us for this one).  This kernel walks the
+// group's instances in two halves of 8 rows per wave: phase 1
+// loads a half (G and x: 64 registers), takes its sums and drops it; after the algebra, phase 2 loads the halves AGAIN
+// (the group's 2 x 200 KB were just read: L2 / Infinity Cache), applies and stores.  One round of the chip, every access
+// 16 bytes; G and x are read twice, of which once from cache.
 template <typename T, int VEC, bool EPI>
 __global__ __launch_bounds__(kWideBlock) void wide_bwd_kernel(WideArgs wa, const T* __restrict__ gy, const T* __restrict__ x,
-                                                              const T* __restrict__ addend, T* __restrict__ dx, GateDev gg,
-                                                              GateGradDev dgr, const double* __restrict__ saved, int add,
-                                                              int relu) {
-    constexpr int CH = VEC, VB = VEC * (int)sizeof(T), BATCH = 4;
+                                                               const T* __restrict__ addend, T* __restrict__ dx, GateDev gg,
+                                                               GateGradDev dgr, const double* __restrict__ saved, int add,
+                                                               int relu) {
+    constexpr int CH = VEC, VB = VEC * (int)sizeof(T), BATCH = 4, HALF = 8, PP = 2;
+    static_assert(VB == 16, "full vectors");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MidArgs a = wa.mid;
     a.sn_two = 0;
     const int N = a.N, C = a.C, M = a.M, R = wa.R;
     const int npad = (N * CH + 63) & ~63;
     float2* sc = (float2*)smem;                                               // [16][BATCH][64][2]
-    constexpr size_t kScratch = (size_t)kWideWaves * BATCH * 64 * 2 * 8, kPark = (size_t)kWideBlock * kWideParkBwd * VB;
-    float* psi = (float*)(smem + (kScratch > kPark ? kScratch : kPark));      // [N][CH] float(mu_c): shift of the second sum
+    float* psi = (float*)(smem + (size_t)kWideWaves * BATCH * 64 * 2 * 8);    // [N][CH] float(mu_c): shift of the second sum
     float* pfa = psi + npad;                                                  // forward slope  (ReLU mask)
     float* pfb = pfa + npad;                                                  // forward offset (ReLU mask)
     float* ps1 = pfb + npad;                                                  // sum G            -> later cG
@@ -321,116 +329,133 @@ __global__ __launch_bounds__(kWideBlock) void wide_bwd_kernel(WideArgs wa, const
     const WideLane<VEC> wl(lane, M);
     const int voff = lane * VB;
     const int gbytes = CH * M * (int)sizeof(T);
+    const int k = threadIdx.x & (CH - 1), c = c0 + k;
 
-    // ---- what the sums and the algebra need from `saved`, a thread per (instance, channel), ahead of the bulk loads
-    const int p = threadIdx.x, np = p / CH, k = p & (CH - 1), c = c0 + k;
-    const bool act = np < N;
-    double r_mu = 0, r_mup = 0, r_sigp = 0, r_g = 0, r_zhg = 0;
-    if (act) {
-        const SvRec ps = sv_rec(np, c, N);
+    // ---- shifts (and the forward's coefficients for the ReLU mask), a thread per (instance, channel)
+#pragma unroll 1
+    for (int i = 0; i < PP; ++i) {
+        const int p = threadIdx.x + i * kWideBlock, np = p / CH;
+        if (np < N) {
+            const SvRec ps = sv_rec(np, c, N);
+            psi[p] = (float)saved[sv_at(ps, SV_MU_C)];
+            if (EPI && relu) {
+                pfa[p] = (float)saved[sv_at(ps, SV_FC0 + FC_A_IN)];
+                pfb[p] = (float)saved[sv_at(ps, SV_FC0 + FC_B_IN)];
+            }
+        }
+    }
+    const float w_g0 = gg.w[2 * c], w_g1 = gg.w[2 * c + 1], gam_g = gg.gamma[c];
+    const double rs_g = saved[SV_ROWS * P + c];
+    __syncthreads();
+
+    MRaw<T, VEC> dg_[HALF], dx_[HALF];
+    // rows h*HALF .. h*HALF+7 of this wave; `again`: the second read (the lines are expected in cache: no nt hint)
+    auto load_half = [&](int h) {
+#pragma unroll
+        for (int rr = 0; rr < HALF; ++rr) {
+            const int r = h * HALF + rr, n = wave * R + r;
+            const bool ok = r < R && n < N;
+            const size_t off = ((size_t)(ok ? n : 0) * C + c0) * M;
+            const int bytes = ok ? gbytes : 0;
+            dg_[rr] = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc((void*)(gy + off), 0, bytes, 0x00020000), voff, 0, 0);
+            dx_[rr] = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc((void*)(x + off), 0, bytes, 0x00020000), voff, 0, 0);
+            if constexpr (EPI) {
+                if (add == ADD_PRE)
+                    dx_[rr] = madd<T, VEC>(dx_[rr], __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc((void*)(addend + off), 0, bytes, 0x00020000), voff, 0, 0));
+            }
+        }
+    };
+    // ReLU mask of row rr of the loaded half (forward affine re-evaluated with the coefficients the forward used)
+    auto mask_row = [&](int rr, int ia, int ib) {
+        if constexpr (EPI) {
+            if (relu) {
+                const float fa = pfa[ia], fb = pfb[ia], fa2 = pfa[ib], fb2 = pfb[ib];
+                float gm[VEC];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    const bool first = q < wl.qs;
+                    const float t = fmaf(first ? fa : fa2, melem<T, VEC>(dx_[rr], q), first ? fb : fb2);
+                    gm[q] = relu_open_r<T>(t) ? melem<T, VEC>(dg_[rr], q) : 0.f;
+                }
+                dg_[rr] = mpack<T, VEC>(gm);
+            }
+        }
+    };
+
+    // ---- phase 1: per-plane sums, half by half
+#pragma unroll 1
+    for (int h = 0; h < kWideRows / HALF; ++h) {
+        if (h * HALF >= R) break;
+        load_half(h);
+#pragma unroll
+        for (int bb = 0; bb < HALF / BATCH; ++bb) {
+#pragma unroll
+            for (int rb = 0; rb < BATCH; ++rb) {
+                const int rr = bb * BATCH + rb, r = h * HALF + rr, n = wave * R + r;
+                const bool ok = r < R && n < N;
+                const int ia = (ok ? n : 0) * CH + wl.a, ib = (ok ? n : 0) * CH + (wl.a + 1 < CH ? wl.a + 1 : wl.a);
+                const float sia = psi[ia], sib = psi[ib];
+                mono_forget(dg_[rr]);
+                mono_forget(dx_[rr]);
+                mask_row(rr, ia, ib);
+                float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    const bool first = q < wl.qs;
+                    const float G = melem<T, VEC>(dg_[rr], q), X = melem<T, VEC>(dx_[rr], q);
+                    const float t = G * (X - (first ? sia : sib));
+                    const bool fa_ = first && wl.live && ok, fb_ = !first && wl.live && ok;
+                    a1 += fa_ ? G : 0.f;
+                    b1 += fb_ ? G : 0.f;
+                    a2 += fa_ ? t : 0.f;
+                    b2 += fb_ ? t : 0.f;
+                }
+                sc[((size_t)(wave * BATCH + rb) * 64 + lane) * 2 + 0] = make_float2(a1, b1);
+                sc[((size_t)(wave * BATCH + rb) * 64 + lane) * 2 + 1] = make_float2(a2, b2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            for (int q = lane; q < BATCH * CH; q += 64) {
+                float s[2];
+                wide_segment<VEC, 2, BATCH>(sc, wave, q, M, s);
+                const int r = h * HALF + bb * BATCH + q / CH, kk = q % CH;
+                const int n = wave * R + r;
+                if (r < R && n < N) {
+                    ps1[n * CH + kk] = s[0];
+                    ps2[n * CH + kk] = s[1];
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- gate / BatchNorm backward, a thread per (instance, channel) pair (two pairs per thread, one at a time);
+    //      the pair's `saved` rows are read here (and once more below) instead of being held across phase 1
+    using Rr = float;
+    auto pair_state = [&](int p, BwdSumsT<Rr>& sums, Rr& dtg, Rr& dtf, double& r_mu, double& r_mup, double& r_sigp, double& r_g,
+                          double& r_zhg) {
+        const SvRec ps = sv_rec(p / CH, c, N);
         r_mu = saved[sv_at(ps, SV_MU_C)];
         r_mup = saved[sv_at(ps, SV_MU_P)];
         r_sigp = saved[sv_at(ps, SV_SIG_P)];
         r_g = saved[sv_at(ps, SV_G)];
         r_zhg = saved[sv_at(ps, SV_ZH_G)];
-        psi[p] = (float)r_mu;
-        if (EPI && relu) {
-            pfa[p] = (float)saved[sv_at(ps, SV_FC0 + FC_A_IN)];
-            pfb[p] = (float)saved[sv_at(ps, SV_FC0 + FC_B_IN)];
-        }
-    }
-    const float w_g0 = gg.w[2 * c], w_g1 = gg.w[2 * c + 1], gam_g = gg.gamma[c];
-    const double rs_g = saved[SV_ROWS * P + c];
-
-    // ---- the only reads of G and x (+ addend)
-    MRaw<T, VEC> dg_[kWideRows], dx_[kWideRows];
-#pragma unroll
-    for (int r = 0; r < kWideRows; ++r) {
-        const int n = wave * R + r;
-        const bool ok = r < R && n < N;
-        const size_t off = ((size_t)(ok ? n : 0) * C + c0) * M;
-        const int bytes = ok ? gbytes : 0;
-        dg_[r] = mload<T, VEC>(__builtin_amdgcn_make_buffer_rsrc((void*)(gy + off), 0, bytes, 0x00020000), voff);
-        dx_[r] = mload<T, VEC>(__builtin_amdgcn_make_buffer_rsrc((void*)(x + off), 0, bytes, 0x00020000), voff);
-        if constexpr (EPI) {
-            if (add == ADD_PRE)
-                dx_[r] = madd<T, VEC>(dx_[r], mload<T, VEC>(__builtin_amdgcn_make_buffer_rsrc((void*)(addend + off), 0, bytes, 0x00020000), voff));
-        }
-    }
-    __syncthreads();  // psi / pfa / pfb are staged
-
-    // ---- ReLU mask (forward affine re-evaluated with the coefficients the forward used) and per-plane sums
-#pragma unroll
-    for (int h = 0; h < kWideRows / BATCH; ++h) {
-        if (h * BATCH >= R) break;  // (workgroup-uniform: no rows in this batch)
-#pragma unroll
-        for (int rr = 0; rr < BATCH; ++rr) {
-            const int r = h * BATCH + rr;
-            const int n = wave * R + r;
-            const bool ok = r < R && n < N;
-            const int ia = (ok ? n : 0) * CH + wl.a, ib = (ok ? n : 0) * CH + (wl.a + 1 < CH ? wl.a + 1 : wl.a);
-            const float sia = psi[ia], sib = psi[ib];
-            mono_forget(dg_[r]);
-            mono_forget(dx_[r]);
-            if constexpr (EPI) {
-                if (relu) {
-                    const float fa = pfa[ia], fb = pfb[ia], fa2 = pfa[ib], fb2 = pfb[ib];
-                    float gm[VEC];
-#pragma unroll
-                    for (int q = 0; q < VEC; ++q) {
-                        const bool first = q < wl.qs;
-                        const float t = fmaf(first ? fa : fa2, melem<T, VEC>(dx_[r], q), first ? fb : fb2);
-                        gm[q] = relu_open_r<T>(t) ? melem<T, VEC>(dg_[r], q) : 0.f;
-                    }
-                    dg_[r] = mpack<T, VEC>(gm);
-                }
-            }
-            float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f;
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) {
-                const bool first = q < wl.qs;
-                const float G = melem<T, VEC>(dg_[r], q), X = melem<T, VEC>(dx_[r], q);
-                const float t = G * (X - (first ? sia : sib));
-                const bool fa_ = first && wl.live && ok, fb_ = !first && wl.live && ok;
-                a1 += fa_ ? G : 0.f;
-                b1 += fb_ ? G : 0.f;
-                a2 += fa_ ? t : 0.f;
-                b2 += fb_ ? t : 0.f;
-            }
-            sc[((size_t)(wave * BATCH + rr) * 64 + lane) * 2 + 0] = make_float2(a1, b1);
-            sc[((size_t)(wave * BATCH + rr) * 64 + lane) * 2 + 1] = make_float2(a2, b2);
-            __builtin_amdgcn_sched_barrier(0);  // bound the interleaving of rows (registers)
-        }
-        __syncthreads();
-        for (int q = lane; q < BATCH * CH; q += 64) {
-            float s[2];
-            wide_segment<VEC, 2, BATCH>(sc, wave, q, M, s);
-            const int r = h * BATCH + q / CH, kk = q % CH;
-            const int n = wave * R + r;
-            if (r < R && n < N) {
-                ps1[n * CH + kk] = s[0];
-                ps2[n * CH + kk] = s[1];
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- the algebra wants registers: half of the x rows wait in the (now idle) scratch
-    constexpr int NPARKED = kWideParkBwd;
-    MRaw<T, VEC>* parked = (MRaw<T, VEC>*)sc;
-#pragma unroll
-    for (int i = 0; i < NPARKED; ++i) parked[(size_t)i * kWideBlock + threadIdx.x] = dx_[kWideRows - NPARKED + i];
-
-    // ---- gate / BatchNorm backward, a thread per (instance, channel); coefficients of dx
-    using Rr = float;
-    BwdSumsT<Rr> sums{};
-    Rr dtg = 0.f, dtf = 0.f;
-    const double r_f = 1.0, r_zhf = 0.0;
-    if (act) {
         sums = fix_sums<Rr>(a, ps1[p], ps2[p], 0.f, 0.f, r_mu, 0.0);
-        gate_dt<Rr>(a, sums, Rr(1), (Rr)r_mu, Rr(0), (Rr)r_mup, (Rr)r_g, (Rr)r_f, dtg, dtf);
+        gate_dt<Rr>(a, sums, Rr(1), (Rr)r_mu, Rr(0), (Rr)r_mup, (Rr)r_g, Rr(1), dtg, dtf);
+    };
+    double s4[2] = {0.0, 0.0};
+#pragma unroll 1
+    for (int i = 0; i < PP; ++i) {
+        const int p = threadIdx.x + i * kWideBlock;
+        if (p / CH < N) {
+            BwdSumsT<Rr> sums{};
+            Rr dtg = 0.f, dtf = 0.f;
+            double r_mu, r_mup, r_sigp, r_g, r_zhg;
+            pair_state(p, sums, dtg, dtf, r_mu, r_mup, r_sigp, r_g, r_zhg);
+            s4[0] += (double)dtg;
+            s4[1] += (double)dtg * r_zhg;
+        }
     }
-    double s4[2] = {(double)dtg, (double)dtg * r_zhg};
     wide_chan_sum<2, CH>(s4, red);
     BnBwd b{};
     b.s_dt_g = s4[0];
@@ -439,16 +464,24 @@ __global__ __launch_bounds__(kWideBlock) void wide_bwd_kernel(WideArgs wa, const
     b.wg1 = w_g1;
     b.kg = (double)gam_g * rs_g;
     double sw[2] = {0, 0};
-    if (act) {
-        const BwdPlaneT<Rr> o = bwd_plane<Rr>(a, b, sums, (double)dtg, (double)dtf, r_zhg, r_zhf, (Rr)r_g, (Rr)r_f, Rr(1), Rr(1),
-                                              (Rr)r_mu, (Rr)r_mup, (Rr)r_sigp, Rr(1), Rr(0));
-        sw[0] = (double)o.dz_g * r_mup;
-        sw[1] = (double)o.dz_g * r_sigp;
-        const BwdCoefs kf = bwd_coefs<Rr>(a, o, Rr(0), Rr(0), (Rr)r_g, Rr(1), (Rr)r_mu, (Rr)r_mup, r_mu, Rr(1), r_mu, Rr(1));
-        ps1[p] = kf.cG_in;  // (every thread read its own ps1 / ps2 before the reduction above)
-        ps2[p] = kf.cX_in;
-        pxr[p] = kf.xr_in;
-        pc0[p] = kf.c0_in;
+#pragma unroll 1
+    for (int i = 0; i < PP; ++i) {
+        const int p = threadIdx.x + i * kWideBlock;
+        if (p / CH < N) {
+            BwdSumsT<Rr> sums{};
+            Rr dtg = 0.f, dtf = 0.f;
+            double r_mu, r_mup, r_sigp, r_g, r_zhg;
+            pair_state(p, sums, dtg, dtf, r_mu, r_mup, r_sigp, r_g, r_zhg);
+            const BwdPlaneT<Rr> o = bwd_plane<Rr>(a, b, sums, (double)dtg, (double)dtf, r_zhg, 0.0, (Rr)r_g, Rr(1), Rr(1), Rr(1),
+                                                  (Rr)r_mu, (Rr)r_mup, (Rr)r_sigp, Rr(1), Rr(0));
+            sw[0] += (double)o.dz_g * r_mup;
+            sw[1] += (double)o.dz_g * r_sigp;
+            const BwdCoefs kf = bwd_coefs<Rr>(a, o, Rr(0), Rr(0), (Rr)r_g, Rr(1), (Rr)r_mu, (Rr)r_mup, r_mu, Rr(1), r_mu, Rr(1));
+            ps1[p] = kf.cG_in;  // (this thread is the only reader of ps1[p] / ps2[p] as sums)
+            ps2[p] = kf.cX_in;
+            pxr[p] = kf.xr_in;
+            pc0[p] = kf.c0_in;
+        }
     }
     wide_chan_sum<2, CH>(sw, red);
     if (threadIdx.x < CH) {
@@ -458,30 +491,34 @@ __global__ __launch_bounds__(kWideBlock) void wide_bwd_kernel(WideArgs wa, const
         dgr.dw[2 * c + 1] = (float)sw[1];
     }
     __syncthreads();  // the coefficient rows are visible
-#pragma unroll
-    for (int i = 0; i < NPARKED; ++i) dx_[kWideRows - NPARKED + i] = parked[(size_t)i * kWideBlock + threadIdx.x];
 
-    // ---- dx from registers, the only write
+    // ---- phase 2: the planes again (from cache), dx, the only write
+#pragma unroll 1
+    for (int h = 0; h < kWideRows / HALF; ++h) {
+        if (h * HALF >= R) break;
+        load_half(h);
 #pragma unroll
-    for (int r = 0; r < kWideRows; ++r) {
-        const int n = wave * R + r;
-        const bool ok = r < R && n < N;
-        if (!ok) continue;
-        const int ia = n * CH + wl.a, ib = n * CH + (wl.a + 1 < CH ? wl.a + 1 : wl.a);
-        const float cG = ps1[ia], cX = ps2[ia], xr = pxr[ia], c0_ = pc0[ia];
-        const float cG2 = ps1[ib], cX2 = ps2[ib], xr2 = pxr[ib], c02 = pc0[ib];
-        mono_forget(dg_[r]);
-        mono_forget(dx_[r]);
-        float ov[VEC];
+        for (int rr = 0; rr < HALF; ++rr) {
+            const int r = h * HALF + rr, n = wave * R + r;
+            const bool ok = r < R && n < N;
+            if (!ok) continue;
+            const int ia = n * CH + wl.a, ib = n * CH + (wl.a + 1 < CH ? wl.a + 1 : wl.a);
+            mono_forget(dg_[rr]);
+            mono_forget(dx_[rr]);
+            mask_row(rr, ia, ib);
+            const float cG = ps1[ia], cX = ps2[ia], xr = pxr[ia], c0_ = pc0[ia];
+            const float cG2 = ps1[ib], cX2 = ps2[ib], xr2 = pxr[ib], c02 = pc0[ib];
+            float ov[VEC];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) {
-            const bool first = q < wl.qs;
-            ov[q] = fmaf(first ? cG : cG2, melem<T, VEC>(dg_[r], q),
-                         fmaf(first ? cX : cX2, melem<T, VEC>(dx_[r], q) - (first ? xr : xr2), first ? c0_ : c02));
+            for (int q = 0; q < VEC; ++q) {
+                const bool first = q < wl.qs;
+                ov[q] = fmaf(first ? cG : cG2, melem<T, VEC>(dg_[rr], q),
+                             fmaf(first ? cX : cX2, melem<T, VEC>(dx_[rr], q) - (first ? xr : xr2), first ? c0_ : c02));
+            }
+            const size_t off = ((size_t)n * C + c0) * M;
+            mstore<T, VEC>(__builtin_amdgcn_make_buffer_rsrc((void*)(dx + off), 0, gbytes, 0x00020000), voff, mpack<T, VEC>(ov));
+            __builtin_amdgcn_sched_barrier(0);
         }
-        const size_t off = ((size_t)n * C + c0) * M;
-        mstore<T, VEC>(__builtin_amdgcn_make_buffer_rsrc((void*)(dx + off), 0, gbytes, 0x00020000), voff, mpack<T, VEC>(ov));
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 

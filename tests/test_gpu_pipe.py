@@ -32,14 +32,14 @@ def restore_env():
     cnsn_amd.set_strategy("auto")
 
 
-def run(shape, dtype, kind, crop, seed, training=True):
+def run(shape, dtype, kind, crop, seed, training=True, is_two=False):
     n, c = shape[:2]
     g = torch.Generator(device="cuda").manual_seed(seed)
     x = (torch.randn(shape, device="cuda", generator=g) * (torch.rand(n, c, 1, 1, device="cuda", generator=g) * 1.5 + 0.5)
          + torch.randn(n, c, 1, 1, device="cuda", generator=g)).to(dtype).requires_grad_()
     gy = torch.randn(shape, device="cuda", generator=g).to(dtype)
     cn = cnsn_amd.CrossNorm(crop, 1) if kind != "sn" else None
-    sn = cnsn_amd.SelfNorm(c) if kind != "cn" else None
+    sn = cnsn_amd.SelfNorm(c, is_two=is_two) if kind != "cn" else None
     mod = (cnsn_amd.CNSN(cn, sn) if sn is not None else cn).cuda()
     mod.train(training)
     torch.manual_seed(seed)
@@ -70,6 +70,19 @@ def test_bit_identical_to_the_plain_kernel(tag, h, w, kind, crop, n):
     for i, (a, b) in enumerate(zip(ref, out)):
         assert torch.isfinite(b.float()).all()
         assert torch.equal(a, b), (tag, shape, kind, crop, i, (a.float() - b.float()).abs().max().item())
+
+
+def test_two_gate_selfnorm_bit_identical():
+    """SelfNorm(is_two=True) (cnsn.py:121-150, both gates): the second gate's rows travel through the pipelined kernels too."""
+    cnsn_amd.set_strategy("resident")
+    for tag, h, w in (("f32", 56, 56), ("bf16", 56, 56), ("f32", 28, 32)):
+        for kind, crop in (("sn", "neither"), ("cnsn", "both")):
+            os.environ["CNSN_PIPE"] = "0"
+            ref = run((37, 3, h, w), DT[tag], kind, crop, 21, is_two=True)
+            os.environ["CNSN_PIPE"] = "2"
+            out = run((37, 3, h, w), DT[tag], kind, crop, 21, is_two=True)
+            for a, b in zip(ref, out):
+                assert torch.equal(a, b), (tag, h, w, kind, crop)
 
 
 # many channels: the pipeline fills (several items per workgroup, the grid wraps around); checked against the oracle's
