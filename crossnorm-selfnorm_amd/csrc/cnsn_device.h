@@ -195,6 +195,8 @@ struct Geom {
     int nvec;  // M / VEC
     Box cb;    // content box (whole plane when the call has none)
     Box sb;    // style box   (whole plane when the call has none)
+    int keep;  // first pass of a two-pass direction with the default cache policy (small tensors: the second pass
+               // finds them in L2 / the Infinity Cache); 0 = non-temporal like every other plane access
 };
 
 }  // namespace cnsn

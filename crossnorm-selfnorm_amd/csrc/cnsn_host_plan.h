@@ -1,6 +1,7 @@
 // Host-side planning shared by the translation units of libcnsn_hip.so: argument validation, launch shape
 // (vector width, lanes per plane), the layout of `saved` and of the workspace, type dispatch.
 #pragma once
+#include <cstdlib>
 #include "../../include/cnsn_hip.h"
 
 #include <hip/hip_runtime.h>
@@ -88,6 +89,7 @@ inline Geom make_geom(int N, int C, int H, int W, int vec, Box cb, Box sb) {
     g.nvec = g.M / vec;
     g.cb = cb;
     g.sb = sb;
+    g.keep = 0;
     return g;
 }
 
@@ -132,6 +134,11 @@ inline int make_plan(const cnsn_problem_t* prob, Plan& pl) {
     if (p.sn_active && p.sn_training && p.N < 2) return CNSN_E_BATCH;
     pl.shape = pick_shape(p.dtype, p.H * p.W, p.W, pl.boxed);
     pl.geom = make_geom(p.N, p.C, p.H, p.W, pl.shape.vec, pl.cb, pl.sb);
+    // two-pass strategy: tensors of up to 512 MiB read their first pass with the default cache policy — the second pass
+    // then hits L2 / the 256 MB Infinity Cache for part of them (measured: (768,3,224,224) bf16 0.362 -> 0.339 ms,
+    // (256,3,224,224) fp32 0.237 -> 0.210; at 822 MB non-temporal is 11 % faster: profiles/r01_resident_tuning.md)
+    pl.geom.keep = ((size_t)p.N * p.C * p.H * p.W * elem_bytes(p.dtype) <= ((size_t)512 << 20)) ? 1 : 0;
+    if (const char* e = getenv("CNSN_KEEP")) pl.geom.keep = e[0] == '1' ? 1 : (e[0] == '0' ? 0 : pl.geom.keep);
     pl.P = (size_t)p.N * p.C;
     MidArgs& m = pl.mid;
     m.N = p.N;

@@ -11,6 +11,8 @@
 #pragma once
 #include "cnsn_device.h"
 
+
+
 namespace cnsn {
 
 #ifndef CNSN_UNROLL
@@ -20,7 +22,13 @@ constexpr int kUnroll = CNSN_UNROLL;
 
 // stream one plane: consume(vec, vec_index)
 template <typename T, int VEC, int LPP, bool NT = false, typename Consume>
-__device__ __forceinline__ void stream1(const T* __restrict__ base, int nvec, int lane, Consume&& consume) {
+__device__ __forceinline__ void stream1(const T* __restrict__ base, int nvec, int lane, Consume&& consume, bool keep = false) {
+    // keep (workgroup-uniform): default cache policy although NT — the first pass over a tensor small enough for the
+    // second pass to find it in L2 / the Infinity Cache
+    if (NT && keep) {
+        stream1<T, VEC, LPP, false>(base, nvec, lane, consume);
+        return;
+    }
     int i = lane;
     for (; i + (kUnroll - 1) * LPP < nvec; i += kUnroll * LPP) {
         Vec<T, VEC> v[kUnroll];
@@ -39,7 +47,11 @@ __device__ __forceinline__ void stream1(const T* __restrict__ base, int nvec, in
 // stream two planes in lock step: consume(vecA, vecB, vec_index)
 template <typename T, int VEC, int LPP, bool NT = false, typename Consume>
 __device__ __forceinline__ void stream2(const T* __restrict__ a, const T* __restrict__ b, int nvec, int lane,
-                                        Consume&& consume) {
+                                        Consume&& consume, bool keep = false) {
+    if (NT && keep) {
+        stream2<T, VEC, LPP, false>(a, b, nvec, lane, consume);
+        return;
+    }
     constexpr int U = kUnroll / 2;
     int i = lane;
     for (; i + (U - 1) * LPP < nvec; i += U * LPP) {
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void plane_stats_kernel(const T* __restrict
                 part[5][0] = fmaf(ms, d2, part[5][0]);
             }
         }
-    });
+    }, g.keep != 0);
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) {
@@ -306,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void bwd_reduce_kernel(const T* __restrict_
                                      part[3][j] += pr;
                                  }
                              }
-                         });
+                         }, g.keep != 0);
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) {
