@@ -10,7 +10,6 @@ namespace cnsn {
 namespace {
 
 constexpr size_t kLdsPerCu = 160 * 1024;
-constexpr int kPipeWgPerCu = 3;
 
 // f(TypeTag<T>, IntTag<VEC>, IntTag<NV>, IntTag<PPW>)
 template <typename F>
