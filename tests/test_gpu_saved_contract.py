@@ -1,0 +1,65 @@
+"""`saved` is one contract for every strategy: the forward of any strategy can be followed by the backward of any other
+(AUTO does mix them — e.g. 16-bit 13-slot planes run the two-pass forward and the cluster-resident backward).  For
+shapes where several strategies are eligible, every (forward strategy, backward strategy) pair must reproduce the
+gradients of the all-two-pass run within float rounding — the layout of `saved` (channel by channel, row by row over
+the batch: csrc/cnsn_layout.h) is exercised from both sides by every kernel family."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import cnsn_amd  # noqa: E402
+
+# shape, dtype, kind, crop, strategies that are eligible there (forced ones fall back to two-pass when they are not)
+CASES = [
+    ((37, 6, 28, 28), torch.float32, "sn", "neither", ["two_pass", "resident", "auto"]),
+    ((37, 6, 28, 28), torch.float32, "cnsn", "both", ["two_pass", "resident", "auto"]),
+    ((40, 8, 56, 56), torch.bfloat16, "cnsn", "neither", ["two_pass", "resident", "auto"]),
+    ((64, 8, 14, 14), torch.float32, "sn", "neither", ["two_pass", "resident", "local", "mono", "auto"]),
+    ((64, 8, 14, 14), torch.bfloat16, "cnsn", "style", ["two_pass", "mono", "auto"]),
+    ((128, 16, 7, 7), torch.bfloat16, "sn", "neither", ["two_pass", "local", "mono", "auto"]),   # mono = the wide kernels here
+    ((128, 8, 8, 8), torch.float32, "sn", "neither", ["two_pass", "local", "mono", "auto"]),
+    ((6, 4, 128, 96), torch.float32, "cnsn", "content", ["two_pass", "resident", "auto"]),          # split planes
+]
+
+
+@pytest.fixture(autouse=True)
+def auto():
+    yield
+    cnsn_amd.set_strategy("auto")
+
+
+@pytest.mark.parametrize("shape,dtype,kind,crop,strategies", CASES, ids=lambda v: str(v).replace(" ", "") if isinstance(v, tuple) else None)
+def test_any_forward_feeds_any_backward(shape, dtype, kind, crop, strategies):
+    n, c = shape[:2]
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = (torch.randn(shape, device="cuda", generator=g) * 1.3 + 0.4).to(dtype).requires_grad_()
+    gy = torch.randn(shape, device="cuda", generator=g).to(dtype)
+    res = {}
+    for fwd, bwd in itertools.product(strategies, strategies):
+        torch.manual_seed(2)
+        np.random.seed(2)
+        mod = cnsn_amd.CNSN(cnsn_amd.CrossNorm(crop, 1) if kind != "sn" else None, cnsn_amd.SelfNorm(c)).cuda().train()
+        with torch.no_grad():
+            for p in mod.parameters():
+                p.copy_(torch.randn_like(p) * 0.5)
+        if mod.crossnorm is not None:
+            mod.crossnorm.active = True
+        cnsn_amd.set_strategy(fwd)
+        y = mod(x)
+        cnsn_amd.set_strategy(bwd)
+        grads = torch.autograd.grad(y, [x] + list(mod.parameters()), gy)
+        res[(fwd, bwd)] = [y.detach().float()] + [t.float() for t in grads]
+    ref = res[("two_pass", "two_pass")]
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    for key, out in res.items():
+        for i, (a, b) in enumerate(zip(ref, out)):
+            scale = max(1.0, float(a.abs().max()))
+            err = float((a - b).abs().max())
+            assert err <= tol * scale, (shape, dtype, kind, crop, key, i, err, scale)
