@@ -84,9 +84,13 @@ MonoPlan mono_cn_plan(const Plan& pl, bool has_chan_perm, int add, bool backward
     if (mp.lds > 64 * 1024) return mp;
     if (p.strategy == CNSN_STRATEGY_AUTO) {
         if ((long long)M * b < 64 || p.N < 16) return mp;
-        // one 16-bit element per lane (7x7 bf16) only pays with crop boxes — measured at (256,2048,7,7), fwd+bwd:
-        // boxed 0.305 vs 0.361 ms packed two-pass, un-boxed 0.286 vs 0.258
-        if (vec * b < 4 && !pl.boxed) return mp;
+        // one element per lane (7x7) only pays with crop boxes — measured at (256,2048,7,7), fwd+bwd: bf16 boxed 0.305 vs
+        // 0.361 ms packed two-pass, un-boxed 0.286 vs 0.258; fp32 un-boxed 0.299 vs 0.289, at N = 96 0.162 vs 0.132
+        if (vec * b <= 4 && !pl.boxed) return mp;
+        // un-boxed calls the cluster kernels can take: with fewer than ~96 planes per channel one workgroup per channel is
+        // under-filled and the cluster kernels win — (64,1024,14,14) bf16 0.099 vs 0.067 ms, fp32 0.107 vs 0.088 on two
+        // boxes; at N = 96 / 128 the two are within noise of each other, at 256 mono leads (profiles/r02_auto_audit.md)
+        if (!pl.boxed && p.N < 96 && resident_plan(p, false, has_chan_perm, backward).ok) return mp;
     }
     mp.vec = vec;
     mp.lpp = lpp;

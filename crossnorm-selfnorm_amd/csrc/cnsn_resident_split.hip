@@ -62,6 +62,9 @@ ResPlan resident_split_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_p
         const int need = (nvec + 255) / 256;
         if ((rp.nv - need) * 4 > need) return rp;  // a register bucket more than 25 % too large is not worth it
         if (p.dtype != CNSN_F32 && rp.nv > 8) return rp;  // 16-bit, 16 slots: spills (not measured)
+        // 16-bit with crop boxes: VALU-bound like the one-plane-per-wave boxed kernels — (16,256,128,128) bf16 crop=both
+        // 0.256 / 0.293 ms (cn / cnsn) against 0.210 / 0.218 two-pass (profiles/r02_auto_audit.md)
+        if (p.dtype != CNSN_F32 && boxed) return rp;
     }
     (void)backward;
     rp.ok = true;

@@ -26,6 +26,10 @@ TABLE = [
     ((256, 1024, 14, 14), F32, FC(**SN), "mono", "resident"),                  # fp32 backward: G and x = 128 VGPRs per lane
     ((96, 1024, 14, 14), BF16, FC(**SN), "mono", "mono"),
     ((256, 1024, 14, 14), BF16, FC(**SN, **CN), "mono", "mono"),               # CrossNorm inside the channel's workgroup
+    ((64, 1024, 14, 14), BF16, FC(**SN, **CN), "resident", "resident"),        # fewer than 96 planes per channel, un-boxed: the cluster kernels
+    ((96, 1024, 14, 14), BF16, FC(**SN, **CN), "mono", "mono"),
+    ((64, 1024, 14, 14), BF16, FC(**SN, **BOTH), "mono", "mono"),              # with crop boxes the channel-in-registers kernels keep it
+    ((256, 2048, 7, 7), F32, FC(**SN, **CN), "packed", "packed"),              # one element per lane pays only with crop boxes
     ((256, 1024, 14, 14), BF16, FC(**SN, **BOTH), "mono", "mono"),             # (was packed two-pass: vectors straddle rows)
     ((128, 128, 8, 8), F32, FC(**SN, **BOTH), "mono", "mono"),                 # WideResNet stage 3, armed site
     ((256, 2048, 7, 7), BF16, FC(**SN, **BOTH), "mono", "mono"),               # 7x7 bf16 with boxes: one element per lane
@@ -37,7 +41,8 @@ TABLE = [
     ((16, 512, 64, 64), F32, FC(sn_active=True, add_mode="post", relu=True), "resident", "resident"),   # segmentation: SN at 'residual'
     ((16, 2048, 64, 64), BF16, FC(sn_active=True, add_mode="post", relu=True), "resident", "resident"),
     ((16, 256, 128, 128), F32, FC(sn_active=True, add_mode="post", relu=True), "resident", "resident"),  # a plane per workgroup (split)
-    ((16, 256, 128, 128), BF16, FC(**CN, style_box=(0, 0, 64, 64)), "resident", "resident"),            # segmentation's separate CrossNorm
+    ((16, 256, 128, 128), BF16, FC(**CN, style_box=(0, 0, 64, 64)), "streaming", "streaming"),          # segmentation's separate CrossNorm: 16-bit boxed = VALU-bound in the cluster kernels
+    ((16, 256, 128, 128), F32, FC(**CN, style_box=(0, 0, 64, 64)), "resident", "resident"),
     ((128, 128, 8, 8), F32, FC(**SN), "mono", "mono"),                        # 256-byte planes, 16 lanes each
     ((128, 64, 16, 16), F32, FC(**SN), "mono", "mono"),                        # WideResNet stage 2
     ((128, 32, 32, 32), F32, FC(**SN, **BOTH), "resident", "resident"),        # WideResNet stage 1
