@@ -96,11 +96,7 @@ int resident_pipe_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, c
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value, NV = decltype(nt)::value, PPW = decltype(pt)::value;
         auto launch = [&](auto kern) {
-            if (lds > 64 * 1024 &&
-                hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-                (void)hipGetLastError();
-                return;
-            }
+            if (!allow_dynamic_lds(kern, lds)) return;
             const int grid = reshost::grid_for(kern, lds, rp.K, ra.items);
             if (grid < rp.K) return;
             ResidentChain chain(stream);
@@ -197,11 +193,7 @@ int resident_pipe_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value, NV = decltype(nt)::value, PPW = decltype(pt)::value;
         auto launch = [&](auto kern) {
-            if (lds > 64 * 1024 &&
-                hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-                (void)hipGetLastError();
-                return;
-            }
+            if (!allow_dynamic_lds(kern, lds)) return;
             const int grid = reshost::grid_for(kern, lds, rp.K, ra.items);
             if (grid < rp.K) return;
             ResidentChain chain(stream);

@@ -20,16 +20,6 @@ bool dispatch_w(int dtype, F&& f) {
 
 inline int wide_grid(int groups) { return ((groups + 7) / 8) * 8; }
 
-template <typename K>
-bool grant_lds(K kern, size_t lds) {
-    if (lds <= 64 * 1024) return true;
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    return true;
-}
-
 }  // namespace
 
 WidePlan wide_plan(const Plan& pl, int add, bool backward) {
@@ -70,7 +60,7 @@ int wide_forward(const Plan& pl, const WidePlan& wp, int add, int relu, const vo
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value;
         auto launch = [&](auto kern) {
-            if (!grant_lds(kern, wp.lds)) return;
+            if (!allow_dynamic_lds(kern, wp.lds)) return;
             kern<<<grid, kWideBlock, wp.lds, stream>>>(wa, (const T*)x, (const T*)(add == ADD_PRE ? addend : nullptr), (T*)y, g,
                                                        saved, epi ? add : ADD_NONE, epi ? relu : 0);
             const hipError_t e = hipGetLastError();
@@ -94,7 +84,7 @@ int wide_backward(const Plan& pl, const WidePlan& wp, int add, int relu, const v
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value;
         auto launch = [&](auto kern) {
-            if (!grant_lds(kern, wp.lds)) return;
+            if (!allow_dynamic_lds(kern, wp.lds)) return;
             kern<<<grid, kWideBlock, wp.lds, stream>>>(wa, (const T*)gy, (const T*)x,
                                                        (const T*)(add == ADD_PRE ? addend : nullptr), (T*)dx, g, dg, saved,
                                                        epi ? add : ADD_NONE, epi ? relu : 0);
