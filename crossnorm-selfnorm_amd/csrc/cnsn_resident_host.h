@@ -5,6 +5,9 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 #include "cnsn_host_common.h"
 #include "cnsn_resident_kernels.h"
@@ -125,8 +128,23 @@ static inline ResArgs make_args(const cnsn_problem_t& p, Box cb, Box sb, const M
 // persistent grid: every workgroup resident, a whole number of clusters
 template <typename Kern>
 int grid_for(Kern kern, size_t lds, int K, int items) {
+    // (asked once per kernel, LDS size and device: the query costs microseconds, and small sites are launch-bound)
+    static std::mutex mu;
+    static std::map<std::tuple<const void*, size_t, int>, int> known;  // (exact key: an over-estimate would over-size a persistent grid)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const auto key = std::make_tuple((const void*)kern, lds, dev);
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kBlock, lds) != hipSuccess) return 0;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = known.find(key);
+        if (it != known.end()) {
+            occ = it->second;
+        } else {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kBlock, lds) != hipSuccess) return 0;
+            known[key] = occ;
+        }
+    }
     // MI355X admits min(API, 8, floor(800 / (ceil(sgpr/16)*16 + 16))) workgroups of 256 threads per CU
     // and the API over-reports by one when SGPRs are the limiter (MI355X_MICROARCH.md, "Residency").
     // Every resident kernel here uses 106-108 SGPRs (checked at build time) -> 6.
