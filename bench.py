@@ -598,7 +598,7 @@ def main():
                                         content_box=(1, 1, 3, 3) if args.crop in ("content", "both") else None,
                                         style_box=(0, 0, 2, 2) if args.crop in ("style", "both") else None)
         path_f, path_b = cnsn_amd.which_path(x, cfg_path, False), cnsn_amd.which_path(x, cfg_path, True)
-        single = {"resident", "local"}
+        single = {"resident", "local", "mono"}   # one launch, every plane read once
         moved_f = (2 if path_f in single else 3) * e * b       # what the kernels of this path read + write
         moved_b = (3 if path_b in single else 5) * e * b
         need_f, need_b = 2 * e * b, 3 * e * b                  # the least any implementation moves

@@ -13,7 +13,7 @@ CNSN_F32, CNSN_BF16, CNSN_F16 = 0, 1, 2
 STRATEGY_AUTO, STRATEGY_TWO_PASS, STRATEGY_RESIDENT, STRATEGY_LOCAL, STRATEGY_MONO = 0, 1, 2, 3, 4
 ADD_NONE, ADD_PRE, ADD_POST = 0, 1, 2
 PATHS = {0: "streaming", 1: "packed", 2: "resident", 3: "local", 4: "mono"}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Problem(C.Structure):
@@ -72,6 +72,7 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GateGrad),
                                       C.POINTER(GateGrad), C.c_void_p, C.c_size_t, C.c_void_p]),
     "cnsn_which_path": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.c_int, C.c_int]),
+    "cnsn_sn_cluster_plan": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.c_int]),
     "cnsn_jsd_workspace_bytes": (C.c_size_t, [C.c_int]),
     "cnsn_jsd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -166,6 +167,29 @@ def check_resident_health(what: str):
             "is shared with work that kept it off the device for seconds.  The outputs of the step that was in flight "
             "are invalid: repeat it.  The library now uses the two-pass kernels (CNSN_RESIDENT=0 selects them from "
             "the start).")
+
+
+def settle_step(device=None):
+    """Call between `loss.backward()` and `optimizer.step()` where a step must never be applied from incomplete
+    gradients: waits for the device's current stream, then polls the time-out counter (check_resident_health).  A
+    cluster launch that gave up has marked the planes it still owed with NaNs and bumped the counter by the time the
+    stream is idle — so the CnsnError is raised BEFORE the optimizer consumes the gradients of that step, and the caller
+    repeats the step (the library has switched to the two-pass kernels by then).  Costs one stream synchronisation per
+    step; `callers.steps` does it by default (`guard=True`)."""
+    import torch
+    torch.cuda.current_stream(device).synchronize()
+    check_resident_health("training step")
+
+
+def under_process_group_defaults():
+    """One process per GPU under an initialised torch.distributed group: a rank whose cluster wait runs out stalls its
+    peers' collectives for as long as the bound — default it to 2 s there instead of 5 s (CNSN_WAIT_MS still overrides)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and "CNSN_WAIT_MS" not in os.environ:
+            os.environ["CNSN_WAIT_MS"] = "2000"
+    except Exception:   # pragma: no cover
+        pass
 
 
 def check(status: int, what: str):

@@ -41,7 +41,9 @@ class IBN(nn.Module):
         self.BN = nn.BatchNorm2d(planes - self.half)
 
     def forward(self, x):
-        split = torch.split(x, self.half, 1)
-        out1 = self.IN(split[0].contiguous())
-        out2 = self.BN(split[1].contiguous())
-        return torch.cat((out1, out2), 1)
+        # the first `half` channels are instance-normalised, the others batch-normalised, order kept
+        # (`.narrow` views are strided: both normalisations want dense tensors, as the reference's split does)
+        rest = x.size(1) - self.half
+        y_in = self.IN(x.narrow(1, 0, self.half).contiguous())
+        y_bn = self.BN(x.narrow(1, self.half, rest).contiguous())
+        return torch.cat([y_in, y_bn], dim=1)

@@ -21,18 +21,45 @@ def jsd_consistency(logits_clean, logits_aug1, logits_aug2):
     return _jsd(logits_clean, logits_aug1, logits_aug2)   # HIP device tensors only, like the op itself
 
 
-def train_step_cn(net, x, target, optimizer, cn_prob):
-    """One feature-level CrossNorm step (cifar.py:123-140): draw r first, then forward with aug."""
-    r = np.random.rand(1)
-    logits = net(x, aug=bool(r < cn_prob))
-    loss = F.cross_entropy(logits, target)
+def _apply(optimizer, loss, guard):
+    """zero_grad / backward / step of the reference's loops (cifar.py:136-138) with the hot path's one addition: with
+    `guard`, the stream is settled and the library's time-out counter polled BEFORE the optimizer runs
+    (_ffi.settle_step), so gradients of a cluster launch that gave up never reach the weights."""
     optimizer.zero_grad()
     loss.backward()
+    if guard and loss.is_cuda:
+        from .. import _ffi
+        _ffi.settle_step(loss.device)
     optimizer.step()
     return loss.detach()
 
 
-def train_step_cn_consistency(net, x, target, optimizer, consist_wt, cn_prob=1.0, jsd=jsd_consistency):
+def repeat_on_timeout(step_fn, *args, **kwargs):
+    """Run one training step; when the library reports that a cluster-resident launch gave up ("repeat the step": the
+    GPU was shared with something that kept part of a persistent grid off the device for seconds) run it once more —
+    by then the library uses the two-pass kernels.  With the steps' default `guard=True` the failed attempt has not
+    touched the weights.  Under data parallelism every rank must take the same number of collectives per step: the
+    guard raises before the optimizer, i.e. after DDP's gradient all-reduce of the failed attempt, and the repeat
+    issues a full second set on EVERY rank only if every rank repeats — so a DDP loop should all-reduce a "repeat" flag
+    (data_parallel.agree_to_repeat) instead of calling this on one rank alone."""
+    from .._ffi import CnsnError
+    try:
+        return step_fn(*args, **kwargs)
+    except CnsnError as e:
+        if "repeat" not in str(e):
+            raise
+        return step_fn(*args, **kwargs)
+
+
+def train_step_cn(net, x, target, optimizer, cn_prob, guard=True):
+    """One feature-level CrossNorm step (cifar.py:123-140): draw r first, then forward with aug."""
+    r = np.random.rand(1)
+    logits = net(x, aug=bool(r < cn_prob))
+    loss = F.cross_entropy(logits, target)
+    return _apply(optimizer, loss, guard)
+
+
+def train_step_cn_consistency(net, x, target, optimizer, consist_wt, cn_prob=1.0, jsd=jsd_consistency, guard=True):
     """Consistency step (cifar.py:163-196).  Draw order of the reference: `r = np.random.rand(1)` FIRST; only when
     `r < cn_prob` the clean view + two independently armed CrossNorm views + JSD run (:165-187), otherwise plain
     cross-entropy on `net(x, aug=False)` (:188-190).  `jsd`: the consistency term (tests of the step structure on
@@ -46,10 +73,7 @@ def train_step_cn_consistency(net, x, target, optimizer, consist_wt, cn_prob=1.0
         loss = loss + consist_wt * jsd(logits_clean, logits_aug1, logits_aug2)
     else:
         loss = F.cross_entropy(net(x, aug=False), target)
-    optimizer.zero_grad()
-    loss.backward()
-    optimizer.step()
-    return loss.detach()
+    return _apply(optimizer, loss, guard)
 
 
 def image_space_crossnorm(images, cn_prob, beta, crop, cn_op):
@@ -61,7 +85,7 @@ def image_space_crossnorm(images, cn_prob, beta, crop, cn_op):
 
 
 def train_step_image_cn_views(net, views, target, optimizer, cn_prob, beta, crop, cn_op, jsd_wt=12.0,
-                              jsd=jsd_consistency):
+                              jsd=jsd_consistency, guard=True):
     """AugMix-style 3-view step (imagenet.py:352-381): concatenate the views, ONE image-space CrossNorm
     call on the (3B,3,H,W) batch with probability cn_prob, one forward, CE on the clean third + 12*JSD."""
     b = views[0].size(0)
@@ -69,10 +93,7 @@ def train_step_image_cn_views(net, views, target, optimizer, cn_prob, beta, crop
     logits = net(batch)
     l_clean, l_a1, l_a2 = torch.split(logits, b)
     loss = F.cross_entropy(l_clean, target) + jsd_wt * jsd(l_clean, l_a1, l_a2)
-    optimizer.zero_grad()
-    loss.backward()
-    optimizer.step()
-    return loss.detach()
+    return _apply(optimizer, loss, guard)
 
 
 class GraphedIdleStep:
@@ -85,17 +106,46 @@ class GraphedIdleStep:
     caller's stream ("HIP graphs")."""
 
     def __init__(self, net, optimizer, x, target, warmup=3):
+        import copy
         self.net, self.opt = net, optimizer
         self.x, self.y = x.clone(), target.clone()
+        for m in net.modules():     # float(num_batches_tracked) would synchronise under capture
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.momentum is None and m.track_running_stats:
+                raise ValueError("GraphedIdleStep: BatchNorm with momentum=None (cumulative average) cannot be captured")
+        # The warm-up and the capture pass run REAL steps (weights, momentum buffers, BatchNorm running statistics,
+        # num_batches_tracked): snapshot everything first and put it back afterwards, so that building the graph does
+        # not move the training trajectory away from the reference loop's.
+        model_state = copy.deepcopy(net.state_dict())
+        opt_before = {p: {k: (v.clone() if torch.is_tensor(v) else copy.deepcopy(v)) for k, v in st.items()}
+                      for p, st in optimizer.state.items()}
         side = torch.cuda.Stream(device=x.device)
         side.wait_stream(torch.cuda.current_stream(x.device))
-        with torch.cuda.stream(side):                       # warm-up off the capture stream (allocator, momentum buffers)
-            for _ in range(warmup):
+        with torch.cuda.stream(side):                       # warm-up off the capture stream (allocator, optimizer state)
+            # a fresh optimizer takes one real step at least: its state tensors (momentum buffers) must exist before the
+            # capture — captured, SGD's first-step `buf = clone(grad)` would be replayed as the first step for ever
+            for _ in range(warmup if len(optimizer.state) else max(warmup, 1)):
                 self._body()
         torch.cuda.current_stream(x.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._body()
+        torch.cuda.synchronize(x.device)
+        with torch.no_grad():                               # in place: the graph holds the parameters' / buffers' addresses
+            live = net.state_dict()
+            for k, v in model_state.items():
+                live[k].copy_(v)
+            for p, st in optimizer.state.items():
+                old = opt_before.get(p)
+                for name, val in st.items():
+                    if not torch.is_tensor(val):
+                        if old is not None and name in old:
+                            st[name] = old[name]
+                        continue
+                    if old is not None and torch.is_tensor(old.get(name)):
+                        val.copy_(old[name])                # the state the optimizer had before the warm-up
+                    else:
+                        val.zero_()                         # created by the warm-up: back to "no step taken yet" (SGD's first
+                                                            # `buf = grad` and `0 * buf + grad` agree; Adam starts from zeros)
 
     def _body(self):
         loss = F.cross_entropy(self.net(self.x, aug=False), self.y)
@@ -105,6 +155,8 @@ class GraphedIdleStep:
         return loss.detach()
 
     def step(self, x, target, cn_prob):
+        from .. import _ffi
+        _ffi.check_resident_health("GraphedIdleStep.step")  # a replay has no per-call poll of its own
         r = np.random.rand(1)                               # drawn first, armed or not (cifar.py:127)
         if r < cn_prob:                                     # armed: eager (fresh draws per step)
             loss = F.cross_entropy(self.net(x, aug=True), target)

@@ -16,6 +16,7 @@
 #include "cnsn_packed.h"
 #include "cnsn_resident_fused.h"
 #include "cnsn_resident_kernels.h"
+#include "cnsn_resident_sn.h"
 #include "cnsn_stream_kernels.h"
 
 using namespace cnsn;
@@ -61,10 +62,13 @@ size_t cnsn_context_bytes(const cnsn_problem_t* prob) {
     bool any = false;
     for (int bw = 0; bw < 2 && !any; ++bw)
         any = resident_plan(p, pl.boxed, false, bw != 0).ok || resident_fused_plan(p, pl.boxed, false, CNSN_ADD_PRE, bw != 0).ok ||
-              resident_split_plan(p, pl.boxed, false, CNSN_ADD_NONE, 0, bw != 0).ok;
+              resident_split_plan(p, pl.boxed, false, CNSN_ADD_NONE, 0, bw != 0).ok ||
+              resident_sn_plan(p, pl.boxed, CNSN_ADD_NONE, 0, bw != 0).ok || resident_sn_plan(p, pl.boxed, CNSN_ADD_PRE, 1, bw != 0).ok;
     // control block + one tagged granule per exchanged scalar (six per plane forward with crop boxes: the most)
     // (+ 256: the scalar-path gather reads whole 256-byte groups)
-    return any ? kCtlBytes + (size_t)p.N * p.C * 6 * 8 + 256 : 0;
+    if (!any) return 0;
+    const size_t general = kCtlBytes + (size_t)p.N * p.C * 6 * 8 + 256, sn = resident_sn_exchange_bytes(p);
+    return general > sn ? general : sn;
 }
 
 int cnsn_context_init(void* context, size_t bytes, void* stream) {
@@ -154,6 +158,11 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
             st = local_forward(pl, lp, 0, 0, x, nullptr, gate_dev(g), gate_dev(f), y, saved ? saved_d : nullptr, stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
+    }
+    if (resident_sn_plan(p, pl.boxed, CNSN_ADD_NONE, 0, false).ok) {  // SelfNorm alone: partial batch moments exchanged
+        st = resident_sn_forward(pl.pr, pl.mid, CNSN_ADD_NONE, 0, x, nullptr, gate_dev(g), y, saved ? saved_d : nullptr,
+                                 workspace, stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
     }
     if (resident_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, false).ok) {
         st = resident_pipe_forward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, x, perm, gate_dev(g), gate_dev(f), y,
@@ -252,6 +261,11 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
                                 gate_grad_dev(df), stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
+    }
+    if (resident_sn_plan(p, pl.boxed, CNSN_ADD_NONE, 0, true).ok) {
+        st = resident_sn_backward(pl.pr, pl.mid, CNSN_ADD_NONE, 0, grad_y, x, nullptr, gate_dev(g), saved_d, grad_x,
+                                  gate_grad_dev(dg), workspace, stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
     }
     if (resident_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, true).ok) {
         st = resident_pipe_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, grad_y, x, perm, gate_dev(g), gate_dev(f),

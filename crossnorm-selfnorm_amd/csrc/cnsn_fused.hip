@@ -11,6 +11,7 @@
 #include "cnsn_wide.h"
 #include "cnsn_packed.h"
 #include "cnsn_resident_fused.h"
+#include "cnsn_resident_sn.h"
 
 using namespace cnsn;
 
@@ -81,11 +82,28 @@ int cnsn_which_path(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int 
     if (mono_plan(pl, fused ? e.add : 0, bwd).ok) return CNSN_PATH_MONO;
     if (mono_cn_plan(pl, chan, fused ? e.add : 0, bwd).ok) return CNSN_PATH_MONO;
     if (local_plan(pl, fused ? e.add : 0, bwd).ok) return CNSN_PATH_LOCAL;
+    if (resident_sn_plan(p, pl.boxed, fused ? e.add : ADD_NONE, fused ? e.relu : 0, bwd).ok) return CNSN_PATH_RESIDENT;
     if (fused ? resident_fused_plan(p, pl.boxed, chan, e.add, bwd).ok : resident_plan(p, pl.boxed, chan, bwd).ok)
         return CNSN_PATH_RESIDENT;
     if (resident_split_plan(p, pl.boxed, chan, fused ? e.add : ADD_NONE, fused ? e.relu : 0, bwd).ok) return CNSN_PATH_RESIDENT;
     PackedGeom pg;
     return packed_plan(pl, pg) ? CNSN_PATH_PACKED : CNSN_PATH_STREAMING;
+}
+
+int cnsn_sn_cluster_plan(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int backward) {
+    EpiPlan e;
+    int st = parse_epilogue_shape(epi, e);
+    if (st) return st;
+    Plan pl;
+    st = make_plan(prob, pl);
+    if (st) return st;
+    const bool bwd = backward != 0;
+    const bool fused = bwd ? (e.relu || e.add == ADD_PRE) : (e.relu || e.add != ADD_NONE);
+    // (the small-plane strategies come first in every entry point)
+    if (wide_plan(pl, fused ? e.add : 0, bwd).ok || mono_plan(pl, fused ? e.add : 0, bwd).ok ||
+        local_plan(pl, fused ? e.add : 0, bwd).ok)
+        return 0;
+    return resident_sn_plan(pl.pr, pl.boxed, fused ? e.add : ADD_NONE, fused ? e.relu : 0, bwd).ok ? 1 : 0;
 }
 
 int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const void* x, const int64_t* perm,
@@ -141,6 +159,11 @@ int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, c
                                stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
+    }
+    if (resident_sn_plan(p, pl.boxed, e.add, e.relu, false).ok) {
+        st = resident_sn_forward(pl.pr, pl.mid, e.add, e.relu, x, e.addend, gate_dev(g), y, saved ? saved_d : nullptr, workspace,
+                                 stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
     }
     if (resident_fused_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, e.add, false).ok) {
         st = resident_fused_forward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, e.add, e.relu, x, e.addend, perm, gate_dev(g),
@@ -257,6 +280,11 @@ int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, 
                                 gate_grad_dev(dg), gate_grad_dev(df), stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
+    }
+    if (resident_sn_plan(p, pl.boxed, e.add, e.relu, true).ok) {
+        st = resident_sn_backward(pl.pr, pl.mid, e.add, e.relu, grad_y, x, e.addend, gate_dev(g), saved_d, grad_x,
+                                  gate_grad_dev(dg), workspace, stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
     }
     if (resident_fused_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, e.add, true).ok) {
         st = resident_fused_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, e.add, e.relu, grad_y, x, e.addend, perm,

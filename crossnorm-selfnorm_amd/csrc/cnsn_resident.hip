@@ -57,12 +57,13 @@ void resident_context_forget(void* context) {
     g_ctx_epoch[context] = 0;
 }
 
-ExchangeArea resident_exchange_area(const cnsn_problem_t& p, size_t tagged_bytes, void* workspace, hipStream_t stream) {
+ExchangeArea resident_exchange_area(const cnsn_problem_t& p, size_t tagged_bytes, void* workspace, hipStream_t stream,
+                                    bool prefer_context) {
     ExchangeArea ea{workspace, 0u};
     if (!p.context || p.context_bytes < tagged_bytes) return ea;
     if (const char* e = getenv("CNSN_CONTEXT")) {
         if (e[0] == '0') return ea;
-    } else if ((size_t)p.N * p.C * p.H * p.W * elem_bytes(p.dtype) >= ((size_t)64 << 20)) {
+    } else if (!prefer_context && (size_t)p.N * p.C * p.H * p.W * elem_bytes(p.dtype) >= ((size_t)64 << 20)) {
         // Large tensors exchange through the workspace: a tagged granule carries ONE float per 8 bytes, an untagged one
         // two, and at this size the gather of a channel's granules (4 KB tagged at N = 256, 12 KB with crop boxes) costs
         // more than the fill launch the context saves — north-star shape 0.849 -> 0.839 ms per step, with crop boxes

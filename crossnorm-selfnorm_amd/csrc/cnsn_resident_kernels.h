@@ -399,6 +399,16 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, int voff, co
         __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, 0, CNSN_RES_STORE_AUX);
 }
 
+// the launch gave up (a bounded wait ran out): make the incomplete outputs loud — a NaN in the first vector of every
+// plane this workgroup still owed (the host additionally sees cnsn_resident_timeouts() go up)
+template <typename T, int VEC>
+__device__ __forceinline__ void poison_plane(T* plane) {
+    float f[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) f[q] = __builtin_nanf("");
+    *reinterpret_cast<Raw<T, VEC>*>(plane) = pack<T, VEC>(f);
+}
+
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 // value of lane `src` (a compile-time constant after unrolling) in every lane
@@ -758,7 +768,12 @@ __global__ __launch_bounds__(kBlock, SPLIT ? (POST ? 2 : 3) : POST ? (data_regs(
         }
 #endif
         __syncthreads();
-        if (*gave_up) return;  // (workgroup-uniform) timed out: see sweep_granules
+        if (*gave_up) {  // (workgroup-uniform) timed out: see sweep_granules; the planes still owed are marked with NaNs
+#pragma unroll
+            for (int s = 0; s < PPW; ++s)
+                if (n0 + s < N && lane == 0 && (!SPLIT || wave == 0)) poison_plane<T, VEC>(y + ((size_t)(n0 + s) * C + c) * ra.M);
+            return;
+        }
 #if CNSN_PRIO
         __builtin_amdgcn_s_setprio(3);
 #endif
@@ -1174,7 +1189,12 @@ __global__ __launch_bounds__(kBlock, SPLIT ? 2 : POST ? 2 : EPI ? bwd_waves_epi(
         }
 #endif
         __syncthreads();
-        if (*gave_up) return;  // (workgroup-uniform) timed out: see sweep_granules
+        if (*gave_up) {  // (workgroup-uniform) timed out: see sweep_granules; the planes still owed are marked with NaNs
+#pragma unroll
+            for (int s = 0; s < PPW; ++s)
+                if (n0 + s < N && lane == 0 && (!SPLIT || wave == 0)) poison_plane<T, VEC>(dx + ((size_t)(n0 + s) * C + c) * ra.M);
+            return;
+        }
 #if CNSN_PRIO
         __builtin_amdgcn_s_setprio(3);
 #endif
@@ -1414,7 +1434,9 @@ struct ExchangeArea {
     void* base;
     unsigned epoch;
 };
-ExchangeArea resident_exchange_area(const cnsn_problem_t& p, size_t tagged_bytes, void* workspace, hipStream_t stream);
+// prefer_context: use the context whatever the tensor size (kernels whose gather is a few hundred bytes per item)
+ExchangeArea resident_exchange_area(const cnsn_problem_t& p, size_t tagged_bytes, void* workspace, hipStream_t stream,
+                                    bool prefer_context = false);
 void resident_context_forget(void* context);
 
 struct ResidentChain {

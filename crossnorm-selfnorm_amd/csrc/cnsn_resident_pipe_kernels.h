@@ -273,7 +273,14 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
             if (lane == 0 && !got) *gave_up = 1;
         }
         __syncthreads();
-        if (*gave_up) return;  // (workgroup-uniform) timed out: see sweep_granules
+        if (*gave_up) {  // (workgroup-uniform) timed out: see sweep_granules; the planes still owed are marked with NaNs
+#pragma unroll
+            for (int s = 0; s < PPW; ++s) {
+                const int n = (k * 4 + wave) * PPW + s;
+                if (n < N && lane == 0) poison_plane<T, VEC>(y + ((size_t)n * C + c) * ra.M);
+            }
+            return;
+        }
         CNSN_STAMP(2);
 #if CNSN_PIPE_PRIO
         __builtin_amdgcn_s_setprio(3);  // the algebra is the short serial section of the cycle: ahead of the neighbours' bulk loops
@@ -689,7 +696,14 @@ __global__ __launch_bounds__(kBlock, pipe_bwd_waves(2 * PPW * NV)) void resident
             if (lane == 0 && !got) *gave_up = 1;
         }
         __syncthreads();
-        if (*gave_up) return;  // (workgroup-uniform) timed out: see sweep_granules
+        if (*gave_up) {  // (workgroup-uniform) timed out: see sweep_granules; the planes still owed are marked with NaNs
+#pragma unroll
+            for (int s = 0; s < PPW; ++s) {
+                const int n = (k * 4 + wave) * PPW + s;
+                if (n < N && lane == 0) poison_plane<T, VEC>(dx + ((size_t)n * C + c) * ra.M);
+            }
+            return;
+        }
         CNSN_STAMP(2);
 #if CNSN_PIPE_PRIO
         __builtin_amdgcn_s_setprio(3);  // the algebra is the short serial section of the cycle: ahead of the neighbours' bulk loops

@@ -1,0 +1,23 @@
+// Cluster-resident kernels for SelfNorm alone (cnsn_resident_sn_kernels.h): host entry points.
+#pragma once
+#include "cnsn_host_plan.h"
+#include "cnsn_resident_kernels.h"
+
+namespace cnsn {
+
+struct SnxPlan {
+    bool ok;
+    int vec, nv, ppw, K, npark;
+};
+// add: ADD_NONE or ADD_PRE; relu 0/1.  ok only for SelfNorm alone in training mode (one gate, no CrossNorm).
+SnxPlan resident_sn_plan(const cnsn_problem_t& p, bool boxed, int add, int relu, bool backward);
+// bytes of exchange area a launch may need (the persistent context is sized for it, cnsn_context_bytes)
+size_t resident_sn_exchange_bytes(const cnsn_problem_t& p);
+
+int resident_sn_forward(const cnsn_problem_t& p, const MidArgs& mid, int add, int relu, const void* x, const void* addend,
+                        GateDev g, void* y, double* saved, void* workspace, hipStream_t stream);
+int resident_sn_backward(const cnsn_problem_t& p, const MidArgs& mid, int add, int relu, const void* gy, const void* x,
+                         const void* addend, GateDev g, const double* saved, void* dx, GateGradDev dg, void* workspace,
+                         hipStream_t stream);
+
+}  // namespace cnsn

@@ -1,0 +1,61 @@
+// SelfNorm-only cluster kernels, forward: host entry points (shared logic in cnsn_resident_sn_host.h).
+#include "cnsn_resident_sn_host.h"
+
+namespace cnsn {
+
+SnxPlan resident_sn_plan(const cnsn_problem_t& p, bool boxed, int add, int relu, bool backward) {
+    return snxhost::plan_impl(p, boxed, add, relu, backward);
+}
+
+size_t resident_sn_exchange_bytes(const cnsn_problem_t& p) {
+    // (the largest a plan can ask for: the backward with the fewest planes per workgroup)
+    const int K = (p.N + 3) / 4;
+    return snxhost::tagged_bytes(p, K, true);
+}
+
+int resident_sn_forward(const cnsn_problem_t& p, const MidArgs& mid, int add, int relu, const void* x, const void* addend,
+                        GateDev g, void* y, double* saved, void* workspace, hipStream_t stream) {
+    const SnxPlan sp = snxhost::plan_impl(p, false, add, relu, false);
+    if (!sp.ok) return CNSN_E_UNSUPPORTED;
+    const bool epi = add != ADD_NONE || relu;
+    ResArgs ra = snxhost::make_args(p, mid, sp);
+    const size_t lds = snxhost::lds_bytes(sp.K, 4 * sp.ppw, sp.npark, false);
+    int status = CNSN_E_UNSUPPORTED;
+    auto run = [&](auto tt, auto vt, auto nt, auto pt, auto et) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value, NV = decltype(nt)::value, PPW = decltype(pt)::value;
+        constexpr bool EPI = decltype(et)::value != 0;
+        auto kern = resident_sn_fwd_kernel<T, VEC, NV, PPW, EPI>;
+        if (!allow_dynamic_lds(kern, lds)) return;
+        const int grid = reshost::grid_for(kern, lds, sp.K, ra.items);
+        if (grid < sp.K) return;
+        ResidentChain chain(stream);  // cluster grids of different streams never overlap
+        const ExchangeArea ea = resident_exchange_area(p, snxhost::tagged_bytes(p, sp.K, false), workspace, stream, true);
+        ra.epoch = ea.epoch;
+        ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
+        unsigned* ctl = (unsigned*)ea.base;
+        unsigned long long* gran = (unsigned long long*)((char*)ea.base + kCtlBytes);
+        hipError_t e = ea.epoch ? hipSuccess
+                                : hipMemsetAsync(workspace, 0xff, kCtlBytes + (size_t)p.C * sp.K * 2 * 8, stream);
+        if (e != hipSuccess) {
+            status = (int)e;
+            return;
+        }
+        kern<<<grid, kBlock, lds, stream>>>(ra, sp.npark, (const T*)x, (const T*)(add == ADD_PRE ? addend : nullptr), relu,
+                                            (T*)y, g, gran, saved, ctl);
+        e = hipGetLastError();
+        status = e == hipSuccess ? CNSN_OK : (int)e;
+    };
+    if (epi)
+        snxhost::dispatch_snx<false, true>(p.dtype, sp.vec, sp.nv,
+                                           [&](auto tt, auto vt, auto nt, auto pt) { run(tt, vt, nt, pt, IntTag<1>{}); });
+    else
+        snxhost::dispatch_snx<false, false>(p.dtype, sp.vec, sp.nv,
+                                            [&](auto tt, auto vt, auto nt, auto pt) { run(tt, vt, nt, pt, IntTag<0>{}); });
+    if (getenv("CNSN_DEBUG"))
+        fprintf(stderr, "[cnsn] sn-cluster fwd: nv=%d ppw=%d K=%d npark=%d epi=%d lds=%zu -> status %d\n", sp.nv, sp.ppw, sp.K,
+                sp.npark, (int)epi, lds, status);
+    return status;
+}
+
+}  // namespace cnsn

@@ -1,0 +1,57 @@
+// SelfNorm-only cluster kernels, backward: host entry point (shared logic in cnsn_resident_sn_host.h).
+#include "cnsn_resident_sn_host.h"
+
+namespace cnsn {
+
+int resident_sn_backward(const cnsn_problem_t& p, const MidArgs& mid, int add, int relu, const void* gy, const void* x,
+                         const void* addend, GateDev g, const double* saved, void* dx, GateGradDev dg, void* workspace,
+                         hipStream_t stream) {
+    const SnxPlan sp = snxhost::plan_impl(p, false, add, relu, true);
+    if (!sp.ok) return CNSN_E_UNSUPPORTED;
+    const bool epi = add != ADD_NONE || relu;
+    ResArgs ra = snxhost::make_args(p, mid, sp);
+    const size_t lds = snxhost::lds_bytes(sp.K, 4 * sp.ppw, sp.npark, true);
+    int status = CNSN_E_UNSUPPORTED;
+    auto run = [&](auto tt, auto vt, auto nt, auto pt, auto et) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value, NV = decltype(nt)::value, PPW = decltype(pt)::value;
+        constexpr bool EPI = decltype(et)::value != 0;
+        auto kern = resident_sn_bwd_kernel<T, VEC, NV, PPW, EPI>;
+        if (!allow_dynamic_lds(kern, lds)) return;
+        const int grid = reshost::grid_for(kern, lds, sp.K, ra.items);
+        if (grid < sp.K) return;
+        ResidentChain chain(stream);
+        const ExchangeArea ea = resident_exchange_area(p, snxhost::tagged_bytes(p, sp.K, true), workspace, stream, true);
+        ra.epoch = ea.epoch;
+        ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
+        unsigned* ctl = (unsigned*)ea.base;
+        unsigned long long* gran = (unsigned long long*)((char*)ea.base + kCtlBytes);
+        // round B behind round A (+ 256: the scalar-path gather of round A reads whole 256-byte groups)
+        const size_t a_gran = (size_t)p.C * sp.K * (ea.epoch ? 4 : 2);
+        unsigned long long* gran_b = gran + ((a_gran + 32 + 31) & ~(size_t)31);
+        const size_t b_gran = (size_t)p.C * sp.K * 4 * (ea.epoch ? 2 : 1);
+        hipError_t e = ea.epoch ? hipSuccess
+                                : hipMemsetAsync(workspace, 0xff, (size_t)((char*)(gran_b + b_gran) - (char*)workspace), stream);
+        if (e != hipSuccess) {
+            status = (int)e;
+            return;
+        }
+        kern<<<grid, kBlock, lds, stream>>>(ra, sp.npark, (const T*)gy, (const T*)x,
+                                            (const T*)(add == ADD_PRE ? addend : nullptr), relu, (T*)dx, g, dg, gran, gran_b,
+                                            saved, ctl);
+        e = hipGetLastError();
+        status = e == hipSuccess ? CNSN_OK : (int)e;
+    };
+    if (epi)
+        snxhost::dispatch_snx<true, true>(p.dtype, sp.vec, sp.nv,
+                                          [&](auto tt, auto vt, auto nt, auto pt) { run(tt, vt, nt, pt, IntTag<1>{}); });
+    else
+        snxhost::dispatch_snx<true, false>(p.dtype, sp.vec, sp.nv,
+                                           [&](auto tt, auto vt, auto nt, auto pt) { run(tt, vt, nt, pt, IntTag<0>{}); });
+    if (getenv("CNSN_DEBUG"))
+        fprintf(stderr, "[cnsn] sn-cluster bwd: nv=%d ppw=%d K=%d npark=%d epi=%d lds=%zu -> status %d\n", sp.nv, sp.ppw, sp.K,
+                sp.npark, (int)epi, lds, status);
+    return status;
+}
+
+}  // namespace cnsn

@@ -1,0 +1,111 @@
+// Host side shared by the two translation units of the SelfNorm-only cluster kernels: eligibility, geometry.
+#pragma once
+#include "cnsn_fused_stream_kernels.h"
+#include "cnsn_resident_host.h"
+#include "cnsn_resident_sn.h"
+#include "cnsn_resident_sn_kernels.h"
+
+namespace cnsn {
+namespace snxhost {
+
+constexpr size_t kLdsPerCu = 160 * 1024;
+
+// planes per wave: the item in flight (x [+ addend]; G, x [+ addend]) has to fit the registers of 3-4 (forward) / 2-3
+// (backward) workgroups per CU next to the kept part of the parked item
+constexpr int fwd_ppw(int nv, bool epi, int elem_bytes) {
+    return nv == 2 ? 4 : nv == 4 ? (epi ? 2 : 4) : nv == 7 ? ((elem_bytes == 2 && !epi) ? 2 : 1) : 1;
+}
+constexpr int bwd_ppw(int nv, bool, int) { return nv == 2 ? 4 : nv == 4 ? 2 : 1; }
+
+// CNSN_SNX=0: never; 2: wherever instantiated (tests); default 1: AUTO rule
+inline int snx_mode() {
+    const char* e = getenv("CNSN_SNX");
+    return e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : 1;
+}
+
+template <bool BWD, bool EPI, typename F>
+bool dispatch_snx(int dtype, int vec, int nv, F&& f) {
+    auto by_nv = [&](auto tt, auto vt) -> bool {
+        using T = typename decltype(tt)::type;
+        constexpr int EB = (int)sizeof(T);
+        switch (nv) {
+            case 2: f(tt, vt, IntTag<2>{}, IntTag<(BWD ? bwd_ppw(2, EPI, EB) : fwd_ppw(2, EPI, EB))>{}); return true;
+            case 4: f(tt, vt, IntTag<4>{}, IntTag<(BWD ? bwd_ppw(4, EPI, EB) : fwd_ppw(4, EPI, EB))>{}); return true;
+            case 7: f(tt, vt, IntTag<7>{}, IntTag<(BWD ? bwd_ppw(7, EPI, EB) : fwd_ppw(7, EPI, EB))>{}); return true;
+            case 8: f(tt, vt, IntTag<8>{}, IntTag<(BWD ? bwd_ppw(8, EPI, EB) : fwd_ppw(8, EPI, EB))>{}); return true;
+            case 13: f(tt, vt, IntTag<13>{}, IntTag<1>{}); return true;
+            case 16:
+                if constexpr (BWD && EPI) return false;  // 48 slots in flight: does not fit
+                else { f(tt, vt, IntTag<16>{}, IntTag<1>{}); return true; }
+            default: return false;
+        }
+    };
+    if (dtype == CNSN_F32 && vec == 4) return by_nv(TypeTag<float>{}, IntTag<4>{});
+    if (dtype == CNSN_BF16 && vec == 8) return by_nv(TypeTag<bf16_t>{}, IntTag<8>{});
+    if (dtype == CNSN_F16 && vec == 8) return by_nv(TypeTag<_Float16>{}, IntTag<8>{});
+    return false;
+}
+
+inline size_t lds_bytes(int K, int own, int np, bool backward) {
+    return backward ? snx_bwd_lds_bytes(K, own, np, 16) : snx_fwd_lds_bytes(K, own, np, 16);
+}
+
+inline SnxPlan plan_impl(const cnsn_problem_t& p, bool boxed, int add, int relu, bool backward) {
+    SnxPlan none{false, 0, 0, 0, 0, 0};
+    const int mode = snx_mode();
+    if (mode == 0) return none;
+    if (!(p.strategy == CNSN_STRATEGY_AUTO || p.strategy == CNSN_STRATEGY_RESIDENT)) return none;
+    if (boxed || p.cn_active || !p.sn_active || !p.sn_training || p.sn_two) return none;
+    if (!(add == ADD_NONE || add == ADD_PRE)) return none;
+    if (resident_timeouts() > 0) return none;
+    if (p.strategy == CNSN_STRATEGY_AUTO && !resident_auto_enabled()) return none;
+    if ((long)p.N * p.C < 16) return none;  // (the exchange area is sized against the two-pass workspace: see cnsn_resident_sn.hip)
+    const bool epi = add != ADD_NONE || relu;
+    const int M = p.H * p.W, eb = elem_bytes(p.dtype);
+    SnxPlan sp = none;
+    sp.vec = pick_vec(p.dtype, M);
+    if (sp.vec * eb != 16) return none;
+    const int nvec = M / sp.vec;
+    if (nvec <= 64) return none;  // one-slot planes: the channel-in-registers kernels' domain
+    const int need = (nvec + 63) / 64;
+    for (const int nv : {2, 4, 7, 8, 13, 16})
+        if (nv >= need) {
+            sp.nv = nv;
+            break;
+        }
+    if (sp.nv == 0) return none;
+    if (backward && epi && sp.nv == 16) return none;
+    if (mode != 2 && (sp.nv - need) * 4 > need) return none;  // a register bucket far larger than the plane
+    sp.ppw = backward ? bwd_ppw(sp.nv, epi, eb) : fwd_ppw(sp.nv, epi, eb);
+    const int own = 4 * sp.ppw;
+    sp.K = (p.N + own - 1) / own;
+    if (sp.K > 2 * reshost::cu_count() || sp.K > 1024) return none;
+    const int slots = (backward ? 2 : 1) * sp.ppw * sp.nv;
+    const int wg_per_cu = backward ? snx_bwd_waves(slots, epi) : snx_fwd_waves(slots, epi, eb);
+    const long grid_max = ((long)wg_per_cu * reshost::cu_count() / sp.K) * sp.K;
+    if (grid_max < sp.K) return none;
+    const size_t budget = (kLdsPerCu / wg_per_cu) & ~(size_t)511;
+    const int first_keep = slots - (backward ? snx_bwd_keep(slots, epi) : snx_fwd_keep(slots));
+    int np = slots;
+    if (!backward && sp.ppw == 1 && nvec % 64 != 0 && nvec % 64 <= 32) np = slots - 1;  // a last, partly filled slot stays in registers
+    if (np < first_keep) np = first_keep;
+    while (np >= first_keep && lds_bytes(sp.K, own, np, backward) > budget) --np;
+    if (np < first_keep) return none;
+    sp.npark = np;
+    sp.ok = true;
+    return sp;
+}
+
+inline ResArgs make_args(const cnsn_problem_t& p, const MidArgs& mid, const SnxPlan& sp) {
+    ResPlan rp{true, sp.vec, sp.nv, sp.ppw, sp.K};
+    const Box whole{0, 0, p.H, p.W};
+    return reshost::make_args(p, whole, whole, mid, rp);
+}
+
+// exchange areas, in granules of 8 bytes: round A per member, round B per wave (backward only)
+inline size_t tagged_bytes(const cnsn_problem_t& p, int K, bool backward) {
+    return kCtlBytes + (size_t)p.C * K * (backward ? 4 + 8 : 4) * 8 + 512;
+}
+
+}  // namespace snxhost
+}  // namespace cnsn

@@ -161,6 +161,7 @@ void attach_context(cnsn_problem_t& p, const at::Device& dev, hipStream_t stream
     }
     static std::mutex mu;
     static std::unordered_map<int, Tensor> ctx;
+    static std::vector<Tensor> retired;  // outgrown buffers stay alive: launches queued on OTHER streams may still exchange through them
     std::lock_guard<std::mutex> lock(mu);
     Tensor& have = ctx[(int)dev.index()];
     if (!have.defined() || (size_t)have.numel() < need) {
@@ -168,6 +169,7 @@ void attach_context(cnsn_problem_t& p, const at::Device& dev, hipStream_t stream
         Tensor buf = at::empty({(int64_t)size}, at::TensorOptions().dtype(at::kByte).device(dev));
         check_status(cnsn_context_init(buf.data_ptr(), size, (void*)stream), "cnsn_context_init");
         TORCH_CHECK(hipStreamSynchronize(stream) == hipSuccess, "cnsn: hipStreamSynchronize");   // once per buffer
+        if (have.defined()) retired.push_back(have);
         have = buf;
     }
     p.context = have.data_ptr();

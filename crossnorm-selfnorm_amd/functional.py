@@ -104,6 +104,7 @@ def _sizes(prob):
 # when a larger problem shows up, allocated and initialised on first use.  With it a resident launch needs no fill
 # launch in front of it.  None while the stream is being captured into a graph (a replay would repeat the launch number).
 _contexts = {}
+_retired_contexts = []     # outgrown buffers are kept: launches still queued on OTHER streams may exchange through them
 
 
 def _context(prob, dev: torch.device):
@@ -118,6 +119,8 @@ def _context(prob, dev: torch.device):
         _ffi.check(_ffi.lib().cnsn_context_init(C.c_void_p(buf.data_ptr()), size, C.c_void_p(stream.cuda_stream)),
                    "cnsn_context_init")
         stream.synchronize()            # once per buffer: ordered before whichever stream uses it next
+        if have is not None:
+            _retired_contexts.append(have)
         _contexts[dev.index] = have = buf
     prob.context = have.data_ptr()
     prob.context_bytes = have.numel()
@@ -210,6 +213,16 @@ def which_path(x: torch.Tensor, cfg: FusedConfig, backward: bool = False, chan_p
     if st < 0:
         _ffi.check(st, "cnsn_which_path")
     return _ffi.PATHS[st]
+
+
+def sn_cluster(x: torch.Tensor, cfg: FusedConfig, backward: bool = False) -> bool:
+    """True when the call runs the SelfNorm-only cluster kernels (cnsn_sn_cluster_plan)."""
+    prob = _problem(x, cfg)
+    epi = _epilogue(cfg, None) if cfg.has_epilogue else None
+    st = _ffi.lib().cnsn_sn_cluster_plan(C.byref(prob), C.byref(epi) if epi else None, int(backward))
+    if st < 0:
+        _ffi.check(st, "cnsn_sn_cluster_plan")
+    return st == 1
 
 
 def _problem(x: torch.Tensor, cfg: FusedConfig) -> _ffi.Problem:

@@ -24,7 +24,13 @@ PLANES = [("f32", 12, 32), ("f32", 28, 32), ("bf16", 12, 64), ("bf16", 28, 64), 
 @pytest.fixture(autouse=True)
 def restore_env():
     old = os.environ.get("CNSN_PIPE")
+    old_snx = os.environ.get("CNSN_SNX")
+    os.environ["CNSN_SNX"] = "0"       # SelfNorm alone: the general kernels, not tests/test_gpu_sn_cluster.py's
     yield
+    if old_snx is None:
+        os.environ.pop("CNSN_SNX", None)
+    else:
+        os.environ["CNSN_SNX"] = old_snx
     if old is None:
         os.environ.pop("CNSN_PIPE", None)
     else:

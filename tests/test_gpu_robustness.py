@@ -93,6 +93,7 @@ os.environ["CNSN_FAULT_INJECT"] = "1"          # the last member of channel 0's 
 bad = run("auto")                              # gives up after CNSN_WAIT_MS, no trap: the context is still alive
 os.environ["CNSN_FAULT_INJECT"] = "0"
 assert _ffi.lib().cnsn_resident_timeouts() == 1, _ffi.lib().cnsn_resident_timeouts()
+assert torch.isnan(bad).any()                  # the incomplete output is loud on the SAME step: NaNs in the planes still owed
 try:
     run("auto")
     raise SystemExit("the time-out was not reported")
@@ -110,9 +111,12 @@ print("TIMEOUT-PATH-OK")
 
 def test_resident_timeout_degrades_instead_of_trapping():
     env = dict(os.environ, CNSN_WAIT_MS="200")
-    for glue, pipe in (("0", "1"), ("1", "1"), ("0", "2")):   # CNSN_PIPE=2: the pipelined forward gives up the same way
+    # CNSN_PIPE=2: the pipelined forward gives up the same way; CNSN_SNX=0: the general kernels instead of the
+    # SelfNorm-only cluster kernels (which AUTO takes for this call)
+    for glue, pipe, snx in (("0", "1", "1"), ("1", "1", "1"), ("0", "1", "0"), ("1", "1", "0"), ("0", "2", "0")):
         env["CNSN_NO_GLUE"] = glue
         env["CNSN_PIPE"] = pipe
+        env["CNSN_SNX"] = snx
         r = subprocess.run([sys.executable, "-c", _TIMEOUT_SCRIPT % ROOT], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0 and "TIMEOUT-PATH-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
