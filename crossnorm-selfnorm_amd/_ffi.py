@@ -41,6 +41,12 @@ class GateGrad(C.Structure):
     _fields_ = [("d_fc_weight", C.c_void_p), ("d_bn_weight", C.c_void_p), ("d_bn_bias", C.c_void_p)]
 
 
+class BnTail(C.Structure):
+    """cnsn_bn_tail_t"""
+    _fields_ = [("struct_bytes", C.c_int32), ("training", C.c_int32), ("eps", C.c_float), ("momentum", C.c_float),
+                ("weight", C.c_void_p), ("bias", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p)]
+
+
 class Epilogue(C.Structure):
     """cnsn_epilogue_t"""
     _fields_ = [("struct_bytes", C.c_int32), ("add_mode", C.c_int32), ("relu", C.c_int32),
@@ -73,6 +79,13 @@ SIGNATURES = {
                                       C.POINTER(GateGrad), C.c_void_p, C.c_size_t, C.c_void_p]),
     "cnsn_which_path": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.c_int, C.c_int]),
     "cnsn_sn_cluster_plan": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.c_int]),
+    "cnsn_bnrelu_plan": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.c_int]),
+    "cnsn_forward_bnrelu": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.POINTER(BnTail), C.c_void_p,
+                                      C.POINTER(Gate), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_size_t, C.c_void_p]),
+    "cnsn_backward_bnrelu": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.POINTER(BnTail), C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.POINTER(Gate), C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.POINTER(GateGrad), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cnsn_jsd_workspace_bytes": (C.c_size_t, [C.c_int]),
     "cnsn_jsd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

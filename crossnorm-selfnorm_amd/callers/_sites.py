@@ -8,6 +8,9 @@ import torch
 # Fold the block's `sum of the two branches -> CNSN -> ReLU` into the op's own launches (CNSN.forward_block,
 # cnsn_forward_fused).  CNSN_FUSE_BLOCK=0 (or setting this to False) keeps the three separate ops.
 FUSE_BLOCK = os.environ.get("CNSN_FUSE_BLOCK", "1") != "0"
+# WideResNet: also hand the NEXT block's relu(bn1(.)) out of the op's launch (CNSN.forward_block_bn, cnsn_forward_bnrelu;
+# SURVEY §8 f1, second half).  CNSN_FUSE_TAIL=0 keeps bn1 / relu1 as separate ops.
+FUSE_TAIL = FUSE_BLOCK and os.environ.get("CNSN_FUSE_TAIL", "1") != "0"
 
 
 def residual_sum(cnsn, pos, residual, skip, relu, skip_first=False):

@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _sites
 from ._sites import CrossNormSites, make_cnsn, residual_sum
 
 
@@ -31,18 +32,28 @@ class _Block(nn.Module):
         self.cnsn = make_cnsn(impl, cnsn_type, crop, beta, width)
         self.pos, self.drop_rate = pos, drop_rate
 
-    def forward(self, x):
+    def cnsn_tail_ok(self):
+        return self.pos == "post" and hasattr(self.cnsn, "forward_block_bn")
+
+    def forward(self, x, pre=None, next_bn=None, want_y=True):
+        """`pre`: relu1(bn1(x)) when the PREVIOUS block's CNSN launch already produced it (SURVEY §8 f1, second half);
+        `next_bn`: the bn1 of the block that follows (the network's last bn1 after the last block) — then this block
+        returns `(y, z)` with z = relu(next_bn(y)) from its own CNSN launch (`CNSN.forward_block_bn`), y = None when
+        `want_y` is False (the next block only consumes z: its widths differ, wideresnet_cnsn.py:69-70)."""
         if not self.same_width:
-            x = self.relu1(self.bn1(x))
+            x = pre if pre is not None else self.relu1(self.bn1(x))
         h = self.cnsn(x) if self.pos == "pre" else x
         if self.same_width:
-            h = self.relu1(self.bn1(h))
+            h = pre if (pre is not None and self.pos != "pre") else self.relu1(self.bn1(h))
         h = self.relu2(self.bn2(self.conv1(h)))
         if self.drop_rate > 0:
             h = F.dropout(h, p=self.drop_rate, training=self.training)
         h = self.conv2(h)
         skip = x if self.same_width else self.conv_shortcut(x)
-        return residual_sum(self.cnsn, self.pos, h, skip, relu=False, skip_first=True)         # :86-96
+        if next_bn is not None and self.pos == "post" and hasattr(self.cnsn, "forward_block_bn") and h.is_cuda:
+            return self.cnsn.forward_block_bn(skip, h, "pre", next_bn, want_y=want_y)         # torch.add(x, out) -> cnsn -> bn1 -> relu
+        y = residual_sum(self.cnsn, self.pos, h, skip, relu=False, skip_first=True)             # :86-96
+        return y if next_bn is None else (y, None)
 
 
 class _Stage(nn.Module):
@@ -73,6 +84,7 @@ class WideResNetCNSN(nn.Module, CrossNormSites):
         self.relu = nn.ReLU(inplace=True)
         self.fc = nn.Linear(w[3], num_classes)
         self.n_channels = w[3]
+        self.pos = pos
         for m in self.modules():                                   # initialisation as :179-187
             if isinstance(m, nn.Conv2d):
                 m.weight.data.normal_(0, math.sqrt(2.0 / (m.kernel_size[0] * m.kernel_size[1] * m.out_channels)))
@@ -86,6 +98,23 @@ class WideResNetCNSN(nn.Module, CrossNormSites):
     def forward(self, x, aug=False):
         if aug:
             self._enable_cross_norm()
-        h = self.block3(self.block2(self.block1(self.conv1(x))))
-        h = F.avg_pool2d(self.relu(self.bn1(h)), 8)
-        return self.fc(h.view(h.size(0), -1))
+        if not (_sites.FUSE_TAIL and self.pos == "post"):
+            h = self.block3(self.block2(self.block1(self.conv1(x))))
+            h = F.avg_pool2d(self.relu(self.bn1(h)), 8)
+            return self.fc(h.view(h.size(0), -1))
+        # every block hands `relu(bn1(.))` of the block that follows (:76-77 / :69-70; after the last one: :222) out of
+        # its own CNSN launch, next to its output; module ownership — and with it every state_dict key — is unchanged
+        blocks = [b for stage in (self.block1, self.block2, self.block3) for b in stage.layer]
+        h, pre = self.conv1(x), None
+        for i, blk in enumerate(blocks):
+            last = i + 1 == len(blocks)
+            nxt = self.bn1 if last else blocks[i + 1].bn1
+            want_y = (not last) and blocks[i + 1].same_width and blocks[i + 1].pos != "pre"   # y is the next shortcut (:93)
+            y, z = blk(h, pre, next_bn=nxt, want_y=want_y or not blk.cnsn_tail_ok())
+            if z is None:                     # (no tail offered at this site this step: the next block does it itself)
+                h, pre = y, None
+                if last:
+                    z = self.relu(self.bn1(y))
+            else:
+                h, pre = (y if y is not None else z), z   # (y None: the next block never looks at h itself)
+        return self.fc(F.avg_pool2d(z, 8).view(z.size(0), -1))

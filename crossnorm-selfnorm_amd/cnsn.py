@@ -185,6 +185,14 @@ class SelfNorm(nn.Module):
         kw = dict(sn_active=True, sn_two=f is not None, sn_training=use_batch, eps_bn=eps, momentum=momentum)
         return kw, g, f
 
+    def _fused_args_peek(self):
+        """the configuration `_fused_args` would return, WITHOUT BatchNorm1d's per-call book-keeping (planning only)"""
+        bn = self.g_bn
+        use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
+        kw = dict(sn_active=True, sn_two=self.f_fc is not None, sn_training=use_batch, eps_bn=float(bn.eps),
+                  momentum=0.0 if bn.momentum is None else float(bn.momentum))
+        return kw, None, None
+
     def forward(self, x):
         kw, g, f = self._fused_args()
         return _F.fused_cnsn(x, FusedConfig(**kw), g=g, f=f)
@@ -247,3 +255,31 @@ class CNSN(nn.Module):
             kw.update(skw)
         cfg = FusedConfig(add_mode=add_mode, relu=bool(relu), **kw)
         return _F.fused_cnsn(x, cfg, perm=perm, chan_perm=chan, g=g, f=f, addend=addend)
+
+    def forward_block_bn(self, x, addend, add_mode, bn, want_y=True):
+        """`y = self(x [+ addend]); z = relu(bn(y))` — the end of one WideResNet block together with the NEXT block's
+        `relu1(bn1(.))` (cifar/wideresnet_cnsn.py:93-96 then :76-77 / :69-70 / :222).  Returns `(y, z)`; `y` is None
+        when `want_y` is False (nothing but the BatchNorm consumes it).  One launch per direction when a fused kernel
+        covers the call (`functional.bnrelu_plan`: SelfNorm alone — the site's CrossNorm idle —, training or eval,
+        planes of at most 64 vectors with the whole channel in one workgroup's registers); otherwise the same three
+        steps as separate calls: `forward_block`, `bn`, ReLU.  BatchNorm2d's per-call book-keeping
+        (`num_batches_tracked`, `momentum=None`) is done here exactly as `nn.BatchNorm2d.forward` does it."""
+        assert add_mode in ("none", "pre")
+        cn, sn = self.crossnorm, self.selfnorm
+        armed = cn is not None and cn.active
+        fused = (type(bn) is nn.BatchNorm2d and bn.affine and bn.track_running_stats and sn is not None
+                 and type(sn) is SelfNorm and sn.f_fc is None and not armed and x.is_cuda
+                 and (cn is None or type(cn) is CrossNorm))
+        if fused:
+            kw, g, _ = sn._fused_args_peek()
+            cfg = FusedConfig(add_mode=add_mode, relu=False, **kw)
+            fused = _F.bnrelu_plan_cached(x, cfg, torch.is_grad_enabled())
+        if not fused:
+            y = self.forward_block(x, addend, add_mode=add_mode, relu=False) if add_mode != "none" else self.forward(x)
+            return (y if want_y else None), torch.relu(bn(y))
+        kw, g, _ = sn._fused_args()
+        bn_batch, bn_eps, bn_mom = SelfNorm._bn_call_state(bn)
+        cfg = FusedConfig(add_mode=add_mode, relu=False, **kw)
+        return _F.fused_cnsn_tail(x, cfg, addend, bool(want_y), g, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                  bn_batch, bn_eps, bn_mom)
+

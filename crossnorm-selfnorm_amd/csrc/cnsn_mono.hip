@@ -113,11 +113,11 @@ int mono_forward(const Plan& pl, const MonoPlan& mp, int add, int relu, const vo
         if (epi) {
             auto kern = mono_fwd_kernel<T, VEC, LPP, RMAX, true>;
             kern<<<mono_grid(pl.pr.C), kMonoBlock, mp.lds, stream>>>(
-                ma, (const T*)x, (const T*)(add == ADD_PRE ? addend : nullptr), (T*)y, g, f, saved, add, relu);
+                ma, (const T*)x, (const T*)(add == ADD_PRE ? addend : nullptr), (T*)y, g, f, saved, add, relu, TailDev{});
         } else {
             auto kern = mono_fwd_kernel<T, VEC, LPP, RMAX, false>;
             kern<<<mono_grid(pl.pr.C), kMonoBlock, mp.lds, stream>>>(ma, (const T*)x, nullptr, (T*)y, g, f, saved,
-                                                                                ADD_NONE, 0);
+                                                                                ADD_NONE, 0, TailDev{});
         }
         const hipError_t e = hipGetLastError();
         status = e == hipSuccess ? CNSN_OK : (int)e;
@@ -136,11 +136,11 @@ int mono_backward(const Plan& pl, const MonoPlan& mp, int add, int relu, const v
         if (epi) {
             auto kern = mono_bwd_kernel<T, VEC, LPP, RMAX, true>;
             kern<<<mono_grid(pl.pr.C), kMonoBlock, mp.lds, stream>>>(
-                ma, (const T*)gy, (const T*)x, (const T*)(add == ADD_PRE ? addend : nullptr), (T*)dx, g, f, dg, df, saved, add, relu);
+                ma, (const T*)gy, (const T*)x, (const T*)(add == ADD_PRE ? addend : nullptr), (T*)dx, g, f, dg, df, saved, add, relu, TailDev{});
         } else {
             auto kern = mono_bwd_kernel<T, VEC, LPP, RMAX, false>;
             kern<<<mono_grid(pl.pr.C), kMonoBlock, mp.lds, stream>>>(ma, (const T*)gy, (const T*)x, nullptr, (T*)dx, g, f,
-                                                                                dg, df, saved, ADD_NONE, 0);
+                                                                                dg, df, saved, ADD_NONE, 0, TailDev{});
         }
         const hipError_t e = hipGetLastError();
         status = e == hipSuccess ? CNSN_OK : (int)e;

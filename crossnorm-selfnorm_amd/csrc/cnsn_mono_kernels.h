@@ -140,9 +140,40 @@ struct MonoArgs {
 
 // cap = plane slots of the workgroup = 16 waves * R rows * (64 / LPP) planes per row (>= N): the per-plane LDS arrays are
 // that long, so a slot row past the batch end indexes real (unused) LDS and needs no clamp
-__host__ __device__ inline size_t mono_lds_bytes(int cap, bool backward) {
+// (tail: the BatchNorm2d + ReLU variant keeps one / two more floats per plane)
+__host__ __device__ inline size_t mono_lds_bytes(int cap, bool backward, bool tail = false) {
     const size_t n = (size_t)cap;
-    return (backward ? 7 * n * 4 + 5 * n * 8 : 2 * n * 4) + (size_t)kMonoWaves * 4 * 8 + 16 * 8;
+    return (backward ? (tail ? 9 : 7) * n * 4 + 5 * n * 8 : (tail ? 3 : 2) * n * 4) + (size_t)kMonoWaves * 4 * 8 + 16 * 8;
+}
+
+// TAIL variant of the two kernels (second half): the NEXT block's `relu(bn1(.))` evaluated in the same launch
+// — models/cifar/wideresnet_cnsn.py:93-96 (`out = torch.add(x, out); return self.cnsn(out)`) followed by :69-70 / :76-77
+// (`self.relu1(self.bn1(x))`) and, after the last block, :222.  The whole channel sits in this workgroup, and SelfNorm's
+// output is y = g[n] * X per plane, so BatchNorm2d's batch statistics over (N, H, W) follow from the plane moments already
+// on chip: mean = sum_n g mu / N, E[y^2] = sum_n g^2 (M2/M + mu^2) / N; z = relu(A[n] * X + B) with A = gamma2*rstd2*g,
+// B = beta2 - gamma2*rstd2*mean2 is a second per-plane affine of the registers — one more store stream, no extra read.
+// Backward: both gradients meet in H = Gy + gamma2*rstd2 * (Gz where z > 0), formed on the way in (gamma2, rstd2 and the
+// mask's coefficients are known from the forward), so the kernel still holds two tensors; the BatchNorm2d backward's two
+// channel sums come from two more per-plane sums taken in the same pass, and its x-dependent part folds into the slope
+// of dx (csrc/cnsn_mono_kernels.h, "tail" blocks; algebra in DESIGN.md §4.7).
+struct TailDev {
+    const float* weight;   // (C) BatchNorm2d weight, bias
+    const float* bias;
+    float* run_mean;       // (C) updated in place when training
+    float* run_var;
+    float* stats;          // (2, C) batch mean and rstd the forward used: written forward, read backward
+    float* d_weight;       // (C) backward
+    float* d_bias;
+    void* z;               // forward: second output, same shape as y
+    const void* gz;        // backward: gradient of z
+    float eps, momentum;
+    int training;
+};
+// z-coefficients of one plane — ONE definition for the forward and the backward's mask
+__device__ __forceinline__ void tail_coefs(float g, float gamma2, float beta2, double m2, double r2, float& A, float& B) {
+    const double k = (double)gamma2 * r2;
+    A = (float)(k * (double)g);
+    B = (float)((double)beta2 - k * m2);
 }
 
 // sum of NACC doubles over the whole workgroup (every thread calls it); red: [kMonoWaves][NACC]
@@ -274,10 +305,10 @@ struct MonoGeom {
 // ================================================================================================
 // forward
 // ================================================================================================
-template <typename T, int VEC, int LPP, int RMAX, bool EPI>
-__global__ __launch_bounds__(kMonoBlock, mono_fwd_waves(RMAX * VEC * (int)sizeof(T) / 4)) void mono_fwd_kernel(MonoArgs ma, const T* __restrict__ x,
+template <typename T, int VEC, int LPP, int RMAX, bool EPI, bool TAIL = false>
+__global__ __launch_bounds__(kMonoBlock, TAIL ? 4 : mono_fwd_waves(RMAX * VEC * (int)sizeof(T) / 4)) void mono_fwd_kernel(MonoArgs ma, const T* __restrict__ x,
                                                                   const T* __restrict__ addend, T* __restrict__ y, GateDev gg,
-                                                                  GateDev gf, double* __restrict__ saved, int add, int relu) {
+                                                                  GateDev gf, double* __restrict__ saved, int add, int relu, TailDev tl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MidArgs a = ma.mid;
     a.sn_two = 0;  // (the host does not send the two-gate form here)
@@ -289,7 +320,8 @@ __global__ __launch_bounds__(kMonoBlock, mono_fwd_waves(RMAX * VEC * (int)sizeof
     char* lds = smem;
     float* pmu = (float*)lds;  // [N] mean, later slope
     float* pm2 = pmu + npad;    // [N] M2, later offset
-    double* red = (double*)(pm2 + npad);
+    float* pza = pm2 + (TAIL ? npad : 0);  // [N] TAIL: slope of z
+    double* red = (double*)(pza + npad);
     double* par = red + kMonoWaves * 4;  // [16] per-channel parameters
     const size_t P = (size_t)N * C;
     MonoGeom<T, VEC, LPP> g(ma);
@@ -309,6 +341,12 @@ __global__ __launch_bounds__(kMonoBlock, mono_fwd_waves(RMAX * VEC * (int)sizeof
             par[9] = gf.beta[c];
             par[10] = gf.run_mean[c];
             par[11] = gf.run_var[c];
+        }
+        if constexpr (TAIL) {
+            par[12] = tl.weight[c];
+            par[13] = tl.bias[c];
+            par[14] = tl.run_mean[c];
+            par[15] = tl.run_var[c];
         }
     }
 
@@ -424,8 +462,58 @@ __global__ __launch_bounds__(kMonoBlock, mono_fwd_waves(RMAX * VEC * (int)sizeof
             saved[sv_at(p, SV_ZH_F)] = zhf;
             if (a.save_coefs) store_fwd_coefs(saved, p, cf);
         }
-        pmu[n] = cf.a_in;  // SelfNorm alone: y = a_in * x + b_in  (xr = 0)
-        pm2[n] = cf.b_in;
+        if constexpr (!TAIL) {
+            pmu[n] = cf.a_in;  // SelfNorm alone: y = a_in * x + b_in  (xr = 0)
+            pm2[n] = cf.b_in;
+        }
+    }
+    float zb = 0.f;
+    if constexpr (TAIL) {
+        // ---- BatchNorm2d over (N, H, W) of y = g * X (wideresnet_cnsn.py:76-77): batch statistics from the plane moments
+        float gt_ = 0.f;
+        double ty[2] = {0.0, 0.0};
+        if (act) {
+            const double zhg = (zg - mg) * rg;  // (the same expressions as above: the gate of this thread's plane)
+            gt_ = sigmoid_r<Rr>((Rr)(par[2] * zhg + par[3]));
+            const double mu = (double)f.mu_p, gd = (double)gt_;
+            ty[0] = gd * mu;
+            ty[1] = gd * gd * ((double)pm2[n] / (double)a.M + mu * mu);
+        }
+        double m2, r2;
+        if (tl.training) {
+            mono_block_sum<2>(ty, red);
+            m2 = ty[0] * a.inv_n;
+            double v2 = ty[1] * a.inv_n - m2 * m2;
+            v2 = v2 > 0.0 ? v2 : 0.0;
+            r2 = (double)__builtin_amdgcn_rsqf((float)(v2 + (double)tl.eps));
+            if (threadIdx.x == 0) {
+                const double cnt = (double)N * (double)a.M, mom_ = tl.momentum;
+                tl.run_mean[c] = (float)((1.0 - mom_) * par[14] + mom_ * m2);
+                tl.run_var[c] = (float)((1.0 - mom_) * par[15] + mom_ * v2 * (cnt / (cnt - 1.0)));
+            }
+        } else {
+            m2 = par[14];
+            r2 = (double)__builtin_amdgcn_rsqf((float)par[15] + tl.eps);
+            __syncthreads();  // (pm2 is read above and rewritten below, as in the training branch's reduction)
+        }
+        if (threadIdx.x == 0 && tl.stats) {
+            tl.stats[c] = (float)m2;
+            tl.stats[C + c] = (float)r2;
+        }
+        // (r2 travels as a float: the backward rebuilds the SAME coefficients from tl.stats)
+        const double m2f = (double)(float)m2, r2f = (double)(float)r2;
+        float za = 0.f;
+        tail_coefs(gt_, (float)par[12], (float)par[13], m2f, r2f, za, zb);
+        if (act) {
+            pmu[n] = gt_;  // y = g * X
+            pm2[n] = 0.f;
+            pza[n] = za;
+            if (saved) {   // the backward's mask re-evaluates z = A * X + B with exactly these numbers
+                const SvRec p = sv_rec(n, c, N);
+                saved[sv_at(p, SV_FC0 + FC_A_IN)] = za;
+                saved[sv_at(p, SV_FC0 + FC_B_IN)] = zb;
+            }
+        }
     }
     __syncthreads();
 
@@ -444,7 +532,14 @@ __global__ __launch_bounds__(kMonoBlock, mono_fwd_waves(RMAX * VEC * (int)sizeof
                 ov[q] = fmaf(ca, melem<T, VEC>(d[r], q), cb);
                 if constexpr (EPI) ov[q] = relu ? fmaxf(ov[q], 0.f) : ov[q];
             }
-            mstore<T, VEC>(g.rsrc(y, c, r), g.off(r), mpack<T, VEC>(ov));
+            if (!TAIL || y) mstore<T, VEC>(g.rsrc(y, c, r), g.off(r), mpack<T, VEC>(ov));
+            if constexpr (TAIL) {  // z = relu(bn1(y)) from the same registers
+                const float za = pza[pn];
+                float oz[VEC];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) oz[q] = fmaxf(fmaf(za, melem<T, VEC>(d[r], q), zb), 0.f);
+                mstore<T, VEC>(g.rsrc((T*)tl.z, c, r), g.off(r), mpack<T, VEC>(oz));
+            }
         }
     }
     }  // (a workgroup past the end of its XCD's range has nothing to do)
@@ -453,11 +548,11 @@ __global__ __launch_bounds__(kMonoBlock, mono_fwd_waves(RMAX * VEC * (int)sizeof
 // ================================================================================================
 // backward
 // ================================================================================================
-template <typename T, int VEC, int LPP, int RMAX, bool EPI>
+template <typename T, int VEC, int LPP, int RMAX, bool EPI, bool TAIL = false>
 __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const T* __restrict__ gy, const T* __restrict__ x,
                                                                   const T* __restrict__ addend, T* __restrict__ dx, GateDev gg,
                                                                   GateDev gf, GateGradDev dgr, GateGradDev dfr,
-                                                                  const double* __restrict__ saved, int add, int relu) {
+                                                                  const double* __restrict__ saved, int add, int relu, TailDev tl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MidArgs a = ma.mid;
     a.sn_two = 0;  // (the host does not send the two-gate form here: the second gate's state would cost ~20 VGPRs)
@@ -474,7 +569,9 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
     float* ps2 = ps1 + npad;    // [N] sum G * (x - mu)              -> later cX
     float* pxr = ps2 + npad;
     float* pc0 = pxr + npad;
-    double* red = (double*)(pc0 + npad);
+    float* pb1 = pc0 + (TAIL ? npad : 0);   // [N] TAIL: sum of the masked Gz
+    float* pb2 = pb1 + (TAIL ? npad : 0);   // [N] TAIL: sum of the masked Gz * (X - mu)
+    double* red = (double*)(pb2 + npad);
     double* psv = red + kMonoWaves * 4;  // [5][N] the five rows of `saved` the algebra needs (parked in LDS: the
                                          // registers belong to the planes until the sums are done)
     const size_t P = (size_t)N * C;
@@ -493,20 +590,27 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
         psv[3 * npad + n] = saved[sv_at(pme, SV_G)];
         psv[4 * npad + n] = saved[sv_at(pme, SV_ZH_G)];
         psi[n] = (float)mu;
-        if (EPI && relu) {
+        if ((EPI && relu) || TAIL) {  // (TAIL: the coefficients of z = A * X + B, for ITS ReLU mask)
             pfa[n] = (float)saved[sv_at(pme, SV_FC0 + FC_A_IN)];
             pfb[n] = (float)saved[sv_at(pme, SV_FC0 + FC_B_IN)];
         }
     }
     const float w_g0 = gg.w[2 * c], w_g1 = gg.w[2 * c + 1], gam_g = gg.gamma[c];
     const double rs_g = saved[SV_ROWS * P + c];
+    double t_m2 = 0.0, t_r2 = 1.0, t_gam = 0.0;
+    if constexpr (TAIL) {
+        t_m2 = (double)tl.stats[c];
+        t_r2 = (double)tl.stats[C + c];
+        t_gam = (double)tl.weight[c];
+    }
 
     // ---- the only reads of G and x (+ addend)
     MRaw<T, VEC> dg_[RMAX], dx_[RMAX];
 #pragma unroll
     for (int r = 0; r < RMAX; ++r)
     {
-        dg_[r] = mload<T, VEC>(g.rsrc(gy, c, r), g.off(r));
+        // (TAIL: y may have had no consumer of its own — a NULL gradient is a zero gradient)
+        dg_[r] = mload<T, VEC>(g.rsrc(gy, c, r), (!TAIL || gy) ? g.off(r) : 0x7ffffff8);
         dx_[r] = mload<T, VEC>(g.rsrc(x, c, r), g.off(r));
     }
     if constexpr (EPI) {
@@ -526,6 +630,39 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
     }
     __syncthreads();  // psi / pfa / pfb are staged
     g.refresh();
+    if constexpr (TAIL) {
+        // ---- the gradient of z joins: H = Gy + gamma2 * rstd2 * (Gz where z > 0), z re-evaluated with the forward's own
+        //      coefficients; the BatchNorm2d backward's two sums over the masked Gz are taken on the way
+        const float kz = (float)(t_gam * t_r2);
+        constexpr int CH = (RMAX * VEC * (int)sizeof(T) > 64) ? RMAX / 2 : RMAX;  // bound the transient registers
+#pragma unroll
+        for (int r0 = 0; r0 < RMAX; r0 += CH) {
+            MRaw<T, VEC> q[CH];
+#pragma unroll
+            for (int r = 0; r < CH; ++r) q[r] = mload<T, VEC>(g.rsrc((const T*)tl.gz, c, r0 + r), g.off(r0 + r));
+#pragma unroll
+            for (int r = 0; r < CH; ++r) {
+                const int pn = g.plane(r0 + r);
+                const float za = pfa[pn], zb = pfb[pn], si = psi[pn];
+                float h[VEC], b1 = 0.f, b2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float X = melem<T, VEC>(dx_[r0 + r], e);
+                    const float gz = relu_open_r<T>(fmaf(za, X, zb)) ? melem<T, VEC>(q[r], e) : 0.f;
+                    h[e] = fmaf(kz, gz, melem<T, VEC>(dg_[r0 + r], e));
+                    b1 += gz;  // (lanes that are not ok() loaded zeros)
+                    b2 = fmaf(gz, X - si, b2);
+                }
+                dg_[r0 + r] = mpack<T, VEC>(h);
+                b1 = mono_group_sum<LPP>(b1);
+                b2 = mono_group_sum<LPP>(b2);
+                if (g.vl == 0 && g.ok(r0 + r)) {
+                    pb1[pn] = b1;
+                    pb2[pn] = b2;
+                }
+            }
+        }
+    }
 
     // ---- ReLU mask (forward affine re-evaluated with the coefficients the forward used) and per-plane sums
 #pragma unroll
@@ -579,10 +716,36 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
         r_g = psv[3 * npad + n];
         r_zhg = psv[4 * npad + n];
     }
-    if (act) {
-        sums = fix_sums<Rr>(a, ps1[n], ps2[n], 0.f, 0.f, r_mu, 0.0);
-        gate_dt<Rr>(a, sums, Rr(1), (Rr)r_mu, Rr(0), (Rr)r_mup, (Rr)r_g, (Rr)r_f, dtg, dtf);
+    if (act) sums = fix_sums<Rr>(a, ps1[n], ps2[n], 0.f, 0.f, r_mu, 0.0);
+    double t_q1 = 0.0, t_q2 = 0.0;  // TAIL: gamma2*rstd2 * {sum gz', sum gz'*yhat} / (N*M)
+    if constexpr (TAIL) {
+        // ---- BatchNorm2d backward (wideresnet_cnsn.py:76-77): d bias = sum gz', d weight = sum gz' * yhat with
+        //      yhat = rstd2 * (g * X - mean2); its dependence on the batch statistics changes the gradient reaching y by
+        //      -q1 - q2 * yhat(X): fold that into the plane sums SelfNorm's backward works from
+        double tt[2] = {0.0, 0.0};
+        if (act) {
+            const double b1 = pb1[n], b2 = (double)pb2[n] + ((double)(float)r_mu - r_mu) * (double)pb1[n];
+            tt[0] = b1;
+            tt[1] = r_g * (b2 + r_mu * b1) - t_m2 * b1;
+        }
+        mono_block_sum<2>(tt, red);
+        const double T1 = tt[0], T2 = t_r2 * tt[1];
+        if (threadIdx.x == 0) {
+            tl.d_weight[c] = (float)T2;
+            tl.d_bias[c] = (float)T1;
+        }
+        if (tl.training) {
+            const double inv = a.inv_n / (double)a.M;
+            t_q1 = t_gam * t_r2 * T1 * inv;
+            t_q2 = t_gam * t_r2 * T2 * inv;
+        }
+        if (act) {
+            const double M_ = (double)a.M, M2n = (r_sigp * r_sigp - (double)a.eps_sn) * (M_ - 1.0);
+            sums.S1in = (Rr)((double)sums.S1in - t_q2 * t_r2 * r_g * M_ * r_mu + M_ * (t_q2 * t_r2 * t_m2 - t_q1));
+            sums.S2in = (Rr)((double)sums.S2in - t_q2 * t_r2 * r_g * M2n);
+        }
     }
+    if (act) gate_dt<Rr>(a, sums, Rr(1), (Rr)r_mu, Rr(0), (Rr)r_mup, (Rr)r_g, (Rr)r_f, dtg, dtf);
     double s4[2] = {(double)dtg, (double)dtg * r_zhg};
     mono_block_sum<2>(s4, red);
     BnBwd b{};
@@ -597,7 +760,12 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
                                               (Rr)r_mu, (Rr)r_mup, (Rr)r_sigp, Rr(1), Rr(0));
         sw[0] = (double)o.dz_g * r_mup;
         sw[1] = (double)o.dz_g * r_sigp;
-        const BwdCoefs k = bwd_coefs<Rr>(a, o, Rr(0), Rr(0), (Rr)r_g, Rr(1), (Rr)r_mu, (Rr)r_mup, r_mu, Rr(1), r_mu, Rr(1));
+        BwdCoefs k = bwd_coefs<Rr>(a, o, Rr(0), Rr(0), (Rr)r_g, Rr(1), (Rr)r_mu, (Rr)r_mup, r_mu, Rr(1), r_mu, Rr(1));
+        if constexpr (TAIL) {  // dx = g * (H - q1 - q2 * yhat(X)) + ...: the X term joins the slope, the rest the constant
+            const double e = r_g * r_g * t_q2 * t_r2;
+            k.c0_in = (float)((double)k.c0_in - e * (double)k.xr_in + r_g * (t_q2 * t_r2 * t_m2 - t_q1));
+            k.cX_in = (float)((double)k.cX_in - e);
+        }
         ps1[n] = k.cG_in;  // (every thread read its own ps1 / ps2 before the reduction above)
         ps2[n] = k.cX_in;
         pxr[n] = k.xr_in;

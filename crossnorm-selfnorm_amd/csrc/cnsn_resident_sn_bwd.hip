@@ -10,6 +10,9 @@ int resident_sn_backward(const cnsn_problem_t& p, const MidArgs& mid, int add, i
     if (!sp.ok) return CNSN_E_UNSUPPORTED;
     const bool epi = add != ADD_NONE || relu;
     ResArgs ra = snxhost::make_args(p, mid, sp);
+#ifdef CNSN_PROF  // tuning builds: time stamps land 4 MiB into the workspace (callers size it accordingly)
+    if (getenv("CNSN_PROF")) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
+#endif
     const size_t lds = snxhost::lds_bytes(sp.K, 4 * sp.ppw, sp.npark, true);
     int status = CNSN_E_UNSUPPORTED;
     auto run = [&](auto tt, auto vt, auto nt, auto pt, auto et) {

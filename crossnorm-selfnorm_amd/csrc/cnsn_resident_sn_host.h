@@ -12,10 +12,16 @@ constexpr size_t kLdsPerCu = 160 * 1024;
 
 // planes per wave: the item in flight (x [+ addend]; G, x [+ addend]) has to fit the registers of 3-4 (forward) / 2-3
 // (backward) workgroups per CU next to the kept part of the parked item
+#ifndef SNX_NV2_PPW
+#define SNX_NV2_PPW 4
+#endif
+#ifndef SNX_NV7_PPW16
+#define SNX_NV7_PPW16 2     // 16-bit 56x56 class, forward without epilogue: planes per wave
+#endif
 constexpr int fwd_ppw(int nv, bool epi, int elem_bytes) {
-    return nv == 2 ? 4 : nv == 4 ? (epi ? 2 : 4) : nv == 7 ? ((elem_bytes == 2 && !epi) ? 2 : 1) : 1;
+    return nv == 2 ? SNX_NV2_PPW : nv == 4 ? (epi ? 2 : 4) : nv == 7 ? ((elem_bytes == 2 && !epi) ? SNX_NV7_PPW16 : 1) : 1;
 }
-constexpr int bwd_ppw(int nv, bool, int) { return nv == 2 ? 4 : nv == 4 ? 2 : 1; }
+constexpr int bwd_ppw(int nv, bool, int) { return nv == 2 ? SNX_NV2_PPW : nv == 4 ? 2 : 1; }
 
 // CNSN_SNX=0: never; 2: wherever instantiated (tests); default 1: AUTO rule
 inline int snx_mode() {
@@ -91,6 +97,16 @@ inline SnxPlan plan_impl(const cnsn_problem_t& p, bool boxed, int add, int relu,
     if (np < first_keep) np = first_keep;
     while (np >= first_keep && lds_bytes(sp.K, own, np, backward) > budget) --np;
     if (np < first_keep) return none;
+    // AUTO / forced-resident without CNSN_SNX=2: where these kernels measured faster than the general resident kernels
+    // on MI355X (profiles/r03_sn_cluster.md, same-process A/B): every call WITH the residual-block epilogue (the general
+    // kernels are not pipelined there: 56x56 bf16 block forward -13 %, backward -31 %); without it every class except
+    // the forward of the 16-bit 56x56 class (two planes per wave spill: +12 % against the general pipelined forward),
+    // the forward of the fp32 28x28 class (+8 %) and the backward of the 16-bit 56x56 class at small batches
+    // (N = 96: +17 %, N = 256: -7 %).
+    if (mode != 2 && !epi) {
+        if (!backward && ((eb == 2 && sp.nv == 7) || (eb == 4 && sp.nv == 4))) return none;
+        if (backward && eb == 2 && sp.nv == 7 && p.N < 128) return none;
+    }
     sp.npark = np;
     sp.ok = true;
     return sp;

@@ -25,10 +25,27 @@
 
 namespace cnsn {
 
+// wave-wide sum of doubles: DPP inside the 16-lane rows (both halves moved by v_mov_b32_dpp), v_readlane across the rows —
+// a tenth of the latency of the ds_bpermute butterfly __shfl_xor compiles to (this sits on the publish-to-publish chain)
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_d<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_d<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_d<0x141>(v);  // row_half_mirror
+    v += dpp_d<0x140>(v);  // row_mirror
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 
 constexpr int kSnxVals = 4;  // floats a member publishes per exchange round
@@ -101,8 +118,17 @@ __device__ __forceinline__ void snx_publish(unsigned long long* gran, size_t mem
 // Workgroups per CU the kernels are compiled for, from the register slots (4 VGPRs each) of the item in flight:
 // forward x [+ addend], backward G, x [+ addend].
 constexpr int snx_fwd_inflight(int slots, bool epi) { return (epi ? 2 : 1) * slots; }
+#ifndef SNX_W_SMALL
+#define SNX_W_SMALL 4       // workgroups per CU asked for the smallest items (tuning builds: up to 6)
+#endif
+#ifndef SNX_FWD_W4_MAX
+#define SNX_FWD_W4_MAX 8    // forward: items of at most this many slots in flight are compiled for 4 workgroups per CU
+#endif
 constexpr int snx_fwd_waves(int slots, bool epi, int elem_bytes = 4) {  // (16-bit: unpacking a vector costs 8 more registers)
-    return snx_fwd_inflight(slots, epi) <= (elem_bytes == 2 ? 7 : 8) ? 4 : snx_fwd_inflight(slots, epi) <= 26 ? 3 : 2;
+    return snx_fwd_inflight(slots, epi) <= (elem_bytes == 2 ? 7 : 8) ? SNX_W_SMALL
+           : snx_fwd_inflight(slots, epi) <= SNX_FWD_W4_MAX         ? 4
+           : snx_fwd_inflight(slots, epi) <= 26                     ? 3
+                                                                     : 2;
 }
 constexpr int snx_bwd_inflight(int slots2, bool epi) { return epi ? slots2 + slots2 / 2 : slots2; }  // slots2 = G and x slots
 constexpr int snx_bwd_waves(int slots2, bool epi) { return snx_bwd_inflight(slots2, epi) <= 24 ? 3 : 2; }
@@ -243,6 +269,8 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
     int item = blockIdx.x;
     if (item >= ra.items) return;  // (the grid never exceeds the items)
     int buf = 0;                   // state[buf]: the parked item; state[buf ^ 1]: the item in flight
+    int iter_ = 0;
+    (void)iter_;
     load_item(item);
     stats_publish(item, buf);
     park_item();
@@ -252,6 +280,7 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
         const int c = item / K, k = item - c * K;
         const int next = item + (int)gridDim.x, next2 = next + (int)gridDim.x;
         const bool more = next < ra.items, more2 = next2 < ra.items;  // workgroup-uniform
+        CNSN_STAMP(0);
 
         // ---- per-channel parameters of item t (scalar loads: in flight during the gather)
         const float pgam = gg.gamma[c], pbet = gg.beta[c], prm = gg.run_mean[c], prv = gg.run_var[c];
@@ -274,6 +303,8 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
             }
             return;
         }
+        CNSN_STAMP(1);
+        CNSN_NOTE(6, passes_);
 
         // ---- BatchNorm1d over the batch from the merged partials; gates of this wave's planes
         {
@@ -315,7 +346,9 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
 
         // ---- item t+1 has arrived long ago: its partial goes out BEFORE item t is applied (the barrier inside also
         //      separates this iteration's readers of vals from the next gather)
+        CNSN_STAMP(2);
         if (more) stats_publish(next, buf ^ 1);
+        CNSN_STAMP(3);
 
         // ---- slot by slot: apply item t (the only write of y), park item t+1's slot in its place, send the loads of
         //      item t+2's slot after it.  y = fma(g, X - 0, 0): the one rounding of the reference's x * g (fwd_coefs)
@@ -358,9 +391,11 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
                 }
             }
         }
+        CNSN_STAMP(4);
         if (!more) break;
         buf ^= 1;
         item = next;
+        ++iter_;
     }
 }
 
@@ -521,6 +556,8 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
     int item = blockIdx.x;
     if (item >= ra.items) return;
     int b0 = 0, b1 = 1, b2 = 2;  // state buffers of items t, t+1, t+2
+    int iter_ = 0;
+    (void)iter_;
     load_item(item, b0);
     sums_publish(item, b0);
     park_item();
@@ -530,6 +567,7 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
         const int c = item / K, k = item - c * K;
         const int next = item + (int)gridDim.x, next2 = next + (int)gridDim.x;
         const bool more = next < ra.items, more2 = next2 < ra.items;  // workgroup-uniform
+        CNSN_STAMP(0);
 
         // ---- per-channel parameters of item t (scalar loads: in flight during the gather)
         const float pw0 = gg.w[2 * c], pw1 = gg.w[2 * c + 1], pgam = gg.gamma[c];
@@ -553,6 +591,8 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
             }
             return;
         }
+        CNSN_STAMP(1);
+        CNSN_NOTE(6, passes_);
 
         // ---- batch sums of the BatchNorm backward; dx coefficients of this wave's planes; round B
         const bool reporter = k == c % K;  // the member that writes the channel's parameter gradients
@@ -604,7 +644,9 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
         }
 
         // ---- item t+1 has arrived long ago: its partial sums go out BEFORE item t is applied
+        CNSN_STAMP(2);
         if (more) sums_publish(next, b1);
+        CNSN_STAMP(3);
 
         // ---- slot by slot: apply item t (the only write of dx), park item t+1's slots in its place, send the loads of
         //      item t+2's slots after it
@@ -650,6 +692,7 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
             }
         }
 
+        CNSN_STAMP(4);
         // ---- the reporter's wave 0 collects round B of channel c (4K wave shares), now that its stores are out
         if (reporter && wave == 0) {
             const int total = 4 * K;
@@ -718,6 +761,7 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
             b2 = t;
         }
         item = next;
+        ++iter_;
     }
 }
 

@@ -364,6 +364,161 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
     }
 };
 
+
+// (y, z) = (SelfNorm(x [+ addend]), relu(BatchNorm2d(y))) — cnsn_forward_bnrelu / cnsn_backward_bnrelu: the end of one
+// WideResNet block and the start of the next in one launch per direction (wideresnet_cnsn.py:93-96, :76-77).
+class FusedCNSNTail : public torch::autograd::Function<FusedCNSNTail> {
+   public:
+    // tcfg: [want_y, bn_training]; tf: [bn_eps, bn_momentum]
+    static variable_list forward(AutogradContext* ctx, const Tensor& x_in, std::vector<int64_t> cfg, std::vector<double> fcfg,
+                                 const Tensor& g_w, const Tensor& g_gamma, const Tensor& g_beta, const Tensor& g_rm,
+                                 const Tensor& g_rv, const c10::optional<Tensor>& addend_in, const Tensor& bn_w,
+                                 const Tensor& bn_b, const Tensor& bn_rm, const Tensor& bn_rv, std::vector<int64_t> tcfg,
+                                 std::vector<double> tf) {
+        TORCH_CHECK(x_in.is_cuda() && x_in.dim() == 4, "cnsn_forward_bnrelu: expected an (N, C, H, W) HIP device tensor");
+        const Config c = parse_config(cfg, fcfg);
+        const bool want_y = tcfg[0] != 0, bn_training = tcfg[1] != 0;
+        const c10::DeviceGuard device_guard(x_in.device());
+        const Tensor x = dense(x_in);
+        Tensor addend;
+        if (c.add_mode != CNSN_ADD_NONE) {
+            TORCH_CHECK(addend_in.has_value() && addend_in->is_cuda() && addend_in->sizes() == x.sizes() &&
+                            addend_in->scalar_type() == x.scalar_type(),
+                        "cnsn_forward_bnrelu: the addend must be a device tensor of x's shape and dtype");
+            addend = dense(*addend_in);
+        }
+        cnsn_problem_t prob = make_problem(x, c);
+        const cnsn_epilogue_t epi = make_epilogue(c, addend);
+        const bool has_epi = c.add_mode != CNSN_ADD_NONE;
+        const at::Device dev = x.device();
+        GateTensors gg, bt;
+        gg.init(g_w, g_gamma, g_beta, g_rm, g_rv);
+        bt.init(bn_w, bn_w, bn_b, bn_rm, bn_rv);  // (w slot unused: weight / bias / running buffers of the BatchNorm2d)
+        cnsn_bn_tail_t tail{};
+        tail.struct_bytes = (int32_t)sizeof(cnsn_bn_tail_t);
+        tail.training = bn_training ? 1 : 0;
+        tail.eps = (float)tf[0];
+        tail.momentum = (float)tf[1];
+        tail.weight = bt.gamma.data_ptr<float>();
+        tail.bias = bt.beta.data_ptr<float>();
+        tail.running_mean = bt.rm.data_ptr<float>();
+        tail.running_var = bt.rv.data_ptr<float>();
+        Tensor y = want_y ? at::empty_like(x) : Tensor();
+        Tensor z = at::empty_like(x);
+        const bool need_bwd = cfg[13] != 0;
+        const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
+        const size_t ws_bytes = cnsn_workspace_bytes(&prob);
+        Tensor saved;
+        if (need_bwd && ws_bytes > 0) saved = at::empty({(int64_t)cnsn_saved_floats(&prob)}, fopt);
+        Tensor stats = at::empty({2 * x.size(1)}, fopt);
+        Tensor ws = at::empty({(int64_t)(ws_bytes / 4) + 1}, fopt);
+        hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+        const int st = cnsn_forward_bnrelu(&prob, has_epi ? &epi : nullptr, &tail, x.data_ptr(), &gg.c,
+                                           want_y ? y.data_ptr() : nullptr, z.data_ptr(),
+                                           saved.defined() ? saved.data_ptr<float>() : nullptr, stats.data_ptr<float>(),
+                                           ws.data_ptr(), ws_bytes, (void*)stream);
+        check_status(st, "cnsn_forward_bnrelu");
+        if (c.sn_training) gg.write_back();
+        if (bn_training) bt.write_back();
+        ctx->set_materialize_grads(false);  // an unused y hands an undefined tensor to the backward, not zeros
+        if (need_bwd) {
+            ctx->saved_data["cfg"] = cfg;
+            ctx->saved_data["fcfg"] = fcfg;
+            ctx->saved_data["tcfg"] = tcfg;
+            ctx->saved_data["tf"] = tf;
+            ctx->saved_data["pd"] = std::vector<int64_t>{(int64_t)g_w.scalar_type(), (int64_t)g_gamma.scalar_type(),
+                                                         (int64_t)g_beta.scalar_type(), (int64_t)bn_w.scalar_type(),
+                                                         (int64_t)bn_b.scalar_type()};
+            Tensor none;
+            ctx->save_for_backward({x, saved, addend.defined() ? addend : none, stats, gg.w, gg.gamma, gg.beta, gg.rm, gg.rv,
+                                    bt.gamma, bt.beta, bt.rm, bt.rv});
+        }
+        return want_y ? variable_list{y, z} : variable_list{z};
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const auto sv = ctx->get_saved_variables();
+        const Tensor &x = sv[0], &saved = sv[1], &addend = sv[2], &stats = sv[3];
+        const auto cfg = ctx->saved_data["cfg"].toIntVector();
+        const auto fcfg = ctx->saved_data["fcfg"].toDoubleVector();
+        const auto tcfg = ctx->saved_data["tcfg"].toIntVector();
+        const auto tf = ctx->saved_data["tf"].toDoubleVector();
+        const auto pd = ctx->saved_data["pd"].toIntVector();
+        const Config c = parse_config(cfg, fcfg);
+        const bool want_y = tcfg[0] != 0;
+        cnsn_problem_t prob = make_problem(x, c);
+        const at::Device dev = x.device();
+        const c10::DeviceGuard device_guard(dev);
+        Tensor gy = want_y ? grads[0] : Tensor();
+        Tensor gz = want_y ? grads[1] : grads[0];
+        if (!gz.defined()) gz = at::zeros_like(x);
+        if (gz.scalar_type() != x.scalar_type()) gz = gz.to(x.scalar_type());
+        gz = dense(gz);
+        if (gy.defined()) {
+            if (gy.scalar_type() != x.scalar_type()) gy = gy.to(x.scalar_type());
+            gy = dense(gy);
+        }
+        cnsn_gate_t gg{};
+        gg.fc_weight = sv[4].data_ptr<float>();
+        gg.bn_weight = sv[5].data_ptr<float>();
+        gg.bn_bias = sv[6].data_ptr<float>();
+        gg.running_mean = sv[7].data_ptr<float>();
+        gg.running_var = sv[8].data_ptr<float>();
+        cnsn_bn_tail_t tail{};
+        tail.struct_bytes = (int32_t)sizeof(cnsn_bn_tail_t);
+        tail.training = tcfg[1] != 0 ? 1 : 0;
+        tail.eps = (float)tf[0];
+        tail.momentum = (float)tf[1];
+        tail.weight = sv[9].data_ptr<float>();
+        tail.bias = sv[10].data_ptr<float>();
+        tail.running_mean = sv[11].data_ptr<float>();
+        tail.running_var = sv[12].data_ptr<float>();
+        const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
+        const int64_t Cn = x.size(1);
+        Tensor dx = at::empty_like(x);
+        Tensor flat = at::empty({6 * Cn}, fopt);  // dw (C,1,2) | dgamma | dbeta | d bn weight | d bn bias
+        cnsn_gate_grad_t dg{flat.data_ptr<float>(), flat.data_ptr<float>() + 2 * Cn, flat.data_ptr<float>() + 3 * Cn};
+        const size_t ws_bytes = cnsn_workspace_bytes(&prob);
+        Tensor ws = at::empty({(int64_t)(ws_bytes / 4) + 1}, fopt);
+        const cnsn_epilogue_t epi = make_epilogue(c, addend);
+        hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+        const int st = cnsn_backward_bnrelu(&prob, c.add_mode != CNSN_ADD_NONE ? &epi : nullptr, &tail,
+                                            gy.defined() ? gy.data_ptr() : nullptr, gz.data_ptr(), x.data_ptr(), &gg,
+                                            saved.data_ptr<float>(), stats.data_ptr<float>(), dx.data_ptr(), &dg,
+                                            flat.data_ptr<float>() + 4 * Cn, flat.data_ptr<float>() + 5 * Cn, ws.data_ptr(),
+                                            ws_bytes, (void*)stream);
+        check_status(st, "cnsn_backward_bnrelu");
+        auto cast = [](const Tensor& t, int64_t code) { return (int64_t)t.scalar_type() != code ? t.to((at::ScalarType)code) : t; };
+        Tensor none;
+        //               x   cfg   fcfg  g_w g_gamma g_beta g_rm g_rv addend bn_w bn_b bn_rm bn_rv tcfg tf
+        variable_list out(15, none);
+        out[0] = dx;
+        out[3] = cast(flat.narrow(0, 0, 2 * Cn).view({Cn, 1, 2}), pd[0]);
+        out[4] = cast(flat.narrow(0, 2 * Cn, Cn), pd[1]);
+        out[5] = cast(flat.narrow(0, 3 * Cn, Cn), pd[2]);
+        if (c.add_mode == CNSN_ADD_PRE) out[8] = dx;
+        out[9] = cast(flat.narrow(0, 4 * Cn, Cn), pd[3]);
+        out[10] = cast(flat.narrow(0, 5 * Cn, Cn), pd[4]);
+        return out;
+    }
+};
+
+std::vector<Tensor> fused_cnsn_tail(const Tensor& x, std::vector<int64_t> cfg, std::vector<double> fcfg, const Tensor& g_w,
+                                    const Tensor& g_gamma, const Tensor& g_beta, const Tensor& g_rm, const Tensor& g_rv,
+                                    const c10::optional<Tensor>& addend, const Tensor& bn_w, const Tensor& bn_b,
+                                    const Tensor& bn_rm, const Tensor& bn_rv, std::vector<int64_t> tcfg,
+                                    std::vector<double> tf) {
+    return FusedCNSNTail::apply(x, cfg, fcfg, g_w, g_gamma, g_beta, g_rm, g_rv, addend, bn_w, bn_b, bn_rm, bn_rv, tcfg, tf);
+}
+
+int64_t bnrelu_plan(const Tensor& x, std::vector<int64_t> cfg, std::vector<double> fcfg, bool backward) {
+    const Config c = parse_config(cfg, fcfg);
+    cnsn_problem_t prob = make_problem(x, c);
+    Tensor none;
+    const cnsn_epilogue_t epi = make_epilogue(c, none);
+    return cnsn_bnrelu_plan(&prob, c.add_mode != CNSN_ADD_NONE ? &epi : nullptr, backward ? 1 : 0);
+}
+
 Tensor fused_cnsn(const Tensor& x, std::vector<int64_t> cfg, std::vector<double> fcfg, const c10::optional<Tensor>& perm,
                   const c10::optional<Tensor>& chan, const c10::optional<Tensor>& g_w,
                   const c10::optional<Tensor>& g_gamma, const c10::optional<Tensor>& g_beta,
@@ -380,5 +535,7 @@ Tensor fused_cnsn(const Tensor& x, std::vector<int64_t> cfg, std::vector<double>
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "C++ autograd glue over the C ABI of libcnsn_hip.so";
     m.def("fused_cnsn", &fused_cnsn, "fused CrossNorm+SelfNorm forward (autograd-aware)");
+    m.def("fused_cnsn_tail", &fused_cnsn_tail, "SelfNorm + the next block's BatchNorm2d + ReLU in one launch (autograd-aware)");
+    m.def("bnrelu_plan", &bnrelu_plan, "1 when a fused kernel takes the call");
     m.def("abi_version", []() { return cnsn_abi_version(); });
 }

@@ -370,6 +370,152 @@ class FusedCNSN(torch.autograd.Function):
         return (dx, None, None, None, *out_g, None, None, *out_f, None, None, d_add)
 
 
+def bnrelu_plan(x: torch.Tensor, cfg: FusedConfig, backward: bool = False) -> bool:
+    """True when a fused kernel evaluates `y = CNSN(x [+ addend]); z = relu(BatchNorm2d(y))` in one launch for this
+    tensor / configuration (cnsn_bnrelu_plan)."""
+    prob = _problem(x, cfg)
+    epi = _epilogue(cfg, None) if cfg.has_epilogue else None
+    st = _ffi.lib().cnsn_bnrelu_plan(C.byref(prob), C.byref(epi) if epi else None, int(backward))
+    if st < 0:
+        _ffi.check(st, "cnsn_bnrelu_plan")
+    return st == 1
+
+
+class FusedCNSNTail(torch.autograd.Function):
+    """(y, z) = (SelfNorm(x [+ addend]), relu(BatchNorm2d(SelfNorm(x [+ addend])))) — cnsn_forward_bnrelu /
+    cnsn_backward_bnrelu: the end of one WideResNet block and the start of the next (wideresnet_cnsn.py:93-96,
+    :76-77) in one launch per direction.  `want_y` False: only z is produced (the next block's widths differ, :69-70)."""
+
+    @staticmethod
+    def forward(ctx, x, cfg: FusedConfig, addend, want_y, g_w, g_gamma, g_beta, g_rm, g_rv, bn_w, bn_b, bn_rm, bn_rv,
+                bn_training, bn_eps, bn_momentum):
+        _require_device(x, "cnsn_forward_bnrelu")
+        with torch.cuda.device(x.device):
+            lib = _ffi.lib()
+            _ffi.check_resident_health("cnsn_forward_bnrelu")
+            x = _dense(x)
+            if cfg.add_mode != "none":
+                _require_device(addend, "cnsn_forward_bnrelu(addend)")
+                assert addend.shape == x.shape and addend.dtype == x.dtype, "addend must match x"
+                addend = _dense(addend)
+            else:
+                addend = None
+            prob = _problem(x, cfg)
+            dev = x.device
+            gate = _GateBuffers(g_w, g_gamma, g_beta, g_rm, g_rv)
+            bw, bb = _f32(bn_w), _f32(bn_b)
+            direct = (bn_rm.dtype == torch.float32 and bn_rm.is_contiguous() and bn_rv.dtype == torch.float32
+                      and bn_rv.is_contiguous())
+            rm = bn_rm.detach() if direct else _f32(bn_rm)
+            rv = bn_rv.detach() if direct else _f32(bn_rv)
+            tail = _ffi.BnTail(C.sizeof(_ffi.BnTail), int(bn_training), float(bn_eps), float(bn_momentum), bw.data_ptr(),
+                               bb.data_ptr(), rm.data_ptr(), rv.data_ptr())
+            y = torch.empty_like(x) if want_y else None
+            z = torch.empty_like(x)
+            need_bwd = any(ctx.needs_input_grad)
+            saved_floats, ws_bytes = _sizes(prob)[:2]
+            saved = torch.empty(saved_floats, dtype=torch.float32, device=dev) if need_bwd else None
+            stats = torch.empty(2 * x.shape[1], dtype=torch.float32, device=dev)
+            ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+            epi = _epilogue(cfg, addend) if cfg.has_epilogue else None
+            st = lib.cnsn_forward_bnrelu(C.byref(prob), C.byref(epi) if epi else None, C.byref(tail), _ptr(x),
+                                         C.byref(gate.c), _ptr(y), _ptr(z), _ptr(saved), _ptr(stats), _ptr(ws), ws_bytes,
+                                         _stream(x))
+            _ffi.check(st, "cnsn_forward_bnrelu")
+            if cfg.sn_training:
+                gate.write_back()
+            if bn_training and not direct:
+                bn_rm.copy_(rm)
+                bn_rv.copy_(rv)
+            ctx.set_materialize_grads(False)    # an unused y hands None to the backward, not a tensor of zeros
+            if need_bwd:
+                ctx.cfg, ctx.prob, ctx.gate, ctx.want_y = cfg, prob, gate, want_y
+                ctx.tail_cfg = (bool(bn_training), float(bn_eps), float(bn_momentum))
+                ctx.param_dtypes = (g_w.dtype, g_gamma.dtype, g_beta.dtype, bn_w.dtype, bn_b.dtype)
+                ctx.bn_buffers = (bw, bb, rm, rv)
+                ctx.save_for_backward(x, saved, addend, stats)
+            return (y, z) if want_y else z
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gy, gz = grads if ctx.want_y else (None, grads[0])
+        x, saved, addend, stats = ctx.saved_tensors
+        with torch.cuda.device(x.device):
+            lib = _ffi.lib()
+            cfg, prob, gate = ctx.cfg, ctx.prob, ctx.gate
+            dev = x.device
+            if gz is None:
+                gz = torch.zeros_like(x)
+            gz = _dense(gz.to(x.dtype))
+            if gy is not None:
+                gy = _dense(gy.to(x.dtype))
+            bw, bb, rm, rv = ctx.bn_buffers
+            tr, eps, mom = ctx.tail_cfg
+            tail = _ffi.BnTail(C.sizeof(_ffi.BnTail), int(tr), eps, mom, bw.data_ptr(), bb.data_ptr(), rm.data_ptr(),
+                               rv.data_ptr())
+            Cn = x.shape[1]
+            dx = torch.empty_like(x)
+            flat = torch.empty(6 * Cn, dtype=torch.float32, device=dev)
+            dw, dgam, dbet = flat[:2 * Cn].view(Cn, 1, 2), flat[2 * Cn:3 * Cn], flat[3 * Cn:4 * Cn]
+            dbw, dbb = flat[4 * Cn:5 * Cn], flat[5 * Cn:]
+            gg = _ffi.GateGrad(_ptr(dw), _ptr(dgam), _ptr(dbet))
+            ws_bytes = _sizes(prob)[1]
+            ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+            epi = _epilogue(cfg, addend) if cfg.has_epilogue else None
+            st = lib.cnsn_backward_bnrelu(C.byref(prob), C.byref(epi) if epi else None, C.byref(tail), _ptr(gy), _ptr(gz),
+                                          _ptr(x), C.byref(gate.c), _ptr(saved), _ptr(stats), _ptr(dx), C.byref(gg),
+                                          _ptr(dbw), _ptr(dbb), _ptr(ws), ws_bytes, _stream(x))
+            _ffi.check(st, "cnsn_backward_bnrelu")
+            pd = ctx.param_dtypes
+            outs = [t if t.dtype == pd[i] else t.to(pd[i]) for i, t in enumerate((dw, dgam, dbet, dbw, dbb))]
+            d_add = dx if cfg.add_mode == "pre" else None
+            #       x   cfg   addend want_y  g_w      g_gamma  g_beta  g_rm  g_rv  bn_w     bn_b    bn_rm bn_rv  tr   eps  mom
+            return (dx, None, d_add, None, outs[0], outs[1], outs[2], None, None, outs[3], outs[4], None, None, None, None, None)
+
+
+def _glue_cfg(cfg: FusedConfig, need_bwd: bool):
+    cb = cfg.content_box if cfg.content_box is not None else (-1, -1, -1, -1)
+    sb = cfg.style_box if cfg.style_box is not None else (-1, -1, -1, -1)
+    icfg = [int(cfg.cn_active), *(int(v) for v in cb), *(int(v) for v in sb), int(cfg.sn_active), int(cfg.sn_two),
+            int(cfg.sn_training), _strategy, int(need_bwd), _ADD_MODES[cfg.add_mode], int(cfg.relu)]
+    fcfg = [0.0 if cfg.lam is None else float(cfg.lam), cfg.eps_cn, cfg.eps_sn, cfg.eps_bn, cfg.momentum]
+    return icfg, fcfg
+
+
+_tail_plan_cache = {}
+
+
+def fused_cnsn_tail(x, cfg: FusedConfig, addend, want_y: bool, g: GateParams, bn_w, bn_b, bn_rm, bn_rv, bn_training: bool,
+                    bn_eps: float, bn_momentum: float):
+    """(y or None, z): FusedCNSNTail through the C++ glue when it is built (same C ABI calls, without the Python
+    per-call overhead — WideResNet's step is launch-bound), else through ctypes."""
+    glue = _ffi.glue()
+    if glue is None:
+        out = FusedCNSNTail.apply(x, cfg, addend, bool(want_y), g.fc_weight, g.bn_weight, g.bn_bias, g.running_mean,
+                                  g.running_var, bn_w, bn_b, bn_rm, bn_rv, bn_training, bn_eps, bn_momentum)
+        return out if want_y else (None, out)
+    _require_device(x, "cnsn_forward_bnrelu")
+    _ffi.check_resident_health("cnsn_forward_bnrelu")
+    need_bwd = torch.is_grad_enabled() and (x.requires_grad or any(
+        t is not None and t.requires_grad for t in (g.fc_weight, g.bn_weight, g.bn_bias, bn_w, bn_b, addend)))
+    icfg, fcfg = _glue_cfg(cfg, need_bwd)
+    out = glue.fused_cnsn_tail(x, icfg, fcfg, g.fc_weight, g.bn_weight, g.bn_bias, g.running_mean, g.running_var,
+                               addend if cfg.add_mode != "none" else None, bn_w, bn_b, bn_rm, bn_rv,
+                               [int(want_y), int(bn_training)], [float(bn_eps), float(bn_momentum)])
+    return (out[0], out[1]) if want_y else (None, out[0])
+
+
+def bnrelu_plan_cached(x: torch.Tensor, cfg: FusedConfig, need_bwd: bool) -> bool:
+    """bnrelu_plan for both directions, remembered per (shape, dtype, configuration, strategy): a per-call ctypes
+    round trip is what the fused tail is there to save"""
+    key = (tuple(x.shape), x.dtype, cfg.add_mode, cfg.sn_training, cfg.sn_two, _strategy, need_bwd)
+    hit = _tail_plan_cache.get(key)
+    if hit is None:
+        hit = bnrelu_plan(x, cfg) and (not need_bwd or bnrelu_plan(x, cfg, backward=True))
+        _tail_plan_cache[key] = hit
+    return hit
+
+
 def fused_cnsn(x, cfg: FusedConfig, perm=None, chan_perm=None, g: Optional[GateParams] = None,
                f: Optional[GateParams] = None, addend: Optional[torch.Tensor] = None):
     ga = (g.fc_weight, g.bn_weight, g.bn_bias, g.running_mean, g.running_var) if g else (None,) * 5

@@ -174,6 +174,41 @@ int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, 
                         void* grad_addend, const cnsn_gate_grad_t* dg, const cnsn_gate_grad_t* df,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- the NEXT block's BatchNorm2d + ReLU behind the op (second half) -------------------------
+ * WideResNet ends a block with `out = torch.add(x, out); return self.cnsn(out)` (models/cifar/wideresnet_cnsn.py:93-96)
+ * and starts the next one with `relu1(bn1(.))` on that tensor (:69-70 when the widths differ, :76-77 when they are
+ * equal — then the un-normalised tensor is ALSO the next block's shortcut, :93; after the last block: :222).  These entry
+ * points evaluate   y = CNSN(x [+ addend]),  z = relu(BatchNorm2d(y))   in the op's own launch: the channel's plane
+ * moments are on chip, y is a per-plane multiple of its input, so BatchNorm2d's batch statistics over (N, H, W) follow
+ * algebraically and z is one more store stream; the backward takes the gradients of BOTH outputs.
+ *   - SelfNorm alone (cn_active = 0, one gate); epilogue: add_mode NONE or PRE, relu = 0.  Anything else, and shapes
+ *     no fused kernel covers (cnsn_bnrelu_plan() == 0), return CNSN_E_UNSUPPORTED: the caller then issues
+ *     cnsn_forward_fused and its own BatchNorm2d + ReLU, which is what the reference does.
+ *   - y / grad_y may be NULL: the next block consumes only z when its widths differ (:69-70) and after the last block.
+ *   - bn_stats: float32 (2, C) — the batch mean and rstd BatchNorm2d normalised with; forward writes, backward reads.
+ *   - `saved` from the forward goes to the backward together with the same `tail` parameters (weight unchanged). */
+typedef struct cnsn_bn_tail {
+    int32_t struct_bytes;   /* = sizeof(cnsn_bn_tail_t)                                              */
+    int32_t training;       /* nn.BatchNorm2d mode: 1 = batch statistics + running-buffer update       */
+    float eps;              /* 1e-5                                                                  */
+    float momentum;         /* 0.1                                                                   */
+    const float* weight;    /* (C)                                                                   */
+    const float* bias;      /* (C)                                                                   */
+    float* running_mean;    /* (C) updated in place when training                                    */
+    float* running_var;     /* (C) (takes the unbiased batch variance, like torch)                   */
+} cnsn_bn_tail_t;
+
+/* 1 when a fused kernel takes the call (pure function of the problem), 0 when not, < 0 argument error */
+int cnsn_bnrelu_plan(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int backward);
+int cnsn_forward_bnrelu(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const cnsn_bn_tail_t* tail,
+                        const void* x, const cnsn_gate_t* g, void* y, void* z, float* saved, float* bn_stats,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* d_bn_weight / d_bn_bias: float32 (C), written (not accumulated) */
+int cnsn_backward_bnrelu(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const cnsn_bn_tail_t* tail,
+                         const void* grad_y, const void* grad_z, const void* x, const cnsn_gate_t* g,
+                         const float* saved, const float* bn_stats, void* grad_x, const cnsn_gate_grad_t* dg,
+                         float* d_bn_weight, float* d_bn_bias, void* workspace, size_t workspace_bytes, void* stream);
+
 /* calc_ins_mean_std (models/cnsn.py:8-17): mean and sqrt(unbiased var + eps) of every (n,c)
  * plane, optionally of a box of it (the reference takes the box by slicing, :66,:77).
  * mean_std: float32 (2, N*C) — row 0 the means, row 1 the stds. */
