@@ -1,0 +1,105 @@
+"""The persistent cluster grids next to a FOREIGN persistent kernel (round-2 review, item 3): what a data-parallel rank
+sees while RCCL's channel kernels hold compute units for the length of an all-reduce (the reference's multi-GPU entry is
+imagenet.py:533; one process per GPU here, gradients all-reduced while the backward still launches).
+
+tools/liboccupy.so starts N workgroups on a side stream that each take a whole CU's LDS — nothing of ours fits beside one —
+and spin for 60-80 ms; meanwhile the cluster kernels (general, pipelined, SelfNorm-only, with crop boxes, fused block) run
+on the main stream.  The grids were sized for an idle chip, so part of every grid cannot be resident at first: the launch
+must still complete (clusters are consecutive blocks and blocks are dispatched in order), bit-identically to a quiet run,
+with no time-out.  The slow-down is recorded in gpurun_out/foreign_kernel.json."""
+import ctypes as C
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import cnsn_amd  # noqa: E402
+from tests.golden.gen_golden_fill import fill_sn  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "tools", "liboccupy.so")
+DEV = torch.device("cuda:0")
+
+
+def workload():
+    """a list of closures, each one forward+backward through a different cluster kernel family; returns their outputs"""
+    cases = []
+    for tag, shape, dtype, kind, crop, block in (
+            ("general pipelined f32", (128, 128, 56, 56), torch.float32, "cnsn", "neither", False),
+            ("general boxed f32", (128, 128, 56, 56), torch.float32, "cnsn", "both", False),
+            ("sn-cluster block bf16", (128, 128, 56, 56), torch.bfloat16, "sn", "neither", True),
+            ("sn-cluster block f32 28x28", (128, 256, 28, 28), torch.float32, "sn", "neither", True),
+            ("split 128x128 bf16", (16, 64, 128, 128), torch.bfloat16, "sn", "neither", False)):
+        n, c = shape[:2]
+        g = torch.Generator(device=DEV).manual_seed(len(cases) + 1)
+        x = (torch.randn(shape, device=DEV, generator=g) + 0.3).to(dtype).requires_grad_()
+        b = (torch.randn(shape, device=DEV, generator=g) * 0.5).to(dtype).requires_grad_() if block else None
+        gy = torch.randn(shape, device=DEV, generator=g).to(dtype)
+        cn = cnsn_amd.CrossNorm(crop, 1) if kind != "sn" else None
+        mod = cnsn_amd.CNSN(cn, fill_sn(cnsn_amd.SelfNorm(c), 3, torch.float32)).to(DEV).train()
+        state = {k: v.clone() for k, v in mod.state_dict().items()}
+        draws = cnsn_amd.draw_cn(shape, crop, 1) if cn is not None else None
+
+        def run(mod=mod, x=x, b=b, gy=gy, cn=cn, draws=draws, state=state, block=block):
+            mod.load_state_dict(state)                      # same running statistics every time
+            if cn is not None:
+                cn.active = True
+                cn.next_draws = draws
+            y = mod.forward_block(x, b, add_mode="pre", relu=True) if block else mod(x)
+            grads = torch.autograd.grad(y, [x] + ([b] if block else []) + list(mod.parameters()), gy)
+            return [y.detach()] + [t.detach() for t in grads] + [v.clone() for v in mod.buffers()]
+        cases.append((tag, run))
+    return cases
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="tools/liboccupy.so not built")
+@pytest.mark.parametrize("cus", [16, 64, 128])
+def test_cluster_kernels_next_to_a_foreign_persistent_kernel(cus):
+    occ = C.CDLL(LIB)
+    occ.occupy_launch.restype = C.c_int
+    occ.occupy_launch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    cases = workload()
+    def timed(run, reps=3):                                  # GPU time of `reps` forward+backward calls (HIP events)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        outs = [run() for _ in range(reps)]
+        e1.record()
+        torch.cuda.current_stream().synchronize()
+        return outs, e0.elapsed_time(e1) / reps * 1e-3
+
+    quiet = []
+    for tag, run in cases:                                   # reference + quiet timing
+        run()
+        torch.cuda.synchronize()
+        outs, t = timed(run)
+        quiet.append((outs[0], t))
+    before = cnsn_amd.lib().cnsn_resident_timeouts()
+    side = torch.cuda.Stream(device=DEV)
+    report = []
+    for (tag, run), (want, t_quiet) in zip(cases, quiet):
+        torch.cuda.synchronize()
+        st = occ.occupy_launch(cus, 160 * 1024, 70, C.c_void_p(side.cuda_stream))
+        assert st == 0, st
+        time.sleep(0.002)                                    # the foreign workgroups are on their CUs
+        got, t_busy = timed(run)                             # half a dozen cluster launches while the CUs are held
+        held = not side.query()                              # the foreign kernel was still running when ours finished
+        side.synchronize()
+        for out in got:
+            for a, b in zip(out, want):
+                assert torch.equal(a, b), (cus, tag)
+        report.append({"case": tag, "cus_held": cus, "quiet_ms": round(t_quiet * 1e3, 3), "busy_ms": round(t_busy * 1e3, 3),
+                       "foreign_kernel_outlived_ours": bool(held)})
+        assert held, "the foreign kernel ended before the cluster launches did: nothing was tested"
+    assert cnsn_amd.lib().cnsn_resident_timeouts() == before, "a cluster wait ran out next to the foreign kernel"
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    path = os.path.join(ROOT, "gpurun_out", "foreign_kernel.json")
+    old = json.load(open(path)) if os.path.exists(path) else []
+    json.dump([r for r in old if r.get("cus_held") != cus] + report, open(path, "w"), indent=1)
