@@ -120,7 +120,7 @@ inline ResArgs make_args(const cnsn_problem_t& p, const MidArgs& mid, const SnxP
 
 // exchange areas, in granules of 8 bytes: round A per member, round B per wave (backward only)
 inline size_t tagged_bytes(const cnsn_problem_t& p, int K, bool backward) {
-    return kCtlBytes + (size_t)p.C * K * (backward ? 4 + 8 : 4) * 8 + 512;
+    return kCtlBytes + (size_t)p.C * K * (backward ? 4 + 8 : 4) * 8 + 1024;
 }
 
 }  // namespace snxhost

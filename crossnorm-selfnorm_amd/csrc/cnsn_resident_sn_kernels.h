@@ -139,6 +139,80 @@ constexpr int snx_bwd_keep(int slots2, bool epi) {
                                            : (slots2 < 13 ? slots2 : (snx_bwd_inflight(slots2, epi) > 32 ? 7 : 13));
 }
 
+// Workgroups that share a CU are not served alike: the hardware issues oldest-first, so the workgroup that arrived first
+// on a CU (blockIdx < #CUs) runs its serial sections at full speed while the one that arrived last is starved — measured at
+// (256,512,28,28) bf16: workgroups 0..63 finish their 11 items after 124 us, workgroups 640..703 their 10 items after 157
+// us, and the chip idles towards the end (profiles/r03_sn_cluster.md).  Wave priority by arrival rank evens it out.
+#ifndef SNX_PRIO_MODE
+#define SNX_PRIO_MODE 0
+#endif
+__device__ __forceinline__ void snx_set_priority() {
+#if SNX_PRIO_MODE == 1
+    const int rank = (int)blockIdx.x / 256;  // (256 CUs: the r-th workgroup to arrive on its CU)
+    if (rank == 1) __builtin_amdgcn_s_setprio(1);
+    if (rank >= 2) __builtin_amdgcn_s_setprio(2);
+#elif SNX_PRIO_MODE == 2
+    const int rank = (int)blockIdx.x / 256;
+    if (rank == 1) __builtin_amdgcn_s_setprio(2);
+    if (rank >= 2) __builtin_amdgcn_s_setprio(3);
+#elif SNX_PRIO_MODE == 3
+    const int rank = (int)blockIdx.x / 256;
+    if (rank >= 2) __builtin_amdgcn_s_setprio(1);
+#endif
+}
+
+// ---- dynamic channel assignment ------------------------------------------------------------------------------------------
+// A cluster is K fixed co-resident workgroups (blockIdx / K); WHICH channel it takes next is decided at run time.  Why:
+// workgroups sharing a CU are not served alike — the one that arrived first runs its serial sections at full speed, the
+// last one is starved (measured at (256,512,28,28) bf16: workgroups 0..63 finish 11 items after 124 us, workgroups
+// 640..703 need 157 us for 10, and the chip idles towards the end; wave priorities by arrival rank change nothing:
+// profiles/r03_sn_cluster.md).  With a static round-robin every cluster gets the same number of channels; here the first
+// two rounds are static (cluster q takes channels q and q + #clusters); from then on the cluster's member 0 draws the
+// channel of item s+2 from a counter when it publishes its partial of item s and sends it along in the partial's spare
+// fourth float — the members learn it from the gather of item s they do anyway, exactly when the loads of item s+2 are
+// due (a separate mailbox polled by every wave was tried first: the polling storm on one line per cluster slowed the
+// kernels 3-40x).  Fast clusters simply take more.  Membership never changes: the residency argument of
+// cnsn_resident_kernels.h holds as it is.
+// MEASURED AND SWITCHED OFF (profiles/r03_sn_cluster.md): the draw is an atomic round trip on the publish-to-publish chain of
+// a whole cluster.  56x56 classes (K = 32..64, few clusters): no change (+-1 %); 28x28 classes (K = 16, 48-64 clusters):
+// 2-3x SLOWER even with the counter on a cache line of its own — fast clusters take more, but every cluster waits for its
+// member 0's draw each item.  The static round-robin stays; the option is kept because the measurement is the
+// documentation of where the end-of-kernel idling does NOT get fixed.
+#ifndef SNX_DYNAMIC
+#define SNX_DYNAMIC 0
+#endif
+constexpr int kNoChan = 0x00ffffff;  // "no more channels" (also what a timed-out mailbox read yields)
+
+__device__ __forceinline__ unsigned long long sload_glc_u64(const void* p) {
+    unsigned long long v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
+// one ticket of the launch's counter ({launch tag, count}: nothing to clear between launches).  It lives in the SECOND
+// 128-byte line of the control block: the first one holds the time-out word every waiting wave polls — with the counter
+// next to it a draw took 150-750 us (max 3 ms), the atomic starved by the readers of its line, and a whole cluster waits
+// for its member 0 meanwhile (profiles/r03_sn_cluster.md).
+__device__ __forceinline__ unsigned snx_ticket(unsigned* ctl, unsigned epoch) {
+    gu64* ctr = (gu64*)(ctl + 32);
+    unsigned long long v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        const unsigned cnt = (unsigned)(v >> 32) == epoch ? (unsigned)v : 0u;
+        const unsigned long long want = ((unsigned long long)epoch << 32) | (unsigned long long)(cnt + 1u);
+        if (__hip_atomic_compare_exchange_strong(ctr, &v, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            return cnt;
+    }
+}
+
+// member 0 of a cluster (its wave 0): the channel of the cluster's item after next, out of the launch's counter
+__device__ __forceinline__ int snx_draw_channel(unsigned* ctl, unsigned epoch, int nq, int C) {
+    unsigned t = 0;
+    if ((threadIdx.x & 63) == 0) t = snx_ticket(ctl, epoch);
+    t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+    const long long ch = 2ll * nq + (long long)t;
+    return ch < (long long)C ? (int)ch : kNoChan;
+}
+
 // ================================================================================================
 // forward:  y = act(g[n,c] * (x [+ addend]))
 // ================================================================================================
@@ -165,17 +239,24 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
     const SlotGeom<VEC, NV, false> sg(ra, lane);
     const int voff = lane * VB;
     Raw<T, VEC>* mypark = park + (size_t)wave * NPARK * 64 + lane;  // slot i of this lane: mypark[i * 64]
+    // this workgroup is member k of cluster q_ (fixed); an "item" below is the channel the cluster works on
+    const int q_ = (int)blockIdx.x / K, k = (int)blockIdx.x - q_ * K, nq = (int)gridDim.x / K;
+    auto static_channel = [&](int seq) {
+        const long long ch = (long long)q_ + (long long)seq * nq;
+        return ch < (long long)C ? (int)ch : kNoChan;
+    };
 
     if (threadIdx.x == 0) *gave_up = 0;
     __syncthreads();
     startup_skew(ra);
+    snx_set_priority();
 
     Raw<T, VEC> d[PPW][NV];                       // the item in flight: x, then x + addend
     Raw<T, VEC> da[EPI ? PPW : 1][EPI ? NV : 1];  // its addend planes
     Raw<T, VEC> keep[KEEP];                       // slots of the parked item that did not go to LDS
 
     auto load_item = [&](int item) {
-        const int c = item / K, k = item - c * K;
+        const int c = __builtin_amdgcn_readfirstlane(item);  // (wave-uniform: plane bases and granule addresses stay scalar)
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
             const int n = (k * 4 + wave) * PPW + s;
@@ -194,8 +275,9 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
 
     // statistics of the planes in d (exact two-pass from registers), z of each -> state[buf]; the member's partial batch
     // moments -> the cluster
-    auto stats_publish = [&](int item, int buf) {
-        const int c = item / K, k = item - c * K;
+    // draw: this cluster will work on the item after `item` too, so its member 0 draws the channel of the one after THAT
+    auto stats_publish = [&](int item, int buf, bool draw) {
+        const int c = __builtin_amdgcn_readfirstlane(item);
         const double w0 = gg.w[2 * c], w1 = gg.w[2 * c + 1];
         SnxFwdState* st = state + buf * OWN;
 #pragma unroll
@@ -249,8 +331,12 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
             }
             // true mean of the member = mp + r/cnt, M2 about it = q - r*r/cnt (r is rounding-sized): fold into lo / M2
             const double corr = r * (double)__builtin_amdgcn_rcpf((float)cnt);
-            if (!(ra.fault && item == K - 1))
-                snx_publish(gran, (size_t)c * K + k, ra.epoch, m_hi, (float)((double)m_lo + corr), (float)(q - r * corr), 0.f);
+            float spare = __uint_as_float((unsigned)kNoChan);
+#if SNX_DYNAMIC
+            if (k == 0 && draw) spare = __uint_as_float((unsigned)snx_draw_channel(ctl, ra.epoch, nq, C));
+#endif
+            if (!(ra.fault && c == 0 && k == K - 1))
+                snx_publish(gran, (size_t)c * K + k, ra.epoch, m_hi, (float)((double)m_lo + corr), (float)(q - r * corr), spare);
         }
     };
     auto park_item = [&]() {
@@ -266,20 +352,19 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
             }
     };
 
-    int item = blockIdx.x;
-    if (item >= ra.items) return;  // (the grid never exceeds the items)
+    int item = static_channel(0);
+    if (item == kNoChan) return;   // (the grid never exceeds the items)
     int buf = 0;                   // state[buf]: the parked item; state[buf ^ 1]: the item in flight
-    int iter_ = 0;
-    (void)iter_;
+    int iter_ = 0;                 // the cluster's item number
+    int next = static_channel(1);
     load_item(item);
-    stats_publish(item, buf);
+    stats_publish(item, buf, next != kNoChan);
     park_item();
-    if (item + (int)gridDim.x < ra.items) load_item(item + (int)gridDim.x);
+    if (next != kNoChan) load_item(next);
 
     for (;;) {
-        const int c = item / K, k = item - c * K;
-        const int next = item + (int)gridDim.x, next2 = next + (int)gridDim.x;
-        const bool more = next < ra.items, more2 = next2 < ra.items;  // workgroup-uniform
+        const int c = __builtin_amdgcn_readfirstlane(item);
+        const bool more = next != kNoChan;  // workgroup-uniform
         CNSN_STAMP(0);
 
         // ---- per-channel parameters of item t (scalar loads: in flight during the gather)
@@ -346,14 +431,25 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
 
         // ---- item t+1 has arrived long ago: its partial goes out BEFORE item t is applied (the barrier inside also
         //      separates this iteration's readers of vals from the next gather)
+        // the channel of the cluster's item after next: it came with member 0's partial (static rounds: computed)
+        int next2 = kNoChan;
+        if (more) {
+#if SNX_DYNAMIC
+            next2 = (int)__float_as_uint(vals[3]);
+#else
+            next2 = static_channel(iter_ + 2);
+#endif
+        }
+        next2 = __builtin_amdgcn_readfirstlane(next2);
+        const bool more2 = next2 != kNoChan;
         CNSN_STAMP(2);
-        if (more) stats_publish(next, buf ^ 1);
+        if (more) stats_publish(next, buf ^ 1, more2);
         CNSN_STAMP(3);
 
         // ---- slot by slot: apply item t (the only write of y), park item t+1's slot in its place, send the loads of
         //      item t+2's slot after it.  y = fma(g, X - 0, 0): the one rounding of the reference's x * g (fwd_coefs)
         {
-            const int c2 = next2 / K, k2 = next2 - c2 * K;
+            const int c2 = next2, k2 = k;
 #pragma unroll
             for (int s = 0; s < PPW; ++s) {
                 const int n = (k * 4 + wave) * PPW + s;
@@ -395,6 +491,7 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
         if (!more) break;
         buf ^= 1;
         item = next;
+        next = next2;
         ++iter_;
     }
 }
@@ -434,6 +531,7 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
     if (threadIdx.x == 0) *gave_up = 0;
     __syncthreads();
     startup_skew(ra);
+    snx_set_priority();
 
     Raw<T, VEC> dg_[PPW][NV], dx_[PPW][NV];       // the item in flight
     Raw<T, VEC> da[EPI ? PPW : 1][EPI ? NV : 1];  // its addend planes

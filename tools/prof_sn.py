@@ -67,7 +67,26 @@ def run(which):
     print(f"  {'full cycle':34s} mean {cyc.mean():7.2f} us")
     gap = (t[:, 1:, 0] - t[:, :-1, 4])[okc] * 0.01
     print(f"  {'end of apply -> next top':34s} mean {gap.mean():7.2f} us")
+    if os.environ.get("PROF_PER_WG"):
+        print("  per workgroup: iterations, mean us of the four phases")
+        for wg in range(64):
+            m = ok[wg]
+            if m.any():
+                print(f"    wg {wg:2d} k={wg % int(os.environ['PROF_PER_WG']):2d}: its {int(m.sum()):2d}  " + "  ".join(f"{d[wg, :, i][m].mean():8.1f}" for i in range(4))
+                      + "   max " + "  ".join(f"{d[wg, :, i][m].max():8.1f}" for i in range(4)))
+    # timeline of the recorded workgroups (chip-wide clock): when each iteration starts / ends relative to the first stamp
+    t0 = t[:, :, 0][ok].min()
+    its = int(ok.sum(1).max())
+    print("  iteration: start (mean over WGs, us since the first stamp) / cycle (us)")
+    for i in range(its):
+        m = ok[:, i]
+        if not m.any():
+            continue
+        st_ = (t[:, i, 0][m] - t0) * 0.01
+        en_ = (t[:, i, 4][m] - t0) * 0.01
+        print(f"    it {i:2d}: start {st_.mean():7.1f} (min {st_.min():6.1f} max {st_.max():6.1f})  end {en_.mean():7.1f}  WGs {int(m.sum())}")
 
 
 run("fwd")
-run("bwd")
+if not os.environ.get("PROF_FWD_ONLY"):
+    run("bwd")
