@@ -4,6 +4,7 @@ with torch ops on the activation tensor.  HIP device tensors only — other inpu
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
 
@@ -83,6 +84,12 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
 
+# The module-level caches below are shared by every thread that calls into the library — torch.nn.DataParallel, the
+# reference's own multi-GPU mode (cifar.py:395, imagenet.py:533), runs one Python thread per replica.  Dictionary reads
+# and writes are atomic under the GIL; the read-modify-write sequences (growing the exchange context, taking a slot of
+# the pinned staging ring) hold this lock (tests/test_gpu_threads.py).
+_lock = threading.RLock()
+
 # sizes of the caller-owned side buffers per problem signature (two ctypes calls saved per launch)
 _size_cache = {}
 
@@ -113,6 +120,15 @@ def _context(prob, dev: torch.device):
         return
     have = _contexts.get(dev.index)
     if have is None or have.numel() < need:
+        with _lock:
+            have = _grow_context(need, dev)
+    prob.context = have.data_ptr()
+    prob.context_bytes = have.numel()
+
+
+def _grow_context(need, dev):
+    have = _contexts.get(dev.index)              # (again, under the lock: another thread may have grown it meanwhile)
+    if have is None or have.numel() < need:
         size = max(need, 2 * have.numel() if have is not None else (4 << 20))
         buf = torch.empty(size, dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream(dev)
@@ -122,8 +138,7 @@ def _context(prob, dev: torch.device):
         if have is not None:
             _retired_contexts.append(have)
         _contexts[dev.index] = have = buf
-    prob.context = have.data_ptr()
-    prob.context_bytes = have.numel()
+    return have
 
 
 class _PinnedRing:
@@ -142,9 +157,10 @@ class _PinnedRing:
         if idx.is_cuda:
             return idx.to(device=dev, dtype=torch.int64).contiguous()
         n = idx.numel()
-        ring = self.rings.setdefault((dev.index, n), {"next": 0, "slots": [None] * self.SLOTS})
-        k = ring["next"] % self.SLOTS
-        ring["next"] += 1
+        with _lock:                                   # (one slot per caller: replicas run as threads under DataParallel)
+            ring = self.rings.setdefault((dev.index, n), {"next": 0, "slots": [None] * self.SLOTS})
+            k = ring["next"] % self.SLOTS
+            ring["next"] += 1
         if ring["slots"][k] is None:
             ring["slots"][k] = (torch.empty(n, dtype=torch.int64).pin_memory(), torch.cuda.Event())
         else:

@@ -33,6 +33,8 @@ extern "C" {
 
 #define CNSN_ABI_VERSION 4
 
+/* Element types of the activation tensors.  float64 is NOT offered (the reference's eager path accepts any float tensor,
+ * models/cnsn.py:12-16): CNSN_E_DTYPE here, a TypeError naming the three supported types in the Python layer. */
 enum cnsn_dtype { CNSN_F32 = 0, CNSN_BF16 = 1, CNSN_F16 = 2 };
 
 enum cnsn_status {

@@ -9,8 +9,12 @@ under a second.  AUTO strategy (what a user gets), plus the forced strategies wh
   configs[4]  segmentation, bs 16:     (16,256,128,128) ... (16,2048,64,64); SN at 'residual', CN(crop=style) at 'post'
   image-space CrossNorm (imagenet.py:215,358): (768,3,224,224)
 
-Tolerances (BASELINE.json north_star): fp32 |hip - truth64| <= max(1e-5 * scale, 2 * |oracle32 - truth64|);
-bf16 |hip - oracle32 on the same quantised input| <= 1e-2 * max|oracle32|."""
+Tolerances (BASELINE.json north_star): fp32 |hip - truth64| <= max(1e-5 * scale, 2 * |oracle32 - truth64|) for EVERY output
+(round 3: parameter gradients too — they were held to 1e-4); bf16 |hip - oracle32 on the same quantised input| <= 1e-2 *
+max|oracle32| for y / dx and 1e-3 for the fp32-accumulated parameter gradients and running statistics (round 3: from 5e-2).
+Every comparison records its observed error next to its bound (gpurun_out/parity_margins.jsonl ->
+profiles/r03_parity_margins.md): the worst fp32 error seen is 1.0e-6 of the scale (a tenth of the bound; the
+2 x oracle-noise alternative is never the binding one at these shapes), bf16 y / dx 3.5e-3, bf16 parameter gradients 2e-6."""
 import numpy as np
 import pytest
 import torch
@@ -104,8 +108,7 @@ def check_case(shape, dtype, kind, crop, seed):
         scale = max(1.0, float(truth.abs().max()))
         noise = float((r32 - truth).abs().max())
         if dtype == torch.float32:
-            # parameter gradients are sums over N*M products: 1e-4 like the golden-vector tests
-            rel = 1e-5 if k in ("y", "dx", "rm", "rv") else 1e-4
+            rel = 1e-5        # north_star's fp32 bar, parameter gradients (sums over N*M products) included
             err = float((g_ - truth).abs().max())
             _record({"shape": list(shape), "dtype": "fp32", "kind": kind, "crop": crop, "out": k, "err": err, "scale": scale,
                      "oracle32_noise": noise, "bound": max(rel * scale, 2 * noise), "rel_tol": rel,
@@ -113,12 +116,12 @@ def check_case(shape, dtype, kind, crop, seed):
             assert err <= max(rel * scale, 2 * noise), f"{shape} fp32 {kind}/{crop} {k}: err {err:.3e}, oracle32 noise {noise:.3e}, scale {scale:.3g}"
         else:
             err = float((g_ - r32).abs().max())
-            rel = 1e-2 if k in ("y", "dx") else 5e-2          # (16-bit: sums of rounded products)
+            rel = 1e-2 if k in ("y", "dx") else 1e-3          # (parameter gradients / running statistics accumulate in fp32)
             _record({"shape": list(shape), "dtype": str(dtype).replace("torch.", ""), "kind": kind, "crop": crop, "out": k,
                      "err": err, "scale": max(float(r32.abs().max()), 1e-6),
-                     "bound": rel * max(float(r32.abs().max()), 1e-6) + (0 if k in ("y", "dx") else 1e-3), "rel_tol": rel,
+                     "bound": rel * max(float(r32.abs().max()), 1e-6) + (0 if k in ("y", "dx") else 1e-5), "rel_tol": rel,
                      "strategy": cnsn_amd.functional._strategy})
-            assert err <= rel * max(float(r32.abs().max()), 1e-6) + (0 if k in ("y", "dx") else 1e-3), \
+            assert err <= rel * max(float(r32.abs().max()), 1e-6) + (0 if k in ("y", "dx") else 1e-5), \
                 f"{shape} {dtype} {kind}/{crop} {k}: err {err:.3e} vs max {float(r32.abs().max()):.3e}"
     del got, o32, o64
     torch.cuda.empty_cache()
