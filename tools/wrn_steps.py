@@ -1,5 +1,7 @@
+"""Tuning aid: WideResNet-40-2+CNSN training steps (bs 128, fp32) timed by kind — idle (no CrossNorm site armed), armed, mixed —
+with the device-allocation count of each phase; CNSN_FUSE_TAIL=0/1 compares the fused BatchNorm2d+ReLU tail (profiles/r03_bn_tail.md)."""
 import os, sys, time, torch, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cnsn_amd
 from cnsn_amd.callers import WideResNetCNSN
 dev = torch.device("cuda:0")
