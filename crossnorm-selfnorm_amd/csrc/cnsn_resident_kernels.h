@@ -346,6 +346,23 @@ __device__ __forceinline__ float elem(const Raw<T, VEC>& r, int q) {
             return (float)__builtin_bit_cast(_Float16, h);
     }
 }
+// two floats -> one 32-bit word of two 16-bit elements (lo in bits 0..15), round to nearest even.  Converting the PAIR as
+// a vector lets the compiler pair the arithmetic that feeds it the same way (v_pk_fma_f32 on {lo, hi}) and finish with one
+// v_cvt_pk_bf16_f32 — converting element by element made it pair the even elements of two words and re-interleave the
+// halves afterwards (v_and / v_lshl / 2 v_or_sdwa per word: a third of the apply loops' vector instructions).
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ int pack2(float lo, float hi) {
+    static_assert(sizeof(T) == 2, "16-bit element types");
+    const v2f_t p = {lo, hi};
+    if constexpr (__is_same(T, bf16_t)) {
+        typedef __bf16 v2bf_t __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(int, __builtin_convertvector(p, v2bf_t));
+    } else {
+        typedef _Float16 v2h_t __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(int, __builtin_convertvector(p, v2h_t));
+    }
+}
 template <typename T, int VEC>
 __device__ __forceinline__ Raw<T, VEC> pack(const float (&f)[VEC]) {
     Raw<T, VEC> r;
@@ -354,17 +371,7 @@ __device__ __forceinline__ Raw<T, VEC> pack(const float (&f)[VEC]) {
         for (int q = 0; q < VEC; ++q) r[q] = __float_as_int(f[q]);
     } else {
 #pragma unroll
-        for (int q = 0; q < VEC; q += 2) {
-            unsigned short lo, hi;
-            if constexpr (__is_same(T, bf16_t)) {
-                lo = from_float<bf16_t>(f[q]).bits;
-                hi = from_float<bf16_t>(f[q + 1]).bits;
-            } else {
-                lo = __builtin_bit_cast(unsigned short, from_float<_Float16>(f[q]));
-                hi = __builtin_bit_cast(unsigned short, from_float<_Float16>(f[q + 1]));
-            }
-            r[q >> 1] = (int)(((unsigned)hi << 16) | (unsigned)lo);
-        }
+        for (int q = 0; q < VEC; q += 2) r[q >> 1] = pack2<T>(f[q], f[q + 1]);
     }
     return r;
 }

@@ -13,7 +13,7 @@ int resident_sn_backward(const cnsn_problem_t& p, const MidArgs& mid, int add, i
 #ifdef CNSN_PROF  // tuning builds: time stamps land 4 MiB into the workspace (callers size it accordingly)
     if (getenv("CNSN_PROF")) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
 #endif
-    const size_t lds = snxhost::lds_bytes(sp.K, 4 * sp.ppw, sp.npark, true);
+    const size_t lds = snxhost::lds_bytes(sp.K, 4 * sp.ppw, sp.npark, true, sp.vec * elem_bytes(p.dtype));
     int status = CNSN_E_UNSUPPORTED;
     auto run = [&](auto tt, auto vt, auto nt, auto pt, auto et) {
         using T = typename decltype(tt)::type;
@@ -39,9 +39,9 @@ int resident_sn_backward(const cnsn_problem_t& p, const MidArgs& mid, int add, i
             status = (int)e;
             return;
         }
-        kern<<<grid, kBlock, lds, stream>>>(ra, sp.npark, (const T*)gy, (const T*)x,
-                                            (const T*)(add == ADD_PRE ? addend : nullptr), relu, (T*)dx, g, dg, gran, gran_b,
-                                            saved, ctl);
+        const SnxBwdKargs<T> ka{ra, sp.npark, (const T*)gy, (const T*)x, (const T*)(add == ADD_PRE ? addend : nullptr), relu,
+                                (T*)dx, g, dg, gran, gran_b, saved, ctl};
+        kern<<<grid, kBlock, lds, stream>>>(ka);
         e = hipGetLastError();
         status = e == hipSuccess ? CNSN_OK : (int)e;
     };

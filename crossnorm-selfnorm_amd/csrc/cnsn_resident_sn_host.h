@@ -18,10 +18,22 @@ constexpr size_t kLdsPerCu = 160 * 1024;
 #ifndef SNX_NV7_PPW16
 #define SNX_NV7_PPW16 2     // 16-bit 56x56 class, forward without epilogue: planes per wave
 #endif
-constexpr int fwd_ppw(int nv, bool epi, int elem_bytes) {
-    return nv == 2 ? SNX_NV2_PPW : nv == 4 ? (epi ? 2 : 4) : nv == 7 ? ((elem_bytes == 2 && !epi) ? SNX_NV7_PPW16 : 1) : 1;
+#ifndef SNX_NV1_PPW8
+#define SNX_NV1_PPW8 16     // one-slot planes of 8-byte vectors (16-bit 14x14): planes per wave
+#endif
+#ifndef SNX_NV1_PPW
+#define SNX_NV1_PPW 8       // one-slot planes of 16-byte vectors (fp32 14x14)
+#endif
+constexpr int fwd_ppw(int nv, bool epi, int elem_bytes, int vb = 16) {
+    return nv == 1   ? (vb == 8 ? SNX_NV1_PPW8 : SNX_NV1_PPW)
+           : nv == 2 ? SNX_NV2_PPW
+           : nv == 4 ? (epi ? 2 : 4)
+           : nv == 7 ? ((elem_bytes == 2 && !epi) ? SNX_NV7_PPW16 : 1)
+                     : 1;
 }
-constexpr int bwd_ppw(int nv, bool, int) { return nv == 2 ? SNX_NV2_PPW : nv == 4 ? 2 : 1; }
+constexpr int bwd_ppw(int nv, bool epi, int, int vb = 16) {  // (one-slot planes with the epilogue: 3 x 16 planes in flight do not fit)
+    return nv == 1 ? (vb == 8 ? (epi ? SNX_NV1_PPW8 / 2 : SNX_NV1_PPW8) : SNX_NV1_PPW) : nv == 2 ? SNX_NV2_PPW : nv == 4 ? 2 : 1;
+}
 
 // CNSN_SNX=0: never; 2: wherever instantiated (tests); default 1: AUTO rule
 inline int snx_mode() {
@@ -46,14 +58,27 @@ bool dispatch_snx(int dtype, int vec, int nv, F&& f) {
             default: return false;
         }
     };
+    // one-slot planes (33..64 vectors, the 14x14 class): many planes per wave
+    auto one_slot = [&](auto tt, auto vt) -> bool {
+        using T = typename decltype(tt)::type;
+        constexpr int EB = (int)sizeof(T), VB = decltype(vt)::value * EB;
+        f(tt, vt, IntTag<1>{}, IntTag<(BWD ? bwd_ppw(1, EPI, EB, VB) : fwd_ppw(1, EPI, EB, VB))>{});
+        return true;
+    };
+    if (nv == 1) {
+        if (dtype == CNSN_F32 && vec == 4) return one_slot(TypeTag<float>{}, IntTag<4>{});
+        if (dtype == CNSN_BF16 && vec == 4) return one_slot(TypeTag<bf16_t>{}, IntTag<4>{});
+        if (dtype == CNSN_F16 && vec == 4) return one_slot(TypeTag<_Float16>{}, IntTag<4>{});
+        return false;
+    }
     if (dtype == CNSN_F32 && vec == 4) return by_nv(TypeTag<float>{}, IntTag<4>{});
     if (dtype == CNSN_BF16 && vec == 8) return by_nv(TypeTag<bf16_t>{}, IntTag<8>{});
     if (dtype == CNSN_F16 && vec == 8) return by_nv(TypeTag<_Float16>{}, IntTag<8>{});
     return false;
 }
 
-inline size_t lds_bytes(int K, int own, int np, bool backward) {
-    return backward ? snx_bwd_lds_bytes(K, own, np, 16) : snx_fwd_lds_bytes(K, own, np, 16);
+inline size_t lds_bytes(int K, int own, int np, bool backward, int vb) {
+    return backward ? snx_bwd_lds_bytes(K, own, np, vb) : snx_fwd_lds_bytes(K, own, np, vb);
 }
 
 inline SnxPlan plan_impl(const cnsn_problem_t& p, bool boxed, int add, int relu, bool backward) {
@@ -70,11 +95,14 @@ inline SnxPlan plan_impl(const cnsn_problem_t& p, bool boxed, int add, int relu,
     const int M = p.H * p.W, eb = elem_bytes(p.dtype);
     SnxPlan sp = none;
     sp.vec = pick_vec(p.dtype, M);
-    if (sp.vec * eb != 16) return none;
+    if ((size_t)p.N * p.C * M * eb >= ((size_t)1 << 31)) return none;  // one descriptor per tensor: see PlaneIo
+    const int vb = sp.vec * eb;
     const int nvec = M / sp.vec;
-    if (nvec <= 64) return none;  // one-slot planes: the channel-in-registers kernels' domain
+    // 16-byte vectors; one-slot planes (the 14x14 class) also with 8-byte ones.  Planes of at most 32 vectors stay with
+    // the channel-in-registers kernels
+    if (!(vb == 16 || (vb == 8 && nvec <= 64 && eb == 2)) || nvec <= 32) return none;
     const int need = (nvec + 63) / 64;
-    for (const int nv : {2, 4, 7, 8, 13, 16})
+    for (const int nv : {1, 2, 4, 7, 8, 13, 16})
         if (nv >= need) {
             sp.nv = nv;
             break;
@@ -82,20 +110,20 @@ inline SnxPlan plan_impl(const cnsn_problem_t& p, bool boxed, int add, int relu,
     if (sp.nv == 0) return none;
     if (backward && epi && sp.nv == 16) return none;
     if (mode != 2 && (sp.nv - need) * 4 > need) return none;  // a register bucket far larger than the plane
-    sp.ppw = backward ? bwd_ppw(sp.nv, epi, eb) : fwd_ppw(sp.nv, epi, eb);
+    sp.ppw = backward ? bwd_ppw(sp.nv, epi, eb, vb) : fwd_ppw(sp.nv, epi, eb, vb);
     const int own = 4 * sp.ppw;
     sp.K = (p.N + own - 1) / own;
     if (sp.K > 2 * reshost::cu_count() || sp.K > 1024) return none;
     const int slots = (backward ? 2 : 1) * sp.ppw * sp.nv;
-    const int wg_per_cu = backward ? snx_bwd_waves(slots, epi) : snx_fwd_waves(slots, epi, eb);
+    const int wg_per_cu = backward ? snx_bwd_waves(slots, epi, vb) : snx_fwd_waves(slots, epi, eb, vb);
     const long grid_max = ((long)wg_per_cu * reshost::cu_count() / sp.K) * sp.K;
     if (grid_max < sp.K) return none;
     const size_t budget = (kLdsPerCu / wg_per_cu) & ~(size_t)511;
-    const int first_keep = slots - (backward ? snx_bwd_keep(slots, epi) : snx_fwd_keep(slots));
+    const int first_keep = slots - (backward ? snx_bwd_keep(slots, epi, vb) : snx_fwd_keep(slots, vb));
     int np = slots;
     if (!backward && sp.ppw == 1 && nvec % 64 != 0 && nvec % 64 <= 32) np = slots - 1;  // a last, partly filled slot stays in registers
     if (np < first_keep) np = first_keep;
-    while (np >= first_keep && lds_bytes(sp.K, own, np, backward) > budget) --np;
+    while (np >= first_keep && lds_bytes(sp.K, own, np, backward, vb) > budget) --np;
     if (np < first_keep) return none;
     // AUTO / forced-resident without CNSN_SNX=2: where these kernels measured faster than the general resident kernels
     // on MI355X (profiles/r03_sn_cluster.md, same-process A/B): every call WITH the residual-block epilogue (the general

@@ -75,13 +75,11 @@ __host__ __device__ inline size_t snx_fwd_lds_bytes(int K, int own, int parked_s
     return (size_t)4 * 64 * parked_slots * vec_bytes  // parked item: [wave][slot][lane]
            + align16((size_t)K * kSnxVals * 4)        // vals[K][4]
            + (size_t)2 * own * sizeof(SnxFwdState)    // own planes of the parked item / the item in flight
-           + align16((size_t)own * 4)                 // gates of the parked item's planes
            + 16;                                      // "this workgroup gave up" flag
 }
 __host__ __device__ inline size_t snx_bwd_lds_bytes(int K, int own, int parked_slots, int vec_bytes) {
     return (size_t)4 * 64 * parked_slots * vec_bytes + align16((size_t)K * kSnxVals * 4)
-           + (size_t)3 * own * sizeof(SnxBwdState)    // items t, t+1, t+2
-           + align16((size_t)own * 4 * 4)             // dx coefficients of the parked item's planes
+           + (size_t)2 * own * sizeof(SnxBwdState)    // items t, t+1 (the rows of item t+2 wait in registers)
            + 16;
 }
 
@@ -117,26 +115,31 @@ __device__ __forceinline__ void snx_publish(unsigned long long* gran, size_t mem
 
 // Workgroups per CU the kernels are compiled for, from the register slots (4 VGPRs each) of the item in flight:
 // forward x [+ addend], backward G, x [+ addend].
-constexpr int snx_fwd_inflight(int slots, bool epi) { return (epi ? 2 : 1) * slots; }
+// (slots of 8-byte vectors — one-slot planes such as 14x14 in 16 bits — count half: vb = bytes per vector)
+constexpr int snx_fwd_inflight(int slots, bool epi, int vb = 16) { return (epi ? 2 : 1) * slots * vb / 16; }
 #ifndef SNX_W_SMALL
 #define SNX_W_SMALL 4       // workgroups per CU asked for the smallest items (tuning builds: up to 6)
 #endif
 #ifndef SNX_FWD_W4_MAX
 #define SNX_FWD_W4_MAX 8    // forward: items of at most this many slots in flight are compiled for 4 workgroups per CU
 #endif
-constexpr int snx_fwd_waves(int slots, bool epi, int elem_bytes = 4) {  // (16-bit: unpacking a vector costs 8 more registers)
-    return snx_fwd_inflight(slots, epi) <= (elem_bytes == 2 ? 7 : 8) ? SNX_W_SMALL
-           : snx_fwd_inflight(slots, epi) <= SNX_FWD_W4_MAX         ? 4
-           : snx_fwd_inflight(slots, epi) <= 26                     ? 3
-                                                                     : 2;
+constexpr int snx_fwd_waves(int slots, bool epi, int elem_bytes = 4, int vb = 16) {  // (16-bit: unpacking a vector costs 8 more registers)
+    return snx_fwd_inflight(slots, epi, vb) <= (elem_bytes == 2 ? 7 : 8) ? SNX_W_SMALL
+           : snx_fwd_inflight(slots, epi, vb) <= SNX_FWD_W4_MAX         ? 4
+           : snx_fwd_inflight(slots, epi, vb) <= 26                     ? 3
+                                                                         : 2;
 }
-constexpr int snx_bwd_inflight(int slots2, bool epi) { return epi ? slots2 + slots2 / 2 : slots2; }  // slots2 = G and x slots
-constexpr int snx_bwd_waves(int slots2, bool epi) { return snx_bwd_inflight(slots2, epi) <= 24 ? 3 : 2; }
+constexpr int snx_bwd_inflight(int slots2, bool epi, int vb = 16) {  // slots2 = G and x slots
+    return (epi ? slots2 + slots2 / 2 : slots2) * vb / 16;
+}
+constexpr int snx_bwd_waves(int slots2, bool epi, int vb = 16) { return snx_bwd_inflight(slots2, epi, vb) <= 24 ? 3 : 2; }
 // slots of the parked item that may stay in registers (the rest always goes to LDS)
-constexpr int snx_fwd_keep(int slots) { return slots < kPipeKeep ? slots : kPipeKeep; }
-constexpr int snx_bwd_keep(int slots2, bool epi) {
-    return snx_bwd_waves(slots2, epi) == 3 ? (slots2 < 8 ? slots2 : (snx_bwd_inflight(slots2, epi) > 16 ? 4 : 8))
-                                           : (slots2 < 13 ? slots2 : (snx_bwd_inflight(slots2, epi) > 32 ? 7 : 13));
+constexpr int snx_min(int a, int b) { return a < b ? a : b; }
+constexpr int snx_fwd_keep(int slots, int vb = 16) { return snx_min(slots, kPipeKeep * 16 / vb); }
+constexpr int snx_bwd_keep(int slots2, bool epi, int vb = 16) {
+    return snx_min(slots2, (snx_bwd_waves(slots2, epi, vb) == 3 ? (snx_bwd_inflight(slots2, epi, vb) > 16 ? 4 : 8)
+                                                                 : (snx_bwd_inflight(slots2, epi, vb) > 32 ? 7 : 13)) *
+                               16 / vb);
 }
 
 // Workgroups that share a CU are not served alike: the hardware issues oldest-first, so the workgroup that arrived first
@@ -213,31 +216,147 @@ __device__ __forceinline__ int snx_draw_channel(unsigned* ctl, unsigned epoch, i
     return ch < (long long)C ? (int)ch : kNoChan;
 }
 
+// ---- plane access: ONE buffer descriptor per tensor ----------------------------------------------------------------------
+// The general resident kernels build a descriptor per plane and slot (cnsn_resident_kernels.h: 4 SGPRs and 64-bit scalar
+// arithmetic each); with many planes per wave in flight the compiler then spills SGPRs into VGPR lanes, and those
+// v_writelane / v_readlane instructions are VALU issue slots — 35-40 % of the vector instructions of the 28x28 and 14x14
+// kernels of this family (ISA count), on classes whose per-plane fixed cost already sits near the VALU budget of a
+// bandwidth-bound kernel.  Here the descriptor covers the whole (N, C, H, W) tensor and a plane is reached through the
+// instruction's scalar offset (one SGPR, 32-bit arithmetic).  gfx950 range-checks soffset + voffset against num_records
+// (probed: tools/dbg/soffset_probe.hip), so:
+//   * a plane past the batch end, or an empty slot, gets soffset = tensor bytes: loads return zeros, stores are dropped;
+//   * lanes past the end of the plane in its partly filled slot get voffset = tensor bytes (same effect).  Slots are
+//     RIGHT-ALIGNED — slot j holds vectors (j - shift)*64 + lane with shift = NV - slots needed — so that the partly filled
+//     slot is always slot NV-1 and the choice between the two voffset registers is made at compile time;
+//   * everything stays below 2^32 as long as the tensor is smaller than 2 GiB (the plan checks).
+template <typename T, int VEC, int NV>
+struct PlaneIo {
+    static constexpr int VB = VEC * (int)sizeof(T), SLOT = 64 * VB;
+    int voff_full, voff_part;  // per lane
+    int shift, tail;           // wave-uniform: empty leading slots; valid lanes of the last slot (1..64)
+    unsigned dead;             // tensor bytes
+    int lane;
+    __device__ __forceinline__ PlaneIo(const ResArgs& ra, int N, int C, int lane_) : lane(lane_) {
+        const int need = (ra.nvec + 63) >> 6;
+        shift = NV - need;
+        tail = ra.nvec - (need - 1) * 64;
+        dead = (unsigned)N * (unsigned)C * (unsigned)ra.M * (unsigned)sizeof(T);
+        voff_full = lane * VB;
+        voff_part = lane < tail ? lane * VB : (int)dead;
+    }
+    __device__ __forceinline__ __amdgpu_buffer_rsrc_t tensor(const T* base) const {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)dead, 0x00020000);
+    }
+    // byte offset of plane (n, c); `live` false: nothing there (reads zeros, drops stores)
+    __device__ __forceinline__ unsigned plane(int n, int c, int C, int M, bool live) const {
+        return live ? ((unsigned)n * (unsigned)C + (unsigned)c) * (unsigned)M * (unsigned)sizeof(T) : dead;
+    }
+    // the planes (n0 + s, c), s = 0.. of one wave: `span` = offset of the first (or `dead` when the item does not exist),
+    // consecutive ones `stride` = C*M*sizeof(T) apart, the first `nlive` of them inside the batch.  Two scalar instructions
+    // per plane and nothing to keep: the per-plane conditions and offsets of the unrolled loops are NOT worth an SGPR each
+    // (the compiler kept them all and spilled)
+    __device__ __forceinline__ unsigned span(int n0, int c, int C, int M, bool exists) const {
+        return exists ? ((unsigned)n0 * (unsigned)C + (unsigned)c) * (unsigned)M * (unsigned)sizeof(T) : dead;
+    }
+    __device__ __forceinline__ unsigned at(unsigned span_off, unsigned stride, int s, int nlive) const {
+        return (s < nlive ? span_off : dead) + (unsigned)s * stride;  // (dead + s*stride < 2^32: the tensor is below 2 GiB)
+    }
+    __device__ __forceinline__ bool valid(int j) const { return j >= shift && (j < NV - 1 || lane < tail); }
+    __device__ __forceinline__ int voff(int j) const { return j == NV - 1 ? voff_part : voff_full; }
+    __device__ __forceinline__ int soff(unsigned plane_off, int j) const {
+        return (int)(j >= shift ? plane_off + (unsigned)((j - shift) * SLOT) : dead);
+    }
+    __device__ __forceinline__ Raw<T, VEC> load(__amdgpu_buffer_rsrc_t r, unsigned plane_off, int j) const {
+        if constexpr (VB == 16)
+            return __builtin_amdgcn_raw_buffer_load_b128(r, voff(j), soff(plane_off, j), CNSN_RES_LOAD_AUX);
+        else
+            return __builtin_amdgcn_raw_buffer_load_b64(r, voff(j), soff(plane_off, j), CNSN_RES_LOAD_AUX);
+    }
+    // Stores carry the plane offset in the VECTOR offset (one v_add_u32), not in soffset: a 16-byte buffer store with an SGPR
+    // soffset may have its data registers overwritten by the next VALU instruction before it has read them — hipcc pads that
+    // hazard only for stores WITHOUT a register soffset (GCNHazardRecognizer assumes the other form is safe), and on gfx950
+    // it is not: the first two elements of lanes 12-15 of every row of 16 came out as the next slot's numbers, now and then
+    // (tests/test_gpu_sn_cluster.py::test_full_pipeline_many_channels, run-to-run differences).
+    __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, unsigned plane_off, int j, const Raw<T, VEC>& v) const {
+        const int vo = voff(j) + soff(plane_off, j);  // (dead + dead < 2^32)
+        if constexpr (VB == 16)
+            __builtin_amdgcn_raw_buffer_store_b128(v, r, vo, 0, CNSN_RES_STORE_AUX);
+        else
+            __builtin_amdgcn_raw_buffer_store_b64(v, r, vo, 0, CNSN_RES_STORE_AUX);
+    }
+};
+
 // ================================================================================================
 // forward:  y = act(g[n,c] * (x [+ addend]))
 // ================================================================================================
+// ---- kernel arguments are read where they are used --------------------------------------------------------------------------
+// These kernels have more wave-uniform state than the 102 SGPRs of a wave: ~46 dwords of ResArgs, a dozen pointers, the
+// tensor descriptors, the item bookkeeping, the per-plane conditions of the unrolled loops.  Left to itself the compiler
+// keeps every kernel argument in an SGPR from the first instruction to the last and spills the excess into VGPR lanes:
+// 35-40 % of the VALU instructions of the hot loops were v_readlane / v_writelane of spilled scalars (ISA count of the 28x28
+// and 14x14 classes, whose per-plane fixed cost already sits at the VALU budget of a bandwidth-bound kernel).  So the
+// arguments travel as ONE struct, and the code re-reads a field from the kernarg segment (s_load through the scalar cache)
+// at the place that needs it: `kargs_now` hides the pointer behind an empty asm, so the loads can neither be hoisted to the
+// top of the kernel nor merged with earlier ones, and the live ranges stay inside one phase of one iteration.
+template <typename KA>
+__device__ __forceinline__ const KA* kargs_now() {
+    typedef const __attribute__((address_space(4))) KA* KP;
+    KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+#ifndef SNX_NO_LAUNDER
+    asm volatile("" : "+s"(p));
+#endif
+    return (const KA*)p;
+}
+
+// a wave-uniform value the optimiser may not look through: what is computed from it inside a loop stays inside the loop.
+// (Loop-invariant scalars of the unrolled plane loops — "plane s is inside the batch", s * stride — were hoisted out of the
+// item loop, one SGPR or SGPR pair per plane, and spilled; recomputing them costs one scalar instruction each.)
+__device__ __forceinline__ int opaque_s(int v) {
+    v = __builtin_amdgcn_readfirstlane(v);
+#ifndef SNX_NO_OPAQUE
+    asm volatile("" : "+s"(v));
+#endif
+    return v;
+}
+__device__ __forceinline__ unsigned opaque_s(unsigned v) { return (unsigned)opaque_s((int)v); }
+
+template <typename T>
+struct SnxFwdKargs {
+    ResArgs ra;
+    int npark;
+    const T* x;
+    const T* addend;  // PRE addend or null
+    int relu;
+    T* y;
+    GateDev gg;
+    unsigned long long* gran;
+    double* saved;
+    unsigned* ctl;
+};
+
 template <typename T, int VEC, int NV, int PPW, bool EPI>
-__global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T))) void resident_sn_fwd_kernel(
-    ResArgs ra, int npark, const T* __restrict__ x, const T* __restrict__ addend, int relu, T* __restrict__ y, GateDev gg,
-    unsigned long long* __restrict__ gran, double* __restrict__ saved, unsigned* __restrict__ ctl) {
+__global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T), VEC * (int)sizeof(T))) void resident_sn_fwd_kernel(
+    SnxFwdKargs<T>) {
+    using KA = SnxFwdKargs<T>;
+#define KA_ (kargs_now<KA>())
     constexpr int OWN = 4 * PPW;
     constexpr int SLOTS = PPW * NV;
-    constexpr int KEEP = snx_fwd_keep(SLOTS), FIRST_KEEP = SLOTS - KEEP;
     constexpr int VB = VEC * (int)sizeof(T);
-    const int NPARK = __builtin_amdgcn_readfirstlane(npark);  // FIRST_KEEP <= NPARK <= SLOTS
+    constexpr int KEEP = snx_fwd_keep(SLOTS, VB), FIRST_KEEP = SLOTS - KEEP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const MidArgs a = ra.mid;
-    const int N = a.N, C = a.C, K = ra.K;
+    // resident for the whole kernel: the geometry, the tensor descriptors, the item bookkeeping
+    const KA* ka0 = KA_;
+    const int NPARK_ = __builtin_amdgcn_readfirstlane(ka0->npark), NPARK = NPARK_;  // FIRST_KEEP <= NPARK <= SLOTS
+    const int N = ka0->ra.mid.N, C = ka0->ra.mid.C, K = ka0->ra.K, M = ka0->ra.M;
+    const bool has_add = EPI && ka0->addend != nullptr;
     Raw<T, VEC>* park = (Raw<T, VEC>*)smem;
     float* vals = (float*)(smem + (size_t)4 * 64 * NPARK * VB);
     SnxFwdState* state = (SnxFwdState*)((char*)vals + align16((size_t)K * kSnxVals * 4));  // [2][OWN]
-    float* gate = (float*)(state + 2 * OWN);
-    int* gave_up = (int*)((char*)gate + align16((size_t)OWN * 4));
+    int* gave_up = (int*)(state + 2 * OWN);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t P = (size_t)N * C;
-    const SlotGeom<VEC, NV, false> sg(ra, lane);
-    const int voff = lane * VB;
+    const PlaneIo<T, VEC, NV> sg(ka0->ra, N, C, lane);
+    const __amdgpu_buffer_rsrc_t rx = sg.tensor(ka0->x), ry = sg.tensor(ka0->y), radd = sg.tensor(has_add ? ka0->addend : ka0->x);
     Raw<T, VEC>* mypark = park + (size_t)wave * NPARK * 64 + lane;  // slot i of this lane: mypark[i * 64]
     // this workgroup is member k of cluster q_ (fixed); an "item" below is the channel the cluster works on
     const int q_ = (int)blockIdx.x / K, k = (int)blockIdx.x - q_ * K, nq = (int)gridDim.x / K;
@@ -245,10 +364,19 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
         const long long ch = (long long)q_ + (long long)seq * nq;
         return ch < (long long)C ? (int)ch : kNoChan;
     };
+    // this wave's planes of ANY item: n0 .. n0 + PPW - 1, the first `nlive` of them inside the batch
+    const int n0 = (k * 4 + wave) * PPW;
+    const int nlive = N - n0 < 0 ? 0 : (N - n0 > PPW ? PPW : N - n0);
+    const unsigned stride = (unsigned)C * (unsigned)M * (unsigned)sizeof(T);
+#ifdef CNSN_PROF
+    struct {
+        unsigned long long* prof;
+    } ra{ka0->ra.prof};
+#endif
 
     if (threadIdx.x == 0) *gave_up = 0;
     __syncthreads();
-    startup_skew(ra);
+    startup_skew(ka0->ra);
     snx_set_priority();
 
     Raw<T, VEC> d[PPW][NV];                       // the item in flight: x, then x + addend
@@ -256,19 +384,17 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
     Raw<T, VEC> keep[KEEP];                       // slots of the parked item that did not go to LDS
 
     auto load_item = [&](int item) {
-        const int c = __builtin_amdgcn_readfirstlane(item);  // (wave-uniform: plane bases and granule addresses stay scalar)
+        const int c = __builtin_amdgcn_readfirstlane(item);  // (wave-uniform: plane offsets and granule addresses stay scalar)
+        const unsigned span = sg.span(n0, c, C, M, true);
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
-            const int n = (k * 4 + wave) * PPW + s;
-            const size_t off = ((size_t)(n < N ? n : 0) * C + c) * ra.M;
-            const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;  // past the batch end: every lane reads zeros
+            const unsigned off = sg.at(span, stride, s, nlive);  // past the batch end: every lane reads zeros
 #pragma unroll
-            for (int j = 0; j < NV; ++j) d[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(x + off, pbytes, j), voff);
+            for (int j = 0; j < NV; ++j) d[s][j] = sg.load(rx, off, j);
             if constexpr (EPI) {
-                const int abytes = addend ? pbytes : 0;
-                const T* ab = addend ? addend + off : x;
+                const unsigned aoff = has_add ? off : sg.dead;
 #pragma unroll
-                for (int j = 0; j < NV; ++j) da[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(ab, abytes, j), voff);
+                for (int j = 0; j < NV; ++j) da[s][j] = sg.load(radd, aoff, j);
             }
         }
     };
@@ -278,12 +404,14 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
     // draw: this cluster will work on the item after `item` too, so its member 0 draws the channel of the one after THAT
     auto stats_publish = [&](int item, int buf, bool draw) {
         const int c = __builtin_amdgcn_readfirstlane(item);
-        const double w0 = gg.w[2 * c], w1 = gg.w[2 * c + 1];
         SnxFwdState* st = state + buf * OWN;
+        const int sl = lane < PPW ? lane : 0;
+        float my_sum = 0.f, my_m2 = 0.f;  // lane s: the sums of this wave's plane s (lanes past PPW: plane 0)
+        const float inv_m = __builtin_amdgcn_rcpf((float)M);
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
             if constexpr (EPI) {
-                if (addend) {  // the op's input is x + addend, rounded to T like the reference's `out += identity`
+                if (has_add) {  // the op's input is x + addend, rounded to T like the reference's `out += identity`
 #pragma unroll
                     for (int j = 0; j < NV; ++j) d[s][j] = add_raw<T, VEC>(d[s][j], da[s][j]);
                 }
@@ -293,7 +421,8 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
             for (int j = 0; j < NV; ++j)
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) sum += elem<T, VEC>(d[s][j], q);
-            const float mean = wave_sum(sum) / (float)ra.M;
+            const float tot = wave_sum(sum);
+            const float mean = tot * inv_m;  // the shift of the second pass (M2 about a point one ulp off the mean is the same number)
             float m2 = 0.f;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
@@ -304,39 +433,65 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
                         m2 = fmaf(t, t, m2);
                     }
                 }
+            m2 = wave_sum(m2);
+            if (sl == s) {
+                my_sum = tot;
+                my_m2 = m2;
+            }
+        }
+        {   // lane s: the plane algebra of plane s — one pass of arithmetic whatever PPW is.  The record is written by lane
+            // s alone (lanes past PPW repeat lane 0's numbers into record 0) and read back by the same lanes, or by wave 0
+            // behind the barrier
+            const KA* ka = KA_;
+            const MidArgs a = ka->ra.mid;
+            const double w0 = ka->gg.w[2 * c], w1 = ka->gg.w[2 * c + 1];
             MomentsT<float> o;
-            o.mu_c = o.mu_s = mean;
-            o.M2c = o.M2s = wave_sum(m2);
+            o.mu_c = o.mu_s = my_sum / (float)M;
+            o.M2c = o.M2s = my_m2;
             o.mu_o = o.M2o = 0.f;
             const FwdPlaneT<float> f = fwd_plane<float>(a, o, 0.f, 0.f);
-            SnxFwdState r;  // (every lane: see SnxFwdState)
+            SnxFwdState r;
             r.z = w0 * (double)f.mu_p + w1 * (double)f.sig_p;
             r.mu = f.mu_p;
             r.sg = f.sig_p;
-            st[wave * PPW + s] = r;
+            st[wave * PPW + sl] = r;
         }
         __syncthreads();
         if (wave == 0) {  // (wave-uniform arithmetic: every lane the same numbers)
             const int cnt = snx_count(N, OWN, k);
-            double m = 0.0;
-            for (int i = 0; i < cnt; ++i) m += st[i].z;
-            m *= (double)__builtin_amdgcn_rcpf((float)cnt);  // (any point near the mean serves: M2 is taken about IT)
-            const float m_hi = (float)m, m_lo = (float)(m - (double)m_hi);
-            const double mp = (double)m_hi + (double)m_lo;
-            double q = 0.0, r = 0.0;
-            for (int i = 0; i < cnt; ++i) {
-                const double t = st[i].z - mp;
-                q += t * t;
-                r += t;
+            double m = 0.0, q = 0.0, r = 0.0, mp;
+            float m_hi, m_lo;
+            if constexpr (OWN <= 8) {  // a handful of planes: a short serial loop beats three wave-wide sums
+                for (int i = 0; i < cnt; ++i) m += st[i].z;
+                m *= (double)__builtin_amdgcn_rcpf((float)cnt);  // (any point near the mean serves: M2 is taken about IT)
+                m_hi = (float)m, m_lo = (float)(m - (double)m_hi);
+                mp = (double)m_hi + (double)m_lo;
+                for (int i = 0; i < cnt; ++i) {
+                    const double t = st[i].z - mp;
+                    q += t * t;
+                    r += t;
+                }
+            } else {  // lane i takes plane i of the member (OWN <= 64)
+                const double zi = lane < cnt ? st[lane < OWN ? lane : 0].z : 0.0;
+                m = wave_sum_d(zi) * (double)__builtin_amdgcn_rcpf((float)cnt);
+                m_hi = (float)m, m_lo = (float)(m - (double)m_hi);
+                mp = (double)m_hi + (double)m_lo;
+                const double t = lane < cnt ? zi - mp : 0.0;
+                q = wave_sum_d(t * t);
+                r = wave_sum_d(t);
             }
             // true mean of the member = mp + r/cnt, M2 about it = q - r*r/cnt (r is rounding-sized): fold into lo / M2
             const double corr = r * (double)__builtin_amdgcn_rcpf((float)cnt);
             float spare = __uint_as_float((unsigned)kNoChan);
+            const KA* ka = KA_;
 #if SNX_DYNAMIC
-            if (k == 0 && draw) spare = __uint_as_float((unsigned)snx_draw_channel(ctl, ra.epoch, nq, C));
+            if (k == 0 && draw) spare = __uint_as_float((unsigned)snx_draw_channel(ka->ctl, ka->ra.epoch, nq, C));
+#else
+            (void)draw;
 #endif
-            if (!(ra.fault && c == 0 && k == K - 1))
-                snx_publish(gran, (size_t)c * K + k, ra.epoch, m_hi, (float)((double)m_lo + corr), (float)(q - r * corr), spare);
+            if (!(ka->ra.fault && c == 0 && k == K - 1))
+                snx_publish(ka->gran, (size_t)c * K + k, ka->ra.epoch, m_hi, (float)((double)m_lo + corr), (float)(q - r * corr),
+                            spare);
         }
     };
     auto park_item = [&]() {
@@ -368,23 +523,31 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
         CNSN_STAMP(0);
 
         // ---- per-channel parameters of item t (scalar loads: in flight during the gather)
-        const float pgam = gg.gamma[c], pbet = gg.beta[c], prm = gg.run_mean[c], prv = gg.run_var[c];
+        float pgam, pbet, prm, prv;
+        {
+            const GateDev gg = KA_->gg;
+            pgam = gg.gamma[c], pbet = gg.beta[c], prm = gg.run_mean[c], prv = gg.run_var[c];
+        }
+        float gate_l = 0.f;  // lane s: the gate of this wave's plane s of item t
 
         // ---- gather the K partials of item t's channel
         unsigned passes_ = 0;
         {
-            const bool got = ra.epoch ? sweep_tagged_scalar(gran + (size_t)c * K * 4, K * 4, vals, ctl, ra.host_flag,
-                                                            ra.wait_ticks, wave, ra.epoch, passes_)
-                                      : sweep_granules_scalar(gran + (size_t)c * K * 2, K * 4, vals, ctl, ra.host_flag,
-                                                              ra.wait_ticks, wave, passes_);
+            const KA* ka = KA_;
+            const unsigned epoch = ka->ra.epoch;
+            const bool got = epoch ? sweep_tagged_scalar(ka->gran + (size_t)c * K * 4, K * 4, vals, ka->ctl, ka->ra.host_flag,
+                                                         ka->ra.wait_ticks, wave, epoch, passes_)
+                                   : sweep_granules_scalar(ka->gran + (size_t)c * K * 2, K * 4, vals, ka->ctl, ka->ra.host_flag,
+                                                           ka->ra.wait_ticks, wave, passes_);
             if (lane == 0 && !got) *gave_up = 1;
         }
         __syncthreads();
         if (*gave_up) {  // (workgroup-uniform) timed out: see sweep_granules
+            T* y = KA_->y;
 #pragma unroll
             for (int s = 0; s < PPW; ++s) {
                 const int n = (k * 4 + wave) * PPW + s;
-                if (n < N && lane == 0) poison_plane<T, VEC>(y + ((size_t)n * C + c) * ra.M);
+                if (n < N && lane == 0) poison_plane<T, VEC>(y + ((size_t)n * C + c) * M);
             }
             return;
         }
@@ -393,38 +556,40 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
 
         // ---- BatchNorm1d over the batch from the merged partials; gates of this wave's planes
         {
+            const KA* ka = KA_;
+            const MidArgs a = ka->ra.mid;
+            double* saved = ka->saved;
             double mg, vg;
             snx_merge(vals, K, N, OWN, a.inv_n, mg, vg);
             // rstd to float accuracy: a uniform scale on the normalised value, and the SAME number reaches the backward
             const double rg = (double)__builtin_amdgcn_rsqf((float)(vg + (double)a.eps_bn));
             if (k == 0 && threadIdx.x == 0) {
                 const double mom_ = a.momentum;
-                gg.run_mean[c] = (float)((1.0 - mom_) * (double)prm + mom_ * mg);
-                gg.run_var[c] = (float)((1.0 - mom_) * (double)prv + mom_ * vg * a.unbias_n);
+                ka->gg.run_mean[c] = (float)((1.0 - mom_) * (double)prm + mom_ * mg);
+                ka->gg.run_var[c] = (float)((1.0 - mom_) * (double)prv + mom_ * vg * a.unbias_n);
                 if (saved) {
+                    const size_t P = (size_t)N * C;
                     saved[SV_ROWS * P + c] = rg;
                     saved[SV_ROWS * P + C + c] = 1.0;
                 }
             }
-            {
-#pragma unroll
-                for (int s = 0; s < PPW; ++s) {
-                    const int n = (k * 4 + wave) * PPW + s;
-                    const SnxFwdState r = state[buf * OWN + wave * PPW + s];
-                    const double zhg = (r.z - mg) * rg;
-                    const float g = sigmoid_r<float>((float)((double)pgam * zhg + (double)pbet));
-                    gate[wave * PPW + s] = g;  // (every lane)
-                    if (saved && n < N && lane == 0) {
-                        const SvRec p = sv_rec(n, c, N);
-                        saved[sv_at(p, SV_MU_C)] = r.mu;
-                        saved[sv_at(p, SV_MU_P)] = r.mu;
-                        saved[sv_at(p, SV_SIG_P)] = r.sg;
-                        saved[sv_at(p, SV_G)] = g;
-                        saved[sv_at(p, SV_ZH_G)] = zhg;
-                        saved[sv_at(p, SV_F)] = 1.0;
-                        saved[sv_at(p, SV_ZH_F)] = 0.0;
-                        if (a.save_coefs) store_fwd_coefs(saved, p, FwdCoefs{g, 0.f, 0.f, g, 0.f});
-                    }
+            {   // lane s < PPW takes plane s of this wave (the others repeat plane 0): the gate stays in a register and is
+                // handed to the apply loop with v_readlane — no LDS, nothing another lane wrote is read
+                const int sl = lane < PPW ? lane : 0;
+                const int n = (k * 4 + wave) * PPW + sl;
+                const SnxFwdState r = state[buf * OWN + wave * PPW + sl];
+                const double zhg = (r.z - mg) * rg;
+                gate_l = sigmoid_r<float>((float)((double)pgam * zhg + (double)pbet));
+                if (saved && n < N && lane < PPW) {   // (consecutive lanes: consecutive doubles of every row)
+                    const SvRec p = sv_rec(n, c, N);
+                    saved[sv_at(p, SV_MU_C)] = r.mu;
+                    saved[sv_at(p, SV_MU_P)] = r.mu;
+                    saved[sv_at(p, SV_SIG_P)] = r.sg;
+                    saved[sv_at(p, SV_G)] = gate_l;
+                    saved[sv_at(p, SV_ZH_G)] = zhg;
+                    saved[sv_at(p, SV_F)] = 1.0;
+                    saved[sv_at(p, SV_ZH_F)] = 0.0;
+                    if (a.save_coefs) store_fwd_coefs(saved, p, FwdCoefs{gate_l, 0.f, 0.f, gate_l, 0.f});
                 }
             }
         }
@@ -449,17 +614,18 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
         // ---- slot by slot: apply item t (the only write of y), park item t+1's slot in its place, send the loads of
         //      item t+2's slot after it.  y = fma(g, X - 0, 0): the one rounding of the reference's x * g (fwd_coefs)
         {
-            const int c2 = next2, k2 = k;
+            const int relu = EPI ? KA_->relu : 0;
+            const unsigned span = sg.span(n0, c, C, M, true), span2 = sg.span(n0, next2, C, M, more2);
+            const unsigned stride_ = opaque_s(stride);
+            const int nlive_ = opaque_s(nlive);
+            const int NPARK = opaque_s(NPARK_);  // (the parked-or-kept choices of the slots: recomputed, not kept)
 #pragma unroll
             for (int s = 0; s < PPW; ++s) {
-                const int n = (k * 4 + wave) * PPW + s;
-                const float a_in = gate[wave * PPW + s];
-                T* yb = y + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
-                const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;  // (a plane past the batch end drops its stores)
-                const int n2 = (k2 * 4 + wave) * PPW + s;
-                const bool live2 = more2 && n2 < N;
-                const size_t off2 = ((size_t)(live2 ? n2 : 0) * C + (more2 ? c2 : 0)) * ra.M;
-                const int pbytes2 = live2 ? ra.M * (int)sizeof(T) : 0;  // nothing to load: zeros, no traffic
+                const float a_in = lane_bcast(gate_l, s);
+                const unsigned yoff = sg.at(span, stride_, s, nlive_);   // (a plane past the batch end drops its stores)
+                const unsigned off2 = sg.at(span2, stride_, s, nlive_);  // nothing to load: zeros, no traffic
+                const unsigned aoff2 = has_add ? off2 : sg.dead;
+                (void)aoff2;
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
                     const int i = s * NV + j;
@@ -474,16 +640,13 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
                         ov[q] = fmaf(a_in, elem<T, VEC>(v, q) - 0.f, 0.f);
                         if constexpr (EPI) ov[q] = relu ? fmaxf(ov[q], 0.f) : ov[q];
                     }
-                    buf_store<T, VEC>(slot_rsrc<T, VEC>(yb, pbytes, j), voff, pack<T, VEC>(ov));
+                    sg.store(ry, yoff, j, pack<T, VEC>(ov));
                     if (i < FIRST_KEEP || i < NPARK)  // park slot i of item t+1 (garbage after the last item: never read)
                         mypark[i * 64] = d[s][j];
                     else
                         keep[i - FIRST_KEEP] = d[s][j];
-                    d[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(x + off2, pbytes2, j), voff);
-                    if constexpr (EPI) {
-                        const int abytes2 = addend ? pbytes2 : 0;
-                        da[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(addend ? addend + off2 : x, abytes2, j), voff);
-                    }
+                    d[s][j] = sg.load(rx, off2, j);
+                    if constexpr (EPI) da[s][j] = sg.load(radd, aoff2, j);
                 }
             }
         }
@@ -494,6 +657,7 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
         next = next2;
         ++iter_;
     }
+#undef KA_
 }
 
 // ================================================================================================
@@ -503,69 +667,101 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
 // every WAVE's partial sums of dz*mean and dz*std over its planes (the Conv1d taps' gradient, cnsn.py:119,137) — only ONE
 // member per channel (rotating) gathers them, AFTER its stores are on their way: nobody else ever waits for them.
 // Slot order of an item: plane s: G slots (s*2*NV + j), then X slots (s*2*NV + NV + j).
+// The `saved` rows of an item's planes are fetched lane-parallel (lane s: plane s of this wave) together with the item's
+// planes, two items ahead, and wait in registers until the item's sums are formed.
+template <typename T>
+struct SnxBwdKargs {
+    ResArgs ra;
+    int npark;
+    const T* gy;
+    const T* x;
+    const T* addend;  // PRE addend or null
+    int relu;
+    T* dx;
+    GateDev gg;
+    GateGradDev dgr;
+    unsigned long long* gran;
+    unsigned long long* gran_b;
+    const double* saved;
+    unsigned* ctl;
+};
+
 template <typename T, int VEC, int NV, int PPW, bool EPI>
-__global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resident_sn_bwd_kernel(
-    ResArgs ra, int npark, const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ addend, int relu,
-    T* __restrict__ dx, GateDev gg, GateGradDev dgr, unsigned long long* __restrict__ gran,
-    unsigned long long* __restrict__ gran_b, const double* __restrict__ saved, unsigned* __restrict__ ctl) {
+__global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int)sizeof(T))) void resident_sn_bwd_kernel(
+    SnxBwdKargs<T>) {
+    using KA = SnxBwdKargs<T>;
+#define KA_ (kargs_now<KA>())
     constexpr int OWN = 4 * PPW;
     constexpr int SLOTS = 2 * PPW * NV;
-    constexpr int KEEP = snx_bwd_keep(SLOTS, EPI), FIRST_KEEP = SLOTS - KEEP;
     constexpr int VB = VEC * (int)sizeof(T);
-    const int NPARK = __builtin_amdgcn_readfirstlane(npark);  // FIRST_KEEP <= NPARK <= SLOTS
+    constexpr int KEEP = snx_bwd_keep(SLOTS, EPI, VB), FIRST_KEEP = SLOTS - KEEP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const MidArgs a = ra.mid;
-    const int N = a.N, C = a.C, K = ra.K;
+    // resident for the whole kernel: the geometry, the tensor descriptors, the item bookkeeping
+    const KA* ka0 = KA_;
+    const int NPARK_ = __builtin_amdgcn_readfirstlane(ka0->npark), NPARK = NPARK_;  // FIRST_KEEP <= NPARK <= SLOTS
+    const int N = ka0->ra.mid.N, C = ka0->ra.mid.C, K = ka0->ra.K, M = ka0->ra.M;
+    const bool has_add = EPI && ka0->addend != nullptr;
     Raw<T, VEC>* park = (Raw<T, VEC>*)smem;
     float* vals = (float*)(smem + (size_t)4 * 64 * NPARK * VB);
-    SnxBwdState* state = (SnxBwdState*)((char*)vals + align16((size_t)K * kSnxVals * 4));  // [3][OWN]
-    float* coef = (float*)(state + 3 * OWN);                                                // [OWN][4]: cG, cX, xr, c0
-    int* gave_up = (int*)((char*)coef + align16((size_t)OWN * 4 * 4));
+    SnxBwdState* state = (SnxBwdState*)((char*)vals + align16((size_t)K * kSnxVals * 4));  // [2][OWN]
+    int* gave_up = (int*)(state + 2 * OWN);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t P = (size_t)N * C;
-    const SlotGeom<VEC, NV, false> sg(ra, lane);
-    const int voff = lane * VB;
+    const PlaneIo<T, VEC, NV> sg(ka0->ra, N, C, lane);
+    const __amdgpu_buffer_rsrc_t t_gy = sg.tensor(ka0->gy), t_x = sg.tensor(ka0->x), t_dx = sg.tensor(ka0->dx),
+                                 t_add = sg.tensor(has_add ? ka0->addend : ka0->x);
     Raw<T, VEC>* mypark = park + (size_t)wave * NPARK * 64 + lane;
+    // this workgroup is member k of cluster q_ (fixed); an "item" below is the channel the cluster works on
+    const int q_ = (int)blockIdx.x / K, k = (int)blockIdx.x - q_ * K, nq = (int)gridDim.x / K;
+    auto static_channel = [&](int seq) {
+        const long long ch = (long long)q_ + (long long)seq * nq;
+        return ch < (long long)C ? (int)ch : kNoChan;
+    };
+    // this wave's planes of ANY item: n0 .. n0 + PPW - 1, the first `nlive` of them inside the batch
+    const int n0 = (k * 4 + wave) * PPW;
+    const int nlive = N - n0 < 0 ? 0 : (N - n0 > PPW ? PPW : N - n0);
+    const unsigned stride = (unsigned)C * (unsigned)M * (unsigned)sizeof(T);
+    const int sl = lane < PPW ? lane : 0;                    // the plane of this wave the lane does the algebra for
+    const int nl = n0 + sl < N ? n0 + sl : (N > 0 ? N - 1 : 0);  // (its batch index, clamped: the rows of a real plane)
+#ifdef CNSN_PROF
+    struct {
+        unsigned long long* prof;
+    } ra{ka0->ra.prof};
+#endif
 
     if (threadIdx.x == 0) *gave_up = 0;
     __syncthreads();
-    startup_skew(ra);
+    startup_skew(ka0->ra);
     snx_set_priority();
 
     Raw<T, VEC> dg_[PPW][NV], dx_[PPW][NV];       // the item in flight
     Raw<T, VEC> da[EPI ? PPW : 1][EPI ? NV : 1];  // its addend planes
     Raw<T, VEC> keep[KEEP > 0 ? KEEP : 1];        // slots of the parked item that did not go to LDS
+    double row_mu = 0.0, row_zh = 0.0, row_g = 0.0, row_sig = 0.0;  // lane s: `saved` rows of plane s of the item in flight
 
-    // `saved` rows of this wave's plane s of an item (wave-uniform loads) -> state[buf]
-    auto fetch_rows = [&](int c, int n, int buf, int s) {
-        const SvRec p = sv_rec((n < N ? n : 0), c, N);
-        SnxBwdState r;
-        r.mu_c = saved[sv_at(p, SV_MU_C)];
-        r.zh = saved[sv_at(p, SV_ZH_G)];
-        r.g = (float)saved[sv_at(p, SV_G)];
-        r.sig_p = (float)saved[sv_at(p, SV_SIG_P)];
-        r.dt = 0.0;
-        r.s1 = r.s2 = 0.f;
-        state[buf * OWN + wave * PPW + s] = r;  // (every lane: see SnxFwdState)
+    auto fetch_rows = [&](int c) {  // (c: any valid channel)
+        const double* saved = KA_->saved;
+        const SvRec p = sv_rec(nl, c, N);
+        row_mu = saved[sv_at(p, SV_MU_C)];
+        row_zh = saved[sv_at(p, SV_ZH_G)];
+        row_g = saved[sv_at(p, SV_G)];
+        row_sig = saved[sv_at(p, SV_SIG_P)];
     };
-    auto load_item = [&](int item, int buf) {
-        const int c = item / K, k = item - c * K;
+    auto load_item = [&](int item) {
+        const int c = __builtin_amdgcn_readfirstlane(item);
+        fetch_rows(c);
+        const unsigned span = sg.span(n0, c, C, M, true);
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
-            const int n = (k * 4 + wave) * PPW + s;
-            fetch_rows(c, n, buf, s);
-            const size_t off = ((size_t)(n < N ? n : 0) * C + c) * ra.M;
-            const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;
+            const unsigned off = sg.at(span, stride, s, nlive);
 #pragma unroll
-            for (int j = 0; j < NV; ++j) dg_[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(gy + off, pbytes, j), voff);
+            for (int j = 0; j < NV; ++j) dg_[s][j] = sg.load(t_gy, off, j);
 #pragma unroll
-            for (int j = 0; j < NV; ++j) dx_[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(x + off, pbytes, j), voff);
+            for (int j = 0; j < NV; ++j) dx_[s][j] = sg.load(t_x, off, j);
             if constexpr (EPI) {
-                const int abytes = addend ? pbytes : 0;
-                const T* ab = addend ? addend + off : x;
+                const unsigned aoff = has_add ? off : sg.dead;
 #pragma unroll
-                for (int j = 0; j < NV; ++j) da[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(ab, abytes, j), voff);
+                for (int j = 0; j < NV; ++j) da[s][j] = sg.load(t_add, aoff, j);
             }
         }
     };
@@ -573,19 +769,22 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
     // per-plane sums of G' against X (shifted by the saved mean, as pass A' does), dt of each plane -> state[buf]; the
     // member's partial batch sums (round A) -> the cluster
     auto sums_publish = [&](int item, int buf) {
-        const int c = item / K, k = item - c * K;
+        const int c = __builtin_amdgcn_readfirstlane(item);
         SnxBwdState* st = state + buf * OWN;
+        const int relu = EPI ? KA_->relu : 0;
+        const float mu_l = (float)row_mu, g_l = (float)row_g;
+        float my_s1 = 0.f, my_s2 = 0.f;
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
-            const double mu_c = st[wave * PPW + s].mu_c;
-            const float g = st[wave * PPW + s].g;
+            const float si = lane_bcast(mu_l, s);  // the saved mean of plane s, rounded as pass A' rounds it
             if constexpr (EPI) {
-                if (addend) {
+                if (has_add) {
 #pragma unroll
                     for (int j = 0; j < NV; ++j) dx_[s][j] = add_raw<T, VEC>(dx_[s][j], da[s][j]);
                 }
                 if (relu) {  // shut the gradient where the forward's output was not positive: the forward affine of a
                              // SelfNorm-only call is y = fma(float(g), X - 0, 0) whichever strategy ran it (fwd_coefs)
+                    const float g = lane_bcast(g_l, s);
 #pragma unroll
                     for (int j = 0; j < NV; ++j) {
                         float gm[VEC];
@@ -598,7 +797,6 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
                     }
                 }
             }
-            const float si = (float)mu_c;
             float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
@@ -611,24 +809,47 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
                     }
                 }
             const float s1 = wave_sum(acc0), s2 = wave_sum(acc1);
-            const BwdSumsT<float> sm = fix_sums<float>(a, s1, s2, 0.f, 0.f, mu_c, 0.0);
+            if (sl == s) {  // lane s keeps the sums of plane s (lanes past PPW: those of plane 0)
+                my_s1 = s1;
+                my_s2 = s2;
+            }
+        }
+        {   // lane s: the gate's dt of plane s — one pass of arithmetic whatever PPW is; the whole record is written by lane
+            // s (lanes past PPW repeat lane 0's numbers into record 0) and read back by the same lanes, or by wave 0 behind
+            // the barrier
+            const MidArgs a = KA_->ra.mid;
+            const BwdSumsT<float> sm = fix_sums<float>(a, my_s1, my_s2, 0.f, 0.f, row_mu, 0.0);
             float dtg, dtf;
-            gate_dt<float>(a, sm, 1.f, si, 0.f, si, g, 1.f, dtg, dtf);
-            st[wave * PPW + s].s1 = s1;  // (every lane)
-            st[wave * PPW + s].s2 = s2;
-            st[wave * PPW + s].dt = (double)dtg;
+            gate_dt<float>(a, sm, 1.f, mu_l, 0.f, mu_l, g_l, 1.f, dtg, dtf);
+            SnxBwdState r;
+            r.mu_c = row_mu;
+            r.zh = row_zh;
+            r.dt = (double)dtg;
+            r.g = g_l;
+            r.sig_p = (float)row_sig;
+            r.s1 = my_s1;
+            r.s2 = my_s2;
+            st[wave * PPW + sl] = r;
         }
         __syncthreads();
-        if (wave == 0) {  // (wave-uniform arithmetic)
+        if (wave == 0) {
             const int cnt = snx_count(N, OWN, k);
             double sa = 0.0, sb = 0.0;
-            for (int i = 0; i < cnt; ++i) {
-                sa += st[i].dt;
-                sb += st[i].dt * st[i].zh;
+            if constexpr (OWN <= 8) {  // (wave-uniform arithmetic)
+                for (int i = 0; i < cnt; ++i) {
+                    sa += st[i].dt;
+                    sb += st[i].dt * st[i].zh;
+                }
+            } else {  // lane i takes plane i of the member (OWN <= 64)
+                const SnxBwdState* ri = st + (lane < OWN ? lane : 0);
+                const double di = lane < cnt ? ri->dt : 0.0;
+                sa = wave_sum_d(di);
+                sb = wave_sum_d(di * ri->zh);
             }
             const float a_hi = (float)sa, b_hi = (float)sb;
-            if (!(ra.fault && item == K - 1))
-                snx_publish(gran, (size_t)c * K + k, ra.epoch, a_hi, (float)(sa - (double)a_hi), b_hi,
+            const KA* ka = KA_;
+            if (!(ka->ra.fault && c == 0 && k == K - 1))
+                snx_publish(ka->gran, (size_t)c * K + k, ka->ra.epoch, a_hi, (float)(sa - (double)a_hi), b_hi,
                             (float)(sb - (double)b_hi));
         }
     };
@@ -646,46 +867,51 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
                     keep[i - FIRST_KEEP] = v;
             }
     };
-    auto parked = [&](int i) -> Raw<T, VEC> {
-        if (i < FIRST_KEEP || i < NPARK) return mypark[i * 64];
-        return keep[i - FIRST_KEEP];
-    };
 
-    int item = blockIdx.x;
-    if (item >= ra.items) return;
-    int b0 = 0, b1 = 1, b2 = 2;  // state buffers of items t, t+1, t+2
+    int item = static_channel(0);
+    if (item == kNoChan) return;  // (the grid never exceeds the items)
+    int b0 = 0;                   // state[b0]: the parked item; state[b0 ^ 1]: the item in flight
     int iter_ = 0;
-    (void)iter_;
-    load_item(item, b0);
+    int next = static_channel(1);
+    load_item(item);
     sums_publish(item, b0);
     park_item();
-    if (item + (int)gridDim.x < ra.items) load_item(item + (int)gridDim.x, b1);
+    if (next != kNoChan) load_item(next);
 
     for (;;) {
-        const int c = item / K, k = item - c * K;
-        const int next = item + (int)gridDim.x, next2 = next + (int)gridDim.x;
-        const bool more = next < ra.items, more2 = next2 < ra.items;  // workgroup-uniform
+        const int c = __builtin_amdgcn_readfirstlane(item);
+        const bool more = next != kNoChan;  // workgroup-uniform
+        const int next2 = __builtin_amdgcn_readfirstlane(more ? static_channel(iter_ + 2) : kNoChan);
+        const bool more2 = next2 != kNoChan;
         CNSN_STAMP(0);
 
         // ---- per-channel parameters of item t (scalar loads: in flight during the gather)
-        const float pw0 = gg.w[2 * c], pw1 = gg.w[2 * c + 1], pgam = gg.gamma[c];
-        const double prs = saved[SV_ROWS * P + c];
+        float pw0, pw1, pgam;
+        double prs;
+        {
+            const KA* ka = KA_;
+            pw0 = ka->gg.w[2 * c], pw1 = ka->gg.w[2 * c + 1], pgam = ka->gg.gamma[c];
+            prs = ka->saved[SV_ROWS * (size_t)N * C + c];
+        }
 
         // ---- gather round A of item t's channel
         unsigned passes_ = 0;
         {
-            const bool got = ra.epoch ? sweep_tagged_scalar(gran + (size_t)c * K * 4, K * 4, vals, ctl, ra.host_flag,
-                                                            ra.wait_ticks, wave, ra.epoch, passes_)
-                                      : sweep_granules_scalar(gran + (size_t)c * K * 2, K * 4, vals, ctl, ra.host_flag,
-                                                              ra.wait_ticks, wave, passes_);
+            const KA* ka = KA_;
+            const unsigned epoch = ka->ra.epoch;
+            const bool got = epoch ? sweep_tagged_scalar(ka->gran + (size_t)c * K * 4, K * 4, vals, ka->ctl, ka->ra.host_flag,
+                                                         ka->ra.wait_ticks, wave, epoch, passes_)
+                                   : sweep_granules_scalar(ka->gran + (size_t)c * K * 2, K * 4, vals, ka->ctl, ka->ra.host_flag,
+                                                           ka->ra.wait_ticks, wave, passes_);
             if (lane == 0 && !got) *gave_up = 1;
         }
         __syncthreads();
         if (*gave_up) {  // (workgroup-uniform) timed out
+            T* dx = KA_->dx;
 #pragma unroll
             for (int s = 0; s < PPW; ++s) {
-                const int n = (k * 4 + wave) * PPW + s;
-                if (n < N && lane == 0) poison_plane<T, VEC>(dx + ((size_t)n * C + c) * ra.M);
+                const int n = n0 + s;
+                if (n < N && lane == 0) poison_plane<T, VEC>(dx + ((size_t)n * C + c) * M);
             }
             return;
         }
@@ -694,7 +920,10 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
 
         // ---- batch sums of the BatchNorm backward; dx coefficients of this wave's planes; round B
         const bool reporter = k == c % K;  // the member that writes the channel's parameter gradients
+        float cG_l, cX_l, xr_l, c0_l;      // lane s: the dx coefficients of this wave's plane s of item t
         {
+            const KA* ka = KA_;
+            const MidArgs a = ka->ra.mid;
             BnBwd b{};
             double sa = 0.0, sb = 0.0;
             for (int l = lane; l < K; l += 64) {
@@ -707,61 +936,66 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
             b.wg1 = pw1;
             b.kg = (double)pgam * prs;
             float pdw0 = 0.f, pdw1 = 0.f;
-#pragma unroll
-            for (int s = 0; s < PPW; ++s) {
-                const int n = (k * 4 + wave) * PPW + s;
-                const SnxBwdState r = state[b0 * OWN + wave * PPW + s];
+            {   // lane s < PPW takes plane s of this wave (the others repeat plane 0); the four dx coefficients stay in
+                // registers and reach the apply loop through v_readlane
+                const SnxBwdState r = state[b0 * OWN + wave * PPW + sl];
                 const float mu = (float)r.mu_c;
                 const BwdSumsT<float> sm = fix_sums<float>(a, r.s1, r.s2, 0.f, 0.f, r.mu_c, 0.0);
                 const BwdPlaneT<float> o =
                     bwd_plane<float>(a, b, sm, r.dt, 0.0, r.zh, 0.0, r.g, 1.f, 1.f, 1.f, mu, mu, r.sig_p, 1.f, 0.f);
                 const BwdCoefs cf = bwd_coefs<float>(a, o, 0.f, 0.f, r.g, 1.f, mu, mu, r.mu_c, 1.f, r.mu_c, 1.f);
-                {
-                    float* oc = coef + (wave * PPW + s) * 4;  // (every lane)
-                    oc[0] = cf.cG_in;
-                    oc[1] = cf.cX_in;
-                    oc[2] = cf.xr_in;
-                    oc[3] = cf.c0_in;
-                }
-                if (n < N) {
-                    pdw0 = fmaf(o.dz_g, mu, pdw0);
-                    pdw1 = fmaf(o.dz_g, r.sig_p, pdw1);
+                cG_l = cf.cG_in;
+                cX_l = cf.cX_in;
+                xr_l = cf.xr_in;
+                c0_l = cf.c0_in;
+                const bool mine = lane < nlive;  // (nlive <= PPW)
+                if constexpr (PPW == 1) {
+                    pdw0 = nlive > 0 ? o.dz_g * mu : 0.f;  // (wave-uniform)
+                    pdw1 = nlive > 0 ? o.dz_g * r.sig_p : 0.f;
+                } else {
+                    pdw0 = wave_sum(mine ? o.dz_g * mu : 0.f);
+                    pdw1 = wave_sum(mine ? o.dz_g * r.sig_p : 0.f);
                 }
             }
             // round B: this wave's share of the taps' gradient (lanes 0 / 1)
             const size_t wm = ((size_t)c * K + k) * 4 + wave;
-            if (ra.epoch) {
-                if (lane < 2) put_tagged(gran_b + wm * 2 + lane, lane == 0 ? pdw0 : pdw1, ra.epoch);
+            const unsigned epoch = ka->ra.epoch;
+            if (epoch) {
+                if (lane < 2) put_tagged(ka->gran_b + wm * 2 + lane, lane == 0 ? pdw0 : pdw1, epoch);
             } else if (lane == 0) {
-                put_granule(gran_b + wm, pdw0, pdw1);
+                put_granule(ka->gran_b + wm, pdw0, pdw1);
             }
             if (reporter && threadIdx.x == 0) {
-                dgr.dgamma[c] = (float)b.s_dtz_g;
-                dgr.dbeta[c] = (float)b.s_dt_g;
+                ka->dgr.dgamma[c] = (float)b.s_dtz_g;
+                ka->dgr.dbeta[c] = (float)b.s_dt_g;
             }
         }
 
         // ---- item t+1 has arrived long ago: its partial sums go out BEFORE item t is applied
         CNSN_STAMP(2);
-        if (more) sums_publish(next, b1);
+        if (more) sums_publish(next, b0 ^ 1);
         CNSN_STAMP(3);
 
         // ---- slot by slot: apply item t (the only write of dx), park item t+1's slots in its place, send the loads of
         //      item t+2's slots after it
         {
-            const int c2 = next2 / K, k2 = next2 - c2 * K;
+            fetch_rows(more2 ? next2 : 0);
+            const unsigned span = sg.span(n0, c, C, M, true), span2 = sg.span(n0, next2, C, M, more2);
+            const unsigned stride_ = opaque_s(stride);
+            const int nlive_ = opaque_s(nlive);
+            const int NPARK = opaque_s(NPARK_);  // (the parked-or-kept choices of the slots: recomputed, not kept)
+            auto parked = [&](int i) -> Raw<T, VEC> {
+                if (i < FIRST_KEEP || i < NPARK) return mypark[i * 64];
+                return keep[i - FIRST_KEEP];
+            };
 #pragma unroll
             for (int s = 0; s < PPW; ++s) {
-                const int n = (k * 4 + wave) * PPW + s;
-                const float* oc = coef + (wave * PPW + s) * 4;
-                const float cG = oc[0], cX = oc[1], xr = oc[2], c0 = oc[3];
-                T* db = dx + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
-                const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;  // (a plane past the batch end drops its stores)
-                const int n2 = (k2 * 4 + wave) * PPW + s;
-                const bool live2 = more2 && n2 < N;
-                fetch_rows(more2 ? c2 : 0, live2 ? n2 : 0, b2, s);
-                const size_t off2 = ((size_t)(live2 ? n2 : 0) * C + (more2 ? c2 : 0)) * ra.M;
-                const int pbytes2 = live2 ? ra.M * (int)sizeof(T) : 0;  // nothing to load: zeros, no traffic
+                const float cG = lane_bcast(cG_l, s), cX = lane_bcast(cX_l, s), xr = lane_bcast(xr_l, s),
+                            c0 = lane_bcast(c0_l, s);
+                const unsigned doff = sg.at(span, stride_, s, nlive_);  // (a plane past the batch end drops its stores)
+                const unsigned off2 = sg.at(span2, stride_, s, nlive_);  // nothing to load: zeros, no traffic
+                const unsigned aoff2 = has_add ? off2 : sg.dead;
+                (void)aoff2;
                 const int base = s * 2 * NV;
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
@@ -771,7 +1005,7 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
 #pragma unroll
                     for (int q = 0; q < VEC; ++q)
                         ov[q] = fmaf(cG, elem<T, VEC>(rg, q), fmaf(cX, elem<T, VEC>(rx, q) - xr, c0));
-                    buf_store<T, VEC>(slot_rsrc<T, VEC>(db, pbytes, j), voff, pack<T, VEC>(ov));
+                    sg.store(t_dx, doff, j, pack<T, VEC>(ov));
                     if (ig < FIRST_KEEP || ig < NPARK)
                         mypark[ig * 64] = dg_[s][j];
                     else
@@ -780,12 +1014,9 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
                         mypark[ix * 64] = dx_[s][j];
                     else
                         keep[ix - FIRST_KEEP] = dx_[s][j];
-                    dg_[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(gy + off2, pbytes2, j), voff);
-                    dx_[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(x + off2, pbytes2, j), voff);
-                    if constexpr (EPI) {
-                        const int abytes2 = addend ? pbytes2 : 0;
-                        da[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(addend ? addend + off2 : x, abytes2, j), voff);
-                    }
+                    dg_[s][j] = sg.load(t_gy, off2, j);
+                    dx_[s][j] = sg.load(t_x, off2, j);
+                    if constexpr (EPI) da[s][j] = sg.load(t_add, aoff2, j);
                 }
             }
         }
@@ -793,6 +1024,11 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
         CNSN_STAMP(4);
         // ---- the reporter's wave 0 collects round B of channel c (4K wave shares), now that its stores are out
         if (reporter && wave == 0) {
+            const KA* ka = KA_;
+            const unsigned epoch = ka->ra.epoch, ctl_idle = ka->ra.ctl_idle;
+            const unsigned long long* gran_b = ka->gran_b;
+            unsigned* ctl = ka->ctl;
+            const long long wait_ticks = ka->ra.wait_ticks;
             const int total = 4 * K;
             double s0 = 0.0, s1 = 0.0;
             bool failed = false;
@@ -804,12 +1040,12 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
                     float v0 = 0.f, v1 = 0.f;
                     if (i < total) {
                         const size_t wm = (size_t)c * K * 4 + i;
-                        if (ra.epoch) {
+                        if (epoch) {
                             const unsigned long long q0 =
                                 __hip_atomic_load((gu64*)(gran_b + wm * 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             const unsigned long long q1 =
                                 __hip_atomic_load((gu64*)(gran_b + wm * 2 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ok = (unsigned)(q0 >> 32) == ra.epoch && (unsigned)(q1 >> 32) == ra.epoch;
+                            ok = (unsigned)(q0 >> 32) == epoch && (unsigned)(q1 >> 32) == epoch;
                             v0 = __uint_as_float((unsigned)q0);
                             v1 = __uint_as_float((unsigned)q1);
                         } else {
@@ -830,12 +1066,13 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
                         const long long now = (long long)wall_clock64();
                         if (t_start == 0) t_start = now;
                         const unsigned seen = __hip_atomic_load((gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (seen != ra.ctl_idle || now - t_start > ra.wait_ticks) {
-                            if (seen == ra.ctl_idle && lane == 0) {
+                        if (seen != ctl_idle || now - t_start > wait_ticks) {
+                            if (seen == ctl_idle && lane == 0) {
                                 const unsigned prev =
                                     __hip_atomic_exchange((gu32*)ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (prev == ra.ctl_idle && ra.host_flag)
-                                    __hip_atomic_fetch_add(ra.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                unsigned* host_flag = ka->ra.host_flag;
+                                if (prev == ctl_idle && host_flag)
+                                    __hip_atomic_fetch_add(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             }
                             failed = true;
                             break;
@@ -846,21 +1083,19 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI)) void resi
             s0 = wave_sum_d(s0);
             s1 = wave_sum_d(s1);
             if (lane == 0) {
-                dgr.dw[2 * c] = failed ? __builtin_nanf("") : (float)s0;
-                dgr.dw[2 * c + 1] = failed ? __builtin_nanf("") : (float)s1;
+                float* dw = ka->dgr.dw;
+                dw[2 * c] = failed ? __builtin_nanf("") : (float)s0;
+                dw[2 * c + 1] = failed ? __builtin_nanf("") : (float)s1;
                 if (failed) *gave_up = 1;
             }
         }
         if (!more) break;
-        {
-            const int t = b0;
-            b0 = b1;
-            b1 = b2;
-            b2 = t;
-        }
+        b0 ^= 1;
         item = next;
+        next = next2;
         ++iter_;
     }
+#undef KA_
 }
 
 }  // namespace cnsn

@@ -26,8 +26,9 @@ from tests.golden.gen_golden_fill import fill_sn  # noqa: E402
 from tests.test_gpu_full_size import check_case  # noqa: E402
 
 DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
-# (tag, H, W): register buckets 2, 4, 7, 8, 13, 16 of 16-byte vectors
-PLANES = [("f32", 12, 32), ("f32", 28, 32), ("f32", 40, 40), ("f32", 60, 32), ("f32", 56, 56), ("f32", 60, 64),
+# (tag, H, W): one-slot planes (33..64 vectors; 8-byte vectors in 16 bits: the 14x14 class, 16 / 8 planes per wave), then the
+# register buckets 2, 4, 7, 8, 13, 16 of 16-byte vectors
+PLANES = [("f32", 14, 14), ("bf16", 14, 14), ("f16", 14, 14), ("f32", 16, 16), ("f32", 12, 32), ("f32", 28, 32), ("f32", 40, 40), ("f32", 60, 32), ("f32", 56, 56), ("f32", 60, 64),
           ("bf16", 12, 64), ("bf16", 28, 64), ("bf16", 56, 56), ("bf16", 60, 64), ("bf16", 96, 64), ("bf16", 120, 64),
           ("f16", 28, 28), ("f16", 56, 56), ("f16", 96, 64)]
 
@@ -121,7 +122,8 @@ def test_against_the_two_pass_kernels(tag, h, w, mode, relu):
         close(a, b, dtype if nm in ("y", "dx", "db") else torch.float32 if dtype == torch.float32 else dtype, f"{tag} {h}x{w} {mode}/{relu} {nm}")
 
 
-@pytest.mark.parametrize("tag,h,w", [("f32", 56, 56), ("bf16", 56, 56), ("bf16", 28, 28), ("f32", 28, 28)], ids=lambda v: str(v))
+@pytest.mark.parametrize("tag,h,w", [("f32", 56, 56), ("bf16", 56, 56), ("bf16", 28, 28), ("f32", 28, 28), ("bf16", 14, 14),
+                                     ("f32", 14, 14)], ids=lambda v: str(v))
 @pytest.mark.parametrize("mode,relu", [("pre", True), ("none", True), ("pre", False)])
 def test_block_against_the_oracle(tag, h, w, mode, relu):
     from tests.test_gpu_fused_block import check, run_case
@@ -169,6 +171,27 @@ def test_more_than_64_members_per_channel():
     """N = 260 at one plane per wave: K = 65 members — the merge loops over the partials"""
     check_case((260, 2, 56, 56), torch.float32, "sn", "neither", 3)
     check_case((260, 2, 28, 32), torch.bfloat16, "sn", "neither", 4)
+
+
+@pytest.mark.parametrize("tag", ["f32", "bf16"])
+@pytest.mark.parametrize("n", [70, 260])
+def test_one_slot_planes_partial_members(tag, n):
+    """14x14: 64 (16-bit) / 32 (fp32) planes per workgroup, the member's partial is summed lane-parallel; N = 70, 260 leave
+    a last member with 6 / 4 planes"""
+    check_case((n, 3, 14, 14), DT[tag], "sn", "neither", 50 + n)
+    assert cnsn_amd.lib().cnsn_resident_timeouts() == 0
+
+
+@pytest.mark.parametrize("tag", ["f32", "bf16"])
+def test_one_slot_planes_full_pipeline(tag):
+    """14x14 with several channels per cluster (the pipeline fills and the grid wraps), deterministic"""
+    shape = (130, 1500, 14, 14)
+    check_case(shape, DT[tag], "sn", "neither", 77)
+    out = run(shape, DT[tag], 5, "pre", True)
+    again = run(shape, DT[tag], 5, "pre", True)
+    for a, b in zip(out, again):
+        assert torch.equal(a, b)
+    assert cnsn_amd.lib().cnsn_resident_timeouts() == 0
 
 
 @pytest.mark.parametrize("tag,h,w", [("f32", 56, 56), ("bf16", 56, 56), ("bf16", 28, 28), ("f32", 28, 28)], ids=lambda v: str(v))

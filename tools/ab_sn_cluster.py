@@ -46,6 +46,12 @@ CASES = [((256, 256, 56, 56), "bf16"), ((256, 512, 28, 28), "bf16"), ((96, 256, 
          ((16, 512, 64, 64), "f32"), ((128, 256, 40, 40), "bf16")]
 if len(sys.argv) > 1 and sys.argv[1] == "short":
     CASES = CASES[:2] + CASES[4:5]
+# side "0": what AUTO runs with the family off; side "1": the family (forced where AUTO prefers another strategy)
+SIDES = {"0": ("auto", "0"), "1": ("auto", "1")}
+if len(sys.argv) > 1 and sys.argv[1] == "small":   # one-slot planes: against the channel-in-registers (mono) kernels
+    CASES = [((256, 1024, 14, 14), "bf16"), ((256, 1024, 14, 14), "f32"), ((96, 1024, 14, 14), "bf16"),
+             ((128, 1024, 14, 14), "bf16"), ((512, 1024, 14, 14), "bf16")]
+    SIDES = {"0": ("auto", "0"), "1": ("resident", "2")}
 
 print("| shape | dtype | call | SNX=0 fwd / bwd ms | SNX=1 fwd / bwd ms | fwd | bwd | of 8 TB/s (new, fwd / bwd) |")
 print("|---|---|---|---|---|---|---|---|")
@@ -66,12 +72,14 @@ for shape, dt in CASES:
         res = {}
         for rep in range(2):                    # interleave the two sides twice, keep the better of each
             for snx in ("0", "1"):
-                os.environ["CNSN_SNX"] = snx
+                cnsn_amd.set_strategy(SIDES[snx][0])
+                os.environ["CNSN_SNX"] = SIDES[snx][1]
                 f, bw = time_pair(fwd, bwd)
                 if snx not in res or f + bw < sum(res[snx]):
                     res[snx] = (f, bw)
         cfg = cnsn_amd.FusedConfig(sn_active=True, add_mode="pre" if call == "block" else "none", relu=call == "block")
-        os.environ["CNSN_SNX"] = "1"
+        cnsn_amd.set_strategy(SIDES["1"][0])
+        os.environ["CNSN_SNX"] = SIDES["1"][1]
         took = cnsn_amd.sn_cluster(a, cfg), cnsn_amd.sn_cluster(a, cfg, backward=True)
         (f0, b0), (f1, b1) = res["0"], res["1"]
         print(f"| {shape} | {dt} | {call}{'' if all(took) else ' (not taken: ' + str(took) + ')'} | {f0:.4f} / {b0:.4f} | {f1:.4f} / {b1:.4f} | "
