@@ -131,6 +131,11 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
     double* saved_d = saved ? (double*)saved : mom + 6 * pl.P;
     float* coef = (float*)(mom + 6 * pl.P + saved_doubles_of(pl));
 
+    if (resident_sn_prefers(p, pl.boxed, CNSN_ADD_NONE, 0, false)) {
+        st = resident_sn_forward(pl.pr, pl.mid, CNSN_ADD_NONE, 0, x, nullptr, gate_dev(g), y, saved ? saved_d : nullptr,
+                                 workspace, stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
+    }
     {
         const WidePlan wp = wide_plan(pl, 0, false);  // planes that are no whole number of vectors (7x7): channel groups in registers
         if (wp.ok) {
@@ -232,6 +237,11 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
     float* coef = sums + 4 * P;
     const double* saved_d = (const double*)saved;
 
+    if (resident_sn_prefers(p, pl.boxed, CNSN_ADD_NONE, 0, true)) {
+        st = resident_sn_backward(pl.pr, pl.mid, CNSN_ADD_NONE, 0, grad_y, x, nullptr, gate_dev(g), saved_d, grad_x,
+                                  gate_grad_dev(dg), workspace, stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
+    }
     {
         const WidePlan wp = wide_plan(pl, 0, true);
         if (wp.ok) {

@@ -102,14 +102,25 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-// every lane ends with the wave's sum (wave-uniform)
-__device__ __forceinline__ float wave_sum(float v) {
+// the wave's sum as the raw bits of lane 63 (an SGPR): the four row sums are folded with two row-broadcast DPP adds —
+// every row takes the last lane of the row before it, then rows 2 and 3 take lane 31: lane 63 = (R2 + R3) + (R0 + R1), the
+// same two-level order as reading the four row sums and adding them pairwise (bit-identical), in 3 instructions instead
+// of 7.  (All rows enabled and bound_ctrl on, so that the DPP move folds into the add; the other rows end with sums nobody
+// reads.)
+__device__ __forceinline__ int wave_sum_bits(float v) {
     v = row16_sum(v);
-    const int b = __builtin_bit_cast(int, v);
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) +
-           __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)) +
-           __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) +
-           __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xF, 0xF, true));  // row_bcast:15
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xF, 0xF, true));  // row_bcast:31
+    return __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63);
+}
+// every lane ends with the wave's sum (wave-uniform)
+__device__ __forceinline__ float wave_sum(float v) { return __builtin_bit_cast(float, wave_sum_bits(v)); }
+// lane LANE of `old` replaced by the wave-uniform `sval` (no builtin in this hipcc).  An SGPR source operand of
+// v_writelane has no wait-state requirement after the v_readlane that produced it (only a lane SELECT would)
+template <int LANE>
+__device__ __forceinline__ int put_lane(int sval, int old) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(sval), "n"(LANE));
+    return old;
 }
 
 // Sum NACC accumulators over the LPP lanes that share a plane (LPP = 16, 64 or 256 = whole block).

@@ -78,6 +78,7 @@ int cnsn_which_path(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int 
     const bool bwd = backward != 0;
     // the backward of an epilogue without ReLU and without PRE add is the plain backward
     const bool fused = bwd ? (e.relu || e.add == ADD_PRE) : (e.relu || e.add != ADD_NONE);
+    if (resident_sn_prefers(p, pl.boxed, fused ? e.add : ADD_NONE, fused ? e.relu : 0, bwd)) return CNSN_PATH_RESIDENT;
     if (wide_plan(pl, fused ? e.add : 0, bwd).ok) return CNSN_PATH_MONO;  // (channel GROUPS in registers: reported as mono)
     if (mono_plan(pl, fused ? e.add : 0, bwd).ok) return CNSN_PATH_MONO;
     if (mono_cn_plan(pl, chan, fused ? e.add : 0, bwd).ok) return CNSN_PATH_MONO;
@@ -99,7 +100,8 @@ int cnsn_sn_cluster_plan(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi,
     if (st) return st;
     const bool bwd = backward != 0;
     const bool fused = bwd ? (e.relu || e.add == ADD_PRE) : (e.relu || e.add != ADD_NONE);
-    // (the small-plane strategies come first in every entry point)
+    // (the small-plane strategies come first in every entry point, unless this family is known to be faster)
+    if (resident_sn_prefers(pl.pr, pl.boxed, fused ? e.add : ADD_NONE, fused ? e.relu : 0, bwd)) return 1;
     if (wide_plan(pl, fused ? e.add : 0, bwd).ok || mono_plan(pl, fused ? e.add : 0, bwd).ok ||
         local_plan(pl, fused ? e.add : 0, bwd).ok)
         return 0;
@@ -131,6 +133,11 @@ int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, c
     double* saved_d = saved ? (double*)saved : mom + 6 * pl.P;
     float* coef = (float*)(mom + 6 * pl.P + saved_doubles_of(pl));
 
+    if (resident_sn_prefers(p, pl.boxed, e.add, e.relu, false)) {
+        st = resident_sn_forward(pl.pr, pl.mid, e.add, e.relu, x, e.addend, gate_dev(g), y, saved ? saved_d : nullptr, workspace,
+                                 stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
+    }
     {
         const WidePlan wp = wide_plan(pl, e.add, false);
         if (wp.ok) {
@@ -250,6 +257,11 @@ int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, 
     float* coef = sums + 4 * P;
     const double* saved_d = (const double*)saved;
 
+    if (resident_sn_prefers(p, pl.boxed, e.add, e.relu, true)) {
+        st = resident_sn_backward(pl.pr, pl.mid, e.add, e.relu, grad_y, x, e.addend, gate_dev(g), saved_d, grad_x,
+                                  gate_grad_dev(dg), workspace, stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
+    }
     {
         const WidePlan wp = wide_plan(pl, e.add, true);
         if (wp.ok) {

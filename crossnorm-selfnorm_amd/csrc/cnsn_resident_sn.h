@@ -11,6 +11,9 @@ struct SnxPlan {
 };
 // add: ADD_NONE or ADD_PRE; relu 0/1.  ok only for SelfNorm alone in training mode (one gate, no CrossNorm).
 SnxPlan resident_sn_plan(const cnsn_problem_t& p, bool boxed, int add, int relu, bool backward);
+// AUTO only: these kernels go BEFORE the channel-in-registers / local strategies the entry points try first (measured
+// classes of one-slot planes: profiles/r03_sn_cluster.md)
+bool resident_sn_prefers(const cnsn_problem_t& p, bool boxed, int add, int relu, bool backward);
 // bytes of exchange area a launch may need (the persistent context is sized for it, cnsn_context_bytes)
 size_t resident_sn_exchange_bytes(const cnsn_problem_t& p);
 

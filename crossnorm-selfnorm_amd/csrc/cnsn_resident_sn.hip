@@ -7,6 +7,16 @@ SnxPlan resident_sn_plan(const cnsn_problem_t& p, bool boxed, int add, int relu,
     return snxhost::plan_impl(p, boxed, add, relu, backward);
 }
 
+bool resident_sn_prefers(const cnsn_problem_t& p, bool boxed, int add, int relu, bool backward) {
+    if (p.strategy != CNSN_STRATEGY_AUTO || snxhost::snx_mode() != 1) return false;
+    const SnxPlan sp = snxhost::plan_impl(p, boxed, add, relu, backward);
+    if (!sp.ok || sp.nv != 1) return false;
+    // one-slot planes (the 14x14 class), same-process A/B against what AUTO ran before (mono up to N = 256, local beyond):
+    // bf16 N = 512: forward -42 %, backward -56 %; fp32 N = 256: forward -2..-4 %, backward -17..-24 %; bf16 N <= 256: the
+    // channel-in-registers kernels stay ahead (forward +20..+39 %, backward -15..+7 %)
+    return p.N >= 384 || (elem_bytes(p.dtype) == 4 && backward && p.N >= 256);
+}
+
 size_t resident_sn_exchange_bytes(const cnsn_problem_t& p) {
     // (the largest a plan can ask for: the backward with the fewest planes per workgroup)
     const int K = (p.N + 3) / 4;

@@ -127,12 +127,11 @@ inline SnxPlan plan_impl(const cnsn_problem_t& p, bool boxed, int add, int relu,
     if (np < first_keep) return none;
     // AUTO / forced-resident without CNSN_SNX=2: where these kernels measured faster than the general resident kernels
     // on MI355X (profiles/r03_sn_cluster.md, same-process A/B): every call WITH the residual-block epilogue (the general
-    // kernels are not pipelined there: 56x56 bf16 block forward -13 %, backward -31 %); without it every class except
-    // the forward of the 16-bit 56x56 class (two planes per wave spill: +12 % against the general pipelined forward),
-    // the forward of the fp32 28x28 class (+8 %) and the backward of the 16-bit 56x56 class at small batches
-    // (N = 96: +17 %, N = 256: -7 %).
+    // kernels are not pipelined there: 56x56 bf16 block forward -18 %, backward -32 %); without it every class except
+    // the forward of the fp32 28x28 class (+3 % against the general pipelined forward) and the backward of the 16-bit
+    // 56x56 class at small batches (N = 96: +9 %, N = 256: -7 %).  One-slot planes: see resident_sn_prefers.
     if (mode != 2 && !epi) {
-        if (!backward && ((eb == 2 && sp.nv == 7) || (eb == 4 && sp.nv == 4))) return none;
+        if (!backward && eb == 4 && sp.nv == 4) return none;
         if (backward && eb == 2 && sp.nv == 7 && p.N < 128) return none;
     }
     sp.npark = np;

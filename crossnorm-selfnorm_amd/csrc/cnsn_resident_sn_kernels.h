@@ -48,6 +48,12 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 
+// put_lane with the lane as a (constant after unrolling) function argument
+__device__ __forceinline__ int put_lane_at(int sval, int lane, int old) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(sval), "n"(lane));
+    return old;
+}
+
 constexpr int kSnxVals = 4;  // floats a member publishes per exchange round
 
 // planes of member k that exist
@@ -405,8 +411,8 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
     auto stats_publish = [&](int item, int buf, bool draw) {
         const int c = __builtin_amdgcn_readfirstlane(item);
         SnxFwdState* st = state + buf * OWN;
-        const int sl = lane < PPW ? lane : 0;
-        float my_sum = 0.f, my_m2 = 0.f;  // lane s: the sums of this wave's plane s (lanes past PPW: plane 0)
+        int my_sum_b = 0, my_m2_b = 0;  // lane s < PPW: the sums of this wave's plane s, as bits (v_writelane puts them there:
+                                        // a select per plane would keep one lane mask per plane alive across the item loop)
         const float inv_m = __builtin_amdgcn_rcpf((float)M);
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
@@ -421,8 +427,9 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
             for (int j = 0; j < NV; ++j)
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) sum += elem<T, VEC>(d[s][j], q);
-            const float tot = wave_sum(sum);
-            const float mean = tot * inv_m;  // the shift of the second pass (M2 about a point one ulp off the mean is the same number)
+            const int tot_b = wave_sum_bits(sum);
+            my_sum_b = put_lane_at(tot_b, s, my_sum_b);
+            const float mean = __int_as_float(tot_b) * inv_m;  // the shift of the second pass (M2 about a point one ulp off the mean is the same number)
             float m2 = 0.f;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
@@ -433,15 +440,12 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
                         m2 = fmaf(t, t, m2);
                     }
                 }
-            m2 = wave_sum(m2);
-            if (sl == s) {
-                my_sum = tot;
-                my_m2 = m2;
-            }
+            my_m2_b = put_lane_at(wave_sum_bits(m2), s, my_m2_b);
         }
-        {   // lane s: the plane algebra of plane s — one pass of arithmetic whatever PPW is.  The record is written by lane
-            // s alone (lanes past PPW repeat lane 0's numbers into record 0) and read back by the same lanes, or by wave 0
-            // behind the barrier
+        {   // lane s < PPW: the plane algebra of plane s — one pass of arithmetic whatever PPW is.  The record is written by
+            // lane s alone and read back by the same lane, or by wave 0 behind the barrier (the lanes past PPW compute on
+            // zeros and keep their results to themselves)
+            const float my_sum = __int_as_float(my_sum_b), my_m2 = __int_as_float(my_m2_b);
             const KA* ka = KA_;
             const MidArgs a = ka->ra.mid;
             const double w0 = ka->gg.w[2 * c], w1 = ka->gg.w[2 * c + 1];
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
             r.z = w0 * (double)f.mu_p + w1 * (double)f.sig_p;
             r.mu = f.mu_p;
             r.sg = f.sig_p;
-            st[wave * PPW + sl] = r;
+            if (lane < PPW) st[wave * PPW + lane] = r;
         }
         __syncthreads();
         if (wave == 0) {  // (wave-uniform arithmetic: every lane the same numbers)
@@ -773,7 +777,7 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
         SnxBwdState* st = state + buf * OWN;
         const int relu = EPI ? KA_->relu : 0;
         const float mu_l = (float)row_mu, g_l = (float)row_g;
-        float my_s1 = 0.f, my_s2 = 0.f;
+        int my_s1_b = 0, my_s2_b = 0;  // lane s < PPW: the sums of this wave's plane s (v_writelane: see the forward)
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
             const float si = lane_bcast(mu_l, s);  // the saved mean of plane s, rounded as pass A' rounds it
@@ -808,15 +812,13 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
                         acc1 = fmaf(G, X - si, acc1);
                     }
                 }
-            const float s1 = wave_sum(acc0), s2 = wave_sum(acc1);
-            if (sl == s) {  // lane s keeps the sums of plane s (lanes past PPW: those of plane 0)
-                my_s1 = s1;
-                my_s2 = s2;
-            }
+            my_s1_b = put_lane_at(wave_sum_bits(acc0), s, my_s1_b);
+            my_s2_b = put_lane_at(wave_sum_bits(acc1), s, my_s2_b);
         }
-        {   // lane s: the gate's dt of plane s — one pass of arithmetic whatever PPW is; the whole record is written by lane
-            // s (lanes past PPW repeat lane 0's numbers into record 0) and read back by the same lanes, or by wave 0 behind
-            // the barrier
+        {   // lane s < PPW: the gate's dt of plane s — one pass of arithmetic whatever PPW is; the whole record is written by
+            // lane s and read back by the same lane, or by wave 0 behind the barrier (the lanes past PPW compute on zeros and
+            // keep their results to themselves)
+            const float my_s1 = __int_as_float(my_s1_b), my_s2 = __int_as_float(my_s2_b);
             const MidArgs a = KA_->ra.mid;
             const BwdSumsT<float> sm = fix_sums<float>(a, my_s1, my_s2, 0.f, 0.f, row_mu, 0.0);
             float dtg, dtf;
@@ -829,7 +831,7 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
             r.sig_p = (float)row_sig;
             r.s1 = my_s1;
             r.s2 = my_s2;
-            st[wave * PPW + sl] = r;
+            if (lane < PPW) st[wave * PPW + lane] = r;
         }
         __syncthreads();
         if (wave == 0) {

@@ -89,10 +89,13 @@ def run(shape, dtype, seed, mode="none", relu=False):
     return [y.detach()] + [t.detach() for t in grads] + [t.clone() for t in mod.buffers()]
 
 
-def close(a, b, dtype, what):
+def close(a, b, dtype, what, params=False):
     a, b = a.double(), b.double()
     scale = max(float(b.abs().max()), 1e-3)
-    tol = 2e-6 if dtype == torch.float32 else 1e-2
+    # fp32: 2e-6 of the largest entry for the planes; 5e-6 for the parameter gradients — sums over the whole batch with
+    # cancellation, fed by per-plane statistics that the two strategies round differently in the last bit (the second pass
+    # of the cluster kernels is taken about sum * rcp(M), the two-pass kernels' about sum / M)
+    tol = (5e-6 if params else 2e-6) if dtype == torch.float32 else 1e-2
     err = float((a - b).abs().max())
     assert err <= tol * scale, f"{what}: {err:.3e} vs scale {scale:.3g}"
 
@@ -119,7 +122,7 @@ def test_against_the_two_pass_kernels(tag, h, w, mode, relu):
     for nm, a, b in zip(names, out, ref):
         if relu and nm in ("dw", "dgamma", "dbeta") and float(((out[0] > 0) != (ref[0] > 0)).float().sum()) > 0:
             continue  # a flipped mask element moves the parameter sums by more than rounding
-        close(a, b, dtype if nm in ("y", "dx", "db") else torch.float32 if dtype == torch.float32 else dtype, f"{tag} {h}x{w} {mode}/{relu} {nm}")
+        close(a, b, dtype, f"{tag} {h}x{w} {mode}/{relu} {nm}", params=nm in ("dw", "dgamma", "dbeta"))
 
 
 @pytest.mark.parametrize("tag,h,w", [("f32", 56, 56), ("bf16", 56, 56), ("bf16", 28, 28), ("f32", 28, 28), ("bf16", 14, 14),
@@ -254,3 +257,10 @@ def test_auto_takes_the_resnet50_blocks():
         x = torch.empty(shape, device="cuda", dtype=torch.bfloat16)
         for bw in (False, True):
             assert cnsn_amd.sn_cluster(x, cfg_of("pre", True), backward=bw), (shape, bw)
+    # one-slot planes: ahead of the channel-in-registers kernels where measured faster (large batches; fp32 backward)
+    x = torch.empty((512, 64, 14, 14), device="cuda", dtype=torch.bfloat16)
+    assert cnsn_amd.sn_cluster(x, cfg_of()) and cnsn_amd.sn_cluster(x, cfg_of("pre", True), backward=True)
+    x = torch.empty((256, 64, 14, 14), device="cuda", dtype=torch.float32)
+    assert cnsn_amd.sn_cluster(x, cfg_of(), backward=True) and not cnsn_amd.sn_cluster(x, cfg_of())
+    x = torch.empty((256, 64, 14, 14), device="cuda", dtype=torch.bfloat16)
+    assert not cnsn_amd.sn_cluster(x, cfg_of()) and not cnsn_amd.sn_cluster(x, cfg_of(), backward=True)

@@ -48,6 +48,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "short":
     CASES = CASES[:2] + CASES[4:5]
 # side "0": what AUTO runs with the family off; side "1": the family (forced where AUTO prefers another strategy)
 SIDES = {"0": ("auto", "0"), "1": ("auto", "1")}
+if len(sys.argv) > 1 and sys.argv[1] == "forced":   # the classes AUTO leaves to the general kernels, forced for comparison
+    CASES = [((256, 256, 56, 56), "bf16"), ((96, 256, 56, 56), "bf16"), ((256, 512, 28, 28), "f32"), ((128, 32, 32, 32), "f32"),
+             ((16, 512, 64, 64), "f32"), ((64, 64, 112, 112), "bf16")]
+    SIDES = {"0": ("auto", "0"), "1": ("resident", "2")}
 if len(sys.argv) > 1 and sys.argv[1] == "small":   # one-slot planes: against the channel-in-registers (mono) kernels
     CASES = [((256, 1024, 14, 14), "bf16"), ((256, 1024, 14, 14), "f32"), ((96, 1024, 14, 14), "bf16"),
              ((128, 1024, 14, 14), "bf16"), ((512, 1024, 14, 14), "bf16")]
