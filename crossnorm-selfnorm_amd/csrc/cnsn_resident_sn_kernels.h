@@ -326,6 +326,20 @@ __device__ __forceinline__ int opaque_s(int v) {
 }
 __device__ __forceinline__ unsigned opaque_s(unsigned v) { return (unsigned)opaque_s((int)v); }
 
+// A phase boundary for the register allocator: every SGPR from s16 up is declared clobbered, so whatever lives across this
+// point is parked in a VGPR lane ONCE and comes back right before its next use — which for most of it is not in the phase
+// that follows.  Without it the allocator hands the registers to the long-lived values first (loop invariants it hoisted,
+// the item bookkeeping, the other phases' operands) and the plane loops, which touch a score of SGPRs, reload their
+// descriptors and offsets from spill lanes at every use (v_readlane is a VALU slot: 13-15 of them per plane, ISA count).
+#ifndef SNX_PHASE_FENCE
+#define SNX_PHASE_FENCE 1
+#endif
+__device__ __forceinline__ void snx_phase_fence() {
+#if SNX_PHASE_FENCE
+    asm volatile("" ::: "s16","s17","s18","s19","s20","s21","s22","s23","s24","s25","s26","s27","s28","s29","s30","s31","s32","s33","s34","s35","s36","s37","s38","s39","s40","s41","s42","s43","s44","s45","s46","s47","s48","s49","s50","s51","s52","s53","s54","s55","s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","s66","s67","s68","s69","s70","s71","s72","s73","s74","s75","s76","s77","s78","s79","s80","s81","s82","s83","s84","s85","s86","s87","s88","s89","s90","s91","s92","s93","s94","s95","s96","s97","s98","s99","s100","s101");
+#endif
+}
+
 template <typename T>
 struct SnxFwdKargs {
     ResArgs ra;
@@ -410,9 +424,13 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
     // draw: this cluster will work on the item after `item` too, so its member 0 draws the channel of the one after THAT
     auto stats_publish = [&](int item, int buf, bool draw) {
         const int c = __builtin_amdgcn_readfirstlane(item);
+        snx_phase_fence();
         SnxFwdState* st = state + buf * OWN;
         int my_sum_b = 0, my_m2_b = 0;  // lane s < PPW: the sums of this wave's plane s, as bits (v_writelane puts them there:
                                         // a select per plane would keep one lane mask per plane alive across the item loop)
+        const int M = KA_->ra.M;
+        const PlaneIo<T, VEC, NV> sg(KA_->ra, 1, 1, lane);  // (only the slot validity is used here)
+        const bool has_add = EPI && KA_->addend != nullptr;
         const float inv_m = __builtin_amdgcn_rcpf((float)M);
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
@@ -548,9 +566,9 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
         __syncthreads();
         if (*gave_up) {  // (workgroup-uniform) timed out: see sweep_granules
             T* y = KA_->y;
-#pragma unroll
+            const int first = opaque_s(n0);  // (a cold path: nothing of it is worth computing ahead of the loop)
             for (int s = 0; s < PPW; ++s) {
-                const int n = (k * 4 + wave) * PPW + s;
+                const int n = first + s;
                 if (n < N && lane == 0) poison_plane<T, VEC>(y + ((size_t)n * C + c) * M);
             }
             return;
@@ -618,11 +636,20 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
         // ---- slot by slot: apply item t (the only write of y), park item t+1's slot in its place, send the loads of
         //      item t+2's slot after it.  y = fma(g, X - 0, 0): the one rounding of the reference's x * g (fwd_coefs)
         {
-            const int relu = EPI ? KA_->relu : 0;
-            const unsigned span = sg.span(n0, c, C, M, true), span2 = sg.span(n0, next2, C, M, more2);
-            const unsigned stride_ = opaque_s(stride);
-            const int nlive_ = opaque_s(nlive);
-            const int NPARK = opaque_s(NPARK_);  // (the parked-or-kept choices of the slots: recomputed, not kept)
+            // (a phase of its own for the register allocator: everything the plane loop touches is defined AFTER the fence,
+            //  from the kernel arguments — a dozen scalar loads — so that it lives in registers for the length of the loop)
+            snx_phase_fence();
+            const KA* ka = KA_;
+            const int relu = EPI ? ka->relu : 0;
+            const int N = ka->ra.mid.N, C = ka->ra.mid.C, M = ka->ra.M;
+            const PlaneIo<T, VEC, NV> sg(ka->ra, N, C, lane);
+            const bool has_add = EPI && ka->addend != nullptr;
+            const __amdgpu_buffer_rsrc_t rx = sg.tensor(ka->x), ry = sg.tensor(ka->y), radd = sg.tensor(has_add ? ka->addend : ka->x);
+            const unsigned stride_ = (unsigned)C * (unsigned)M * (unsigned)sizeof(T);
+            const int n0_ = opaque_s(n0);
+            const int nlive_ = N - n0_ < 0 ? 0 : (N - n0_ > PPW ? PPW : N - n0_);
+            const unsigned span = sg.span(n0_, c, C, M, true), span2 = sg.span(n0_, next2, C, M, more2);
+            const int NPARK = __builtin_amdgcn_readfirstlane(ka->npark);  // (the parked-or-kept choices of the slots)
 #pragma unroll
             for (int s = 0; s < PPW; ++s) {
                 const float a_in = lane_bcast(gate_l, s);
@@ -653,6 +680,7 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
                     if constexpr (EPI) da[s][j] = sg.load(radd, aoff2, j);
                 }
             }
+            snx_phase_fence();
         }
         CNSN_STAMP(4);
         if (!more) break;
@@ -774,8 +802,11 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
     // member's partial batch sums (round A) -> the cluster
     auto sums_publish = [&](int item, int buf) {
         const int c = __builtin_amdgcn_readfirstlane(item);
+        snx_phase_fence();
         SnxBwdState* st = state + buf * OWN;
         const int relu = EPI ? KA_->relu : 0;
+        const PlaneIo<T, VEC, NV> sg(KA_->ra, 1, 1, lane);  // (only the slot validity is used here)
+        const bool has_add = EPI && KA_->addend != nullptr;
         const float mu_l = (float)row_mu, g_l = (float)row_g;
         int my_s1_b = 0, my_s2_b = 0;  // lane s < PPW: the sums of this wave's plane s (v_writelane: see the forward)
 #pragma unroll
@@ -910,9 +941,9 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
         __syncthreads();
         if (*gave_up) {  // (workgroup-uniform) timed out
             T* dx = KA_->dx;
-#pragma unroll
+            const int first = opaque_s(n0);  // (a cold path: nothing of it is worth computing ahead of the loop)
             for (int s = 0; s < PPW; ++s) {
-                const int n = n0 + s;
+                const int n = first + s;
                 if (n < N && lane == 0) poison_plane<T, VEC>(dx + ((size_t)n * C + c) * M);
             }
             return;
@@ -982,10 +1013,19 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
         //      item t+2's slots after it
         {
             fetch_rows(more2 ? next2 : 0);
-            const unsigned span = sg.span(n0, c, C, M, true), span2 = sg.span(n0, next2, C, M, more2);
-            const unsigned stride_ = opaque_s(stride);
-            const int nlive_ = opaque_s(nlive);
-            const int NPARK = opaque_s(NPARK_);  // (the parked-or-kept choices of the slots: recomputed, not kept)
+            // (a phase of its own for the register allocator: see the forward)
+            snx_phase_fence();
+            const KA* ka = KA_;
+            const int N = ka->ra.mid.N, C = ka->ra.mid.C, M = ka->ra.M;
+            const PlaneIo<T, VEC, NV> sg(ka->ra, N, C, lane);
+            const bool has_add = EPI && ka->addend != nullptr;
+            const __amdgpu_buffer_rsrc_t t_gy = sg.tensor(ka->gy), t_x = sg.tensor(ka->x), t_dx = sg.tensor(ka->dx),
+                                         t_add = sg.tensor(has_add ? ka->addend : ka->x);
+            const unsigned stride_ = (unsigned)C * (unsigned)M * (unsigned)sizeof(T);
+            const int n0_ = opaque_s(n0);
+            const int nlive_ = N - n0_ < 0 ? 0 : (N - n0_ > PPW ? PPW : N - n0_);
+            const unsigned span = sg.span(n0_, c, C, M, true), span2 = sg.span(n0_, next2, C, M, more2);
+            const int NPARK = __builtin_amdgcn_readfirstlane(ka->npark);  // (the parked-or-kept choices of the slots)
             auto parked = [&](int i) -> Raw<T, VEC> {
                 if (i < FIRST_KEEP || i < NPARK) return mypark[i * 64];
                 return keep[i - FIRST_KEEP];
@@ -1021,6 +1061,7 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
                     if constexpr (EPI) da[s][j] = sg.load(t_add, aoff2, j);
                 }
             }
+            snx_phase_fence();
         }
 
         CNSN_STAMP(4);
