@@ -13,8 +13,11 @@ constexpr size_t kLdsPerCu = 160 * 1024;
 // planes per wave: the item in flight (x [+ addend]; G, x [+ addend]) has to fit the registers of 3-4 (forward) / 2-3
 // (backward) workgroups per CU next to the kept part of the parked item
 #ifndef SNX_NV2_PPW
-#define SNX_NV2_PPW 4
+#define SNX_NV2_PPW 4       // two-slot planes (28x28 in 16 bits) with the epilogue
 #endif
+#ifndef SNX_NV2_PPW_PLAIN
+#define SNX_NV2_PPW_PLAIN 8 // ... without it (measured after the algebra went lane-parallel: 8 planes per wave -6 % / -2 %
+#endif                      //     against 4, 2 planes per wave +14 % / +19 %: the fewer members the better)
 #ifndef SNX_NV7_PPW16
 #define SNX_NV7_PPW16 2     // 16-bit 56x56 class, forward without epilogue: planes per wave
 #endif
@@ -26,13 +29,16 @@ constexpr size_t kLdsPerCu = 160 * 1024;
 #endif
 constexpr int fwd_ppw(int nv, bool epi, int elem_bytes, int vb = 16) {
     return nv == 1   ? (vb == 8 ? SNX_NV1_PPW8 : SNX_NV1_PPW)
-           : nv == 2 ? SNX_NV2_PPW
+           : nv == 2 ? (epi ? SNX_NV2_PPW : SNX_NV2_PPW_PLAIN)
            : nv == 4 ? (epi ? 2 : 4)
            : nv == 7 ? ((elem_bytes == 2 && !epi) ? SNX_NV7_PPW16 : 1)
                      : 1;
 }
 constexpr int bwd_ppw(int nv, bool epi, int, int vb = 16) {  // (one-slot planes with the epilogue: 3 x 16 planes in flight do not fit)
-    return nv == 1 ? (vb == 8 ? (epi ? SNX_NV1_PPW8 / 2 : SNX_NV1_PPW8) : SNX_NV1_PPW) : nv == 2 ? SNX_NV2_PPW : nv == 4 ? 2 : 1;
+    return nv == 1 ? (vb == 8 ? (epi ? SNX_NV1_PPW8 / 2 : SNX_NV1_PPW8) : SNX_NV1_PPW)
+           : nv == 2 ? (epi ? SNX_NV2_PPW : SNX_NV2_PPW_PLAIN)
+           : nv == 4 ? 2
+                     : 1;
 }
 
 // CNSN_SNX=0: never; 2: wherever instantiated (tests); default 1: AUTO rule
