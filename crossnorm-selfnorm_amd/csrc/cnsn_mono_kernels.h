@@ -232,6 +232,23 @@ __device__ __forceinline__ void mono_forget(V& v) {
 // (x = b % 8), the few workgroups past the end of a range leave at once.  (A persistent walk — G8 workgroups per XCD
 // stepping through the range, LDS state in two alternating copies — was measured and dropped: the loop cost 20-70
 // spilled VGPRs and the forward got slower, 0.082 -> 0.088 ms at (256,1024,14,14) bf16, 0.095 -> 0.120 ms fp32.)
+// Tuning builds (-DMONO_SKEW=steps of s_sleep(127), -DMONO_SKEW_MODE): every workgroup of a launch starts its load phase at
+// the same moment, computes while the memory system idles and stores together again; delaying every other workgroup of a CU
+// was tried as a way to interleave the phases of the two that share it.
+#ifndef MONO_SKEW
+#define MONO_SKEW 0
+#endif
+#ifndef MONO_SKEW_MODE
+#define MONO_SKEW_MODE 0
+#endif
+__device__ __forceinline__ void mono_startup_skew() {
+#if MONO_SKEW > 0
+    const bool late = MONO_SKEW_MODE == 0 ? ((blockIdx.x >> 8) & 1) : (MONO_SKEW_MODE == 1 ? (blockIdx.x & 1) : ((blockIdx.x >> 3) & 1));
+    if (late)
+        for (int i = 0; i < MONO_SKEW; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+}
+
 struct MonoWalk {
     int start, count, j;
     __device__ __forceinline__ MonoWalk(int C) {
@@ -315,6 +332,7 @@ __global__ __launch_bounds__(kMonoBlock, TAIL ? 4 : mono_fwd_waves(RMAX * VEC * 
     const int N = a.N, C = a.C;
     const int npad = kMonoWaves * ma.R * (64 / LPP);
     const MonoWalk wk(C);
+    mono_startup_skew();
     if (wk.j < wk.count) {
     const int c = wk.start + wk.j;
     char* lds = smem;
@@ -559,6 +577,7 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
     const int N = a.N, C = a.C;
     const int npad = kMonoWaves * ma.R * (64 / LPP);
     const MonoWalk wk(C);
+    mono_startup_skew();
     if (wk.j < wk.count) {
     const int c = wk.start + wk.j;
     char* lds = smem;
