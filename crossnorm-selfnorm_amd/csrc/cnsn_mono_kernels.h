@@ -234,7 +234,9 @@ __device__ __forceinline__ void mono_forget(V& v) {
 // spilled VGPRs and the forward got slower, 0.082 -> 0.088 ms at (256,1024,14,14) bf16, 0.095 -> 0.120 ms fp32.)
 // Tuning builds (-DMONO_SKEW=steps of s_sleep(127), -DMONO_SKEW_MODE): every workgroup of a launch starts its load phase at
 // the same moment, computes while the memory system idles and stores together again; delaying every other workgroup of a CU
-// was tried as a way to interleave the phases of the two that share it.
+// was tried as a way to interleave the phases of the two that share it.  MEASURED, NOT KEPT (profiles/r03_sn_cluster.md §8):
+// (256,1024,14,14) bf16 forward / backward 0.063 / 0.097 ms -> 0.066-0.079 / 0.104-0.115 with 2-4 steps on any of the three
+// partitions, 7x7 unchanged or slower: the delay only lengthens the tail of a launch that has two rounds of workgroups.
 #ifndef MONO_SKEW
 #define MONO_SKEW 0
 #endif
