@@ -229,7 +229,7 @@ __device__ __forceinline__ int snx_draw_channel(unsigned* ctl, unsigned epoch, i
 // kernels of this family (ISA count), on classes whose per-plane fixed cost already sits near the VALU budget of a
 // bandwidth-bound kernel.  Here the descriptor covers the whole (N, C, H, W) tensor and a plane is reached through the
 // instruction's scalar offset (one SGPR, 32-bit arithmetic).  gfx950 range-checks soffset + voffset against num_records
-// (probed: tools/dbg/soffset_probe.hip), so:
+// (probed: tools/soffset_probe.hip), so:
 //   * a plane past the batch end, or an empty slot, gets soffset = tensor bytes: loads return zeros, stores are dropped;
 //   * lanes past the end of the plane in its partly filled slot get voffset = tensor bytes (same effect).  Slots are
 //     RIGHT-ALIGNED — slot j holds vectors (j - shift)*64 + lane with shift = NV - slots needed — so that the partly filled
