@@ -308,6 +308,15 @@ struct SlotGeom {
         const int p = j * VEC + q;
         return (sbits[p >> 5] & (1u << (p & 31))) != 0u;
     }
+    // the same memberships as all-ones / all-zeros words (one v_bfe_i32): `bits(x) & mask` keeps or zeroes a float
+    __device__ __forceinline__ int mask_c(int j, int q) const {
+        const int p = j * VEC + q;
+        return (int)(cbits[p >> 5] << (31 - (p & 31))) >> 31;
+    }
+    __device__ __forceinline__ int mask_s(int j, int q) const {
+        const int p = j * VEC + q;
+        return (int)(sbits[p >> 5] << (31 - (p & 31))) >> 31;
+    }
 };
 
 // Plane access through buffer instructions.  Every register slot j of a plane gets its own resource
@@ -374,6 +383,27 @@ __device__ __forceinline__ Raw<T, VEC> pack(const float (&f)[VEC]) {
         for (int q = 0; q < VEC; q += 2) r[q >> 1] = pack2<T>(f[q], f[q + 1]);
     }
     return r;
+}
+
+__device__ __forceinline__ float keep_if(float v, int mask) { return __int_as_float(__float_as_int(v) & mask); }
+
+// Region moments of a plane with crop boxes from ONE masked pass about a common shift k (the plane mean, from a cheap
+// unmasked pass before): sums of d = x - k and d*d over the whole plane, inside the content box and inside the style box.
+// The outside-the-content-box moments follow by subtraction.  (The first version made two masked passes with three
+// selects each — 26 vector instructions per element against 5 without boxes, which made the boxed kernels VALU-bound.)
+//   in: St, Qt, Sc, Qc, Ss, Qs (wave-uniform sums), k, region sizes      out: pub[6] = mu_c, M2c, mu_o, M2o, mu_s, M2s
+__device__ __forceinline__ void boxed_moments(float k, const float (&t)[6], int M, int Mc, int Ms, float (&pub)[6]) {
+    const float St = t[0], Qt = t[1], Sc = t[2], Qc = t[3], Ss = t[4], Qs = t[5];
+    const int Mo = M - Mc;
+    const float rc = 1.f / (float)Mc, rs = 1.f / (float)Ms;
+    pub[0] = k + Sc * rc;
+    pub[1] = fmaxf(Qc - Sc * Sc * rc, 0.f);
+    const float So = St - Sc, Qo = Qt - Qc;
+    const float ro = Mo > 0 ? 1.f / (float)Mo : 0.f;
+    pub[2] = Mo > 0 ? k + So * ro : 0.f;
+    pub[3] = Mo > 0 ? fmaxf(Qo - So * So * ro, 0.f) : 0.f;
+    pub[4] = k + Ss * rs;
+    pub[5] = fmaxf(Qs - Ss * Ss * rs, 0.f);
 }
 
 // descriptor of slot j of the plane starting at `base` (plane_bytes = 0 for planes past the batch end)
@@ -636,45 +666,34 @@ __global__ __launch_bounds__(kBlock, SPLIT ? (POST ? 2 : 3) : POST ? (data_regs(
                 pub[0] = mean;
                 pub[1] = tq[0];
             } else {
-                float sc = 0.f, so = 0.f, ss = 0.f;
+                float s0 = 0.f;
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) {
-                        const float f = elem<T, VEC>(d[s][j], q);  // invalid slots hold 0 and no box bit
-                        const bool ic = sg.in_c(j, q), is = sg.in_s(j, q);
-                        sc += ic ? f : 0.f;
-                        so += ic ? 0.f : f;
-                        ss += is ? f : 0.f;
-                    }
-                const int Mo = a.M - a.Mc;
-                float tot[3] = {wave_sum(sc), wave_sum(so), wave_sum(ss)};
-                if constexpr (SPLIT) split_merge<3>(tot, xch, wave, lane);
-                const float mc = tot[0] / (float)a.Mc;
-                const float mo = Mo > 0 ? tot[1] / (float)Mo : 0.f;
-                const float ms = tot[2] / (float)a.Ms;
-                float qc = 0.f, qo = 0.f, qs = 0.f;
+                    for (int q = 0; q < VEC; ++q) s0 += elem<T, VEC>(d[s][j], q);  // invalid slots hold 0
+                float tot[1] = {wave_sum(s0)};
+                if constexpr (SPLIT) split_merge<1>(tot, xch, wave, lane);
+                const float k = tot[0] / (float)a.M;
+                float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
                     if (sg.valid(j)) {
 #pragma unroll
                         for (int q = 0; q < VEC; ++q) {
-                            const float f = elem<T, VEC>(d[s][j], q);
-                            const bool ic = sg.in_c(j, q), is = sg.in_s(j, q);
-                            const float tc = f - mc, to = f - mo, ts = f - ms;
-                            qc += ic ? tc * tc : 0.f;
-                            qo += ic ? 0.f : to * to;
-                            qs += is ? ts * ts : 0.f;
+                            const float dd = elem<T, VEC>(d[s][j], q) - k;
+                            const float dc = keep_if(dd, sg.mask_c(j, q)), ds = keep_if(dd, sg.mask_s(j, q));
+                            t[0] += dd;
+                            t[1] = fmaf(dd, dd, t[1]);
+                            t[2] += dc;
+                            t[3] = fmaf(dc, dc, t[3]);
+                            t[4] += ds;
+                            t[5] = fmaf(ds, ds, t[5]);
                         }
                     }
-                float tq[3] = {wave_sum(qc), wave_sum(qo), wave_sum(qs)};
-                if constexpr (SPLIT) split_merge<3>(tq, xch + 32, wave, lane);
-                pub[0] = mc;
-                pub[1] = tq[0];
-                pub[2] = mo;
-                pub[3] = tq[1];
-                pub[4] = ms;
-                pub[5] = tq[2];
+#pragma unroll
+                for (int m = 0; m < 6; ++m) t[m] = wave_sum(t[m]);
+                if constexpr (SPLIT) split_merge<6>(t, xch + 32, wave, lane);
+                boxed_moments(k, t, a.M, a.Mc, a.Ms, pub);
             }
             if constexpr (SOLO) {
                 solo_mean[s] = pub[0];
@@ -1145,17 +1164,23 @@ __global__ __launch_bounds__(kBlock, SPLIT ? 2 : POST ? 2 : EPI ? bwd_waves_epi(
                         if constexpr (!BOXED) {
                             acc[0] += G;
                             acc[1] = fmaf(G, X - si, acc[1]);
-                        } else {
-                            const bool ic = sg.in_c(j, q);
-                            acc[0] += ic ? G : 0.f;
-                            acc[1] += ic ? G * (X - si) : 0.f;
-                            acc[2] += ic ? 0.f : G;
-                            acc[3] += ic ? 0.f : G * (X - so);
+                        } else {  // whole-plane sums in acc[2..3], content-box sums in acc[0..1], both about float(mu_c)
+                            const float Xc = X - si, Gc = keep_if(G, sg.mask_c(j, q));
+                            acc[0] += Gc;
+                            acc[1] = fmaf(Gc, Xc, acc[1]);
+                            acc[2] += G;
+                            acc[3] = fmaf(G, Xc, acc[3]);
                         }
                     }
                 }
 #pragma unroll
             for (int m = 0; m < NS; ++m) acc[m] = wave_sum(acc[m]);
+            if constexpr (BOXED) {  // outside the box = whole plane - box, re-centred on float(mu_o):
+                                    // sum_o G*(X - so) = sum_o G*(X - si) + (si - so) * sum_o G
+                const float o1 = acc[2] - acc[0];
+                acc[3] = (acc[3] - acc[1]) + (si - so) * o1;
+                acc[2] = o1;
+            }
             if constexpr (SPLIT) split_merge<NS>(acc, xch, wave, lane);
             if (ra.epoch) {
                 if (n < N && lane < NS && (!SPLIT || wave == 0) && !(ra.fault && item == ra.K - 1)) {

@@ -157,43 +157,32 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
                     }
                 pub[0] = mean;
                 pub[1] = wave_sum(m2);
-            } else {
-                float sc = 0.f, so = 0.f, ss = 0.f;
+            } else {  // (one masked pass about the plane mean: boxed_moments, cnsn_resident_kernels.h)
+                float s0 = 0.f;
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) {
-                        const float f = elem<T, VEC>(d[s][j], q);  // invalid slots hold 0 and no box bit
-                        const bool ic = sg.in_c(j, q), is = sg.in_s(j, q);
-                        sc += ic ? f : 0.f;
-                        so += ic ? 0.f : f;
-                        ss += is ? f : 0.f;
-                    }
-                const int Mo = a.M - a.Mc;
-                const float mc = wave_sum(sc) / (float)a.Mc;
-                const float so_t = wave_sum(so);
-                const float mo = Mo > 0 ? so_t / (float)Mo : 0.f;
-                const float ms = wave_sum(ss) / (float)a.Ms;
-                float qc = 0.f, qo = 0.f, qs = 0.f;
+                    for (int q = 0; q < VEC; ++q) s0 += elem<T, VEC>(d[s][j], q);  // invalid slots hold 0
+                const float k = wave_sum(s0) / (float)a.M;
+                float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
                     if (sg.valid(j)) {
 #pragma unroll
                         for (int q = 0; q < VEC; ++q) {
-                            const float f = elem<T, VEC>(d[s][j], q);
-                            const bool ic = sg.in_c(j, q), is = sg.in_s(j, q);
-                            const float tc = f - mc, to = f - mo, ts = f - ms;
-                            qc += ic ? tc * tc : 0.f;
-                            qo += ic ? 0.f : to * to;
-                            qs += is ? ts * ts : 0.f;
+                            const float dd = elem<T, VEC>(d[s][j], q) - k;
+                            const float dc = keep_if(dd, sg.mask_c(j, q)), ds = keep_if(dd, sg.mask_s(j, q));
+                            t[0] += dd;
+                            t[1] = fmaf(dd, dd, t[1]);
+                            t[2] += dc;
+                            t[3] = fmaf(dc, dc, t[3]);
+                            t[4] += ds;
+                            t[5] = fmaf(ds, ds, t[5]);
                         }
                     }
-                pub[0] = mc;
-                pub[1] = wave_sum(qc);
-                pub[2] = mo;
-                pub[3] = wave_sum(qo);
-                pub[4] = ms;
-                pub[5] = wave_sum(qs);
+#pragma unroll
+                for (int m = 0; m < 6; ++m) t[m] = wave_sum(t[m]);
+                boxed_moments(k, t, a.M, a.Mc, a.Ms, pub);
             }
             if (ra.epoch) {  // persistent context: lane m publishes pub[m] with the launch's tag
                 if (n < N && lane < NG && !(ra.fault && item == ra.K - 1)) {
@@ -549,17 +538,22 @@ __global__ __launch_bounds__(kBlock, pipe_bwd_waves(2 * PPW * NV)) void resident
                         if constexpr (!BOXED) {
                             acc[0] += G;
                             acc[1] = fmaf(G, X - si, acc[1]);
-                        } else {
-                            const bool ic = sg.in_c(j, q);
-                            acc[0] += ic ? G : 0.f;
-                            acc[1] += ic ? G * (X - si) : 0.f;
-                            acc[2] += ic ? 0.f : G;
-                            acc[3] += ic ? 0.f : G * (X - so);
+                        } else {  // whole-plane sums in acc[2..3], content-box sums in acc[0..1], both about float(mu_c)
+                            const float Xc = X - si, Gc = keep_if(G, sg.mask_c(j, q));
+                            acc[0] += Gc;
+                            acc[1] = fmaf(Gc, Xc, acc[1]);
+                            acc[2] += G;
+                            acc[3] = fmaf(G, Xc, acc[3]);
                         }
                     }
                 }
 #pragma unroll
             for (int m = 0; m < NS; ++m) acc[m] = wave_sum(acc[m]);
+            if constexpr (BOXED) {  // outside the box = whole plane - box, re-centred on float(mu_o) (cnsn_resident_kernels.h)
+                const float o1 = acc[2] - acc[0];
+                acc[3] = (acc[3] - acc[1]) + (si - so) * o1;
+                acc[2] = o1;
+            }
             if (ra.epoch) {
                 if (n < N && lane < NS && !(ra.fault && item == ra.K - 1)) {
                     float v = acc[0];
