@@ -14,7 +14,12 @@
 //
 // Schedule = the pipelined kernels' (cnsn_resident_pipe_kernels.h): item t parked (LDS + a few registers), item t+1 in
 // flight into registers; gather t -> algebra t -> statistics of t+1, publish -> slot by slot: apply t and store, park
-// t+1's slot, issue t+2's loads.
+// t+1's slot, issue t+2's loads.  An item is a channel; a cluster is K fixed workgroups; a wave holds PPW planes of it
+// (1 at 56x56 ... 16 for one-slot planes such as 14x14 in 16 bits).
+//
+// Register discipline: one buffer descriptor per TENSOR (PlaneIo), kernel arguments re-read from the
+// kernarg segment where they are used (kargs_now), plane algebra lane-parallel, phase fences for the register allocator
+// around the plane loops (snx_phase_fence) — without them a third of the hot loops' vector instructions were SGPR spills.
 //
 // Numerics: plane statistics exactly as the other resident kernels (two-pass from registers, float); z per plane in
 // double from those; a member's partial = (mean, M2) of its planes' z in double, published as mean_hi + mean_lo + M2
@@ -63,11 +68,12 @@ __device__ __forceinline__ int snx_count(int N, int own, int k) {
 }
 
 // per-plane state a wave keeps for its own planes between the phases of the pipeline.  It lives in LDS (one record per
-// plane): these are wave-uniform scalars, and VGPRs are what the planes in flight need.  EVERY lane of the owning wave
-// writes the (identical) record and reads it back, so each thread only ever reads what it wrote itself: a record
-// written by lane 0 alone and read by its 63 neighbours is a data race in the compiler's memory model — lanes are
-// independent threads there — and hipcc did forward lane 0's store past the branch and hoist the others' loads ABOVE
-// it (wrong batch sums in the first version of these kernels).  Other waves read a record only behind a barrier.
+// plane).  The record of plane s of a wave is written by LANE s of that wave, which does the plane's scalar algebra (all
+// planes of the wave at once, lane-parallel), and is read back by the same lane in the next phase — or by wave 0 behind a
+// workgroup barrier.  Never "lane 0 writes, its 63 neighbours read": that is a data race in the compiler's memory model
+// — lanes are independent threads there — and hipcc did forward lane 0's store past the branch and hoist the others'
+// loads ABOVE it (wrong batch sums in the first version of these kernels).  What the plane loops need from a record
+// (gate, dx coefficients, saved mean) travels from lane s to the whole wave through v_readlane, not through LDS.
 struct SnxFwdState {
     double z;      // w0*mean + w1*std
     float mu, sg;  // plane mean, sqrt(var + eps_sn)
