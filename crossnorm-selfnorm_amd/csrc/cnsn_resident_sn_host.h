@@ -27,17 +27,30 @@ constexpr size_t kLdsPerCu = 160 * 1024;
 #ifndef SNX_NV1_PPW
 #define SNX_NV1_PPW 8       // one-slot planes of 16-byte vectors (fp32 14x14)
 #endif
+#ifndef SNX_NV4_PPW_EPI
+#define SNX_NV4_PPW_EPI 2   // four-slot planes (fp32 28x28, 40x40 in 16 bits), forward with the epilogue
+#endif
+#ifndef SNX_NV4_BWD_PPW
+#define SNX_NV4_BWD_PPW 4   // ... backward without the epilogue ((128,256,40,40) bf16: 0.091 -> 0.071 ms; fp32 28x28 level); with it: 2
+#endif
+#ifndef SNX_NV7_PPW_EPI
+#define SNX_NV7_PPW_EPI 2   // seven-slot planes in 16 bits (56x56), forward with the epilogue: 2 planes per wave -6 % at N = 256
+#endif                      // (0.266 -> 0.249 ms), +3 % at N = 96; fp32 (40x40): 1
+#ifndef SNX_NV7_BWD_PPW
+#define SNX_NV7_BWD_PPW 2   // ... backward without the epilogue in 16 bits (-2 %); with it (does not fit) and fp32: 1
+#endif
 constexpr int fwd_ppw(int nv, bool epi, int elem_bytes, int vb = 16) {
     return nv == 1   ? (vb == 8 ? SNX_NV1_PPW8 : SNX_NV1_PPW)
            : nv == 2 ? (epi ? SNX_NV2_PPW : SNX_NV2_PPW_PLAIN)
-           : nv == 4 ? (epi ? 2 : 4)
-           : nv == 7 ? ((elem_bytes == 2 && !epi) ? SNX_NV7_PPW16 : 1)
+           : nv == 4 ? (epi ? SNX_NV4_PPW_EPI : 4)
+           : nv == 7 ? (elem_bytes == 2 ? (epi ? SNX_NV7_PPW_EPI : SNX_NV7_PPW16) : 1)
                      : 1;
 }
-constexpr int bwd_ppw(int nv, bool epi, int, int vb = 16) {  // (one-slot planes with the epilogue: 3 x 16 planes in flight do not fit)
+constexpr int bwd_ppw(int nv, bool epi, int elem_bytes, int vb = 16) {  // (one-slot planes with the epilogue: 3 x 16 planes in flight do not fit)
     return nv == 1 ? (vb == 8 ? (epi ? SNX_NV1_PPW8 / 2 : SNX_NV1_PPW8) : SNX_NV1_PPW)
            : nv == 2 ? (epi ? SNX_NV2_PPW : SNX_NV2_PPW_PLAIN)
-           : nv == 4 ? 2
+           : nv == 4 ? (epi ? 2 : SNX_NV4_BWD_PPW)
+           : nv == 7 ? ((!epi && elem_bytes == 2) ? SNX_NV7_BWD_PPW : 1)
                      : 1;
 }
 
