@@ -39,11 +39,15 @@ constexpr size_t kLdsPerCu = 160 * 1024;
 #ifndef SNX_NV7_BWD_PPW
 #define SNX_NV7_BWD_PPW 2   // ... backward without the epilogue in 16 bits (-2 %); with it (does not fit) and fp32: 1
 #endif
+#ifndef SNX_NV13_FWD_PPW
+#define SNX_NV13_FWD_PPW 1  // thirteen-slot planes (fp32 56x56), forward without the epilogue
+#endif
 constexpr int fwd_ppw(int nv, bool epi, int elem_bytes, int vb = 16) {
     return nv == 1   ? (vb == 8 ? SNX_NV1_PPW8 : SNX_NV1_PPW)
            : nv == 2 ? (epi ? SNX_NV2_PPW : SNX_NV2_PPW_PLAIN)
            : nv == 4 ? (epi ? SNX_NV4_PPW_EPI : 4)
            : nv == 7 ? (elem_bytes == 2 ? (epi ? SNX_NV7_PPW_EPI : SNX_NV7_PPW16) : 1)
+           : nv == 13 ? (epi ? 1 : SNX_NV13_FWD_PPW)
                      : 1;
 }
 constexpr int bwd_ppw(int nv, bool epi, int elem_bytes, int vb = 16) {  // (one-slot planes with the epilogue: 3 x 16 planes in flight do not fit)
@@ -70,7 +74,7 @@ bool dispatch_snx(int dtype, int vec, int nv, F&& f) {
             case 4: f(tt, vt, IntTag<4>{}, IntTag<(BWD ? bwd_ppw(4, EPI, EB) : fwd_ppw(4, EPI, EB))>{}); return true;
             case 7: f(tt, vt, IntTag<7>{}, IntTag<(BWD ? bwd_ppw(7, EPI, EB) : fwd_ppw(7, EPI, EB))>{}); return true;
             case 8: f(tt, vt, IntTag<8>{}, IntTag<(BWD ? bwd_ppw(8, EPI, EB) : fwd_ppw(8, EPI, EB))>{}); return true;
-            case 13: f(tt, vt, IntTag<13>{}, IntTag<1>{}); return true;
+            case 13: f(tt, vt, IntTag<13>{}, IntTag<(BWD ? bwd_ppw(13, EPI, EB) : fwd_ppw(13, EPI, EB))>{}); return true;
             case 16:
                 if constexpr (BWD && EPI) return false;  // 48 slots in flight: does not fit
                 else { f(tt, vt, IntTag<16>{}, IntTag<1>{}); return true; }
