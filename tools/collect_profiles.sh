@@ -9,7 +9,8 @@ stats() {  # name, command...
   name=$1; shift
   rm -rf /tmp/rp_$name
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$name -- "$@" > /tmp/rp_$name.log 2>&1
-  f=$(find /tmp/rp_$name -name "*kernel_stats.csv" | head -1)
+  # (bench.py spawns tools/pattern_bench: one stats file per process — take the one with the library's kernels in it)
+  f=$(for g in $(find /tmp/rp_$name -name "*kernel_stats.csv"); do echo "$(grep -c cnsn:: $g) $g"; done | sort -rn | head -1 | cut -d" " -f2)
   [ -n "$f" ] && python $R/profiles/summarize.py "$f" $OUT/${name}_kernel_stats.csv
   echo "stats $name: $(grep -c cnsn $OUT/${name}_kernel_stats.csv) cnsn rows"
 }
