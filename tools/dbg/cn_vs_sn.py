@@ -1,3 +1,5 @@
+"""Same-process forward / backward times at the north-star shape: CrossNorm+SelfNorm (general pipelined kernels), SelfNorm alone
+(partial-moment cluster kernels) and SelfNorm alone through the general kernels."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import cnsn_amd

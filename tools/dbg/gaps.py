@@ -1,3 +1,5 @@
+"""rocprofv3 --kernel-trace CSV of a bench.py run -> the kernels of three mid-run steps with the idle time before each, and
+the busy / idle totals per step (profiles/r03_sn_cluster.md section 9).  usage: gaps.py <rocprofv3 output dir>"""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))

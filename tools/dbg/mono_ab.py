@@ -1,3 +1,5 @@
+"""Forward / backward times of the small-plane sites (14x14, 7x7) through the module surface, for A/B runs of tuning builds
+(CNSN_LIB_PATH=tools/dbg/lib_<variant>.so): profiles/r03_sn_cluster.md section 8."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import cnsn_amd

@@ -1,3 +1,5 @@
+"""Run-to-run bit equality of every output of the SelfNorm cluster kernels, with the lane / dword pattern of any difference
+(how the gfx950 store hazard of DESIGN.md 4.2h was found)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["CNSN_SNX"] = "2"

@@ -1,3 +1,5 @@
+"""cProfile of 2000 forward+backward calls of one small site: where the host time of a call goes (tools/host_floor.py has the
+per-call totals)."""
 import cProfile, pstats, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import cnsn_amd
