@@ -137,9 +137,9 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
         if (st != CNSN_E_UNSUPPORTED) return st;
     }
     {
-        const WidePlan wp = wide_plan(pl, 0, false);  // planes that are no whole number of vectors (7x7): channel groups in registers
+        const WidePlan wp = wide_plan(pl, 0, false, chan_perm != nullptr);  // planes that are no whole number of vectors (7x7): channel groups in registers
         if (wp.ok) {
-            st = wide_forward(pl, wp, 0, 0, x, nullptr, gate_dev(g), y, saved ? saved_d : nullptr, stream);
+            st = wide_forward(pl, wp, 0, 0, x, nullptr, perm, gate_dev(g), y, saved ? saved_d : nullptr, stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
     }
@@ -243,9 +243,9 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
         if (st != CNSN_E_UNSUPPORTED) return st;
     }
     {
-        const WidePlan wp = wide_plan(pl, 0, true);
+        const WidePlan wp = wide_plan(pl, 0, true, chan_perm != nullptr);
         if (wp.ok) {
-            st = wide_backward(pl, wp, 0, 0, grad_y, x, nullptr, gate_dev(g), saved_d, grad_x, gate_grad_dev(dg), stream);
+            st = wide_backward(pl, wp, 0, 0, grad_y, x, nullptr, perm, gate_dev(g), saved_d, grad_x, gate_grad_dev(dg), stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
     }

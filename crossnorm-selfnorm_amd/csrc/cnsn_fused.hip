@@ -79,7 +79,7 @@ int cnsn_which_path(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int 
     // the backward of an epilogue without ReLU and without PRE add is the plain backward
     const bool fused = bwd ? (e.relu || e.add == ADD_PRE) : (e.relu || e.add != ADD_NONE);
     if (resident_sn_prefers(p, pl.boxed, fused ? e.add : ADD_NONE, fused ? e.relu : 0, bwd)) return CNSN_PATH_RESIDENT;
-    if (wide_plan(pl, fused ? e.add : 0, bwd).ok) return CNSN_PATH_MONO;  // (channel GROUPS in registers: reported as mono)
+    if (wide_plan(pl, fused ? e.add : 0, bwd, chan).ok) return CNSN_PATH_MONO;  // (channel GROUPS in registers: reported as mono)
     if (mono_plan(pl, fused ? e.add : 0, bwd).ok) return CNSN_PATH_MONO;
     if (mono_cn_plan(pl, chan, fused ? e.add : 0, bwd).ok) return CNSN_PATH_MONO;
     if (local_plan(pl, fused ? e.add : 0, bwd).ok) return CNSN_PATH_LOCAL;
@@ -139,9 +139,9 @@ int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, c
         if (st != CNSN_E_UNSUPPORTED) return st;
     }
     {
-        const WidePlan wp = wide_plan(pl, e.add, false);
+        const WidePlan wp = wide_plan(pl, e.add, false, chan_perm != nullptr);
         if (wp.ok) {
-            st = wide_forward(pl, wp, e.add, e.relu, x, e.addend, gate_dev(g), y, saved ? saved_d : nullptr, stream);
+            st = wide_forward(pl, wp, e.add, e.relu, x, e.addend, perm, gate_dev(g), y, saved ? saved_d : nullptr, stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
     }
@@ -263,9 +263,9 @@ int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, 
         if (st != CNSN_E_UNSUPPORTED) return st;
     }
     {
-        const WidePlan wp = wide_plan(pl, e.add, true);
+        const WidePlan wp = wide_plan(pl, e.add, true, chan_perm != nullptr);
         if (wp.ok) {
-            st = wide_backward(pl, wp, e.add, e.relu, grad_y, x, e.addend, gate_dev(g), saved_d, grad_x, gate_grad_dev(dg), stream);
+            st = wide_backward(pl, wp, e.add, e.relu, grad_y, x, e.addend, perm, gate_dev(g), saved_d, grad_x, gate_grad_dev(dg), stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
     }

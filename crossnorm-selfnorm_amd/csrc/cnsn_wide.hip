@@ -22,11 +22,13 @@ inline int wide_grid(int groups) { return ((groups + 7) / 8) * 8; }
 
 }  // namespace
 
-WidePlan wide_plan(const Plan& pl, int add, bool backward) {
+WidePlan wide_plan(const Plan& pl, int add, bool backward, bool has_chan_perm) {
     WidePlan wp{false, 0, 0, 0};
     const cnsn_problem_t& p = pl.pr;
     if (p.strategy != CNSN_STRATEGY_AUTO && p.strategy != CNSN_STRATEGY_MONO) return wp;
-    if (p.cn_active || !p.sn_active || p.sn_two || add == ADD_POST) return wp;
+    if (!p.sn_active || p.sn_two || add == ADD_POST) return wp;
+    // CrossNorm: without crop boxes and without the channel permutation (the pairing stays inside one channel)
+    if (p.cn_active && (pl.boxed || has_chan_perm)) return wp;
     int mode = 1;  // CNSN_WIDE=0: never; CNSN_WIDE=2: wherever eligible (tests: fp32 and small batches too)
     if (const char* e = getenv("CNSN_WIDE")) mode = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);
     if (mode == 0) return wp;
@@ -44,14 +46,16 @@ WidePlan wide_plan(const Plan& pl, int add, bool backward) {
     }
     wp.vec = vec;
     wp.R = (p.N + kWideWaves - 1) / kWideWaves;
-    wp.lds = backward ? wide_lds_bytes(p.N, vec, 4, 2, 7, 0) : wide_lds_bytes(p.N, vec, 8, 1, 2, kWideParkFwd * 16);
+    const bool cn = p.cn_active != 0;
+    wp.lds = backward ? wide_lds_bytes(p.N, vec, 4, 2, cn ? 10 : 7, 0, cn ? p.N : 0)
+                      : wide_lds_bytes(p.N, vec, 8, 1, cn ? 3 : 2, kWideParkFwd * 16, cn ? p.N : 0);
     if (wp.lds > 160 * 1024) return wp;
     wp.ok = true;
     return wp;
 }
 
-int wide_forward(const Plan& pl, const WidePlan& wp, int add, int relu, const void* x, const void* addend, GateDev g, void* y,
-                 double* saved, hipStream_t stream) {
+int wide_forward(const Plan& pl, const WidePlan& wp, int add, int relu, const void* x, const void* addend, const int64_t* perm,
+                 GateDev g, void* y, double* saved, hipStream_t stream) {
     WideArgs wa{pl.mid, wp.R};
     const bool epi = add == ADD_PRE || relu;
     const int grid = wide_grid(pl.pr.C / wp.vec);
@@ -62,20 +66,25 @@ int wide_forward(const Plan& pl, const WidePlan& wp, int add, int relu, const vo
         auto launch = [&](auto kern) {
             if (!allow_dynamic_lds(kern, wp.lds)) return;
             kern<<<grid, kWideBlock, wp.lds, stream>>>(wa, (const T*)x, (const T*)(add == ADD_PRE ? addend : nullptr), (T*)y, g,
-                                                       saved, epi ? add : ADD_NONE, epi ? relu : 0);
+                                                       saved, epi ? add : ADD_NONE, epi ? relu : 0, perm);
             const hipError_t e = hipGetLastError();
             status = e == hipSuccess ? CNSN_OK : (int)e;
         };
+        const bool cn = pl.pr.cn_active != 0;
+        if (cn && !perm) {
+            status = CNSN_E_NULL;
+            return;
+        }
         if (epi)
-            launch(wide_fwd_kernel<T, VEC, true>);
+            cn ? launch(wide_fwd_kernel<T, VEC, true, true>) : launch(wide_fwd_kernel<T, VEC, true, false>);
         else
-            launch(wide_fwd_kernel<T, VEC, false>);
+            cn ? launch(wide_fwd_kernel<T, VEC, false, true>) : launch(wide_fwd_kernel<T, VEC, false, false>);
     });
     return status;
 }
 
 int wide_backward(const Plan& pl, const WidePlan& wp, int add, int relu, const void* gy, const void* x, const void* addend,
-                  GateDev g, const double* saved, void* dx, GateGradDev dg, hipStream_t stream) {
+                  const int64_t* perm, GateDev g, const double* saved, void* dx, GateGradDev dg, hipStream_t stream) {
     WideArgs wa{pl.mid, wp.R};
     const bool epi = add == ADD_PRE || relu;
     const int grid = wide_grid(pl.pr.C / wp.vec);
@@ -87,14 +96,19 @@ int wide_backward(const Plan& pl, const WidePlan& wp, int add, int relu, const v
             if (!allow_dynamic_lds(kern, wp.lds)) return;
             kern<<<grid, kWideBlock, wp.lds, stream>>>(wa, (const T*)gy, (const T*)x,
                                                        (const T*)(add == ADD_PRE ? addend : nullptr), (T*)dx, g, dg, saved,
-                                                       epi ? add : ADD_NONE, epi ? relu : 0);
+                                                       epi ? add : ADD_NONE, epi ? relu : 0, perm);
             const hipError_t e = hipGetLastError();
             status = e == hipSuccess ? CNSN_OK : (int)e;
         };
+        const bool cn = pl.pr.cn_active != 0;
+        if (cn && !perm) {
+            status = CNSN_E_NULL;
+            return;
+        }
         if (epi)
-            launch(wide_bwd_kernel<T, VEC, true>);
+            cn ? launch(wide_bwd_kernel<T, VEC, true, true>) : launch(wide_bwd_kernel<T, VEC, true, false>);
         else
-            launch(wide_bwd_kernel<T, VEC, false>);
+            cn ? launch(wide_bwd_kernel<T, VEC, false, true>) : launch(wide_bwd_kernel<T, VEC, false, false>);
     });
     return status;
 }

