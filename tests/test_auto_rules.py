@@ -29,14 +29,14 @@ TABLE = [
     ((64, 1024, 14, 14), BF16, FC(**SN, **CN), "resident", "resident"),        # fewer than 96 planes per channel, un-boxed: the cluster kernels
     ((96, 1024, 14, 14), BF16, FC(**SN, **CN), "mono", "mono"),
     ((64, 1024, 14, 14), BF16, FC(**SN, **BOTH), "mono", "mono"),              # with crop boxes the channel-in-registers kernels keep it
-    ((256, 2048, 7, 7), F32, FC(**SN, **CN), "packed", "packed"),              # one element per lane pays only with crop boxes
+    ((256, 2048, 7, 7), F32, FC(**SN, **CN), "mono", "mono"),                  # CrossNorm without boxes: the channel-group kernels (round 3)
     ((256, 1024, 14, 14), BF16, FC(**SN, **BOTH), "mono", "mono"),             # (was packed two-pass: vectors straddle rows)
     ((128, 128, 8, 8), F32, FC(**SN, **BOTH), "mono", "mono"),                 # WideResNet stage 3, armed site
     ((256, 2048, 7, 7), BF16, FC(**SN, **BOTH), "mono", "mono"),               # 7x7 bf16 with boxes: one element per lane
     ((256, 2048, 7, 7), BF16, FC(**SN), "mono", "mono"),                       # 98-byte planes: 8 / 4 adjacent channels per workgroup ("wide")
     ((256, 2048, 7, 7), BF16, FC(**BLOCK), "mono", "mono"),
     ((96, 2048, 7, 7), BF16, FC(**SN), "local", "local"),                      # small batch: the channel-local kernels
-    ((256, 2048, 7, 7), BF16, FC(**SN, **CN), "packed", "packed"),             # CrossNorm: not channel-local
+    ((256, 2048, 7, 7), BF16, FC(**SN, **CN), "mono", "mono"),                 # CrossNorm without boxes: channel groups in registers ("wide", round 3)
     ((256, 2048, 7, 7), F32, FC(**SN), "mono", "mono"),                        # fp32 7x7: one element (4 B) per lane
     ((16, 512, 64, 64), F32, FC(sn_active=True, add_mode="post", relu=True), "resident", "resident"),   # segmentation: SN at 'residual'
     ((16, 2048, 64, 64), BF16, FC(sn_active=True, add_mode="post", relu=True), "resident", "resident"),
