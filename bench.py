@@ -59,6 +59,9 @@ def parse():
                          "training steps of the caller backbones (images/s)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch of the model workloads (0 = config default)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--block-graphs", action="store_true",
+                    help="wrn40: armed steps replay one captured graph per idle block (measured SLOWER on ROCm 7.2: 8.45 vs "
+                         "7.11 ms per step; off by default)")
     ap.add_argument("--no-graph", action="store_true",
                     help="wrn40: run the steps whose CrossNorm sites are idle eagerly instead of replaying them from a HIP graph")
     ap.add_argument("--sweep", action="store_true", help="print the SURVEY d1 shape sweep as a markdown table and exit")
@@ -461,8 +464,9 @@ def model_workload(args, dist, world, rank, dev):
         # launch-bound network: the steps with idle CrossNorm sites (half of them at cn_prob 0.5) replay a captured
         # step — forward, loss, backward, SGD — instead of ~700 eager launches; armed steps stay eager
         from cnsn_amd.callers import GraphedIdleStep
-        graphed = GraphedIdleStep(net, opt, x, y)
-        name += "; idle-site steps replayed from a HIP graph"
+        graphed = GraphedIdleStep(net, opt, x, y, graph_blocks=args.block_graphs)
+        name += "; idle-site steps replayed from a HIP graph" + (", armed steps from one graph per idle block"
+                                                                 if args.block_graphs else "")
 
         def step():                                                                              # noqa: F811
             graphed.step(x, y, 0.5)

@@ -96,6 +96,80 @@ def train_step_image_cn_views(net, views, target, optimizer, cn_prob, beta, crop
     return _apply(optimizer, loss, guard)
 
 
+class _IdleBlock(torch.nn.Module):
+    """One WideResNet block in the form `WideResNetCNSN.forward` calls it with the fused tail, as a tensor-in / tensor-out
+    module (what torch.cuda.make_graphed_callables captures).  Shares the block's (and the next BatchNorm's) parameters."""
+
+    def __init__(self, blk, next_bn, want_y, has_pre):
+        super().__init__()
+        self.blk, self.next_bn, self.want_y, self.has_pre = blk, next_bn, want_y, has_pre
+
+    def forward(self, h, pre=None):
+        y, z = self.blk(h, pre if self.has_pre else None, next_bn=self.next_bn, want_y=self.want_y)
+        assert z is not None and (y is not None) == self.want_y
+        return (y, z) if self.want_y else z
+
+
+class _GraphedBlocks:
+    """An ARMED WideResNet step cannot be replayed as a whole (which sites fire, their permutations and crop boxes are drawn
+    per step and are launch ARGUMENTS), but 16 of its 18 blocks are idle all the same.  Every block is captured once in its
+    idle form — forward and backward, through torch.cuda.make_graphed_callables — and an armed step replays the idle ones and
+    runs the two armed ones eagerly: ~700 launches become ~60.  Same arithmetic as `WideResNetCNSN.forward(x, aug=True)`,
+    same RNG draws (`_enable_cross_norm` is called first, exactly as there).
+    MEASURED AND LEFT OFF (bench.py --workload wrn40, MI355X, ROCm 7.2, torch 2.10): 8.45 ms per step against 7.11 with the
+    armed steps fully eager — 36 graph launches per step, each with its input copies into the callable's static buffers and
+    the graphed autograd function's own book-keeping, cost more than the ~640 launches they replace.  Kept as an option
+    (`GraphedIdleStep(..., graph_blocks=True)`, `bench.py --block-graphs`) and under test: the trajectory equals the eager one."""
+
+    def __init__(self, net, x):
+        from . import _sites
+        assert _sites.FUSE_TAIL and net.pos == "post", "per-block graphs follow the fused-tail form of WideResNetCNSN.forward"
+        self.net = net
+        self.blocks = [b for stage in (net.block1, net.block2, net.block3) for b in stage.layer]
+        n = len(self.blocks)
+        self.next_bn = [net.bn1 if i + 1 == n else self.blocks[i + 1].bn1 for i in range(n)]
+        self.want_y = []
+        for i, blk in enumerate(self.blocks):
+            last = i + 1 == n
+            w = (not last) and self.blocks[i + 1].same_width and self.blocks[i + 1].pos != "pre"
+            self.want_y.append(w or not blk.cnsn_tail_ok())
+        # sample inputs of every block: one eager pass in the idle form
+        samples, h, pre = [], net.conv1(x), None
+        with torch.no_grad():
+            for i, blk in enumerate(self.blocks):
+                samples.append((h, pre))
+                y, z = blk(h, pre, next_bn=self.next_bn[i], want_y=self.want_y[i])
+                assert z is not None, "per-block graphs need the fused tail at every site (CNSN.forward_block_bn)"
+                h, pre = (y if y is not None else z), z
+        mods, args = [], []
+        for i, (hh, pp) in enumerate(samples):
+            mods.append(_IdleBlock(self.blocks[i], self.next_bn[i], self.want_y[i], pp is not None).to(x.device).train())
+            a = (hh.detach().clone().requires_grad_(),) + ((pp.detach().clone().requires_grad_(),) if pp is not None else ())
+            args.append(a)
+        self.graphed = torch.cuda.make_graphed_callables(tuple(mods), tuple(args), allow_unused_input=True)
+
+    def forward(self, x):
+        net = self.net
+        net._enable_cross_norm()
+        h, pre = net.conv1(x), None
+        z = None
+        for i, blk in enumerate(self.blocks):
+            cn = getattr(blk.cnsn, "crossnorm", None)
+            if cn is not None and cn.active:               # armed: eager, fresh draws
+                y, z = blk(h, pre, next_bn=self.next_bn[i], want_y=self.want_y[i])
+                if z is None:                               # (no tail at this site this step)
+                    h, pre = y, None
+                    if i + 1 == len(self.blocks):
+                        z = net.relu(net.bn1(y))
+                else:
+                    h, pre = (y if y is not None else z), z
+            else:                                           # idle: the block's captured forward (and, later, backward)
+                out = self.graphed[i](h, pre) if pre is not None else self.graphed[i](h)
+                y, z = out if self.want_y[i] else (None, out)
+                h, pre = (y if y is not None else z), z
+        return net.fc(F.avg_pool2d(z, 8).view(z.size(0), -1))
+
+
 class GraphedIdleStep:
     """Launch-bound networks (WideResNet-40-2: ~700 small launches per step for 8 ms of host time against ~3 ms of GPU
     work): a training step whose CrossNorm sites are all IDLE (`aug=False`: SelfNorm only — nothing is drawn on the host)
@@ -105,9 +179,12 @@ class GraphedIdleStep:
     the captured buffers.  The op itself needs nothing special for this: every entry point only enqueues work on the
     caller's stream ("HIP graphs")."""
 
-    def __init__(self, net, optimizer, x, target, warmup=3):
+    def __init__(self, net, optimizer, x, target, warmup=3, graph_blocks=False):
+        """graph_blocks: ARMED steps replay one small graph per idle block as well (`_GraphedBlocks` below) — WideResNet with
+        the fused tail only; the armed blocks, the head, the loss and the optimizer stay eager."""
         import copy
         self.net, self.opt = net, optimizer
+        self.blocks = None
         self.x, self.y = x.clone(), target.clone()
         for m in net.modules():     # float(num_batches_tracked) would synchronise under capture
             if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.momentum is None and m.track_running_stats:
@@ -130,6 +207,8 @@ class GraphedIdleStep:
         with torch.cuda.graph(self.graph):
             self.loss = self._body()
         torch.cuda.synchronize(x.device)
+        if graph_blocks:
+            self.blocks = _GraphedBlocks(net, self.x)       # (its warm-up passes move BatchNorm statistics too: restored below)
         with torch.no_grad():                               # in place: the graph holds the parameters' / buffers' addresses
             live = net.state_dict()
             for k, v in model_state.items():
@@ -159,7 +238,8 @@ class GraphedIdleStep:
         _ffi.check_resident_health("GraphedIdleStep.step")  # a replay has no per-call poll of its own
         r = np.random.rand(1)                               # drawn first, armed or not (cifar.py:127)
         if r < cn_prob:                                     # armed: eager (fresh draws per step)
-            loss = F.cross_entropy(self.net(x, aug=True), target)
+            logits = self.blocks.forward(x) if self.blocks is not None else self.net(x, aug=True)
+            loss = F.cross_entropy(logits, target)
             self.opt.zero_grad(set_to_none=True)
             loss.backward()
             self.opt.step()

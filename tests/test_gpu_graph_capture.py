@@ -73,7 +73,7 @@ def test_graphed_idle_step_matches_eager_steps():
     import numpy as np
     from cnsn_amd.callers import GraphedIdleStep, WideResNetCNSN, train_step_cn
 
-    def run(graphed):
+    def run(graphed, blocks=False):
         torch.manual_seed(11)
         np.random.seed(11)
         net = WideResNetCNSN(10, 10, 1, active_num=1, pos="post", beta=1, crop="both", cnsn_type="cnsn").to(DEV).train()
@@ -83,7 +83,7 @@ def test_graphed_idle_step_matches_eager_steps():
         y = torch.randint(0, 10, (16,), device=DEV, generator=g)
         for _ in range(2):                      # (both variants: two eager steps first — MIOpen picks its kernels outside a capture)
             train_step_cn(net, x, y, opt, 0.5)
-        stepper = GraphedIdleStep(net, opt, x, y, warmup=0) if graphed else None
+        stepper = GraphedIdleStep(net, opt, x, y, warmup=0, graph_blocks=blocks) if graphed else None
         np.random.seed(12)
         torch.manual_seed(12)
         for _ in range(6):
@@ -97,6 +97,10 @@ def test_graphed_idle_step_matches_eager_steps():
     eager, n_e = run(False)
     graph, n_g = run(True)
     assert n_g == n_e                          # capturing records the step, it does not run it
+    per_block, n_b = run(True, blocks=True)    # armed steps: one captured graph per idle block, the armed blocks eager
+    assert n_b == n_e
+    worst_b = max(float((a - b).abs().max() / (b.abs().max() + 1e-12)) for a, b in zip(per_block, eager))
+    assert worst_b < 2e-2, worst_b
     worst = max(float((a - b).abs().max() / (b.abs().max() + 1e-12)) for a, b in zip(graph, eager))
     assert worst < 2e-2, worst                 # same arithmetic; MIOpen's convolutions are not bit-reproducible run to run
                                                # (six SGD steps amplify that: 1e-4 .. 6e-3 seen, depending on what ran before)
