@@ -133,14 +133,32 @@ int mono_backward(const Plan& pl, const MonoPlan& mp, int add, int relu, const v
     dispatch_m(pl.pr.dtype, mp.vec, mp.lpp, mp.rmax, [&](auto tt, auto vt, auto lt, auto rt) {
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value, LPP = decltype(lt)::value, RMAX = decltype(rt)::value;
-        if (epi) {
-            auto kern = mono_bwd_kernel<T, VEC, LPP, RMAX, true>;
-            kern<<<mono_grid(pl.pr.C), kMonoBlock, mp.lds, stream>>>(
-                ma, (const T*)gy, (const T*)x, (const T*)(add == ADD_PRE ? addend : nullptr), (T*)dx, g, f, dg, df, saved, add, relu, TailDev{});
+        // sixteen slot rows of G and x do not leave registers for a second workgroup on the CU: two-phase variant (RELOAD)
+        // (with 16-byte vectors a half is 64 data registers again: those classes keep the single-phase kernel)
+        constexpr bool kReloadFits = RMAX == 16 && VEC * (int)sizeof(T) <= 8;
+        bool reload = kReloadFits;
+        if (const char* e = getenv("CNSN_MONO_RELOAD")) reload = reload && e[0] != '0';
+        auto launch = [&](auto kern) {
+            kern<<<mono_grid(pl.pr.C), kMonoBlock, mp.lds, stream>>>(ma, (const T*)gy, (const T*)x,
+                                                                                (const T*)(epi && add == ADD_PRE ? addend : nullptr),
+                                                                                (T*)dx, g, f, dg, df, saved, epi ? add : ADD_NONE,
+                                                                                epi ? relu : 0, TailDev{});
+        };
+        if constexpr (kReloadFits) {
+            if (reload) {
+                if (epi)
+                    launch(mono_bwd_kernel<T, VEC, LPP, RMAX, true, false, true>);
+                else
+                    launch(mono_bwd_kernel<T, VEC, LPP, RMAX, false, false, true>);
+            } else if (epi) {
+                launch(mono_bwd_kernel<T, VEC, LPP, RMAX, true>);
+            } else {
+                launch(mono_bwd_kernel<T, VEC, LPP, RMAX, false>);
+            }
+        } else if (epi) {
+            launch(mono_bwd_kernel<T, VEC, LPP, RMAX, true>);
         } else {
-            auto kern = mono_bwd_kernel<T, VEC, LPP, RMAX, false>;
-            kern<<<mono_grid(pl.pr.C), kMonoBlock, mp.lds, stream>>>(ma, (const T*)gy, (const T*)x, nullptr, (T*)dx, g, f,
-                                                                                dg, df, saved, ADD_NONE, 0, TailDev{});
+            launch(mono_bwd_kernel<T, VEC, LPP, RMAX, false>);
         }
         const hipError_t e = hipGetLastError();
         status = e == hipSuccess ? CNSN_OK : (int)e;

@@ -99,6 +99,19 @@ __device__ __forceinline__ MRaw<T, VEC> mload(__amdgpu_buffer_rsrc_t r, int voff
     else
         return __builtin_amdgcn_raw_buffer_load_b16(r, voff, 0, CNSN_RES_LOAD_AUX);
 }
+// the same load with the default cache policy (no non-temporal hint): what a kernel reads TWICE (mono_bwd_kernel, RELOAD)
+template <typename T, int VEC>
+__device__ __forceinline__ MRaw<T, VEC> mload_cached(__amdgpu_buffer_rsrc_t r, int voff) {
+    constexpr int B = (int)sizeof(T) * VEC;
+    if constexpr (B == 16)
+        return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    else if constexpr (B == 8)
+        return __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+    else if constexpr (B == 4)
+        return __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0);
+    else
+        return __builtin_amdgcn_raw_buffer_load_b16(r, voff, 0, 0);
+}
 template <typename T, int VEC>
 __device__ __forceinline__ void mstore(__amdgpu_buffer_rsrc_t r, int voff, const MRaw<T, VEC>& v) {
     constexpr int B = (int)sizeof(T) * VEC;
@@ -568,11 +581,18 @@ __global__ __launch_bounds__(kMonoBlock, TAIL ? 4 : mono_fwd_waves(RMAX * VEC * 
 // ================================================================================================
 // backward
 // ================================================================================================
-template <typename T, int VEC, int LPP, int RMAX, bool EPI, bool TAIL = false>
-__global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const T* __restrict__ gy, const T* __restrict__ x,
+// RELOAD (two phases, as cnsn_wide_kernels.h's backward): G and x of 16 slot rows are 64+ data registers, which leaves ONE
+// 1024-thread workgroup per CU with its phases in series (16-bit (256,1024,14,14): 0.37-0.39 of the HBM peak).  Here the
+// rows are taken in two halves: load a half, mask it, take its sums, drop it; after the algebra load the halves AGAIN
+// (read a few microseconds ago with the default cache policy: L2 / Infinity Cache), mask, apply, store.  Half the data
+// registers -> 64 VGPRs -> two workgroups per CU whose phases overlap.
+template <typename T, int VEC, int LPP, int RMAX, bool EPI, bool TAIL = false, bool RELOAD = false>
+__global__ __launch_bounds__(kMonoBlock, RELOAD ? 8 : 4) void mono_bwd_kernel(MonoArgs ma, const T* __restrict__ gy, const T* __restrict__ x,
                                                                   const T* __restrict__ addend, T* __restrict__ dx, GateDev gg,
                                                                   GateDev gf, GateGradDev dgr, GateGradDev dfr,
                                                                   const double* __restrict__ saved, int add, int relu, TailDev tl) {
+    static_assert(!(TAIL && RELOAD), "the tail variant holds the whole channel");
+    constexpr int NH = RELOAD ? 2 : 1, CNT = RMAX / NH;  // halves of the slot rows, rows per half
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MidArgs a = ma.mid;
     a.sn_two = 0;  // (the host does not send the two-gate form here: the second gate's state would cost ~20 VGPRs)
@@ -625,30 +645,55 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
         t_gam = (double)tl.weight[c];
     }
 
-    // ---- the only reads of G and x (+ addend)
-    MRaw<T, VEC> dg_[RMAX], dx_[RMAX];
+    // ---- the reads of G and x (+ addend): the whole channel, or one half of its slot rows at a time (RELOAD)
+    MRaw<T, VEC> dg_[CNT], dx_[CNT];
+    auto load_rows = [&](int h) {
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r)
-    {
-        // (TAIL: y may have had no consumer of its own — a NULL gradient is a zero gradient)
-        dg_[r] = mload<T, VEC>(g.rsrc(gy, c, r), (!TAIL || gy) ? g.off(r) : 0x7ffffff8);
-        dx_[r] = mload<T, VEC>(g.rsrc(x, c, r), g.off(r));
-    }
-    if constexpr (EPI) {
-        if (add == ADD_PRE) {
-            constexpr int CH = (RMAX * VEC * (int)sizeof(T) > 64) ? RMAX / 2 : RMAX;
-#pragma unroll
-            for (int r0 = 0; r0 < RMAX; r0 += CH) {
-                MRaw<T, VEC> q[CH];
-#pragma unroll
-                for (int r = 0; r < CH; ++r)
-                    q[r] = mload<T, VEC>(g.rsrc(addend, c, r0 + r), g.off(r0 + r));
-#pragma unroll
-                for (int r = 0; r < CH; ++r)
-                    dx_[r0 + r] = madd<T, VEC>(dx_[r0 + r], q[r]);
+        for (int rr = 0; rr < CNT; ++rr) {
+            const int r = h * CNT + rr;
+            if constexpr (RELOAD) {
+                dg_[rr] = mload_cached<T, VEC>(g.rsrc(gy, c, r), g.off(r));
+                dx_[rr] = mload_cached<T, VEC>(g.rsrc(x, c, r), g.off(r));
+            } else {
+                // (TAIL: y may have had no consumer of its own — a NULL gradient is a zero gradient)
+                dg_[rr] = mload<T, VEC>(g.rsrc(gy, c, r), (!TAIL || gy) ? g.off(r) : 0x7ffffff8);
+                dx_[rr] = mload<T, VEC>(g.rsrc(x, c, r), g.off(r));
             }
         }
-    }
+        if constexpr (EPI) {
+            if (add == ADD_PRE) {
+                constexpr int CH = (CNT * VEC * (int)sizeof(T) > 64) ? CNT / 2 : CNT;
+#pragma unroll
+                for (int r0 = 0; r0 < CNT; r0 += CH) {
+                    MRaw<T, VEC> q[CH];
+#pragma unroll
+                    for (int rr = 0; rr < CH; ++rr) {
+                        const int r = h * CNT + r0 + rr;
+                        q[rr] = RELOAD ? mload_cached<T, VEC>(g.rsrc(addend, c, r), g.off(r))
+                                       : mload<T, VEC>(g.rsrc(addend, c, r), g.off(r));
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < CH; ++rr) dx_[r0 + rr] = madd<T, VEC>(dx_[r0 + rr], q[rr]);
+                }
+            }
+        }
+    };
+    // ReLU mask of row rr of the loaded rows (forward affine re-evaluated with the coefficients the forward used)
+    auto mask_row = [&](int rr, int pi) {
+        if constexpr (EPI) {
+            if (relu) {
+                const float fa = pfa[pi], fb = pfb[pi];
+                float gm[VEC];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    const float t = fmaf(fa, melem<T, VEC>(dx_[rr], q) - 0.f, fb);
+                    gm[q] = relu_open_r<T>(t) ? melem<T, VEC>(dg_[rr], q) : 0.f;
+                }
+                dg_[rr] = mpack<T, VEC>(gm);
+            }
+        }
+    };
+    load_rows(0);
     __syncthreads();  // psi / pfa / pfb are staged
     g.refresh();
     if constexpr (TAIL) {
@@ -685,42 +730,39 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
         }
     }
 
-    // ---- ReLU mask (forward affine re-evaluated with the coefficients the forward used) and per-plane sums
+    // ---- ReLU mask and per-plane sums
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-        {
-            const int pn = g.plane(r);
-            const int pi = pn;
-            const float si = psi[pi];
-            if constexpr (EPI) {
-                if (relu) {
-                    const float fa = pfa[pi], fb = pfb[pi];
-                    float gm[VEC];
+    for (int h = 0; h < NH; ++h) {
+        if (RELOAD && h > 0) {
+            load_rows(h);
+            g.refresh();
+        }
+#pragma unroll
+        for (int rr = 0; rr < CNT; ++rr) {
+            const int r = h * CNT + rr;
+            {
+                const int pn = g.plane(r);
+                const int pi = pn;
+                const float si = psi[pi];
+                mask_row(rr, pi);
+                float s1 = 0.f, s2 = 0.f;
+                if (g.ok(r)) {
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
-                        const float t = fmaf(fa, melem<T, VEC>(dx_[r], q) - 0.f, fb);
-                        gm[q] = relu_open_r<T>(t) ? melem<T, VEC>(dg_[r], q) : 0.f;
+                        const float G = melem<T, VEC>(dg_[rr], q), X = melem<T, VEC>(dx_[rr], q);
+                        s1 += G;
+                        s2 = fmaf(G, X - si, s2);
                     }
-                    dg_[r] = mpack<T, VEC>(gm);
+                }
+                s1 = mono_group_sum<LPP>(s1);
+                s2 = mono_group_sum<LPP>(s2);
+                if (g.vl == 0 && g.ok(r)) {
+                    ps1[pn] = s1;
+                    ps2[pn] = s2;
                 }
             }
-            float s1 = 0.f, s2 = 0.f;
-            if (g.ok(r)) {
-#pragma unroll
-                for (int q = 0; q < VEC; ++q) {
-                    const float G = melem<T, VEC>(dg_[r], q), X = melem<T, VEC>(dx_[r], q);
-                    s1 += G;
-                    s2 = fmaf(G, X - si, s2);
-                }
-            }
-            s1 = mono_group_sum<LPP>(s1);
-            s2 = mono_group_sum<LPP>(s2);
-            if (g.vl == 0 && g.ok(r)) {
-                ps1[pn] = s1;
-                ps2[pn] = s2;
-            }
+            if ((rr & (MONO_ILP - 1)) == MONO_ILP - 1) __builtin_amdgcn_sched_barrier(0);  // bound the interleaving (registers)
         }
-        if ((r & (MONO_ILP - 1)) == MONO_ILP - 1) __builtin_amdgcn_sched_barrier(0);  // bound the interleaving (registers)
     }
     __syncthreads();
 
@@ -801,26 +843,37 @@ __global__ __launch_bounds__(kMonoBlock) void mono_bwd_kernel(MonoArgs ma, const
     }
     // (mono_block_sum ends with every thread past its second barrier: the coefficient rows are visible)
 
-    // ---- dx from registers, the only write
+    // ---- dx, the only write: from the registers, or (RELOAD) from the halves read again
     g.refresh();
+    if constexpr (!RELOAD) {
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-        mono_forget(dg_[r]);
-        mono_forget(dx_[r]);
+        for (int r = 0; r < CNT; ++r) {
+            mono_forget(dg_[r]);
+            mono_forget(dx_[r]);
+        }
     }
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-        {
-            const int pn = g.plane(r);
-            const int pi = pn;
-            const float cG = ps1[pi], cX = ps2[pi], xr = pxr[pi], c0 = pc0[pi];
-            float ov[VEC];
-#pragma unroll
-            for (int q = 0; q < VEC; ++q)
-                ov[q] = fmaf(cG, melem<T, VEC>(dg_[r], q), fmaf(cX, melem<T, VEC>(dx_[r], q) - xr, c0));
-            mstore<T, VEC>(g.rsrc(dx, c, r), g.off(r), mpack<T, VEC>(ov));
+    for (int h = 0; h < NH; ++h) {
+        if constexpr (RELOAD) {
+            load_rows(h);
+            g.refresh();
         }
-        if ((r & (MONO_ILP - 1)) == MONO_ILP - 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rr = 0; rr < CNT; ++rr) {
+            const int r = h * CNT + rr;
+            {
+                const int pn = g.plane(r);
+                const int pi = pn;
+                if constexpr (RELOAD) mask_row(rr, pi);
+                const float cG = ps1[pi], cX = ps2[pi], xr = pxr[pi], c0 = pc0[pi];
+                float ov[VEC];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q)
+                    ov[q] = fmaf(cG, melem<T, VEC>(dg_[rr], q), fmaf(cX, melem<T, VEC>(dx_[rr], q) - xr, c0));
+                mstore<T, VEC>(g.rsrc(dx, c, r), g.off(r), mpack<T, VEC>(ov));
+            }
+            if ((rr & (MONO_ILP - 1)) == MONO_ILP - 1) __builtin_amdgcn_sched_barrier(0);
+        }
     }
     }  // (a workgroup past the end of its XCD's range has nothing to do)
 }
