@@ -80,7 +80,14 @@ MonoPlan mono_plan(const Plan& pl, int add, bool backward) {
     if (R > 16 || p.N > kMonoBlock) return mp;
     const int rmax = R <= 8 ? 8 : 16;
     // registers: RMAX slots of vec*b bytes per tensor held (x forward; G and x backward) out of 128 VGPRs per lane
-    const int data_regs = rmax * vec * b / 4 * (backward ? 2 : 1);
+    // (the backward of the 16-row classes walks its rows in parts — halves with 8-byte vectors, quarters with 16-byte ones:
+    //  mono_bwd_kernel's NH_ — and holds one part at a time)
+    // Quarters: 16-bit tensors only — (256,512,16,16) bf16 backward 0.081 -> 0.053 ms against the two-pass kernels it ran before
+    // (16 x 16-byte rows of G and x did not fit at all); in fp32 the cluster kernels of cnsn_resident_sn_kernels.h are ahead
+    // of the quarter-wise mono backward (14x14: 0.145 vs 0.156 ms, 16x16: 0.086 vs 0.098), so fp32 stays as it was.
+    const bool parts_off = [] { const char* e = getenv("CNSN_MONO_RELOAD"); return e && e[0] == '0'; }();  // (A/B runs)
+    const int parts = (backward && rmax == 16 && !parts_off) ? (vec * b <= 8 ? 2 : (b == 2 ? 4 : 1)) : 1;
+    const int data_regs = rmax * vec * b / 4 * (backward ? 2 : 1) / parts;
     if (data_regs > 72) return mp;
     if ((long long)ppr * p.C * M * b >= 0x7ffffff0ll) return mp;   // 31-bit lane offsets inside a slot row
     if (p.strategy == CNSN_STRATEGY_AUTO) {
@@ -134,8 +141,10 @@ int mono_backward(const Plan& pl, const MonoPlan& mp, int add, int relu, const v
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value, LPP = decltype(lt)::value, RMAX = decltype(rt)::value;
         // sixteen slot rows of G and x do not leave registers for a second workgroup on the CU: two-phase variant (RELOAD)
-        // (with 16-byte vectors a half is 64 data registers again: those classes keep the single-phase kernel)
-        constexpr bool kReloadFits = RMAX == 16 && VEC * (int)sizeof(T) <= 8;
+        // (halves with 8-byte vectors, quarters with 16-byte ones in 16 bits: 32 data registers either way — mono_plan admits the
+        //  call on that basis)
+        constexpr int kParts = RMAX != 16 ? 1 : (VEC * (int)sizeof(T) <= 8 ? 2 : (sizeof(T) == 2 ? 4 : 1));
+        constexpr bool kReloadFits = kParts > 1;
         bool reload = kReloadFits;
         if (const char* e = getenv("CNSN_MONO_RELOAD")) reload = reload && e[0] != '0';
         auto launch = [&](auto kern) {
@@ -147,9 +156,9 @@ int mono_backward(const Plan& pl, const MonoPlan& mp, int add, int relu, const v
         if constexpr (kReloadFits) {
             if (reload) {
                 if (epi)
-                    launch(mono_bwd_kernel<T, VEC, LPP, RMAX, true, false, true>);
+                    launch(mono_bwd_kernel<T, VEC, LPP, RMAX, true, false, kParts>);
                 else
-                    launch(mono_bwd_kernel<T, VEC, LPP, RMAX, false, false, true>);
+                    launch(mono_bwd_kernel<T, VEC, LPP, RMAX, false, false, kParts>);
             } else if (epi) {
                 launch(mono_bwd_kernel<T, VEC, LPP, RMAX, true>);
             } else {

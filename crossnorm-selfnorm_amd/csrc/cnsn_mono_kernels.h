@@ -586,13 +586,15 @@ __global__ __launch_bounds__(kMonoBlock, TAIL ? 4 : mono_fwd_waves(RMAX * VEC * 
 // rows are taken in two halves: load a half, mask it, take its sums, drop it; after the algebra load the halves AGAIN
 // (read a few microseconds ago with the default cache policy: L2 / Infinity Cache), mask, apply, store.  Half the data
 // registers -> 64 VGPRs -> two workgroups per CU whose phases overlap.
-template <typename T, int VEC, int LPP, int RMAX, bool EPI, bool TAIL = false, bool RELOAD = false>
-__global__ __launch_bounds__(kMonoBlock, RELOAD ? 8 : 4) void mono_bwd_kernel(MonoArgs ma, const T* __restrict__ gy, const T* __restrict__ x,
+// (NH_ = 2: halves; 4: quarters — 16-byte vectors, where a half would be 64 data registers again)
+template <typename T, int VEC, int LPP, int RMAX, bool EPI, bool TAIL = false, int NH_ = 1>
+__global__ __launch_bounds__(kMonoBlock, NH_ > 1 ? 8 : 4) void mono_bwd_kernel(MonoArgs ma, const T* __restrict__ gy, const T* __restrict__ x,
                                                                   const T* __restrict__ addend, T* __restrict__ dx, GateDev gg,
                                                                   GateDev gf, GateGradDev dgr, GateGradDev dfr,
                                                                   const double* __restrict__ saved, int add, int relu, TailDev tl) {
+    constexpr bool RELOAD = NH_ > 1;
     static_assert(!(TAIL && RELOAD), "the tail variant holds the whole channel");
-    constexpr int NH = RELOAD ? 2 : 1, CNT = RMAX / NH;  // halves of the slot rows, rows per half
+    constexpr int NH = NH_, CNT = RMAX / NH;  // parts of the slot rows, rows per part
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MidArgs a = ma.mid;
     a.sn_two = 0;  // (the host does not send the two-gate form here: the second gate's state would cost ~20 VGPRs)

@@ -24,6 +24,8 @@ CASES = [
     ((96, 4, 14, 14), BF16),    # R = 6
     ((128, 4, 16, 16), F32),    # 16 B, all 64 lanes, R = 8             (WideResNet stage 2)
     ((128, 4, 16, 16), F16),    # 16 B, 32 of 64 lanes
+    ((256, 4, 16, 16), BF16),   # 16 B, R = 16: the backward walks the rows in QUARTERS (16 x 16-byte rows of G and x do not fit)
+    ((250, 3, 16, 16), F16),    # ... with a partial last wave
     ((130, 3, 8, 8), F32),      # 16 B, 16 lanes per plane, 4 planes per row, R = 3
     ((1000, 2, 8, 8), F32),     # 16 lanes, R = 16: 1000 planes per channel
     ((33, 4, 8, 8), BF16),      # 8 B (16-byte vectors would leave 8 per plane), 16 lanes
@@ -83,6 +85,8 @@ def test_what_mono_declines():
     big = torch.empty((256, 4, 14, 14), device="cuda")
     assert cnsn_amd.which_path(big, FC(sn_active=True), backward=False) == "mono"
     assert cnsn_amd.which_path(big, FC(sn_active=True), backward=True) != "mono"          # fp32: G and x do not fit
+    wide16 = torch.empty((256, 4, 16, 16), dtype=BF16, device="cuda")                       # 16 rows of 16-byte vectors in 16 bits:
+    assert cnsn_amd.which_path(wide16, FC(sn_active=True), backward=True) == "mono"       # the backward takes them in quarters
     cnsn_amd.set_strategy("auto")
     assert cnsn_amd.which_path(torch.empty((256, 1024, 14, 14), dtype=BF16, device="cuda"), FC(sn_active=True), backward=True) == "mono"
     assert cnsn_amd.which_path(torch.empty((8, 4, 14, 14), device="cuda"), FC(sn_active=True)) != "mono"   # N < 16 under AUTO
