@@ -61,6 +61,7 @@ SIGNATURES = {
     "cnsn_context_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "cnsn_resident_timeouts": (C.c_int, []),
     "cnsn_resident_enable": (None, [C.c_int]),
+    "cnsn_reload_env": (None, []),
     "cnsn_saved_floats": (C.c_size_t, [C.POINTER(Problem)]),
     "cnsn_workspace_bytes": (C.c_size_t, [C.POINTER(Problem)]),
     "cnsn_forward": (C.c_int, [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -194,6 +195,41 @@ def settle_step(device=None):
     check_resident_health("training step")
 
 
+def reload_env():
+    """The library reads its CNSN_* environment knobs once, when it is loaded (csrc/cnsn_env.h); call this after changing
+    one through `os.environ` inside a running process (tests, A/B tools).  Not while another thread is in a launch."""
+    lib().cnsn_reload_env()
+
+
+_following = False
+
+
+def follow_environ():
+    """For tests and A/B tools that flip CNSN_* knobs through `os.environ` inside one process: from now on every
+    assignment to / deletion of a CNSN_* variable is followed by `cnsn_reload_env()` (if the library is loaded).
+    `os.environ` hands its changes to the module-level `os.putenv` / `os.unsetenv`; those are wrapped.  A training
+    process never needs this: it sets its knobs before the import."""
+    global _following
+    if _following:
+        return
+    _following = True
+    put, unset = os.putenv, os.unsetenv
+
+    def reread(key):
+        if os.fsdecode(key).startswith("CNSN_") and _lib is not None:
+            _lib.cnsn_reload_env()
+
+    def putenv(key, value):
+        put(key, value)
+        reread(key)
+
+    def unsetenv(key):
+        unset(key)
+        reread(key)
+
+    os.putenv, os.unsetenv = putenv, unsetenv
+
+
 def under_process_group_defaults():
     """One process per GPU under an initialised torch.distributed group: a rank whose cluster wait runs out stalls its
     peers' collectives for as long as the bound — default it to 2 s there instead of 5 s (CNSN_WAIT_MS still overrides)."""
@@ -201,6 +237,7 @@ def under_process_group_defaults():
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and "CNSN_WAIT_MS" not in os.environ:
             os.environ["CNSN_WAIT_MS"] = "2000"
+            reload_env()
     except Exception:   # pragma: no cover
         pass
 

@@ -2,6 +2,7 @@
 // Validates arguments, picks the launch shape (vector width, lanes per plane) and enqueues the
 // kernels on the caller's stream.  No allocation, no synchronisation, no global state.
 #include "../../include/cnsn_hip.h"
+#include "cnsn_env.h"
 
 #include <hip/hip_runtime.h>
 
@@ -26,7 +27,7 @@ namespace cnsn {
 // channels per workgroup of the mid kernels: tiles of 8 once there are enough channels to fill the chip with tiles
 // (measured at C = 2048, N = 256: mid_fwd 115 -> see profiles/r01_small_planes.md); CNSN_MID_TILE=1 disables
 static int mid_tile(const cnsn_problem_t& p) {
-    if (const char* e = getenv("CNSN_MID_TILE"))
+    if (const char* e = knob(K_MID_TILE))
         if (e[0] == '1') return 1;
     return (p.C >= 512 && p.C % 8 == 0) ? 8 : 1;
 }
@@ -83,6 +84,7 @@ int cnsn_context_init(void* context, size_t bytes, void* stream) {
 
 int cnsn_resident_timeouts(void) { return resident_timeouts(); }
 void cnsn_resident_enable(int on) { resident_set_enabled(on != 0); }
+void cnsn_reload_env(void) { reload_knobs(); }
 
 const char* cnsn_status_string(int status) {
     switch (status) {

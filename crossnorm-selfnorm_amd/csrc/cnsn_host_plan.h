@@ -2,6 +2,7 @@
 // (vector width, lanes per plane), the layout of `saved` and of the workspace, type dispatch.
 #pragma once
 #include <cstdlib>
+#include "cnsn_env.h"
 #include "../../include/cnsn_hip.h"
 
 #include <hip/hip_runtime.h>
@@ -138,7 +139,7 @@ inline int make_plan(const cnsn_problem_t* prob, Plan& pl) {
     // then hits L2 / the 256 MB Infinity Cache for part of them (measured: (768,3,224,224) bf16 0.362 -> 0.339 ms,
     // (256,3,224,224) fp32 0.237 -> 0.210; at 822 MB non-temporal is 11 % faster: profiles/r01_resident_tuning.md)
     pl.geom.keep = ((size_t)p.N * p.C * p.H * p.W * elem_bytes(p.dtype) <= ((size_t)512 << 20)) ? 1 : 0;
-    if (const char* e = getenv("CNSN_KEEP")) pl.geom.keep = e[0] == '1' ? 1 : (e[0] == '0' ? 0 : pl.geom.keep);
+    if (const char* e = knob(K_KEEP)) pl.geom.keep = e[0] == '1' ? 1 : (e[0] == '0' ? 0 : pl.geom.keep);
     pl.P = (size_t)p.N * p.C;
     MidArgs& m = pl.mid;
     m.N = p.N;

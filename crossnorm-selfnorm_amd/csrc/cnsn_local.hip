@@ -1,5 +1,6 @@
 // Channel-local strategy: eligibility, geometry, launches.
 #include "cnsn_local.h"
+#include "cnsn_env.h"
 
 #include <cstdlib>
 #include <mutex>
@@ -17,7 +18,7 @@ constexpr size_t kLocalLdsCap = 128 * 1024;  // of the 160 KiB a gfx950 workgrou
 // (measured, profiles/r01_small_planes.md: 256 threads win whenever two or more workgroups fit a CU — images up to
 // 64 KiB —, 1024 threads when a workgroup is alone on its CU)
 int block_for(size_t lds256) {
-    if (const char* e = getenv("CNSN_LOCAL_LB")) return atoi(e) == 256 ? 256 : kLocalBigBlock;
+    if (const char* e = knob(K_LOCAL_LB)) return atoi(e) == 256 ? 256 : kLocalBigBlock;
     return lds256 > 64 * 1024 ? kLocalBigBlock : 256;
 }
 size_t fwd_lds_lb(int N, int CG, int M, int b, int LB) {
@@ -98,7 +99,7 @@ LocalPlan local_plan(const Plan& pl, int add, bool backward) {
     // reaches 4-byte vectors wins ((256,2048,7,7) bf16 forward: CG 1/2/4 = 0.141/0.092/0.125 ms), and an image
     // over 64 KiB (one workgroup per CU) loses to the other strategies.  CNSN_LOCAL_CG overrides (tuning).
     int CG = 0, W = 0;
-    const char* force = getenv("CNSN_LOCAL_CG");
+    const char* force = knob(K_LOCAL_CG);
     for (int cg : {1, 2, 4, 8}) {
         if (p.C % cg || (force && atoi(force) != cg)) continue;
         const size_t need = backward ? bwd_lds(p.N, cg, M, b) : fwd_lds(p.N, cg, M, b);

@@ -1,5 +1,6 @@
 // Channel-in-registers strategy: eligibility, geometry, launches.
 #include "cnsn_mono.h"
+#include "cnsn_env.h"
 
 #include <cstdlib>
 
@@ -64,7 +65,7 @@ MonoPlan mono_plan(const Plan& pl, int add, bool backward) {
     const cnsn_problem_t& p = pl.pr;
     if (p.strategy != CNSN_STRATEGY_AUTO && p.strategy != CNSN_STRATEGY_MONO) return mp;
     if (p.cn_active || !p.sn_active || p.sn_two || add == ADD_POST) return mp;  // (two-gate form: never used by a caller)
-    if (const char* e = getenv("CNSN_MONO"))
+    if (const char* e = knob(K_MONO))
         if (e[0] == '0' && p.strategy == CNSN_STRATEGY_AUTO) return mp;
     const int b = elem_bytes(p.dtype), M = p.H * p.W;
     // widest vector (16 .. 2 bytes) that divides the plane; a 16-byte vector that would leave fewer than 16 vectors
@@ -85,7 +86,7 @@ MonoPlan mono_plan(const Plan& pl, int add, bool backward) {
     // Quarters: 16-bit tensors only — (256,512,16,16) bf16 backward 0.081 -> 0.053 ms against the two-pass kernels it ran before
     // (16 x 16-byte rows of G and x did not fit at all); in fp32 the cluster kernels of cnsn_resident_sn_kernels.h are ahead
     // of the quarter-wise mono backward (14x14: 0.145 vs 0.156 ms, 16x16: 0.086 vs 0.098), so fp32 stays as it was.
-    const bool parts_off = [] { const char* e = getenv("CNSN_MONO_RELOAD"); return e && e[0] == '0'; }();  // (A/B runs)
+    const bool parts_off = [] { const char* e = knob(K_MONO_RELOAD); return e && e[0] == '0'; }();  // (A/B runs)
     const int parts = (backward && rmax == 16 && !parts_off) ? (vec * b <= 8 ? 2 : (b == 2 ? 4 : 1)) : 1;
     const int data_regs = rmax * vec * b / 4 * (backward ? 2 : 1) / parts;
     if (data_regs > 72) return mp;
@@ -146,7 +147,7 @@ int mono_backward(const Plan& pl, const MonoPlan& mp, int add, int relu, const v
         constexpr int kParts = RMAX != 16 ? 1 : (VEC * (int)sizeof(T) <= 8 ? 2 : (sizeof(T) == 2 ? 4 : 1));
         constexpr bool kReloadFits = kParts > 1;
         bool reload = kReloadFits;
-        if (const char* e = getenv("CNSN_MONO_RELOAD")) reload = reload && e[0] != '0';
+        if (const char* e = knob(K_MONO_RELOAD)) reload = reload && e[0] != '0';
         auto launch = [&](auto kern) {
             kern<<<mono_grid(pl.pr.C), kMonoBlock, mp.lds, stream>>>(ma, (const T*)gy, (const T*)x,
                                                                                 (const T*)(epi && add == ADD_PRE ? addend : nullptr),

@@ -1,5 +1,6 @@
 // Channel-in-registers strategy with CrossNorm: eligibility, geometry, launches (kernels: cnsn_mono_cn_kernels.h).
 #include <cstdlib>
+#include "cnsn_env.h"
 
 #include "cnsn_mono.h"
 #include "cnsn_mono_cn_kernels.h"
@@ -63,7 +64,7 @@ MonoPlan mono_cn_plan(const Plan& pl, bool has_chan_perm, int add, bool backward
     const cnsn_problem_t& p = pl.pr;
     if (p.strategy != CNSN_STRATEGY_AUTO && p.strategy != CNSN_STRATEGY_MONO) return mp;
     if (!p.cn_active || has_chan_perm || (p.sn_active && p.sn_two) || add == ADD_POST) return mp;
-    if (const char* e = getenv("CNSN_MONO"))
+    if (const char* e = knob(K_MONO))
         if (e[0] == '0' && p.strategy == CNSN_STRATEGY_AUTO) return mp;
     const int b = elem_bytes(p.dtype), M = p.H * p.W;
     int vec = 16 / b;  // masks are per element: a vector may straddle rows of the plane

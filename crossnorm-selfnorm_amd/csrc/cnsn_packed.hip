@@ -1,5 +1,6 @@
 // Host side of the packed small-plane kernels (cnsn_packed_kernels.h): eligibility, run geometry, launches.
 #include "cnsn_packed.h"
+#include "cnsn_env.h"
 
 #include "cnsn_packed_kernels.h"
 
@@ -78,7 +79,7 @@ bool packed_plan(const Plan& pl, PackedGeom& g) {
     // cannot use full 16-byte vectors (7x7 in any type: 1.4-1.6x; 14x14 bf16: 1.15-1.3x) and lose a little where
     // they can (8x8 / 14x14 / 16x16 fp32), so they take exactly the former.
     if (pl.shape.vec * b >= 16) return false;
-    if (const char* e = getenv("CNSN_NO_PACKED"))
+    if (const char* e = knob(K_NO_PACKED))
         if (e[0] == '1') return false;
     // planes per run: a multiple of 4 (four 16-lane groups per wave) whose bytes are a multiple of 16,
     // at least ~2 KiB per run and at most 64 planes (one lane fetches the scalars of one plane)

@@ -1,5 +1,6 @@
 // Channel-resident strategy, the op alone: host entry points (shared logic in cnsn_resident_host.h).
 #include "cnsn_resident_host.h"
+#include "cnsn_env.h"
 
 #include <atomic>
 #include <cstring>
@@ -38,7 +39,7 @@ int resident_timeouts() {
 bool resident_auto_enabled() {
     int e = g_enabled.load(std::memory_order_relaxed);
     if (e < 0) {
-        const char* env = getenv("CNSN_RESIDENT");
+        const char* env = knob(K_RESIDENT);
         e = (env && env[0] == '0') ? 0 : 1;
         g_enabled.store(e, std::memory_order_relaxed);
     }
@@ -61,7 +62,7 @@ ExchangeArea resident_exchange_area(const cnsn_problem_t& p, size_t tagged_bytes
                                     bool prefer_context) {
     ExchangeArea ea{workspace, 0u};
     if (!p.context || p.context_bytes < tagged_bytes) return ea;
-    if (const char* e = getenv("CNSN_CONTEXT")) {
+    if (const char* e = knob(K_CONTEXT)) {
         if (e[0] == '0') return ea;
     } else if (!prefer_context && (size_t)p.N * p.C * p.H * p.W * elem_bytes(p.dtype) >= ((size_t)64 << 20)) {
         // Large tensors exchange through the workspace: a tagged granule carries ONE float per 8 bytes, an untagged one
@@ -80,7 +81,7 @@ ExchangeArea resident_exchange_area(const cnsn_problem_t& p, size_t tagged_bytes
         std::lock_guard<std::mutex> lock(g_ctx_mu);
         auto it = g_ctx_epoch.find(p.context);
         if (it == g_ctx_epoch.end()) return ea;  // never initialised through cnsn_context_init: not trusted
-        if (const char* e = getenv("CNSN_EPOCH_START"))  // (tests: start close to the wrap-around)
+        if (const char* e = knob(K_EPOCH_START))  // (tests: start close to the wrap-around)
             if (it->second == 0) it->second = (unsigned)strtoul(e, nullptr, 0);
         epoch = ++it->second;
         if (epoch == 0) {  // wrapped: every tag in the context is stale-but-plausible now — clear it once, in order

@@ -2,6 +2,7 @@
 // alone; cnsn_resident_fused.hip: the op with the residual-block epilogue): eligibility, launch geometry, dispatch.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "cnsn_env.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -112,15 +113,15 @@ static inline ResArgs make_args(const cnsn_problem_t& p, Box cb, Box sb, const M
     ra.sb = sb;
     ra.K = rp.K;
     ra.items = p.C * rp.K;
-    const char* st = getenv("CNSN_STAGGER");
+    const char* st = knob(K_STAGGER);
     ra.stagger = st ? atoi(st) : 0;
     ra.prof = nullptr;
     ra.epoch = 0;
     ra.ctl_idle = kCtlIdle;
     ra.host_flag = resident_host_flag();
-    const char* wm = getenv("CNSN_WAIT_MS");
+    const char* wm = knob(K_WAIT_MS);
     ra.wait_ticks = (wm && atoll(wm) > 0) ? atoll(wm) * 100000ll : kWaitLimitTicks;
-    const char* fi = getenv("CNSN_FAULT_INJECT");
+    const char* fi = knob(K_FAULT_INJECT);
     ra.fault = (fi && fi[0] == '1') ? 1 : 0;
     return ra;
 }
@@ -149,7 +150,7 @@ int grid_for(Kern kern, size_t lds, int K, int items) {
     // and the API over-reports by one when SGPRs are the limiter (MI355X_MICROARCH.md, "Residency").
     // Every resident kernel here uses 106-108 SGPRs (checked at build time) -> 6.
     if (occ > 6) occ = 6;
-    if (getenv("CNSN_DEBUG"))
+    if (knob(K_DEBUG))
         fprintf(stderr, "[cnsn] resident grid: occupancy %d/CU x %d CUs, K=%d, items=%d, lds=%zu\n", occ, cu_count(),
                 K, items, lds);
     long g = (long)occ * cu_count();
@@ -220,7 +221,7 @@ int forward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidA
     const bool solo = !boxed && !p.cn_active && !(p.sn_active && p.sn_training);
     const int NG = boxed ? 6 : 2;
 #ifdef CNSN_PROF  // tuning builds: time stamps land 4 MiB into the workspace (callers size it accordingly)
-    if (getenv("CNSN_PROF")) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
+    if (knob(K_PROF)) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
 #endif
     const size_t lds = res_lds_bytes(p.N, NG, 4 * rp.ppw, FC_ROWS, false);
     const ExchangeArea ea = solo ? ExchangeArea{workspace, 0u}
@@ -283,7 +284,7 @@ int backward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const Mid
     ResArgs ra = make_args(p, cb, sb, mid, rp);
     const int NS = boxed ? 4 : 2;
 #ifdef CNSN_PROF
-    if (getenv("CNSN_PROF")) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
+    if (knob(K_PROF)) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
 #endif
     const size_t lds = res_lds_bytes(p.N, NS, 4 * rp.ppw, BC_ROWS, true);
     const ExchangeArea ea = resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NS * 8, workspace, stream);

@@ -3,6 +3,7 @@
 // of 7+ register slots (40x40 fp32 / 56x56 16-bit and larger) — the classes whose items are large enough (>= 25 KB per
 // workgroup) for the exposed cluster wait to be the bottleneck.
 #include "cnsn_resident_host.h"
+#include "cnsn_env.h"
 #include "cnsn_resident_pipe_kernels.h"
 
 namespace cnsn {
@@ -34,7 +35,7 @@ bool dispatch_pipe(int dtype, int vec, int nv, F&& f) {
 
 // CNSN_PIPE=0: never; CNSN_PIPE=2: also for grids with fewer than three items per workgroup (tests)
 int pipe_mode() {
-    const char* e = getenv("CNSN_PIPE");
+    const char* e = knob(K_PIPE);
     return e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : 1;
 }
 
@@ -82,7 +83,7 @@ int resident_pipe_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, c
     ResArgs ra = reshost::make_args(p, cb, sb, mid, rp);
     const int NG = boxed ? 6 : 2;
 #ifdef CNSN_PROF
-    if (getenv("CNSN_PROF")) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
+    if (knob(K_PROF)) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
 #endif
     const size_t lds = pipe_lds_bytes(p.N, NG, 4 * rp.ppw, npark, rp.vec * elem_bytes(p.dtype), p.cn_active != 0);
     const ExchangeArea ea = resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NG * 8 + 256, workspace, stream);
@@ -179,7 +180,7 @@ int resident_pipe_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
     ResArgs ra = reshost::make_args(p, cb, sb, mid, rp);
     const int NS = boxed ? 4 : 2;
 #ifdef CNSN_PROF
-    if (getenv("CNSN_PROF")) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
+    if (knob(K_PROF)) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
 #endif
     const size_t lds = pipe_bwd_lds_bytes(p.N, NS, 4 * rp.ppw, npark, rp.vec * elem_bytes(p.dtype));
     const ExchangeArea ea = resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NS * 8 + 256, workspace, stream);

@@ -1,5 +1,6 @@
 // SelfNorm-only cluster kernels, backward: host entry point (shared logic in cnsn_resident_sn_host.h).
 #include "cnsn_resident_sn_host.h"
+#include "cnsn_env.h"
 
 namespace cnsn {
 
@@ -11,7 +12,7 @@ int resident_sn_backward(const cnsn_problem_t& p, const MidArgs& mid, int add, i
     const bool epi = add != ADD_NONE || relu;
     ResArgs ra = snxhost::make_args(p, mid, sp);
 #ifdef CNSN_PROF  // tuning builds: time stamps land 4 MiB into the workspace (callers size it accordingly)
-    if (getenv("CNSN_PROF")) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
+    if (knob(K_PROF)) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
 #endif
     const size_t lds = snxhost::lds_bytes(sp.K, 4 * sp.ppw, sp.npark, true, sp.vec * elem_bytes(p.dtype));
     int status = CNSN_E_UNSUPPORTED;
@@ -51,7 +52,7 @@ int resident_sn_backward(const cnsn_problem_t& p, const MidArgs& mid, int add, i
     else
         snxhost::dispatch_snx<true, false>(p.dtype, sp.vec, sp.nv,
                                            [&](auto tt, auto vt, auto nt, auto pt) { run(tt, vt, nt, pt, IntTag<0>{}); });
-    if (getenv("CNSN_DEBUG"))
+    if (knob(K_DEBUG))
         fprintf(stderr, "[cnsn] sn-cluster bwd: nv=%d ppw=%d K=%d npark=%d epi=%d lds=%zu -> status %d\n", sp.nv, sp.ppw, sp.K,
                 sp.npark, (int)epi, lds, status);
     return status;

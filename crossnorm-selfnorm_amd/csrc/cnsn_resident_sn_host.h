@@ -1,6 +1,7 @@
 // Host side shared by the two translation units of the SelfNorm-only cluster kernels: eligibility, geometry.
 #pragma once
 #include "cnsn_fused_stream_kernels.h"
+#include "cnsn_env.h"
 #include "cnsn_resident_host.h"
 #include "cnsn_resident_sn.h"
 #include "cnsn_resident_sn_kernels.h"
@@ -60,7 +61,7 @@ constexpr int bwd_ppw(int nv, bool epi, int elem_bytes, int vb = 16) {  // (one-
 
 // CNSN_SNX=0: never; 2: wherever instantiated (tests); default 1: AUTO rule
 inline int snx_mode() {
-    const char* e = getenv("CNSN_SNX");
+    const char* e = knob(K_SNX);
     return e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : 1;
 }
 

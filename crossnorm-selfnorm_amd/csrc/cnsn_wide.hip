@@ -1,5 +1,6 @@
 // Channel-group-in-registers strategy: eligibility, geometry, launches.
 #include "cnsn_wide.h"
+#include "cnsn_env.h"
 
 #include <cstdlib>
 
@@ -30,7 +31,7 @@ WidePlan wide_plan(const Plan& pl, int add, bool backward, bool has_chan_perm) {
     // CrossNorm: without crop boxes and without the channel permutation (the pairing stays inside one channel)
     if (p.cn_active && (pl.boxed || has_chan_perm)) return wp;
     int mode = 1;  // CNSN_WIDE=0: never; CNSN_WIDE=2: wherever eligible (tests: fp32 and small batches too)
-    if (const char* e = getenv("CNSN_WIDE")) mode = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);
+    if (const char* e = knob(K_WIDE)) mode = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);
     if (mode == 0) return wp;
     const int b = elem_bytes(p.dtype), M = p.H * p.W;
     if (M > 64 || (M * b) % 8 == 0) return wp;  // whole 8-byte vectors: the mono / cluster kernels' ground

@@ -285,6 +285,13 @@ int cnsn_resident_timeouts(void);
  * at load time); on = 1: allowed again.  CNSN_STRATEGY_RESIDENT is not affected. */
 void cnsn_resident_enable(int on);
 
+/* ---- environment knobs ---------------------------------------------------------------------------
+ * The library's CNSN_* environment variables (tuning and test switches: CNSN_WAIT_MS, CNSN_RESIDENT, CNSN_PIPE, ... —
+ * the list is csrc/cnsn_env.h) are read ONCE, when the library is loaded; no launch calls getenv().  This re-reads
+ * them, for tests and A/B tools that change a knob inside one process.  Not to be called while another thread is
+ * inside the library.  Nothing in the reference corresponds to this. */
+void cnsn_reload_env(void);
+
 /* ---- Jensen-Shannon consistency of three views ----------------------------------
  * imagenet.py:367-381 / cifar.py:173-186: p_i = softmax(logits_i, 1); lm = clamp(mean_i p_i, 1e-7, 1).log();
  * loss = mean_i F.kl_div(lm, p_i, reduction='batchmean').  One launch computes the loss and, when the three

@@ -21,6 +21,15 @@ def pytest_sessionstart(session):
         __graft_entry__.build()
 
 
+@pytest.fixture(scope="session", autouse=True)
+def knobs_follow_the_environment():
+    """The library reads its CNSN_* knobs once at load (csrc/cnsn_env.h); the GPU tests flip them through os.environ
+    mid-process, so changes are followed by cnsn_reload_env() here (`cnsn_amd.follow_environ`)."""
+    import cnsn_amd
+    cnsn_amd.follow_environ()
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

@@ -75,3 +75,37 @@ def test_forced_strategies_fall_back():
         assert which_path(torch.empty((8, 4, 7, 7), dtype=BF16, device="meta"), FC(**SN, **CN)) == "packed"
     finally:
         cnsn_amd.set_strategy("auto")
+
+
+def test_environment_knobs_are_read_at_load_not_per_call():
+    """csrc/cnsn_env.h: CNSN_* is snapshotted when the library is loaded; a later change takes effect only through
+    cnsn_reload_env() — run in a child process so that the session's `follow_environ` hook is not in the way."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, cnsn_amd
+from cnsn_amd import FusedConfig as FC, which_path
+x = torch.empty((256, 1024, 14, 14), dtype=torch.bfloat16, device="meta")
+cfg = FC(sn_active=True)
+assert which_path(x, cfg) == "mono"
+os.environ["CNSN_MONO"] = "0"                       # after the load: not seen
+assert which_path(x, cfg) == "mono"
+cnsn_amd.reload_env()                               # ... until the table is re-read
+assert which_path(x, cfg) != "mono"
+cnsn_amd.follow_environ()                           # tests / tools: every CNSN_* change re-reads
+del os.environ["CNSN_MONO"]
+assert which_path(x, cfg) == "mono"
+os.environ["CNSN_MONO"] = "0"
+assert which_path(x, cfg) != "mono"
+print("KNOBS-OK")
+"""
+    env = {k: v for k, v in os.environ.items() if not k.startswith("CNSN_")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "KNOBS-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+    probe = code.split("assert which_path")[0] + 'print(which_path(x, cfg))\n'
+    r = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, env=dict(env, CNSN_MONO="0"), timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() != "mono", (r.stdout, r.stderr[-2000:])

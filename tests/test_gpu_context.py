@@ -20,6 +20,7 @@ import os, sys, torch, numpy as np
 sys.path.insert(0, %r)
 import cnsn_amd
 from cnsn_amd import functional as F
+cnsn_amd.follow_environ()
 from tests.golden.gen_golden_fill import fill_sn
 dev = torch.device("cuda:0")
 cnsn_amd.set_strategy("resident")

@@ -24,19 +24,25 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_resident_kernels_under_data_parallel_communication(tmp_path):
+@pytest.mark.parametrize("world", [2, 1], ids=["two_ranks", "one_rank_rccl"])
+def test_resident_kernels_under_data_parallel_communication(tmp_path, world):
+    """world = 2: see the module docstring.  world = 1: ONE rank on its own device, so the group is a real RCCL
+    communicator (backend nccl, `device_id` bound, torch DDP with its reducer hooks and streams) next to the cluster
+    kernels with their shorter wait bound under a process group — all that a 1-GPU box can show of the nccl path."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_ddp_worker.py"), str(tmp_path)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
-    reps = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(2)]
+    reps = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(world)]
     keep = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(keep):                                   # evidence for profiles/
-        json.dump(reps, open(os.path.join(keep, "ddp_concurrency.json"), "w"), indent=1)
+        json.dump(reps, open(os.path.join(keep, "ddp_concurrency.json" if world == 2 else "rccl_one_rank.json"), "w"), indent=1)
     for rep in reps:
-        assert rep["world"] == 2 and rep["sites"] == 16
+        assert rep["world"] == world and rep["sites"] == 16
+        if world == 1:
+            assert rep["backend"] == "nccl" and rep["mode"] == "ddp" and rep["wait_ms"] == "2000", rep
         if not rep["shared_device"]:
             assert "resident" in rep["paths"], rep             # one rank per GPU: the cluster kernels were in play
         assert rep["timeouts"] == 0, rep                       # no bounded wait ran out

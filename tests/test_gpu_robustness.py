@@ -76,6 +76,7 @@ import os, sys, torch, numpy as np
 sys.path.insert(0, %r)
 import cnsn_amd
 from cnsn_amd import _ffi
+cnsn_amd.follow_environ()
 from tests.golden.gen_golden_fill import fill_sn
 dev = torch.device("cuda:0")
 torch.manual_seed(0); np.random.seed(0)

@@ -10,6 +10,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import cnsn_amd  # noqa: E402
+cnsn_amd.follow_environ()   # CNSN_* knobs are read at load: re-read after every change below
 from tools.ab_sn_cluster import time_pair  # noqa: E402  (prints its own table first when imported: run with `none`)
 
 dev = torch.device("cuda:0")

@@ -3,6 +3,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import cnsn_amd
+cnsn_amd.follow_environ()   # CNSN_* knobs are read at load: re-read after every change below
 from tools.ab_sn_cluster import time_pair, cond
 dev = torch.device("cuda:0")
 for dt in ("f32", "bf16"):

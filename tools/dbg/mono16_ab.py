@@ -3,6 +3,7 @@ and what AUTO runs (the cluster kernels where they are preferred)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import cnsn_amd
+cnsn_amd.follow_environ()   # CNSN_* knobs are read at load: re-read after every change below
 from tools.ab_sn_cluster import time_pair, cond
 dev = torch.device("cuda:0")
 for shape, dt in (((256, 1024, 14, 14), "f32"), ((256, 512, 16, 16), "bf16"), ((256, 512, 16, 16), "f32")):

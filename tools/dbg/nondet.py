@@ -4,6 +4,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["CNSN_SNX"] = "2"
 import cnsn_amd
+cnsn_amd.follow_environ()   # CNSN_* knobs are read at load: re-read after every change below
 from tests.golden.gen_golden_fill import fill_sn
 cnsn_amd.set_strategy("resident")
 def run(shape, dtype, seed, mode, relu):

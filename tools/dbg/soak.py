@@ -3,6 +3,7 @@ launch's (rare hazards and races show up as run-to-run differences), the time-ou
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import cnsn_amd
+cnsn_amd.follow_environ()   # CNSN_* knobs are read at load: re-read after every change below
 dev = torch.device("cuda:0")
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 for shape, dt, call in (((37, 384, 28, 28), torch.bfloat16, "block"), ((64, 256, 56, 56), torch.bfloat16, "block"),

@@ -3,6 +3,7 @@ packed two-pass kernels), forward / backward ms, SelfNorm behind CrossNorm alone
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import cnsn_amd
+cnsn_amd.follow_environ()   # CNSN_* knobs are read at load: re-read after every change below
 from tools.ab_sn_cluster import time_pair, cond
 dev = torch.device("cuda:0")
 for dt in ("bf16", "f32"):

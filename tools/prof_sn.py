@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["CNSN_PROF"] = "1"
 import cnsn_amd  # noqa: E402
+cnsn_amd.follow_environ()   # CNSN_* knobs are read at load: re-read after every change below
 from cnsn_amd import _ffi  # noqa: E402
 from cnsn_amd.functional import FusedConfig, _epilogue, _problem  # noqa: E402
 
