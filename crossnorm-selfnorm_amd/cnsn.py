@@ -169,6 +169,53 @@ class SelfNorm(nn.Module):
         use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
         return use_batch, float(bn.eps), momentum
 
+    @staticmethod
+    def _bn_peek(bn):
+        """`_bn_call_state` without moving the counter (the cumulative-average momentum of `momentum=None` left out:
+        it changes every call and both gates' counters move together)"""
+        use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
+        return use_batch, float(bn.eps), (None if bn.momentum is None else float(bn.momentum)), bool(
+            bn.training and bn.track_running_stats)
+
+    def _fusable(self) -> bool:
+        """Can ONE launch evaluate this module's gates?  Yes for what the constructor builds — plain, affine
+        nn.BatchNorm1d modules, both gates of `is_two` in one configuration.  No when
+          * a gate's BatchNorm1d has become an nn.SyncBatchNorm: the reference's segmentation trainer converts every
+            BatchNorm of the model when `sync_bn` is set (segmentation/tool/train_cnsn.py:160), and the gate's batch
+            statistic then spans the GLOBAL batch — a collective the launch cannot make;
+          * `g_bn` and `f_bn` differ in mode, eps or momentum (one of them frozen, say): the kernels evaluate both
+            gates with one BatchNorm1d configuration;
+          * a gate's BatchNorm1d is not affine (no weight / bias to hand to the kernel).
+        `forward` then composes the op from its building blocks (`_forward_composed`)."""
+        mods = self._modules                        # (plain dict reads: this runs on every forward)
+        g_bn = mods["g_bn"]
+        if type(g_bn) is not nn.BatchNorm1d or g_bn._parameters["weight"] is None or g_bn._parameters["bias"] is None:
+            return False
+        if self.f_fc is None:
+            return True
+        f_bn = mods["f_bn"]
+        if type(f_bn) is not nn.BatchNorm1d or f_bn._parameters["weight"] is None or f_bn._parameters["bias"] is None:
+            return False
+        return self._bn_peek(g_bn) == self._bn_peek(f_bn)
+
+    def _forward_composed(self, x):
+        """The reference's own sequence (models/cnsn.py:130-150) on this library's building blocks: plane statistics
+        (cnsn_plane_stats, differentiable), the two-tap FC and the gate's BatchNorm modules CALLED as modules in fp32 —
+        so an nn.SyncBatchNorm all-reduces its (sum, sum of squares, count) over the process group forward and its two
+        sums backward, exactly as in the reference —, then one per-plane affine launch (cnsn_plane_affine):
+        3 + 5 tensor passes instead of 2 + 3, (N, C)-sized torch ops in between."""
+        b, c = int(x.size(0)), int(x.size(1))
+        mean, std = _F.PlaneStats.apply(x, 1e-12, None, True)                 # fp32 (N,C,1,1)
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            stats = torch.cat((mean.view(b, c, 1), std.view(b, c, 1)), -1)    # (N,C,2), cnsn.py:134
+            g_y = torch.sigmoid(self.g_bn(self.g_fc(stats))).view(b, c, 1, 1)
+            if self.f_fc is not None:
+                f_y = torch.sigmoid(self.f_bn(self.f_fc(stats))).view(b, c, 1, 1)
+                shift = mean * (f_y - g_y)                                    # cnsn.py:148
+            else:
+                shift = torch.zeros_like(g_y)
+        return _F.PlaneAffine.apply(x, g_y, shift)
+
     def _fused_args(self):
         """(config fields, g, f) for the fused call; does each BatchNorm1d's own per-call book-keeping."""
         state = self._bn_call_state(self.g_bn)
@@ -176,8 +223,8 @@ class SelfNorm(nn.Module):
         f = None
         if self.f_fc is not None:
             state_f = self._bn_call_state(self.f_bn)
-            if state_f != state:   # one kernel launch evaluates both gates with ONE BatchNorm1d configuration
-                raise _F._ffi.CnsnError(
+            if state_f != state:   # (`_fusable` has sent differing configurations to `_forward_composed`;
+                raise _F._ffi.CnsnError(   # what is left: momentum=None with counters that have drifted apart)
                     "SelfNorm(is_two=True): g_bn and f_bn must share mode, eps and momentum "
                     f"(g_bn: training/eps/momentum = {state}, f_bn: {state_f})")
             f = self._gate(self.f_fc, self.f_bn)
@@ -194,6 +241,8 @@ class SelfNorm(nn.Module):
         return kw, None, None
 
     def forward(self, x):
+        if not self._fusable():
+            return self._forward_composed(x)
         kw, g, f = self._fused_args()
         return _F.fused_cnsn(x, FusedConfig(**kw), g=g, f=f)
 
@@ -209,7 +258,7 @@ class CNSN(nn.Module):
 
     def forward(self, x):
         cn, sn = self.crossnorm, self.selfnorm
-        fuse = (cn is not None and sn is not None and type(cn) is CrossNorm and type(sn) is SelfNorm
+        fuse = (cn is not None and sn is not None and type(cn) is CrossNorm and type(sn) is SelfNorm and sn._fusable()
                 and cn.active and cn.training)
         if not fuse:                                    # literal reference control flow
             if cn and cn.active:
@@ -234,7 +283,7 @@ class CNSN(nn.Module):
         assert add_mode in ("none", "pre", "post")
         assert (addend is None) == (add_mode == "none")
         cn, sn = self.crossnorm, self.selfnorm
-        ours = (cn is None or type(cn) is CrossNorm) and (sn is None or type(sn) is SelfNorm)
+        ours = (cn is None or type(cn) is CrossNorm) and (sn is None or (type(sn) is SelfNorm and sn._fusable()))
         cn_on = cn is not None and cn.active and cn.training
         if not ours or not (cn_on or sn is not None):       # nothing of ours to fuse into: plain ops
             if add_mode == "pre":
@@ -268,7 +317,7 @@ class CNSN(nn.Module):
         cn, sn = self.crossnorm, self.selfnorm
         armed = cn is not None and cn.active
         fused = (type(bn) is nn.BatchNorm2d and bn.affine and bn.track_running_stats and sn is not None
-                 and type(sn) is SelfNorm and sn.f_fc is None and not armed and x.is_cuda
+                 and type(sn) is SelfNorm and sn.f_fc is None and sn._fusable() and not armed and x.is_cuda
                  and (cn is None or type(cn) is CrossNorm))
         if fused:
             kw, g, _ = sn._fused_args_peek()

@@ -160,12 +160,14 @@ def _sn_gate(stats, fc_weight, bn_weight, bn_bias, run_mean, run_var, training, 
 
 
 def selfnorm_forward(x, g_fc_w, g_bn_w, g_bn_b, g_run_mean, g_run_var, training=True,
-                     f_params=None, momentum=0.1, bn_eps=1e-5):
+                     f_params=None, momentum=0.1, bn_eps=1e-5, f_training=None):
     """x * g  (or x*g + mean*(f-g) for the two-gate form)  (cnsn.py:130-150).
 
     Statistics use eps = 1e-12 (cnsn.py:133).  Running buffers are updated in place in training
     mode exactly as `nn.BatchNorm1d` does (momentum 0.1, unbiased running variance).
-    `f_params` = (f_fc_w, f_bn_w, f_bn_b, f_run_mean, f_run_var) or None.
+    `f_params` = (f_fc_w, f_bn_w, f_bn_b, f_run_mean, f_run_var) or None.  `f_training`: the mode of the second gate's
+    BatchNorm1d when it differs from the first's (the reference calls `self.g_bn` / `self.f_bn` as modules, each with its
+    own `.training`, cnsn.py:138,144); None = the same.
     """
     n, c = x.shape[0], x.shape[1]
     mean, std = calc_ins_mean_std(x, eps=1e-12)                    # cnsn.py:133
@@ -174,8 +176,8 @@ def selfnorm_forward(x, g_fc_w, g_bn_w, g_bn_b, g_run_mean, g_run_var, training=
                  training, momentum, bn_eps).view(n, c, 1, 1)      # cnsn.py:137-140
     if f_params is not None:
         f_fc_w, f_bn_w, f_bn_b, f_rm, f_rv = f_params
-        f = _sn_gate(stats, f_fc_w, f_bn_w, f_bn_b, f_rm, f_rv,
-                     training, momentum, bn_eps).view(n, c, 1, 1)  # cnsn.py:143-146
+        f = _sn_gate(stats, f_fc_w, f_bn_w, f_bn_b, f_rm, f_rv, training if f_training is None else f_training,
+                     momentum, bn_eps).view(n, c, 1, 1)            # cnsn.py:143-146
         return x * g.expand_as(x) + mean.expand_as(x) * (f.expand_as(x) - g.expand_as(x))  # :148
     return x * g.expand_as(x)                                      # cnsn.py:150
 
@@ -230,8 +232,9 @@ class SelfNorm(torch.nn.Module):
         if self.f_fc is not None:
             fw, fb, frm, frv = self._bn_args(self.f_bn)
             f_params = (self.f_fc.weight, fw, fb, frm, frv)
-        return selfnorm_forward(x, self.g_fc.weight, gw, gb, grm, grv, self.training, f_params,
-                                momentum=self.g_bn.momentum, bn_eps=self.g_bn.eps)
+        return selfnorm_forward(x, self.g_fc.weight, gw, gb, grm, grv, self.g_bn.training, f_params,
+                                momentum=self.g_bn.momentum, bn_eps=self.g_bn.eps,
+                                f_training=self.f_bn.training if self.f_fc is not None else None)
 
 
 class CNSN(torch.nn.Module):

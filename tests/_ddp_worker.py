@@ -38,6 +38,10 @@ def main(out_dir, steps=3, batch=32):
 
     import cnsn_amd
     from cnsn_amd import _ffi, data_parallel as dp
+    avg_ok = None
+    if backend == "nccl":                          # what data_parallel.allreduce_gradients asks of RCCL (ReduceOp.AVG)
+        probe = torch.full((1024,), float(rank + 1), device=dev)
+        avg_ok = bool(dp._nccl_avg_ok(probe, None)) and float(probe[0]) == (world + 1) / 2
     _ffi.under_process_group_defaults()            # (what bench.py and callers.steps do: a 2 s bound on cluster waits)
     if shared:
         # two PROCESSES on one GPU: their persistent cluster grids could each hold what the other waits for (observed
@@ -153,7 +157,7 @@ def main(out_dir, steps=3, batch=32):
                site_outputs_bit_identical=bool(same_sites), site_max_abs_diff=max(site_diff) if site_diff else None,
                grad_rel_err=grad_err, grads_bit_identical=bool(grads_equal),
                timeouts=int(_ffi.lib().cnsn_resident_timeouts()), paths=paths, loss=last_loss,
-               wait_ms=os.environ.get("CNSN_WAIT_MS"),
+               wait_ms=os.environ.get("CNSN_WAIT_MS"), nccl_avg_ok=avg_ok,
                finite=bool(np.isfinite(last_loss)))
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
         json.dump(res, f)

@@ -175,6 +175,11 @@ def test_selfnorm_batchnorm_bookkeeping_follows_each_bn_module():
     two = cnsn_amd.SelfNorm(4, is_two=True).train()
     kw, g, f = two._fused_args()
     assert f is not None and kw["sn_two"] and int(two.g_bn.num_batches_tracked) == int(two.f_bn.num_batches_tracked) == 1
+    assert two._fusable()
     two.f_bn.eval()
+    assert not two._fusable()                              # -> SelfNorm.forward composes the op (tests/test_gpu_sync_bn.py)
     with pytest.raises(cnsn_amd.CnsnError):
         two._fused_args()
+    conv = torch.nn.SyncBatchNorm.convert_sync_batchnorm(cnsn_amd.SelfNorm(4))
+    assert type(conv.g_bn) is torch.nn.SyncBatchNorm and not conv._fusable()      # segmentation/tool/train_cnsn.py:160
+    assert cnsn_amd.SelfNorm(4)._fusable() and cnsn_amd.SelfNorm(4).eval()._fusable()
