@@ -36,7 +36,8 @@ def main(out_dir):
     for case, (shape, is_two) in enumerate([((12, 6, 28, 28), False), ((8, 5, 14, 14), True), ((6, 16, 56, 56), False)]):
         n_global, c = shape[0], shape[1]
         g = torch.Generator().manual_seed(40 + case)                   # the same global batch on every rank
-        x_all = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(dev)
+        x_all = torch.randn(shape, generator=g) * (torch.rand(n_global, c, 1, 1, generator=g) * 1.5 + 0.5)
+        x_all = (x_all + torch.randn(n_global, c, 1, 1, generator=g)).to(dev)      # per-plane scales / offsets
         gy_all = torch.randn(shape, generator=g).to(dev)
         lo, hi = rank * n_global // world, (rank + 1) * n_global // world
 

@@ -26,17 +26,21 @@ from tests.golden.gen_golden_fill import fill_sn  # noqa: E402
 DEV = torch.device("cuda:0")
 
 
-def _close(got, want64, ref32, tol=1e-5):
+def _close(got, want64, ref32, tol=1e-5, what=""):
     got, want64, ref32 = got.double().cpu(), want64.double(), ref32.double()
     scale = max(1.0, float(want64.abs().max()))
     e, e32 = float((got - want64).abs().max()), float((ref32 - want64).abs().max())
-    assert e <= max(tol * scale, 2 * e32), (e, e32, scale)
+    keep = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(keep):                       # observed error against its bound (evidence for profiles/)
+        with open(os.path.join(keep, "sync_bn_margins.jsonl"), "a") as f:
+            f.write(json.dumps(dict(what=what, err=e, err_oracle32=e32, scale=scale, bound=max(tol * scale, 2 * e32))) + "\n")
+    assert e <= max(tol * scale, 2 * e32), (what, e, e32, scale)
 
 
 def _oracle(c, is_two, seed, dt, x, gy, prepare):
     sn = fill_sn(orc.SelfNorm(c, is_two=is_two), seed, dt).train()
     prepare(sn)
-    xr = x.to(dt).requires_grad_()
+    xr = x.detach().clone().to(dt).requires_grad_()
     y = sn(xr)
     y.backward(gy.to(dt))
     return y.detach(), xr.grad, {k: v.grad for k, v in sn.named_parameters() if v.grad is not None}, dict(sn.state_dict())
@@ -47,9 +51,12 @@ def _oracle(c, is_two, seed, dt, x, gy, prepare):
 def test_composed_selfnorm_matches_the_oracle(shape, case):
     n, c = shape[:2]
     is_two = case != "sync_no_group"
-    torch.manual_seed(11)
-    x = torch.randn(shape, dtype=torch.float64) * 1.3 + 0.4
-    gy = torch.randn(shape, dtype=torch.float64)
+    g = torch.Generator().manual_seed(11)
+    # per-plane scales and offsets (the gate's BatchNorm over N divides by the spread of the plane statistics —
+    # planes that all look alike make every implementation ill-conditioned), values exact in fp32 for both sides
+    x = torch.randn(shape, generator=g, dtype=torch.float64) * (torch.rand(n, c, 1, 1, generator=g, dtype=torch.float64) * 1.5 + 0.5)
+    x = (x + torch.randn(n, c, 1, 1, generator=g, dtype=torch.float64)).float().double()
+    gy = torch.randn(shape, generator=g, dtype=torch.float64).float().double()
 
     def prepare(sn):
         if case == "f_eval":
@@ -65,7 +72,7 @@ def test_composed_selfnorm_matches_the_oracle(shape, case):
     sn = sn.to(DEV).train()
     prepare(sn)
     assert not sn._fusable()
-    xg = x.float().to(DEV).requires_grad_()
+    xg = x.detach().clone().float().to(DEV).requires_grad_()
     for wrap in (False, True):        # alone, and as the SelfNorm of a CNSN site whose CrossNorm is idle
         if wrap:
             for p in sn.parameters():
@@ -74,25 +81,26 @@ def test_composed_selfnorm_matches_the_oracle(shape, case):
             sn2 = fill_sn(cnsn_amd.SelfNorm(c, is_two=is_two), 5, torch.float32)
             if case.startswith("sync"):
                 sn2 = torch.nn.SyncBatchNorm.convert_sync_batchnorm(sn2)
-            sn = sn2.to(DEV).train()
-            prepare(sn)
-            y = cnsn_amd.CNSN(cnsn_amd.CrossNorm("neither", 1), sn).to(DEV).train()(xg)
+            sn = sn2.to(DEV)
+            site = cnsn_amd.CNSN(cnsn_amd.CrossNorm("neither", 1), sn).to(DEV).train()
+            prepare(sn)                   # (after the site's .train(): that call reaches every sub-module)
+            y = site(xg)
         else:
             y = sn(xg)
         y.backward(gy.float().to(DEV))
         torch.cuda.synchronize()
-        _close(y.detach(), t64[0], o32[0])
-        _close(xg.grad, t64[1], o32[1])
+        _close(y.detach(), t64[0], o32[0], what=f"{case} {shape} y")
+        _close(xg.grad, t64[1], o32[1], 1e-5, what=f"{case} {shape} dx")
         grads = {k: v.grad for k, v in sn.named_parameters() if v.grad is not None}
         assert set(grads) == set(t64[2])
         for k in grads:
-            _close(grads[k], t64[2][k], o32[2][k], 1e-5)
+            _close(grads[k], t64[2][k], o32[2][k], 1e-5, what=f"{case} {shape} grad {k}")
         st = sn.state_dict()
         for k in t64[3]:
             if "num_batches" in k:
                 assert int(st[k]) == int(t64[3][k]), k
             else:
-                _close(st[k], t64[3][k], o32[3][k])
+                _close(st[k], t64[3][k], o32[3][k], what=f"{case} {shape} state {k}")
 
 
 def test_armed_site_with_a_sync_gate_takes_the_reference_control_flow():
@@ -113,7 +121,7 @@ def test_armed_site_with_a_sync_gate_takes_the_reference_control_flow():
     fused.crossnorm.active = True
     fused.crossnorm.next_draws = d
     want = fused(x)                     # one launch; without a process group the two statistics are the same
-    assert float((y - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert float((y - want).detach().abs().max()) <= 2e-5 * float(want.detach().abs().max())
 
 
 def _free_port():
@@ -136,6 +144,6 @@ def test_sync_gate_statistic_spans_the_global_batch(tmp_path):
     for rep in reps:
         assert rep["world"] == 2 and len(rep["cases"]) == 3
         for case in rep["cases"]:
-            for k, e in case["errs"].items():
-                assert e <= 2e-5, (case["shape"], k, e)
+            for k, e in case["errs"].items():      # composed (fp32 gate, fp32 plane sums) against the fused launch (fp64 inside)
+                assert e <= 1e-5, (case["shape"], k, e)
             assert case["local_vs_global"] > 1e-3, case      # half-batch statistics would have given something else
