@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--strategy", type=str, default="auto", choices=["auto", "two_pass", "resident", "local"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (crop=both, bf16)")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the copy / triad / access-order ceilings (child runs)")
     ap.add_argument("--workload", type=str, default="cnsn", choices=["cnsn", "resnet50", "resnet50_jsd", "wrn40"],
                     help="cnsn: the fused op at the north-star shape (headline); resnet50 / wrn40: whole "
                          "training steps of the caller backbones (images/s)")
@@ -333,6 +334,54 @@ def model_line(workload, steps, warmup, timeout_s):
                 "wall_s_incl_startup": round(time.perf_counter() - t0, 1)}
     except Exception as e:  # noqa: BLE001  (time-out, no JSON line: report, never fail the headline over it)
         return {"images_per_s": None, "error": f"{type(e).__name__}: {str(e)[:160]}", "wall_s": round(time.perf_counter() - t0, 1)}
+
+
+def live_traffic(args, timeout_s=150):
+    """`roofline.traffic` measured NOW instead of replayed from profiles/: this bench re-run as a child process under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE`, then `--pmc WRITE_SIZE` — counters in passes of their own next to the
+    kernel trace only, as MI355X_MICROARCH.md prescribes — a few steps each, same shape / dtype / crop / strategy.  HBM bytes
+    per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced
+    stream (calibrated against kernels of known traffic in profiles/r01_pmc_traffic.txt).  Returns
+    ({"fwd": bytes, "bwd": bytes}, source) or (None, reason): a box without rocprofv3 or counters never fails the headline."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2", "--no-extra", "--no-cpu-baseline",
+             "--no-ceiling", "--shape", args.shape, "--dtype", args.dtype, "--crop", args.crop, "--kind", args.kind,
+             "--strategy", args.strategy]
+    mean = {}                                              # (direction, counter) -> KiB per launch
+    t0 = time.perf_counter()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="cnsn_pmc_", dir="/tmp")
+        try:
+            subprocess.run([rocprof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", *child],
+                           capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            per = {}                                       # kernel name -> values of its dispatches
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "cnsn::" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                        per.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            for direction in ("fwd", "bwd"):               # a two-pass path has several kernels per launch: add their means
+                vals = [sum(v) / len(v) for k, v in per.items() if f"_{direction}_" in k or f"{direction}_kernel" in k]
+                if vals:
+                    mean[(direction, ctr)] = sum(vals)
+        except Exception as e:  # noqa: BLE001
+            return None, f"live collection failed ({type(e).__name__}: {str(e)[:120]})"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for direction in ("fwd", "bwd"):
+        if (direction, "FETCH_SIZE") in mean and (direction, "WRITE_SIZE") in mean:
+            out[direction] = int((2 * mean[(direction, "FETCH_SIZE")] + mean[(direction, "WRITE_SIZE")]) * 1024)
+    if "bwd" not in out:
+        return None, "live collection failed (no counter rows for the library's kernels)"
+    return out, (f"live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this command (4 steps) run as child "
+                 f"processes just now ({time.perf_counter() - t0:.0f} s); bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, "
+                 "the gfx950 correction of MI355X_MICROARCH.md calibrated in profiles/r01_pmc_traffic.txt")
 
 
 SWEEP_SHAPES = [(8, 64, 32, 32), (128, 32, 32, 32), (128, 64, 16, 16), (128, 128, 8, 8), (256, 256, 56, 56),
@@ -734,7 +783,17 @@ def main():
                                      "frac": round(need_f / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
                                      "survey_d3_frac": round(3 * e * b / fwd_s / 1e9 / HBM_PEAK_GBS, 4)}},
         }
-        if world == 1:
+        if world == 1 and not args.no_extra:
+            live, why = live_traffic(args)
+            if live is not None:
+                out["roofline"]["traffic"], out["roofline"]["traffic_source"] = live["bwd"], why
+                out["roofline"]["traffic_over_bytes"] = round(live["bwd"] / need_b, 4)
+                if "fwd" in live:
+                    out["roofline"]["forward"]["traffic"] = live["fwd"]
+                    out["roofline"]["forward"]["traffic_over_bytes"] = round(live["fwd"] / need_f, 4)
+            elif traffic_source is not None:
+                out["roofline"]["traffic_source"] = traffic_source + "; " + why
+        if world == 1 and not args.no_ceiling:
             ceil = copy_triad_ceiling(dev)
             out["roofline"]["ceiling"] = ceil
             if "resident_order_triad_GBps" in ceil and list(shape) == [256, 256, 56, 56] and b == 4:

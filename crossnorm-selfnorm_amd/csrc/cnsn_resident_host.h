@@ -2,6 +2,7 @@
 // alone; cnsn_resident_fused.hip: the op with the residual-block epilogue): eligibility, launch geometry, dispatch.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <optional>
 #include "cnsn_env.h"
 
 #include <cstdio>
@@ -224,6 +225,8 @@ int forward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidA
     if (knob(K_PROF)) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
 #endif
     const size_t lds = res_lds_bytes(p.N, NG, 4 * rp.ppw, FC_ROWS, false);
+    std::optional<ResidentChain> chain;  // cluster grids of different streams never overlap
+    if (!solo) chain.emplace(stream);  // (the exchange area is taken inside the chain: a context's wrap-around clear is ordered like a launch)
     const ExchangeArea ea = solo ? ExchangeArea{workspace, 0u}
                                  : resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NG * 8, workspace, stream);
     ra.epoch = ea.epoch;
@@ -243,7 +246,6 @@ int forward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidA
                 kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, (const T*)addend,
                                                     relu);
             } else {
-                ResidentChain chain(stream);  // cluster grids of different streams never overlap
                 if (!ea.epoch) e = hipMemsetAsync(workspace, 0xff, fill_bytes, stream);  // 'empty' granules, idle control word
                 if (e != hipSuccess) {
                     status = (int)e;
@@ -287,6 +289,8 @@ int backward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const Mid
     if (knob(K_PROF)) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
 #endif
     const size_t lds = res_lds_bytes(p.N, NS, 4 * rp.ppw, BC_ROWS, true);
+    ResidentChain chain(stream);  // cluster grids of different streams never overlap
+    // (the exchange area is taken inside the chain: a context's wrap-around clear is ordered like a launch)
     const ExchangeArea ea = resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NS * 8, workspace, stream);
     ra.epoch = ea.epoch;
     ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
@@ -300,7 +304,6 @@ int backward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const Mid
         auto launch = [&](auto kern) {
             const int grid = grid_for(kern, lds, rp.K, ra.items);
             if (grid < rp.K) return;
-            ResidentChain chain(stream);  // cluster grids of different streams never overlap
             hipError_t e = ea.epoch ? hipSuccess : hipMemsetAsync(workspace, 0xff, fill_bytes, stream);  // 'empty' granules
             if (e != hipSuccess) {
                 status = (int)e;

@@ -86,6 +86,8 @@ int resident_pipe_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, c
     if (knob(K_PROF)) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
 #endif
     const size_t lds = pipe_lds_bytes(p.N, NG, 4 * rp.ppw, npark, rp.vec * elem_bytes(p.dtype), p.cn_active != 0);
+    ResidentChain chain(stream);  // cluster grids of different streams never overlap
+    // (the exchange area is taken inside the chain: a context's wrap-around clear is ordered like a launch)
     const ExchangeArea ea = resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NG * 8 + 256, workspace, stream);
     ra.epoch = ea.epoch;
     ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
@@ -100,7 +102,6 @@ int resident_pipe_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, c
             if (!allow_dynamic_lds(kern, lds)) return;
             const int grid = reshost::grid_for(kern, lds, rp.K, ra.items);
             if (grid < rp.K) return;
-            ResidentChain chain(stream);
             hipError_t e = ea.epoch ? hipSuccess : hipMemsetAsync(workspace, 0xff, fill_bytes, stream);
             if (e != hipSuccess) {
                 status = (int)e;
@@ -183,6 +184,8 @@ int resident_pipe_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
     if (knob(K_PROF)) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
 #endif
     const size_t lds = pipe_bwd_lds_bytes(p.N, NS, 4 * rp.ppw, npark, rp.vec * elem_bytes(p.dtype));
+    ResidentChain chain(stream);  // cluster grids of different streams never overlap
+    // (the exchange area is taken inside the chain: a context's wrap-around clear is ordered like a launch)
     const ExchangeArea ea = resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NS * 8 + 256, workspace, stream);
     ra.epoch = ea.epoch;
     ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
@@ -197,7 +200,6 @@ int resident_pipe_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
             if (!allow_dynamic_lds(kern, lds)) return;
             const int grid = reshost::grid_for(kern, lds, rp.K, ra.items);
             if (grid < rp.K) return;
-            ResidentChain chain(stream);
             hipError_t e = ea.epoch ? hipSuccess : hipMemsetAsync(workspace, 0xff, fill_bytes, stream);
             if (e != hipSuccess) {
                 status = (int)e;

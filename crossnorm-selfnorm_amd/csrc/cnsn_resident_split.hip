@@ -4,6 +4,7 @@
 // segmentation/model/cnsn_resnet.py:273-311).  Offered: the op alone (boxed or not, training or inference) and the POST
 // add / ReLU epilogue of an un-boxed call (SelfNorm at 'residual'); a PRE add runs two-pass.
 #include "cnsn_fused_stream_kernels.h"
+#include <optional>
 #include "cnsn_resident_host.h"
 
 namespace cnsn {
@@ -81,6 +82,8 @@ int resident_split_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
     const bool post = add == ADD_POST, epi = post || relu;
     const int NG = boxed ? 6 : 2;
     const size_t lds = res_lds_bytes(p.N, NG, 1, FC_ROWS, false);
+    std::optional<ResidentChain> chain;  // cluster grids of different streams never overlap
+    if (!solo) chain.emplace(stream);  // (the exchange area is taken inside the chain: a context's wrap-around clear is ordered like a launch)
     const ExchangeArea ea = solo ? ExchangeArea{workspace, 0u}
                                  : resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NG * 8, workspace, stream);
     ra.epoch = ea.epoch;
@@ -99,7 +102,6 @@ int resident_split_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
             if (solo) {
                 kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, (const T*)addend, relu);
             } else {
-                ResidentChain chain(stream);
                 if (!ea.epoch) e = hipMemsetAsync(workspace, 0xff, fill_bytes, stream);
                 if (e != hipSuccess) {
                     status = (int)e;
@@ -146,6 +148,8 @@ int resident_split_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed,
     ResArgs ra = reshost::make_args(p, cb, sb, mid, rp);
     const int NS = boxed ? 4 : 2;
     const size_t lds = res_lds_bytes(p.N, NS, 1, BC_ROWS, true);
+    ResidentChain chain(stream);  // cluster grids of different streams never overlap
+    // (the exchange area is taken inside the chain: a context's wrap-around clear is ordered like a launch)
     const ExchangeArea ea = resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NS * 8, workspace, stream);
     ra.epoch = ea.epoch;
     ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
@@ -159,7 +163,6 @@ int resident_split_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed,
         auto launch = [&](auto kern) {
             const int grid = reshost::grid_for(kern, lds, rp.K, ra.items);
             if (grid < rp.K) return;
-            ResidentChain chain(stream);
             hipError_t e = ea.epoch ? hipSuccess : hipMemsetAsync(workspace, 0xff, fill_bytes, stream);
             if (e != hipSuccess) {
                 status = (int)e;
