@@ -336,6 +336,25 @@ def model_line(workload, steps, warmup, timeout_s):
         return {"images_per_s": None, "error": f"{type(e).__name__}: {str(e)[:160]}", "wall_s": round(time.perf_counter() - t0, 1)}
 
 
+def pmc_means(directory, counter):
+    """{"fwd": KiB, "bwd": KiB}: the mean of `counter` per dispatch of the library's forward / backward kernels in the
+    `*counter_collection.csv` files rocprofv3 left under `directory` (a two-pass path has several kernels per launch: their
+    means are added)."""
+    import csv
+    import glob
+    per = {}                                               # kernel name -> values of its dispatches
+    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "cnsn::" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                per.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    out = {}
+    for direction in ("fwd", "bwd"):
+        vals = [sum(v) / len(v) for k, v in per.items() if f"_{direction}_" in k or f"{direction}_kernel" in k]
+        if vals:
+            out[direction] = sum(vals)
+    return out
+
+
 def live_traffic(args, timeout_s=150):
     """`roofline.traffic` measured NOW instead of replayed from profiles/: this bench re-run as a child process under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE`, then `--pmc WRITE_SIZE` — counters in passes of their own next to the
@@ -343,8 +362,6 @@ def live_traffic(args, timeout_s=150):
     per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced
     stream (calibrated against kernels of known traffic in profiles/r01_pmc_traffic.txt).  Returns
     ({"fwd": bytes, "bwd": bytes}, source) or (None, reason): a box without rocprofv3 or counters never fails the headline."""
-    import csv
-    import glob
     import shutil
     import tempfile
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -360,15 +377,8 @@ def live_traffic(args, timeout_s=150):
         try:
             subprocess.run([rocprof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", *child],
                            capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
-            per = {}                                       # kernel name -> values of its dispatches
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for r in csv.DictReader(open(f)):
-                    if "cnsn::" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
-                        per.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
-            for direction in ("fwd", "bwd"):               # a two-pass path has several kernels per launch: add their means
-                vals = [sum(v) / len(v) for k, v in per.items() if f"_{direction}_" in k or f"{direction}_kernel" in k]
-                if vals:
-                    mean[(direction, ctr)] = sum(vals)
+            for direction, kib in pmc_means(d, ctr).items():
+                mean[(direction, ctr)] = kib
         except Exception as e:  # noqa: BLE001
             return None, f"live collection failed ({type(e).__name__}: {str(e)[:120]})"
         finally:

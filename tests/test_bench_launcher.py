@@ -46,3 +46,28 @@ def test_single_process_stays_single():
     assert mod.pick_backend(8, 8) == "nccl" and mod.pick_backend(2, 1) == "gloo"
     cmd = mod.launcher_command(4, ["--gpus", "4"], port=29511)
     assert cmd[cmd.index("--master-port") + 1] == "29511"
+
+
+def test_pmc_means_reads_rocprofv3_counter_files(tmp_path):
+    """bench.py::live_traffic's parser: per-dispatch means of the library's forward / backward kernels, other kernels and
+    other counters ignored, the kernels of a multi-kernel (two-pass) launch added."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    d = tmp_path / "host" / "123"
+    d.mkdir(parents=True)
+    rows = ["Correlation_Id,Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"]
+    k_b = '"void cnsn::resident_bwd_pipe_kernel<float, 4, 13, 1, false>(cnsn::ResArgs)"'
+    k_f = '"void cnsn::resident_fwd_pipe_kernel<float, 4, 13, 1, false>(cnsn::ResArgs)"'
+    for i, v in enumerate((100.0, 300.0)):
+        rows.append(f"{i},{i},{k_b},FETCH_SIZE,{v}")
+        rows.append(f"{i},{i},{k_f},FETCH_SIZE,{v / 2}")
+        rows.append(f"{i},{i},{k_b},WRITE_SIZE,7.0")
+        rows.append(f'{i},{i},"void at::native::vectorized_elementwise_kernel<4>(int)",FETCH_SIZE,999.0')
+    rows.append('9,9,"void cnsn::apply_bwd_kernel<float, 4, 256, false>(float const*)",FETCH_SIZE,50.0')
+    (d / "123_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    got = bench.pmc_means(str(tmp_path), "FETCH_SIZE")
+    assert got == {"fwd": 100.0, "bwd": 250.0}
+    assert bench.pmc_means(str(tmp_path), "WRITE_SIZE") == {"bwd": 7.0}
+    assert bench.pmc_means(str(tmp_path), "SQ_WAVES") == {}
