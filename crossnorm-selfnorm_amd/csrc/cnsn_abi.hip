@@ -69,7 +69,8 @@ size_t cnsn_context_bytes(const cnsn_problem_t* prob) {
     // (+ 256: the scalar-path gather reads whole 256-byte groups)
     if (!any) return 0;
     const size_t general = kCtlBytes + (size_t)p.N * p.C * 6 * 8 + 256, sn = resident_sn_exchange_bytes(p);
-    return general > sn ? general : sn;
+    // + the two untagged granule regions at the end (resident_pong_acquire)
+    return (general > sn ? general : sn) + 2 * kPongRegion;
 }
 
 int cnsn_context_init(void* context, size_t bytes, void* stream) {

@@ -12,6 +12,7 @@ const char* const kNames[K_COUNT] = {
     "CNSN_LOCAL_LB", "CNSN_LOCAL_CG", "CNSN_STAGGER",     "CNSN_WAIT_MS", "CNSN_FAULT_INJECT", "CNSN_DEBUG",
     "CNSN_PROF",     "CNSN_MONO",     "CNSN_MONO_RELOAD", "CNSN_NO_PACKED", "CNSN_MID_TILE",   "CNSN_SNX",
     "CNSN_RESIDENT", "CNSN_CONTEXT",  "CNSN_EPOCH_START", "CNSN_KEEP",    "CNSN_PIPE",         "CNSN_WIDE",
+    "CNSN_PONG",
 };
 
 struct Table {

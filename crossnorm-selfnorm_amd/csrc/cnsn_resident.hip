@@ -53,15 +53,61 @@ std::mutex g_ctx_mu;
 std::unordered_map<void*, unsigned> g_ctx_epoch;  // launches counted per context (host side)
 }  // namespace
 
+namespace {
+struct PongState {
+    size_t bytes = 0;          // context size the region addresses were derived from
+    size_t clean[2] = {0, 0};  // leading bytes of each region known to hold 'empty'
+    int next = 0;
+};
+std::unordered_map<void*, PongState> g_pong;  // (under g_ctx_mu)
+}  // namespace
+
 void resident_context_forget(void* context) {
     std::lock_guard<std::mutex> lock(g_ctx_mu);
     g_ctx_epoch[context] = 0;
+    g_pong.erase(context);
+}
+
+bool resident_pong_acquire(const cnsn_problem_t& p, size_t fill_bytes, hipStream_t stream, PongArea* out) {
+    // (+ 512: the scalar-path gather reads whole 256-byte groups, past the last granule)
+    if (!p.context || fill_bytes + 512 > kPongRegion || (fill_bytes & 7) || p.context_bytes < 2 * kPongRegion + 4096) return false;
+    if (const char* e = knob(K_PONG))
+        if (e[0] == '0') return false;
+    if (const char* e = knob(K_CONTEXT))
+        if (e[0] == '0') return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return false;  // a replay would reuse the region chosen at capture time
+    }
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    if (g_ctx_epoch.find(p.context) == g_ctx_epoch.end()) return false;  // never initialised through cnsn_context_init
+    PongState& st = g_pong[p.context];
+    if (st.bytes != (size_t)p.context_bytes) st = PongState{(size_t)p.context_bytes, {0, 0}, 0};
+    const int r = st.next;
+    char* end = (char*)p.context + (size_t)p.context_bytes;
+    char* region[2] = {end - 2 * kPongRegion, end - kPongRegion};
+    out->base = region[r];
+    out->clear = (unsigned long long*)region[r ^ 1];
+    out->clear_qwords = (unsigned)(fill_bytes / 8);
+    out->need_fill = st.clean[r] < fill_bytes;
+    st.clean[r] = 0;  // dirty from now on, launched or not (the fill in front of an abandoned launch leaves it clean: unused)
+    return true;
+}
+
+void resident_pong_commit(const cnsn_problem_t& p, size_t fill_bytes) {
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    auto it = g_pong.find(p.context);
+    if (it == g_pong.end()) return;
+    PongState& st = it->second;
+    st.clean[st.next ^ 1] = fill_bytes;  // this launch's workgroups store 'empty' over that much of the other region
+    st.next ^= 1;
 }
 
 ExchangeArea resident_exchange_area(const cnsn_problem_t& p, size_t tagged_bytes, void* workspace, hipStream_t stream,
                                     bool prefer_context) {
     ExchangeArea ea{workspace, 0u};
-    if (!p.context || p.context_bytes < tagged_bytes) return ea;
+    if (!p.context || p.context_bytes < tagged_bytes + 2 * kPongRegion) return ea;  // (the last two regions are not for tagged granules)
     if (const char* e = knob(K_CONTEXT)) {
         if (e[0] == '0') return ea;
     } else if (!prefer_context && (size_t)p.N * p.C * p.H * p.W * elem_bytes(p.dtype) >= ((size_t)64 << 20)) {
@@ -91,6 +137,7 @@ ExchangeArea resident_exchange_area(const cnsn_problem_t& p, size_t tagged_bytes
                 return ea;
             }
             epoch = it->second = 1;
+            g_pong.erase(p.context);  // (the clear zeroed the granule regions too: not 'empty' any more)
         }
     }
     ea.base = p.context;

@@ -1471,6 +1471,22 @@ ExchangeArea resident_exchange_area(const cnsn_problem_t& p, size_t tagged_bytes
                                     bool prefer_context = false);
 void resident_context_forget(void* context);
 
+// Untagged granules WITHOUT a fill launch (pipelined kernels, tensors of 64 MiB and more — where a tagged context costs more
+// than it saves): two regions of kPongRegion bytes at the END of the persistent context, used alternately.  A launch
+// exchanges through one and its workgroups clear the other (same extent) for the launch after it; the host keeps, per
+// context, which region comes next and how many bytes of each are known to be clean, and says when a fill is needed after
+// all (first use, a larger extent than the previous launch cleared, a re-initialised context).  Tagged launches never
+// reach into the regions (resident_exchange_area leaves them out of what it offers).  Call inside the ResidentChain.
+constexpr size_t kPongRegion = (size_t)2 << 20;
+struct PongArea {
+    void* base;                  // region of this launch: control block + granules
+    unsigned long long* clear;   // the other region
+    unsigned clear_qwords;
+    bool need_fill;              // `base` is not known to be clean over fill_bytes: memset it first
+};
+bool resident_pong_acquire(const cnsn_problem_t& p, size_t fill_bytes, hipStream_t stream, PongArea* out);
+void resident_pong_commit(const cnsn_problem_t& p, size_t fill_bytes);  // the launch was issued: the other region will be clean
+
 struct ResidentChain {
     explicit ResidentChain(hipStream_t stream);
     ~ResidentChain();

@@ -91,9 +91,14 @@ int resident_pipe_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, c
     const ExchangeArea ea = resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NG * 8 + 256, workspace, stream);
     ra.epoch = ea.epoch;
     ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
-    unsigned* ctl = (unsigned*)ea.base;
-    unsigned long long* gran = (unsigned long long*)((char*)ea.base + kCtlBytes);
     const size_t fill_bytes = kCtlBytes + (size_t)p.N * p.C * (NG / 2) * 8;
+    // workspace form (large tensors): through a granule region of the context that the previous launch left clean, if there
+    // is one — no fill launch (resident_pong_acquire)
+    PongArea pong{nullptr, nullptr, 0u, false};
+    const bool use_pong = !ea.epoch && resident_pong_acquire(p, fill_bytes, stream, &pong);
+    void* area = use_pong ? pong.base : ea.base;
+    unsigned* ctl = (unsigned*)area;
+    unsigned long long* gran = (unsigned long long*)((char*)area + kCtlBytes);
     int status = CNSN_E_UNSUPPORTED;
     dispatch_pipe(p.dtype, rp.vec, rp.nv, [&](auto tt, auto vt, auto nt, auto pt) {
         using T = typename decltype(tt)::type;
@@ -102,14 +107,17 @@ int resident_pipe_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, c
             if (!allow_dynamic_lds(kern, lds)) return;
             const int grid = reshost::grid_for(kern, lds, rp.K, ra.items);
             if (grid < rp.K) return;
-            hipError_t e = ea.epoch ? hipSuccess : hipMemsetAsync(workspace, 0xff, fill_bytes, stream);
+            hipError_t e = hipSuccess;
+            if (!ea.epoch && (!use_pong || pong.need_fill)) e = hipMemsetAsync(area, 0xff, fill_bytes, stream);
             if (e != hipSuccess) {
                 status = (int)e;
                 return;
             }
-            kern<<<grid, kBlock, lds, stream>>>(ra, npark, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl);
+            kern<<<grid, kBlock, lds, stream>>>(ra, npark, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, pong.clear,
+                                                pong.clear_qwords);
             e = hipGetLastError();
             status = e == hipSuccess ? CNSN_OK : (int)e;
+            if (use_pong && e == hipSuccess) resident_pong_commit(p, fill_bytes);
         };
         if (boxed)
             launch(resident_fwd_pipe_kernel<T, VEC, NV, PPW, true>);
@@ -189,9 +197,14 @@ int resident_pipe_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
     const ExchangeArea ea = resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NS * 8 + 256, workspace, stream);
     ra.epoch = ea.epoch;
     ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
-    unsigned* ctl = (unsigned*)ea.base;
-    unsigned long long* gran = (unsigned long long*)((char*)ea.base + kCtlBytes);
     const size_t fill_bytes = kCtlBytes + (size_t)p.N * p.C * (NS / 2) * 8;
+    // workspace form (large tensors): through a granule region of the context that the previous launch left clean, if there
+    // is one — no fill launch (resident_pong_acquire)
+    PongArea pong{nullptr, nullptr, 0u, false};
+    const bool use_pong = !ea.epoch && resident_pong_acquire(p, fill_bytes, stream, &pong);
+    void* area = use_pong ? pong.base : ea.base;
+    unsigned* ctl = (unsigned*)area;
+    unsigned long long* gran = (unsigned long long*)((char*)area + kCtlBytes);
     int status = CNSN_E_UNSUPPORTED;
     dispatch_pipe_bwd(p.dtype, rp.vec, rp.nv, [&](auto tt, auto vt, auto nt, auto pt) {
         using T = typename decltype(tt)::type;
@@ -200,15 +213,17 @@ int resident_pipe_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
             if (!allow_dynamic_lds(kern, lds)) return;
             const int grid = reshost::grid_for(kern, lds, rp.K, ra.items);
             if (grid < rp.K) return;
-            hipError_t e = ea.epoch ? hipSuccess : hipMemsetAsync(workspace, 0xff, fill_bytes, stream);
+            hipError_t e = hipSuccess;
+            if (!ea.epoch && (!use_pong || pong.need_fill)) e = hipMemsetAsync(area, 0xff, fill_bytes, stream);
             if (e != hipSuccess) {
                 status = (int)e;
                 return;
             }
             kern<<<grid, kBlock, lds, stream>>>(ra, npark, (const T*)gy, (const T*)x, (T*)dx, perm, g, f, dg, df, gran, saved,
-                                                ctl);
+                                                ctl, pong.clear, pong.clear_qwords);
             e = hipGetLastError();
             status = e == hipSuccess ? CNSN_OK : (int)e;
+            if (use_pong && e == hipSuccess) resident_pong_commit(p, fill_bytes);
         };
         if (boxed)
             launch(resident_bwd_pipe_kernel<T, VEC, NV, PPW, true>);

@@ -267,6 +267,8 @@ int cnsn_sn_cluster_plan(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi,
  *   cnsn_context_init(...)    zero-fills a context on `stream` and forgets its launch count; REQUIRED once for
  *                             every buffer before it is passed as cnsn_problem_t.context; the caller orders the
  *                             fill before the first use (same stream, or a synchronisation)
+ * Its last 4 MiB are two regions of untagged granules that launches on large tensors use alternately, each launch
+ * clearing the other region for the next one (no fill launch; cnsn_context_bytes includes them).
  * One context per device, used by one stream at a time or by streams the library orders itself (its per-device
  * launch chaining).  Not used while `stream` is being captured into a graph (a replay would repeat the launch
  * number): such calls fall back to the workspace.  Nothing in the reference corresponds to this. */
