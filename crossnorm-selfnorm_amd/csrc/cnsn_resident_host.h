@@ -231,9 +231,12 @@ int forward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidA
                                  : resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NG * 8, workspace, stream);
     ra.epoch = ea.epoch;
     ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
-    unsigned* ctl = (unsigned*)ea.base;
-    unsigned long long* gran = (unsigned long long*)((char*)ea.base + kCtlBytes);
     const size_t fill_bytes = kCtlBytes + (size_t)p.N * p.C * (NG / 2) * 8;  // control block + granules (workspace form)
+    PongArea pong{nullptr, nullptr, 0u, false};  // (a granule region of the context instead of workspace + fill: resident_pong_acquire)
+    const bool use_pong = !solo && !ea.epoch && resident_pong_acquire(p, fill_bytes, stream, &pong);
+    void* area = use_pong ? pong.base : ea.base;
+    unsigned* ctl = (unsigned*)area;
+    unsigned long long* gran = (unsigned long long*)((char*)area + kCtlBytes);
     int status = CNSN_E_UNSUPPORTED;
     dispatch_res<false, EPI>(p.dtype, rp.vec, rp.nv, [&](auto tt, auto vt, auto nt, auto pt) {
         using T = typename decltype(tt)::type;
@@ -244,18 +247,19 @@ int forward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidA
             hipError_t e = hipSuccess;
             if (solo) {  // no cluster, nothing to wait for
                 kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, (const T*)addend,
-                                                    relu);
+                                                    relu, nullptr, 0u);
             } else {
-                if (!ea.epoch) e = hipMemsetAsync(workspace, 0xff, fill_bytes, stream);  // 'empty' granules, idle control word
+                if (!ea.epoch && (!use_pong || pong.need_fill)) e = hipMemsetAsync(area, 0xff, fill_bytes, stream);  // 'empty' granules, idle control word
                 if (e != hipSuccess) {
                     status = (int)e;
                     return;
                 }
                 kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, (const T*)addend,
-                                                    relu);
+                                                    relu, pong.clear, pong.clear_qwords);
             }
             e = hipGetLastError();
             status = e == hipSuccess ? CNSN_OK : (int)e;
+            if (use_pong && e == hipSuccess) resident_pong_commit(p, fill_bytes);
         };
         if constexpr (EPI) {
             if (post) {  // (never boxed)
@@ -294,9 +298,12 @@ int backward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const Mid
     const ExchangeArea ea = resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NS * 8, workspace, stream);
     ra.epoch = ea.epoch;
     ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
-    unsigned* ctl = (unsigned*)ea.base;
-    unsigned long long* gran = (unsigned long long*)((char*)ea.base + kCtlBytes);
     const size_t fill_bytes = kCtlBytes + (size_t)p.N * p.C * (NS / 2) * 8;
+    PongArea pong{nullptr, nullptr, 0u, false};  // (a granule region of the context instead of workspace + fill: resident_pong_acquire)
+    const bool use_pong = !ea.epoch && resident_pong_acquire(p, fill_bytes, stream, &pong);
+    void* area = use_pong ? pong.base : ea.base;
+    unsigned* ctl = (unsigned*)area;
+    unsigned long long* gran = (unsigned long long*)((char*)area + kCtlBytes);
     int status = CNSN_E_UNSUPPORTED;
     dispatch_res<true, EPI>(p.dtype, rp.vec, rp.nv, [&](auto tt, auto vt, auto nt, auto pt) {
         using T = typename decltype(tt)::type;
@@ -304,15 +311,17 @@ int backward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const Mid
         auto launch = [&](auto kern) {
             const int grid = grid_for(kern, lds, rp.K, ra.items);
             if (grid < rp.K) return;
-            hipError_t e = ea.epoch ? hipSuccess : hipMemsetAsync(workspace, 0xff, fill_bytes, stream);  // 'empty' granules
+            hipError_t e = hipSuccess;
+            if (!ea.epoch && (!use_pong || pong.need_fill)) e = hipMemsetAsync(area, 0xff, fill_bytes, stream);  // 'empty' granules
             if (e != hipSuccess) {
                 status = (int)e;
                 return;
             }
             kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)gy, (const T*)x, (T*)dx, perm, g, f, dg, df, gran,
-                                                saved, ctl, (const T*)addend, relu, (T*)d_addend);
+                                                saved, ctl, (const T*)addend, relu, (T*)d_addend, pong.clear, pong.clear_qwords);
             e = hipGetLastError();
             status = e == hipSuccess ? CNSN_OK : (int)e;
+            if (use_pong && e == hipSuccess) resident_pong_commit(p, fill_bytes);
         };
         if constexpr (EPI) {
             if (post) {

@@ -526,6 +526,14 @@ __host__ __device__ inline size_t res_lds_bytes(int N, int NG, int OWN, int coef
            + (backward ? align16((size_t)N * D_N * 8) + align16((size_t)N * F_N * 4) : 0);  // staged `saved`
 }
 
+// Granule regions without a fill launch (cnsn_resident.hip, resident_pong_*): the exchange of a launch runs through one of two
+// untagged regions at the end of the persistent context; every workgroup first stores 'empty' (all ones) over its share of the
+// OTHER region — control block and granules of the same extent — so that the next launch finds it clean.  The stores are
+// ordered before that launch by the kernel boundary; nobody reads the other region during this launch.  clear_n = 0: nothing.
+__device__ __forceinline__ void pipe_clear_other_region(unsigned long long* __restrict__ clear, unsigned clear_n) {
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < clear_n; i += gridDim.x * kBlock) clear[i] = ~0ull;
+}
+
 // ================================================================================================
 // forward
 // ================================================================================================
@@ -544,7 +552,9 @@ __global__ __launch_bounds__(kBlock, SPLIT ? (POST ? 2 : 3) : POST ? (data_regs(
                                                               const int64_t* __restrict__ perm, GateDev gg, GateDev gf,
                                                               unsigned long long* __restrict__ gran,
                                                               double* __restrict__ saved, unsigned* __restrict__ ctl,
-                                                              const T* __restrict__ addend, int relu) {
+                                                              const T* __restrict__ addend, int relu,
+                                                              unsigned long long* __restrict__ clear, unsigned clear_n) {
+    pipe_clear_other_region(clear, clear_n);
     constexpr int NG = BOXED ? 6 : 2;
     constexpr int OWN = SPLIT ? 1 : 4 * PPW;
     static_assert(!SPLIT || (PPW == 1 && !CNSN_WAVE_COEF), "a split plane is the workgroup's only plane");
@@ -1006,7 +1016,9 @@ __global__ __launch_bounds__(kBlock, SPLIT ? 2 : POST ? 2 : EPI ? bwd_waves_epi(
                                                               const double* __restrict__ saved,
                                                               unsigned* __restrict__ ctl,
                                                               const T* __restrict__ addend, int relu,
-                                                              T* __restrict__ d_addend) {
+                                                              T* __restrict__ d_addend,
+                                                              unsigned long long* __restrict__ clear, unsigned clear_n) {
+    pipe_clear_other_region(clear, clear_n);
     constexpr int NS = BOXED ? 4 : 2;
     constexpr int OWN = SPLIT ? 1 : 4 * PPW;
     static_assert(!SPLIT || (PPW == 1 && !CNSN_WAVE_COEF), "a split plane is the workgroup's only plane");

@@ -82,14 +82,6 @@ __host__ __device__ inline size_t pipe_lds_bytes(int N, int NG, int own, int par
 constexpr int kPipeKeep = 6;
 // workgroups per CU the forward is compiled for: small items (8 slots = 32 data registers) want more neighbours
 constexpr int pipe_fwd_waves(int slots) { return slots <= 8 ? 4 : 3; }
-// Granule regions without a fill launch (cnsn_resident.hip, resident_pong_*): the exchange of a launch runs through one of two
-// untagged regions at the end of the persistent context; every workgroup first stores 'empty' (all ones) over its share of the
-// OTHER region — control block and granules of the same extent — so that the next launch finds it clean.  The stores are
-// ordered before that launch by the kernel boundary; nobody reads the other region during this launch.  clear_n = 0: nothing.
-__device__ __forceinline__ void pipe_clear_other_region(unsigned long long* __restrict__ clear, unsigned clear_n) {
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < clear_n; i += gridDim.x * kBlock) clear[i] = ~0ull;
-}
-
 template <typename T, int VEC, int NV, int PPW, bool BOXED>
 __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd_pipe_kernel(ResArgs ra, int npark, const T* __restrict__ x,
                                                                       T* __restrict__ y, const int64_t* __restrict__ perm,

@@ -88,9 +88,12 @@ int resident_split_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
                                  : resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NG * 8, workspace, stream);
     ra.epoch = ea.epoch;
     ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
-    unsigned* ctl = (unsigned*)ea.base;
-    unsigned long long* gran = (unsigned long long*)((char*)ea.base + kCtlBytes);
     const size_t fill_bytes = kCtlBytes + (size_t)p.N * p.C * (NG / 2) * 8;
+    PongArea pong{nullptr, nullptr, 0u, false};  // (a granule region of the context instead of workspace + fill: resident_pong_acquire)
+    const bool use_pong = !solo && !ea.epoch && resident_pong_acquire(p, fill_bytes, stream, &pong);
+    void* area = use_pong ? pong.base : ea.base;
+    unsigned* ctl = (unsigned*)area;
+    unsigned long long* gran = (unsigned long long*)((char*)area + kCtlBytes);
     int status = CNSN_E_UNSUPPORTED;
     dispatch_split(p.dtype, rp.nv, [&](auto tt, auto vt, auto nt) {
         using T = typename decltype(tt)::type;
@@ -100,14 +103,17 @@ int resident_split_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
             if (grid < rp.K) return;
             hipError_t e = hipSuccess;
             if (solo) {
-                kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, (const T*)addend, relu);
+                kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, (const T*)addend, relu,
+                                                    nullptr, 0u);
             } else {
-                if (!ea.epoch) e = hipMemsetAsync(workspace, 0xff, fill_bytes, stream);
+                if (!ea.epoch && (!use_pong || pong.need_fill)) e = hipMemsetAsync(area, 0xff, fill_bytes, stream);
                 if (e != hipSuccess) {
                     status = (int)e;
                     return;
                 }
-                kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, (const T*)addend, relu);
+                kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, (const T*)addend, relu,
+                                                    pong.clear, pong.clear_qwords);
+                if (use_pong && hipPeekAtLastError() == hipSuccess) resident_pong_commit(p, fill_bytes);
             }
             e = hipGetLastError();
             status = e == hipSuccess ? CNSN_OK : (int)e;
@@ -153,9 +159,12 @@ int resident_split_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed,
     const ExchangeArea ea = resident_exchange_area(p, kCtlBytes + (size_t)p.N * p.C * NS * 8, workspace, stream);
     ra.epoch = ea.epoch;
     ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
-    unsigned* ctl = (unsigned*)ea.base;
-    unsigned long long* gran = (unsigned long long*)((char*)ea.base + kCtlBytes);
     const size_t fill_bytes = kCtlBytes + (size_t)p.N * p.C * (NS / 2) * 8;
+    PongArea pong{nullptr, nullptr, 0u, false};  // (a granule region of the context instead of workspace + fill: resident_pong_acquire)
+    const bool use_pong = !ea.epoch && resident_pong_acquire(p, fill_bytes, stream, &pong);
+    void* area = use_pong ? pong.base : ea.base;
+    unsigned* ctl = (unsigned*)area;
+    unsigned long long* gran = (unsigned long long*)((char*)area + kCtlBytes);
     int status = CNSN_E_UNSUPPORTED;
     dispatch_split(p.dtype, rp.nv, [&](auto tt, auto vt, auto nt) {
         using T = typename decltype(tt)::type;
@@ -163,14 +172,16 @@ int resident_split_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed,
         auto launch = [&](auto kern) {
             const int grid = reshost::grid_for(kern, lds, rp.K, ra.items);
             if (grid < rp.K) return;
-            hipError_t e = ea.epoch ? hipSuccess : hipMemsetAsync(workspace, 0xff, fill_bytes, stream);
+            hipError_t e = hipSuccess;
+            if (!ea.epoch && (!use_pong || pong.need_fill)) e = hipMemsetAsync(area, 0xff, fill_bytes, stream);
             if (e != hipSuccess) {
                 status = (int)e;
                 return;
             }
             kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)gy, (const T*)x, (T*)dx, perm, g, f, dg, df, gran, saved, ctl,
-                                                (const T*)(post ? addend : nullptr), relu, (T*)d_addend);
+                                                (const T*)(post ? addend : nullptr), relu, (T*)d_addend, pong.clear, pong.clear_qwords);
             e = hipGetLastError();
+            if (use_pong && e == hipSuccess) resident_pong_commit(p, fill_bytes);
             status = e == hipSuccess ? CNSN_OK : (int)e;
         };
         //                         T  VEC NV PPW BOXED  EPI    POST   SPLIT
