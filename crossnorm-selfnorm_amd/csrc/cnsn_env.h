@@ -27,7 +27,7 @@ enum Knob {
     K_KEEP,           // CNSN_KEEP          cache policy of the two-pass kernels' first pass
     K_PIPE,           // CNSN_PIPE          pipelined cluster kernels: 0 never, 1 AUTO rule, 2 wherever instantiated
     K_WIDE,           // CNSN_WIDE          channel-group kernels: 0 never, 1 AUTO rule, 2 wherever eligible
-    K_PONG,           // CNSN_PONG          0: a fill launch in front of every workspace-form cluster launch (no granule regions)
+    K_PONG,           // CNSN_PONG          granule regions: 0 never (fill launches), 2 also for small tensors (tests)
     K_COUNT
 };
 

@@ -110,7 +110,8 @@ ExchangeArea resident_exchange_area(const cnsn_problem_t& p, size_t tagged_bytes
     if (!p.context || p.context_bytes < tagged_bytes + 2 * kPongRegion) return ea;  // (the last two regions are not for tagged granules)
     if (const char* e = knob(K_CONTEXT)) {
         if (e[0] == '0') return ea;
-    } else if (!prefer_context && (size_t)p.N * p.C * p.H * p.W * elem_bytes(p.dtype) >= ((size_t)64 << 20)) {
+    } else if (!prefer_context && ((size_t)p.N * p.C * p.H * p.W * elem_bytes(p.dtype) >= ((size_t)64 << 20) ||
+                                   (knob(K_PONG) && knob(K_PONG)[0] == '2'))) {  // (CNSN_PONG=2, tests: small tensors too)
         // Large tensors exchange through the workspace: a tagged granule carries ONE float per 8 bytes, an untagged one
         // two, and at this size the gather of a channel's granules (4 KB tagged at N = 256, 12 KB with crop boxes) costs
         // more than the fill launch the context saves — north-star shape 0.849 -> 0.839 ms per step, with crop boxes

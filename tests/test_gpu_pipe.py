@@ -157,3 +157,51 @@ def test_pipelined_kernels_replay_from_a_graph():
         assert torch.equal(a, b)
     assert torch.equal(mod.selfnorm.g_bn.running_var, ref.selfnorm.g_bn.running_var)
     assert cnsn_amd.lib().cnsn_resident_timeouts() == 0
+
+
+# ---- granule regions instead of the fill launch (CNSN_PONG: 0 never, 2 also for tensors under 64 MiB) --------------
+_PONG_SEQ = [  # (shape, dtype tag, kind, crop): extents that grow and shrink, boxed and not, the split-plane and the SelfNorm-only kernels in between
+    ((37, 3, 56, 56), "f32", "cnsn", "neither"), ((37, 3, 56, 56), "f32", "cnsn", "neither"), ((64, 6, 28, 32), "f32", "cnsn", "both"),
+    ((5, 3, 56, 56), "bf16", "cnsn", "neither"), ((16, 4, 128, 128), "f32", "cnsn", "style"), ((37, 3, 56, 56), "f32", "sn", "neither"),
+    ((64, 6, 28, 32), "bf16", "cn", "style"), ((37, 8, 40, 40), "f32", "cnsn", "content"), ((37, 3, 56, 56), "f32", "cnsn", "neither"),
+]
+
+
+def _pong_sequence(pipe):
+    os.environ["CNSN_PIPE"] = pipe
+    outs = []
+    for rep in range(2):
+        for i, (shape, tag, kind, crop) in enumerate(_PONG_SEQ):
+            outs.append(run(shape, DT[tag], kind, crop, 100 + 10 * rep + i))
+    torch.cuda.synchronize()
+    return outs
+
+
+@pytest.mark.parametrize("pipe", ["2", "0"], ids=["pipelined", "plain"])
+def test_granule_regions_give_the_same_bits_as_fill_launches(pipe):
+    """The same sequence of calls — shapes whose exchange extents grow and shrink, with and without crop boxes, forward and
+    backward, other kernel families in between — with a fill launch per cluster launch (CNSN_PONG=0) and through the
+    context's two granule regions (CNSN_PONG=2: small tensors too): every output, gradient and running statistic
+    bit-identical, no bounded wait running out; then once more — on the ctypes path after the context has been re-created
+    (cnsn_context_init forgets the regions' state), with the C++ glue simply continuing on the same context."""
+    cnsn_amd.set_strategy("resident")
+    old = os.environ.get("CNSN_PONG")
+    try:
+        os.environ["CNSN_PONG"] = "0"
+        ref = _pong_sequence(pipe)
+        os.environ["CNSN_PONG"] = "2"
+        got = _pong_sequence(pipe)
+        from cnsn_amd import functional as F
+        F._contexts.clear()                       # the Python layer's context: a new buffer, cnsn_context_init again
+        again = _pong_sequence(pipe)
+    finally:
+        if old is None:
+            os.environ.pop("CNSN_PONG", None)
+        else:
+            os.environ["CNSN_PONG"] = old
+    assert cnsn_amd.lib().cnsn_resident_timeouts() == 0
+    for seq in (got, again):
+        assert len(seq) == len(ref)
+        for a, b in zip(ref, seq):
+            for u, v in zip(a, b):
+                assert torch.equal(u, v)
