@@ -355,7 +355,7 @@ def pmc_means(directory, counter):
     return out
 
 
-def live_traffic(args, timeout_s=150):
+def live_traffic(args, timeout_s=45):
     """`roofline.traffic` measured NOW instead of replayed from profiles/: this bench re-run as a child process under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE`, then `--pmc WRITE_SIZE` — counters in passes of their own next to the
     kernel trace only, as MI355X_MICROARCH.md prescribes — a few steps each, same shape / dtype / crop / strategy.  HBM bytes
@@ -367,6 +367,8 @@ def live_traffic(args, timeout_s=150):
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ):
+        return None, "this process is itself being profiled: no nested rocprofv3 passes"
     child = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2", "--no-extra", "--no-cpu-baseline",
              "--no-ceiling", "--shape", args.shape, "--dtype", args.dtype, "--crop", args.crop, "--kind", args.kind,
              "--strategy", args.strategy]
