@@ -166,39 +166,93 @@ def glue():
 
 
 _timeouts_reported = 0
+_defer_depth = 0          # > 0: check_resident_health() does not raise (a step guard polls at the step boundary instead)
+
+
+def _timeout_count() -> int:
+    """Cluster launches that gave up so far in this process (a plain host read of the library's pinned word)."""
+    return lib().cnsn_resident_timeouts()
+
+
+_TIMEOUT_TEXT = ("{what}: an earlier cluster-resident launch timed out waiting for part of its grid ({n} so far) — the GPU "
+                 "is shared with work that kept it off the device for seconds.  The outputs of the step that was in flight "
+                 "are invalid: repeat it.  The library now uses the two-pass kernels (CNSN_RESIDENT=0 selects them from "
+                 "the start).")
 
 
 def check_resident_health(what: str):
     """Poll the library's time-out counter (a plain host read).  A cluster-resident launch that gave up leaves its
     outputs incomplete; the library has already stopped choosing that strategy (two-pass from now on) — raise ONCE
-    per event so the training loop can repeat the step instead of consuming garbage."""
+    per event so the training loop can repeat the step instead of consuming garbage.  Inside `deferred_timeouts()`
+    nothing is raised here: the step guard that opened it polls at the step boundary (`poll_timeouts`), where every
+    data-parallel rank can take the same decision."""
     global _timeouts_reported
-    n = lib().cnsn_resident_timeouts()
+    if _defer_depth:
+        return
+    n = _timeout_count()
     if n > _timeouts_reported:
         _timeouts_reported = n
-        raise CnsnError(
-            f"{what}: an earlier cluster-resident launch timed out waiting for part of its grid ({n} so far) — the GPU "
-            "is shared with work that kept it off the device for seconds.  The outputs of the step that was in flight "
-            "are invalid: repeat it.  The library now uses the two-pass kernels (CNSN_RESIDENT=0 selects them from "
-            "the start).")
+        raise CnsnError(_TIMEOUT_TEXT.format(what=what, n=n))
 
 
-def settle_step(device=None):
+class deferred_timeouts:
+    """`with deferred_timeouts():` — the per-call poll of the module layer stays silent inside the block.  A CnsnError
+    raised in the MIDDLE of a step takes one data-parallel rank out of the step while its peers go on to the gradient
+    all-reduce: their collectives no longer pair up.  A step guard (`callers.steps.StepGuard`, `bench.py`) therefore
+    lets the step run to its end — the launch that gave up has marked its outputs with NaNs, nothing is applied from
+    them — and asks `poll_timeouts()` at the boundary, where all ranks agree (`data_parallel.agree_to_repeat`)."""
+
+    def __enter__(self):
+        global _defer_depth
+        _defer_depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _defer_depth
+        _defer_depth -= 1
+        return False
+
+
+def poll_timeouts() -> int:
+    """Cluster launches that gave up since the last report (0 = healthy); marks them reported, never raises.  The
+    caller must have waited for the work it asks about (the counter moves when the kernel runs, not when it is queued)."""
+    global _timeouts_reported
+    n = _timeout_count()
+    new = max(0, n - _timeouts_reported)
+    _timeouts_reported = max(n, _timeouts_reported)
+    return new
+
+
+def settle_step(device=None, raise_on_timeout: bool = True) -> int:
     """Call between `loss.backward()` and `optimizer.step()` where a step must never be applied from incomplete
-    gradients: waits for the device's current stream, then polls the time-out counter (check_resident_health).  A
-    cluster launch that gave up has marked the planes it still owed with NaNs and bumped the counter by the time the
-    stream is idle — so the CnsnError is raised BEFORE the optimizer consumes the gradients of that step, and the caller
-    repeats the step (the library has switched to the two-pass kernels by then).  Costs one stream synchronisation per
-    step; `callers.steps` does it by default (`guard=True`)."""
+    gradients: waits for the device's current stream, then polls the time-out counter.  A cluster launch that gave up
+    has marked the planes it still owed with NaNs and bumped the counter by the time the stream is idle — so the
+    CnsnError is raised BEFORE the optimizer consumes the gradients of that step, and the caller repeats the step (the
+    library has switched to the two-pass kernels by then).  Costs one stream synchronisation per step.
+    `raise_on_timeout=False`: returns the number of new time-outs instead (what `StepGuard` all-reduces over the ranks)."""
     import torch
     torch.cuda.current_stream(device).synchronize()
+    if not raise_on_timeout:
+        return poll_timeouts()
     check_resident_health("training step")
+    return 0
+
+
+_plan_caches = []       # dictionaries of remembered planning answers (functional.py registers its own): emptied when a knob moves
+
+
+def forget_plans():
+    """Planning answers the Python layer remembers (which kernel family takes a call, side-buffer sizes) depend on the
+    CNSN_* knobs, the strategy setting and `set_resident`: whoever changes one of those calls this."""
+    for c in _plan_caches:
+        c.clear()
 
 
 def reload_env():
     """The library reads its CNSN_* environment knobs once, when it is loaded (csrc/cnsn_env.h); call this after changing
     one through `os.environ` inside a running process (tests, A/B tools).  Not while another thread is in a launch."""
     lib().cnsn_reload_env()
+    forget_plans()
 
 
 _following = False
@@ -218,6 +272,7 @@ def follow_environ():
     def reread(key):
         if os.fsdecode(key).startswith("CNSN_") and _lib is not None:
             _lib.cnsn_reload_env()
+            forget_plans()
 
     def putenv(key, value):
         put(key, value)

@@ -6,9 +6,9 @@ structure (random CrossNorm site activation, 3-view JSD consistency).  Stock `nn
 from .ibn import IBN, InstanceNorm2d
 from .resnet import ResNet50CNSN
 from .segmentation import FCNHead, SegResNet50CNSN, poly_learning_rate
-from .steps import (GraphedIdleStep, image_space_crossnorm, jsd_consistency, train_step_cn, train_step_cn_consistency,
+from .steps import (GraphedIdleStep, StepGuard, image_space_crossnorm, jsd_consistency, train_step_cn, train_step_cn_consistency,
                     train_step_image_cn_views)
 from .wideresnet import WideResNetCNSN
 
 __all__ = ["WideResNetCNSN", "ResNet50CNSN", "SegResNet50CNSN", "FCNHead", "poly_learning_rate", "IBN", "InstanceNorm2d", "jsd_consistency", "train_step_cn", "train_step_cn_consistency",
-           "image_space_crossnorm", "train_step_image_cn_views", "GraphedIdleStep"]
+           "image_space_crossnorm", "train_step_image_cn_views", "GraphedIdleStep", "StepGuard"]

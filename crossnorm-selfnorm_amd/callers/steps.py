@@ -21,28 +21,122 @@ def jsd_consistency(logits_clean, logits_aug1, logits_aug2):
     return _jsd(logits_clean, logits_aug1, logits_aug2)   # HIP device tensors only, like the op itself
 
 
-def _apply(optimizer, loss, guard):
-    """zero_grad / backward / step of the reference's loops (cifar.py:136-138) with the hot path's one addition: with
-    `guard`, the stream is settled and the library's time-out counter polled BEFORE the optimizer runs
-    (_ffi.settle_step), so gradients of a cluster launch that gave up never reach the weights."""
+class StepGuard:
+    """One training step that is applied from complete gradients or not at all — on every data-parallel rank alike.
+
+    A cluster-resident launch whose bounded wait runs out ("when a bounded wait runs out": the GPU was shared
+    with something that kept part of a persistent grid off the device for seconds) gives up, marks the planes it still
+    owed with NaNs and bumps a host counter.  What that attempt touched besides the gradients:
+      * every BatchNorm running statistic downstream ((1-m)*rm + m*NaN = NaN) and SelfNorm's gate buffers,
+      * every `num_batches_tracked` (incremented once more by the repeat),
+      * the host RNG streams CrossNorm draws from (torch CPU generator, numpy global: cnsn.py:62-76) and `r < cn_prob`.
+    `run()` snapshots those before the attempt (ONE multi-tensor copy per dtype), lets the attempt run to its END with
+    the module layer's per-call poll silenced (`_ffi.deferred_timeouts`: a CnsnError in the middle of a forward would
+    take this rank out of the step while its peers go on to DDP's gradient all-reduce), waits for the stream, and
+    all-reduces "did a launch of mine give up" over the ranks (`data_parallel.agree_to_repeat`, 4 bytes, MAX) BEFORE the
+    optimizer runs.  If any rank says yes, every rank restores its snapshot, switches the cluster kernels off
+    (`data_parallel.degrade_all`) and repeats: the ranks issue the same collectives in the same order whatever happens.
+    The reference's loops (cifar.py:136-138, imagenet.py:240-244) have no counterpart: eager PyTorch cannot time out."""
+
+    def __init__(self, *modules, group=None, restore_rng=True, max_attempts=3):
+        self.slots = [(m, name) for mod in modules for m in mod.modules() for name, b in m._buffers.items() if b is not None]
+        self.group, self.restore_rng, self.max_attempts = group, restore_rng, max_attempts
+        self.snap, self.rng = None, None
+        self.repeats = 0                 # steps repeated so far (all ranks count the same)
+        self.local_timeouts = 0          # launches of THIS rank that gave up
+        self._defaults_done = False
+
+    def _live(self):
+        return [m._buffers[name] for m, name in self.slots]
+
+    def save(self):
+        live = self._live()
+        if self.snap is None or any(s.shape != b.shape or s.dtype != b.dtype or s.device != b.device
+                                    for s, b in zip(self.snap, live)):
+            self.snap = [torch.empty_like(b) for b in live]
+        if live:
+            with torch.no_grad():
+                torch._foreach_copy_(self.snap, live)
+        if self.restore_rng:
+            self.rng = (np.random.get_state(), torch.get_rng_state())
+
+    def restore(self):
+        live = self._live()
+        if live:
+            with torch.no_grad():
+                torch._foreach_copy_(live, self.snap)
+        if self.restore_rng and self.rng is not None:
+            np.random.set_state(self.rng[0])
+            torch.set_rng_state(self.rng[1])
+
+    def run(self, compute_loss, optimizer):
+        """compute_loss(): the forward(s) of the step, returns the loss (RNG draws included: a repeat re-draws the same
+        values).  Then zero_grad / backward [gradient all-reduce inside] / settle / agree / optimizer.step."""
+        from .. import _ffi
+        from .. import data_parallel as dp
+        if not self._defaults_done:
+            _ffi.under_process_group_defaults()      # (a 2 s bound on cluster waits when peers would wait with us)
+            self._defaults_done = True
+        for _ in range(self.max_attempts):
+            self.save()
+            with _ffi.deferred_timeouts():
+                loss = compute_loss()
+                optimizer.zero_grad()
+                loss.backward()
+            dev = loss.device if loss.is_cuda else None
+            new = _ffi.settle_step(dev, raise_on_timeout=False) if dev is not None else _ffi.poll_timeouts()
+            self.local_timeouts += new
+            if dp.agree_to_repeat(new, dev, self.group) == 0:
+                optimizer.step()
+                return loss.detach()
+            self.repeats += 1                        # some rank's cluster launch gave up: nobody applies this attempt
+            dp.degrade_all()
+            self.restore()
+        raise _ffi.CnsnError(f"training step: cluster-resident launches still time out after {self.max_attempts} attempts "
+                             "(every rank raises this together)")
+
+
+_guards = None
+
+
+def _guard_of(net):
+    """the StepGuard of a network (built on first use, kept while the network lives)"""
+    global _guards
+    if _guards is None:
+        import weakref
+        _guards = weakref.WeakKeyDictionary()
+    g = _guards.get(net)
+    if g is None:
+        g = _guards[net] = StepGuard(net)
+    return g
+
+
+def _apply(net, optimizer, compute_loss, guard):
+    """zero_grad / backward / step of the reference's loops (cifar.py:136-138) around `compute_loss()`; with `guard` through
+    the network's `StepGuard`: gradients of a cluster launch that gave up never reach the weights, the buffers and RNG
+    streams the failed attempt moved are put back, and data-parallel ranks repeat together."""
+    if guard:
+        return _guard_of(net).run(compute_loss, optimizer)
+    loss = compute_loss()
     optimizer.zero_grad()
     loss.backward()
-    if guard and loss.is_cuda:
-        from .. import _ffi
-        _ffi.settle_step(loss.device)
     optimizer.step()
     return loss.detach()
 
 
 def repeat_on_timeout(step_fn, *args, **kwargs):
-    """Run one training step; when the library reports that a cluster-resident launch gave up ("repeat the step": the
-    GPU was shared with something that kept part of a persistent grid off the device for seconds) run it once more —
-    by then the library uses the two-pass kernels.  With the steps' default `guard=True` the failed attempt has not
-    touched the weights.  Under data parallelism every rank must take the same number of collectives per step: the
-    guard raises before the optimizer, i.e. after DDP's gradient all-reduce of the failed attempt, and the repeat
-    issues a full second set on EVERY rank only if every rank repeats — so a DDP loop should all-reduce a "repeat" flag
-    (data_parallel.agree_to_repeat) instead of calling this on one rank alone."""
+    """For a loop that does NOT go through `StepGuard` (`guard=False` steps, a user's own step function) on ONE process:
+    run the step; when the library reports that a cluster-resident launch gave up ("repeat the step") run it once more —
+    by then the library uses the two-pass kernels.  Only the weights are protected, and only if `step_fn` settles the
+    stream before its optimizer runs (`_ffi.settle_step`); BatchNorm running statistics the failed attempt moved stay
+    moved.  Under an initialised process group this refuses to run: one rank repeating alone would issue a second set of
+    gradient all-reduces its peers never match — use `StepGuard` (the steps' default `guard=True`), whose repeat is
+    agreed by all ranks (`data_parallel.agree_to_repeat`)."""
+    import torch.distributed as dist
     from .._ffi import CnsnError
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        raise CnsnError("repeat_on_timeout is for single-process loops; under a process group use callers.steps.StepGuard "
+                        "(all ranks repeat together)")
     try:
         return step_fn(*args, **kwargs)
     except CnsnError as e:
@@ -53,10 +147,10 @@ def repeat_on_timeout(step_fn, *args, **kwargs):
 
 def train_step_cn(net, x, target, optimizer, cn_prob, guard=True):
     """One feature-level CrossNorm step (cifar.py:123-140): draw r first, then forward with aug."""
-    r = np.random.rand(1)
-    logits = net(x, aug=bool(r < cn_prob))
-    loss = F.cross_entropy(logits, target)
-    return _apply(optimizer, loss, guard)
+    def compute_loss():
+        r = np.random.rand(1)
+        return F.cross_entropy(net(x, aug=bool(r < cn_prob)), target)
+    return _apply(net, optimizer, compute_loss, guard)
 
 
 def train_step_cn_consistency(net, x, target, optimizer, consist_wt, cn_prob=1.0, jsd=jsd_consistency, guard=True):
@@ -64,16 +158,16 @@ def train_step_cn_consistency(net, x, target, optimizer, consist_wt, cn_prob=1.0
     `r < cn_prob` the clean view + two independently armed CrossNorm views + JSD run (:165-187), otherwise plain
     cross-entropy on `net(x, aug=False)` (:188-190).  `jsd`: the consistency term (tests of the step structure on
     host tensors pass a host restatement)."""
-    r = np.random.rand(1)
-    if r < cn_prob:
-        logits_clean = net(x, aug=False)
-        loss = F.cross_entropy(logits_clean, target)
-        logits_aug1 = net(x, aug=True)
-        logits_aug2 = net(x, aug=True)
-        loss = loss + consist_wt * jsd(logits_clean, logits_aug1, logits_aug2)
-    else:
-        loss = F.cross_entropy(net(x, aug=False), target)
-    return _apply(optimizer, loss, guard)
+    def compute_loss():
+        r = np.random.rand(1)
+        if r < cn_prob:
+            logits_clean = net(x, aug=False)
+            loss = F.cross_entropy(logits_clean, target)
+            logits_aug1 = net(x, aug=True)
+            logits_aug2 = net(x, aug=True)
+            return loss + consist_wt * jsd(logits_clean, logits_aug1, logits_aug2)
+        return F.cross_entropy(net(x, aug=False), target)
+    return _apply(net, optimizer, compute_loss, guard)
 
 
 def image_space_crossnorm(images, cn_prob, beta, crop, cn_op):
@@ -89,11 +183,12 @@ def train_step_image_cn_views(net, views, target, optimizer, cn_prob, beta, crop
     """AugMix-style 3-view step (imagenet.py:352-381): concatenate the views, ONE image-space CrossNorm
     call on the (3B,3,H,W) batch with probability cn_prob, one forward, CE on the clean third + 12*JSD."""
     b = views[0].size(0)
-    batch = image_space_crossnorm(torch.cat(views, 0), cn_prob, beta, crop, cn_op)
-    logits = net(batch)
-    l_clean, l_a1, l_a2 = torch.split(logits, b)
-    loss = F.cross_entropy(l_clean, target) + jsd_wt * jsd(l_clean, l_a1, l_a2)
-    return _apply(optimizer, loss, guard)
+
+    def compute_loss():
+        batch = image_space_crossnorm(torch.cat(views, 0), cn_prob, beta, crop, cn_op)
+        l_clean, l_a1, l_a2 = torch.split(net(batch), b)
+        return F.cross_entropy(l_clean, target) + jsd_wt * jsd(l_clean, l_a1, l_a2)
+    return _apply(net, optimizer, compute_loss, guard)
 
 
 class _IdleBlock(torch.nn.Module):
@@ -186,6 +281,10 @@ class GraphedIdleStep:
         self.net, self.opt = net, optimizer
         self.blocks = None
         self.x, self.y = x.clone(), target.clone()
+        for grp in optimizer.param_groups:    # the restore below turns warm-up-created state into "no step taken yet" by zeroing
+            if grp.get("dampening", 0) != 0:  # it: SGD's first step is buf = grad, a zeroed buffer gives (1 - dampening) * grad
+                raise ValueError("GraphedIdleStep: SGD with dampening != 0 is not supported (the first real step after the "
+                                 "warm-up would differ from the reference loop's)")
         for m in net.modules():     # float(num_batches_tracked) would synchronise under capture
             if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.momentum is None and m.track_running_stats:
                 raise ValueError("GraphedIdleStep: BatchNorm with momentum=None (cumulative average) cannot be captured")
@@ -219,6 +318,11 @@ class GraphedIdleStep:
                     if not torch.is_tensor(val):
                         if old is not None and name in old:
                             st[name] = old[name]
+                        elif isinstance(val, (int, float)) and not isinstance(val, bool):
+                            st[name] = type(val)(0)     # a counter the warm-up created (a float `step`): not taken yet
+                        elif val is not None:
+                            raise ValueError(f"GraphedIdleStep: optimizer state {name!r} of type {type(val).__name__} was "
+                                             "created by the warm-up and cannot be put back to its initial value")
                         continue
                     if old is not None and torch.is_tensor(old.get(name)):
                         val.copy_(old[name])                # the state the optimizer had before the warm-up

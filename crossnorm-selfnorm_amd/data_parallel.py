@@ -75,6 +75,49 @@ def _nccl_avg_ok(flat: torch.Tensor, group) -> bool:
         return False
 
 
+def agree_to_repeat(local_timeouts: int, device: Optional[torch.device] = None,
+                    group: Optional[dist.ProcessGroup] = None) -> int:
+    """The one collective of the time-out protocol: MAX over the ranks of "cluster launches of mine that gave up during
+    this step" (4 bytes).  Returns the same number on every rank — 0: apply the step; > 0: EVERY rank repeats it, and
+    every rank stops choosing the cluster kernels (`degrade_all`), so the ranks' launch sequences and collectives stay
+    in lock-step.  Without a process group the local number comes back.  Call it once per step on every rank, at the
+    same point of the step (after the backward and its gradient all-reduce, before `optimizer.step()`): the reference's
+    multi-GPU loops (imagenet.py:533, cifar.py:395, segmentation/tool/train_cnsn.py:175-177) have no such point because
+    eager PyTorch has no launch that can give up."""
+    n = int(local_timeouts)
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return n
+    on_device = dist.get_backend(group) == "nccl"
+    if on_device and device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    flag = torch.tensor([n], dtype=torch.int32, device=device if on_device else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    return int(flag.item())
+
+
+def degrade_all() -> None:
+    """What every rank does once ANY rank reported a time-out: CNSN_STRATEGY_AUTO stops choosing the cluster-resident
+    kernels (`cnsn_resident_enable(0)`), so all ranks run the same (two-pass / single-workgroup) kernels from the repeat
+    on — a rank that kept its cluster kernels would be faster than the degraded one and wait for it in every collective,
+    and could be the next to time out if the cause (a shared GPU, a foreign persistent kernel) is node-wide."""
+    from . import functional
+    functional.set_resident(False)
+
+
+def gather_ints(value: int, device: Optional[torch.device] = None, group: Optional[dist.ProcessGroup] = None):
+    """[value of rank 0, value of rank 1, ...] on every rank (bench / logging: per-rank time-out counters)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [int(value)]
+    world = dist.get_world_size(group)
+    on_device = dist.get_backend(group) == "nccl"
+    if on_device and device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    mine = torch.tensor([int(value)], dtype=torch.int64, device=device if on_device else "cpu")
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    return [int(t.item()) for t in out]
+
+
 def shard_batch(n_total: int, rank: int, world: int):
     """[begin, end) of the global batch owned by `rank` (contiguous, sizes differ by at most one)."""
     base, rem = divmod(n_total, world)

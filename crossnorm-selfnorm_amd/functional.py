@@ -25,12 +25,14 @@ def set_strategy(name: str):
     global _strategy
     _strategy = {"auto": _ffi.STRATEGY_AUTO, "two_pass": _ffi.STRATEGY_TWO_PASS,
                  "resident": _ffi.STRATEGY_RESIDENT, "local": _ffi.STRATEGY_LOCAL, "mono": _ffi.STRATEGY_MONO}[name]
+    _ffi.forget_plans()
 
 
 def set_resident(enabled: bool):
     """Allow (default) or forbid CNSN_STRATEGY_AUTO to choose the cluster-resident kernels (cnsn_resident_enable);
     the environment variable CNSN_RESIDENT=0 does the same from process start."""
     _ffi.lib().cnsn_resident_enable(int(bool(enabled)))
+    _ffi.forget_plans()
 
 
 def _require_device(x: torch.Tensor, what: str):
@@ -92,6 +94,7 @@ _lock = threading.RLock()
 
 # sizes of the caller-owned side buffers per problem signature (two ctypes calls saved per launch)
 _size_cache = {}
+_ffi._plan_caches.append(_size_cache)
 
 
 def _sizes(prob):
@@ -499,6 +502,7 @@ def _glue_cfg(cfg: FusedConfig, need_bwd: bool):
 
 
 _tail_plan_cache = {}
+_ffi._plan_caches.append(_tail_plan_cache)
 
 
 def fused_cnsn_tail(x, cfg: FusedConfig, addend, want_y: bool, g: GateParams, bn_w, bn_b, bn_rm, bn_rv, bn_training: bool,
@@ -524,7 +528,7 @@ def fused_cnsn_tail(x, cfg: FusedConfig, addend, want_y: bool, g: GateParams, bn
 def bnrelu_plan_cached(x: torch.Tensor, cfg: FusedConfig, need_bwd: bool) -> bool:
     """bnrelu_plan for both directions, remembered per (shape, dtype, configuration, strategy): a per-call ctypes
     round trip is what the fused tail is there to save"""
-    key = (tuple(x.shape), x.dtype, cfg.add_mode, cfg.sn_training, cfg.sn_two, _strategy, need_bwd)
+    key = (tuple(x.shape), x.dtype, x.device.index, cfg.add_mode, cfg.sn_training, cfg.sn_two, _strategy, need_bwd)
     hit = _tail_plan_cache.get(key)
     if hit is None:
         hit = bnrelu_plan(x, cfg) and (not need_bwd or bnrelu_plan(x, cfg, backward=True))

@@ -21,6 +21,51 @@ def pytest_sessionstart(session):
         __graft_entry__.build()
 
 
+def pytest_collection_modifyitems(config, items):
+    """Tests that take the `strategy` fixture run one case under every forced kernel strategy.  pytest makes the fixture
+    parameter the SLOWEST-varying one (all cases under two_pass, then all under resident, ...); re-order each such
+    function's items so that the strategies of one case run back to back — the oracle's results for the case are then
+    computed once and reused (tests/_memo.py).  Nothing is added, dropped or skipped."""
+    def case_key(it):
+        cs = getattr(it, "callspec", None)
+        if cs is None or "strategy" not in cs.params:
+            return None
+        return tuple(sorted((k, repr(v)) for k, v in cs.params.items() if k != "strategy"))
+
+    out, i = [], 0
+    while i < len(items):
+        it = items[i]
+        if case_key(it) is None:
+            out.append(it)
+            i += 1
+            continue
+        fn = (it.fspath, getattr(it, "originalname", it.name))
+        j = i
+        while j < len(items) and case_key(items[j]) is not None and \
+                (items[j].fspath, getattr(items[j], "originalname", items[j].name)) == fn:
+            j += 1
+        run = items[i:j]
+        first = {}
+        for k, r in enumerate(run):
+            first.setdefault(case_key(r), k)
+        out.extend(sorted(run, key=lambda r: first[case_key(r)]))      # (stable: strategies keep their order inside a case)
+        i = j
+    items[:] = out
+
+
+@pytest.fixture(scope="session", autouse=True)
+def host_threads_for_small_tensors():
+    """The oracle's eager CPU ops run on tensors of a few thousand to a million elements.  torch's default intra-op pool is
+    one thread per hardware thread — 256 on the MI355X hosts — and waking that pool for every one of the ~100 small ops of
+    a case costs more than the arithmetic (test_many_channels: 1.26 s per case on the GPU box against 0.35 s on 8 cores).
+    Eight threads for the whole session; tests that time or size the CPU path themselves set their own count."""
+    import torch
+    before = torch.get_num_threads()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    yield
+    torch.set_num_threads(before)
+
+
 @pytest.fixture(scope="session", autouse=True)
 def knobs_follow_the_environment():
     """The library reads its CNSN_* knobs once at load (csrc/cnsn_env.h); the GPU tests flip them through os.environ

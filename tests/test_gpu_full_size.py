@@ -40,11 +40,14 @@ def make_input(shape, dtype, seed):
     return x.to(dtype), gy.to(dtype)
 
 
-def oracle_run(x, gy, kind, crop, draws, c, dtype64):
-    """the oracle's eager ops on the GPU in fp32 or fp64, on the SAME (already quantised) x / gy"""
+def oracle_run(x, gy, kind, crop, draws, c, dtype64, device=DEV):
+    """the oracle's eager ops in fp32 or fp64 on the SAME (already quantised) x / gy — on the GPU (ATen-on-ROCm: fast
+    enough for every case) or, `device='cpu'`, literally "the reference PyTorch CPU path on identical inputs" of
+    BASELINE.json's north_star (seconds per case at full size: one case per config, test_full_size_against_the_cpu_path)"""
     dt = torch.float64 if dtype64 else torch.float32
-    sn = fill_sn(orc.SelfNorm(c), 4, dt).to(DEV).train() if kind != "cn" else None
-    xo = x.detach().to(dt).clone().requires_grad_()
+    sn = fill_sn(orc.SelfNorm(c), 4, dt).to(device).train() if kind != "cn" else None
+    xo = x.detach().to(device=device, dtype=dt).clone().requires_grad_()
+    gy = gy.to(device)
     u = xo
     if kind != "sn":
         u = orc.cn_op_2ins_space_chan(u, crop=crop, draws=orc.CNDraws(draws.perm, draws.style_box, None, draws.content_box))
@@ -57,7 +60,7 @@ def oracle_run(x, gy, kind, crop, draws, c, dtype64):
         res["dbeta"] = sn.g_bn.bias.grad
         res["rm"] = sn.g_bn.running_mean
         res["rv"] = sn.g_bn.running_var
-    return res
+    return {k: v.to(DEV) for k, v in res.items()}
 
 
 def hip_run(x, gy, kind, crop, draws, c):
@@ -94,14 +97,14 @@ def _record(row):
         pass
 
 
-def check_case(shape, dtype, kind, crop, seed):
+def check_case(shape, dtype, kind, crop, seed, oracle32_on="gpu"):
     torch.manual_seed(seed)
     np.random.seed(seed)
     c = shape[1]
     x, gy = make_input(shape, dtype, seed)
     draws = cnsn_amd.draw_cn(shape, crop, 1) if kind != "sn" else None
     got = hip_run(x, gy, kind, crop, draws, c)
-    o32 = oracle_run(x, gy, kind, crop, draws, c, False)
+    o32 = oracle_run(x, gy, kind, crop, draws, c, False, DEV if oracle32_on == "gpu" else torch.device("cpu"))
     o64 = oracle_run(x, gy, kind, crop, draws, c, True)
     for k, truth in o64.items():
         g_, r32 = got[k].double(), o32[k].double()
@@ -112,7 +115,7 @@ def check_case(shape, dtype, kind, crop, seed):
             err = float((g_ - truth).abs().max())
             _record({"shape": list(shape), "dtype": "fp32", "kind": kind, "crop": crop, "out": k, "err": err, "scale": scale,
                      "oracle32_noise": noise, "bound": max(rel * scale, 2 * noise), "rel_tol": rel,
-                     "strategy": cnsn_amd.functional._strategy})
+                     "strategy": cnsn_amd.functional._strategy, "oracle32_on": oracle32_on})
             assert err <= max(rel * scale, 2 * noise), f"{shape} fp32 {kind}/{crop} {k}: err {err:.3e}, oracle32 noise {noise:.3e}, scale {scale:.3g}"
         else:
             err = float((g_ - r32).abs().max())
@@ -120,7 +123,7 @@ def check_case(shape, dtype, kind, crop, seed):
             _record({"shape": list(shape), "dtype": str(dtype).replace("torch.", ""), "kind": kind, "crop": crop, "out": k,
                      "err": err, "scale": max(float(r32.abs().max()), 1e-6),
                      "bound": rel * max(float(r32.abs().max()), 1e-6) + (0 if k in ("y", "dx") else 1e-5), "rel_tol": rel,
-                     "strategy": cnsn_amd.functional._strategy})
+                     "strategy": cnsn_amd.functional._strategy, "oracle32_on": oracle32_on})
             assert err <= rel * max(float(r32.abs().max()), 1e-6) + (0 if k in ("y", "dx") else 1e-5), \
                 f"{shape} {dtype} {kind}/{crop} {k}: err {err:.3e} vs max {float(r32.abs().max()):.3e}"
     del got, o32, o64
@@ -159,6 +162,28 @@ def test_image_space_crossnorm_full_size(dtype, crop):
 @pytest.mark.parametrize("shape", WRN, ids=ids)
 def test_wideresnet_sites_full_size(shape, kind, crop):
     check_case(shape, torch.float32, kind, crop, 15)
+
+
+# north_star: "correctness is checked against the reference PyTorch CPU path on identical inputs within 1e-5 fp32 / 1e-2
+# bf16".  Everything above runs the oracle's fp32 ops on the GPU (same ops, ATen-on-ROCm); here the fp32 oracle runs on
+# CPU tensors, at FULL size, one case per BASELINE.json config (2-6 s of host time each at 32 threads) — the bound is the
+# same, with the fp32 noise priced from the CPU result itself.
+CPU_CASES = [((8, 64, 32, 32), torch.float32, "cnsn", "both"),         # configs[0]
+             ((128, 32, 32, 32), torch.float32, "cnsn", "both"),       # configs[1]: WideResNet-40-2 site, armed
+             ((256, 256, 56, 56), torch.bfloat16, "sn", "neither"),    # configs[2]: ResNet-50 layer-1 site, bf16
+             ((96, 256, 56, 56), torch.bfloat16, "cnsn", "neither"),   # configs[3]: 3 x 32 views per GPU
+             ((16, 256, 128, 128), torch.float32, "cn", "style"),      # configs[4]: segmentation layer 1, crop=style
+             ((256, 256, 56, 56), torch.float32, "cnsn", "neither")]   # the headline workload itself
+
+
+@pytest.mark.parametrize("shape,dtype,kind,crop", CPU_CASES, ids=lambda v: ids(v) if isinstance(v, tuple) else str(v).replace("torch.", ""))
+def test_full_size_against_the_cpu_path(shape, dtype, kind, crop):
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    try:
+        check_case(shape, dtype, kind, crop, 18, oracle32_on="cpu")
+    finally:
+        torch.set_num_threads(threads)
 
 
 # the forced strategies at the full-size small-plane sites (AUTO picks one of them per direction; the others are the

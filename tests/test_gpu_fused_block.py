@@ -57,25 +57,57 @@ def build(lib, kind, crop, c, seed, dtype):
     return lib.CNSN(cn, sn).train()
 
 
-def run_case(shape, kind, crop, mode, relu, dtype, seed):
+def _arm(mod, draws):
+    if mod.crossnorm is not None:
+        mod.crossnorm.active = True
+        mod.crossnorm.next_draws = draws
+
+
+def _inputs(shape, kind, crop, dtype, seed):
     torch.manual_seed(seed)
     np.random.seed(seed)
-    n, c = shape[:2]
     x64 = cond_input(shape, seed)
     b64 = cond_input(shape, seed + 1) * 0.7
     gy64 = torch.randn(shape, dtype=torch.float64)
     if dtype != torch.float32:
         x64, b64, gy64 = (v.to(dtype).double() for v in (x64, b64, gy64))
     d = orc.draw_cn(shape, crop, beta=1) if kind != "sn" else None
+    return x64, b64, gy64, d
 
-    def arm(mod, draws):
-        if mod.crossnorm is not None:
-            mod.crossnorm.active = True
-            mod.crossnorm.next_draws = draws
+
+def _oracle_side(shape, kind, crop, mode, relu, dtype, seed, mask):
+    """the oracle's forward with its own ReLU and its backward THROUGH THE DEVICE'S MASK, fp64 and fp32: depends on the
+    case and on the mask only, not on the kernel strategy (tests/_memo.py keys it on the mask's bytes)"""
+    x64, b64, gy64, d = _inputs(shape, kind, crop, dtype, seed)
+    c = shape[1]
+    out = {}
+    for tag, odt in (("t64", torch.float64), ("o32", torch.float32)):
+        ref = build(orc, kind, crop, c, seed, odt)
+        _arm(ref, d)
+        xr = x64.detach().clone().to(odt).requires_grad_()
+        br = b64.detach().clone().to(odt).requires_grad_() if mode != "none" else None
+        with torch.no_grad():                              # the oracle's own ReLU, for the forward comparison
+            probe = build(orc, kind, crop, c, seed, odt)
+            _arm(probe, d)
+            y_own, pre = oracle_block(probe, xr.detach(), br.detach() if br is not None else None, mode, relu, None, dtype)
+        out["own_" + tag] = dict(y=y_own, pre=pre)
+        y, _ = oracle_block(ref, xr, br, mode, relu, mask, dtype)
+        y.backward(gy64.to(odt))
+        out[tag] = dict(y=y.detach(), dx=xr.grad, db=br.grad if br is not None else None,
+                        pg={k: v.grad for k, v in ref.named_parameters()},
+                        st={k: v for k, v in ref.state_dict().items()})
+    return out
+
+
+def run_case(shape, kind, crop, mode, relu, dtype, seed):
+    from tests._memo import memo
+    n, c = shape[:2]
+    case = (tuple(shape), kind, crop, str(dtype), seed)
+    x64, b64, gy64, d = memo(("block-in",) + case, lambda: _inputs(shape, kind, crop, dtype, seed))
 
     # device
     mod = build(cnsn_amd, kind, crop, c, seed, torch.float32).to(DEV)
-    arm(mod, to_draws(d) if d else None)
+    _arm(mod, to_draws(d) if d else None)
     xg = x64.detach().clone().to(dtype).to(DEV).requires_grad_()
     bg = b64.detach().clone().to(dtype).to(DEV).requires_grad_() if mode != "none" else None
     yg = mod.forward_block(xg, bg, add_mode=mode, relu=relu)
@@ -86,23 +118,10 @@ def run_case(shape, kind, crop, mode, relu, dtype, seed):
                pg={k: v.grad.cpu() for k, v in mod.named_parameters()},
                st={k: v.cpu() for k, v in mod.state_dict().items()})
     mask = (hip["y"] > 0) if relu else None
-
-    out = {"hip": hip}
-    for tag, odt in (("t64", torch.float64), ("o32", torch.float32)):
-        ref = build(orc, kind, crop, c, seed, odt)
-        arm(ref, d)
-        xr = x64.detach().clone().to(odt).requires_grad_()
-        br = b64.detach().clone().to(odt).requires_grad_() if mode != "none" else None
-        with torch.no_grad():                              # the oracle's own ReLU, for the forward comparison
-            probe = build(orc, kind, crop, c, seed, odt)
-            arm(probe, d)
-            y_own, pre = oracle_block(probe, xr.detach(), br.detach() if br is not None else None, mode, relu, None, dtype)
-        out["own_" + tag] = dict(y=y_own, pre=pre)
-        y, _ = oracle_block(ref, xr, br, mode, relu, mask, dtype)
-        y.backward(gy64.to(odt))
-        out[tag] = dict(y=y.detach(), dx=xr.grad, db=br.grad if br is not None else None,
-                        pg={k: v.grad for k, v in ref.named_parameters()},
-                        st={k: v for k, v in ref.state_dict().items()})
+    mask_key = hash(mask.numpy().tobytes()) if mask is not None else None
+    out = dict(memo(("block-ref",) + case + (mode, relu, mask_key),
+                    lambda: _oracle_side(shape, kind, crop, mode, relu, dtype, seed, mask)))
+    out["hip"] = hip
     return out
 
 

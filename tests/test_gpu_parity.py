@@ -218,8 +218,9 @@ SHAPES = [
 ]
 
 
-def run_pair(shape, crop, kind, dtype, seed, lam=None, chan=False, is_two=False, training=True):
-    """Run oracle (fp64 truth + fp32) and the HIP modules on identical inputs/draws."""
+def oracle_pair(shape, crop, kind, dtype, seed, lam=None, chan=False, is_two=False, training=True):
+    """inputs, draws and the oracle's results (fp64 truth + fp32) of one case: independent of the kernel strategy under
+    test, so computed once per case (tests/_memo.py) and shared by the strategies that run it"""
     torch.manual_seed(seed)
     np.random.seed(seed)
     n, c = shape[:2]
@@ -229,7 +230,7 @@ def run_pair(shape, crop, kind, dtype, seed, lam=None, chan=False, is_two=False,
         x64 = x64.to(dtype).double()
         gy64 = gy64.to(dtype).double()
     d = orc.draw_cn(shape, crop, beta=1, chan=chan)
-    out = {}
+    out = {"x64": x64, "gy64": gy64, "d": d}
     for tag, odt in (("t64", torch.float64), ("o32", torch.float32)):
         sn = fill_sn(orc.SelfNorm(c, is_two=is_two), seed, odt) if kind != "cn" else None
         xr = x64.detach().clone().to(odt).requires_grad_()
@@ -243,6 +244,17 @@ def run_pair(shape, crop, kind, dtype, seed, lam=None, chan=False, is_two=False,
         out[tag] = dict(y=y.detach(), dx=xr.grad,
                         pg={k: v.grad for k, v in sn.named_parameters()} if sn else {},
                         st={k: v for k, v in sn.state_dict().items()} if sn else {})
+    return out
+
+
+def run_pair(shape, crop, kind, dtype, seed, lam=None, chan=False, is_two=False, training=True):
+    """Run oracle (fp64 truth + fp32) and the HIP modules on identical inputs/draws."""
+    from tests._memo import memo
+    key = ("pair", tuple(shape), crop, kind, str(dtype), seed, lam, chan, is_two, training)
+    ora = memo(key, lambda: oracle_pair(shape, crop, kind, dtype, seed, lam, chan, is_two, training))
+    x64, gy64, d = ora["x64"], ora["gy64"], ora["d"]
+    n, c = shape[:2]
+    out = {"t64": ora["t64"], "o32": ora["o32"]}
     sn = fill_sn(cnsn_amd.SelfNorm(c, is_two=is_two), seed, torch.float32).to(DEV) if kind != "cn" else None
     xg = x64.detach().clone().to(dtype).to(DEV).requires_grad_()
     if kind == "sn":
