@@ -13,7 +13,9 @@ CNSN_F32, CNSN_BF16, CNSN_F16 = 0, 1, 2
 STRATEGY_AUTO, STRATEGY_TWO_PASS, STRATEGY_RESIDENT, STRATEGY_LOCAL, STRATEGY_MONO = 0, 1, 2, 3, 4
 ADD_NONE, ADD_PRE, ADD_POST = 0, 1, 2
 PATHS = {0: "streaming", 1: "packed", 2: "resident", 3: "local", 4: "mono"}
-ABI_VERSION = 4
+ABI_VERSION = 5
+PERM_INLINE_MAX = 1024       # CNSN_PERM_INLINE_MAX
+E_UNSUPPORTED = -9
 
 
 class Problem(C.Structure):
@@ -27,13 +29,14 @@ class Problem(C.Structure):
         ("eps_sn", C.c_float), ("eps_bn", C.c_float), ("momentum", C.c_float),
         ("strategy", C.c_int32), ("reserved", C.c_int32),
         ("context", C.c_void_p), ("context_bytes", C.c_uint64),
+        ("perm_host", C.c_void_p),
     ]
 
 
 class Gate(C.Structure):
     """cnsn_gate_t"""
     _fields_ = [("fc_weight", C.c_void_p), ("bn_weight", C.c_void_p), ("bn_bias", C.c_void_p),
-                ("running_mean", C.c_void_p), ("running_var", C.c_void_p)]
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p)]
 
 
 class GateGrad(C.Structure):
@@ -44,7 +47,8 @@ class GateGrad(C.Structure):
 class BnTail(C.Structure):
     """cnsn_bn_tail_t"""
     _fields_ = [("struct_bytes", C.c_int32), ("training", C.c_int32), ("eps", C.c_float), ("momentum", C.c_float),
-                ("weight", C.c_void_p), ("bias", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p)]
+                ("weight", C.c_void_p), ("bias", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("num_batches_tracked", C.c_void_p)]
 
 
 class Epilogue(C.Structure):
@@ -62,6 +66,8 @@ SIGNATURES = {
     "cnsn_resident_timeouts": (C.c_int, []),
     "cnsn_resident_enable": (None, [C.c_int]),
     "cnsn_reload_env": (None, []),
+    "cnsn_set_wait_ms": (None, [C.c_int]),
+    "cnsn_wait_ms": (C.c_int, []),
     "cnsn_saved_floats": (C.c_size_t, [C.POINTER(Problem)]),
     "cnsn_workspace_bytes": (C.c_size_t, [C.POINTER(Problem)]),
     "cnsn_forward": (C.c_int, [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -287,12 +293,12 @@ def follow_environ():
 
 def under_process_group_defaults():
     """One process per GPU under an initialised torch.distributed group: a rank whose cluster wait runs out stalls its
-    peers' collectives for as long as the bound — default it to 2 s there instead of 5 s (CNSN_WAIT_MS still overrides)."""
+    peers' collectives for as long as the bound — 2 s there instead of 5 s (`cnsn_set_wait_ms`; an explicit CNSN_WAIT_MS
+    in the environment still wins).  Called by `callers.steps.StepGuard` on its first step and by bench.py."""
     try:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and "CNSN_WAIT_MS" not in os.environ:
-            os.environ["CNSN_WAIT_MS"] = "2000"
-            reload_env()
+            lib().cnsn_set_wait_ms(2000)
     except Exception:   # pragma: no cover
         pass
 

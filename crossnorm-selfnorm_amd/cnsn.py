@@ -148,25 +148,34 @@ class SelfNorm(nn.Module):
             self.f_fc = None
 
     @staticmethod
-    def _gate(fc, bn) -> GateParams:
+    def _gate(fc, bn, counter=None) -> GateParams:
         rm, rv = bn.running_mean, bn.running_var
         if rm is None or rv is None:      # track_running_stats=False: batch statistics always; the kernel's
             w = fc.weight                 # running-buffer update goes to scratch that nobody reads
             rm = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)
             rv = torch.ones(w.shape[0], dtype=torch.float32, device=w.device)
-        return GateParams(fc.weight, bn.weight, bn.bias, rm, rv)
+        return GateParams(fc.weight, bn.weight, bn.bias, rm, rv, counter)
 
     @staticmethod
-    def _bn_call_state(bn):
+    def _bn_call_state(bn, in_kernel=False):
         """What nn.BatchNorm1d.forward decides per call (torch/nn/modules/batchnorm.py): the counter moves only
         under `training and track_running_stats`; `momentum=None` means the cumulative average 1/num_batches_tracked;
-        batch statistics are used in training mode or when there are no running buffers."""
+        batch statistics are used in training mode or when there are no running buffers.
+        `in_kernel`: the caller hands `num_batches_tracked` to the forward launch, which adds the 1 itself
+        (cnsn_gate_t.num_batches_tracked) — returned as a fourth value, None when the counter was moved here (the
+        cumulative average needs its new value on the host) or does not move at all."""
         momentum = 0.0 if bn.momentum is None else float(bn.momentum)
+        counter = None
         if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
-            if bn.momentum is None:
-                momentum = 1.0 / float(bn.num_batches_tracked)
+            if in_kernel and bn.momentum is not None and bn.num_batches_tracked.is_cuda:
+                counter = bn.num_batches_tracked
+            else:
+                bn.num_batches_tracked.add_(1)
+                if bn.momentum is None:
+                    momentum = 1.0 / float(bn.num_batches_tracked)
         use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
+        if in_kernel:
+            return use_batch, float(bn.eps), momentum, counter
         return use_batch, float(bn.eps), momentum
 
     @staticmethod
@@ -218,16 +227,18 @@ class SelfNorm(nn.Module):
 
     def _fused_args(self):
         """(config fields, g, f) for the fused call; does each BatchNorm1d's own per-call book-keeping."""
-        state = self._bn_call_state(self.g_bn)
-        g = self._gate(self.g_fc, self.g_bn)
+        *state, counter = self._bn_call_state(self.g_bn, in_kernel=True)
+        state = tuple(state)
+        g = self._gate(self.g_fc, self.g_bn, counter)
         f = None
         if self.f_fc is not None:
-            state_f = self._bn_call_state(self.f_bn)
+            *state_f, counter_f = self._bn_call_state(self.f_bn, in_kernel=True)
+            state_f = tuple(state_f)
             if state_f != state:   # (`_fusable` has sent differing configurations to `_forward_composed`;
                 raise _F._ffi.CnsnError(   # what is left: momentum=None with counters that have drifted apart)
                     "SelfNorm(is_two=True): g_bn and f_bn must share mode, eps and momentum "
                     f"(g_bn: training/eps/momentum = {state}, f_bn: {state_f})")
-            f = self._gate(self.f_fc, self.f_bn)
+            f = self._gate(self.f_fc, self.f_bn, counter_f)
         use_batch, eps, momentum = state
         kw = dict(sn_active=True, sn_two=f is not None, sn_training=use_batch, eps_bn=eps, momentum=momentum)
         return kw, g, f
@@ -327,8 +338,8 @@ class CNSN(nn.Module):
             y = self.forward_block(x, addend, add_mode=add_mode, relu=False) if add_mode != "none" else self.forward(x)
             return (y if want_y else None), torch.relu(bn(y))
         kw, g, _ = sn._fused_args()
-        bn_batch, bn_eps, bn_mom = SelfNorm._bn_call_state(bn)
+        bn_batch, bn_eps, bn_mom, bn_counter = SelfNorm._bn_call_state(bn, in_kernel=True)
         cfg = FusedConfig(add_mode=add_mode, relu=False, **kw)
         return _F.fused_cnsn_tail(x, cfg, addend, bool(want_y), g, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                  bn_batch, bn_eps, bn_mom)
+                                  bn_batch, bn_eps, bn_mom, bn_counter)
 

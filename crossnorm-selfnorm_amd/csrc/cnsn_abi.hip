@@ -86,6 +86,8 @@ int cnsn_context_init(void* context, size_t bytes, void* stream) {
 int cnsn_resident_timeouts(void) { return resident_timeouts(); }
 void cnsn_resident_enable(int on) { resident_set_enabled(on != 0); }
 void cnsn_reload_env(void) { reload_knobs(); }
+void cnsn_set_wait_ms(int ms) { resident_set_wait_ms(ms); }
+int cnsn_wait_ms(void) { return (int)(resident_wait_ticks() / 100000ll); }
 
 const char* cnsn_status_string(int status) {
     switch (status) {
@@ -124,7 +126,10 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
     const cnsn_problem_t& p = pl.pr;
     if (!x || !y || !workspace) return CNSN_E_NULL;
     if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)workspace) & 15u) != 0) return CNSN_E_ALIGN;
-    if (p.cn_active && !perm) return CNSN_E_NULL;
+    // (ABI 5) no device array: the permutation travels as a launch argument (cnsn_problem_t.perm_host) — cluster-resident
+    // kernels only; every other family below needs the array and is skipped, and the call ends CNSN_E_UNSUPPORTED
+    const bool perm_inline = p.cn_active && !perm;
+    if (perm_inline && (!p.perm_host || chan_perm || p.N > CNSN_PERM_INLINE_MAX)) return p.perm_host ? CNSN_E_UNSUPPORTED : CNSN_E_NULL;
     if (p.sn_active && !gate_ok(g)) return CNSN_E_NULL;
     if (p.sn_active && p.sn_two && !gate_ok(f)) return CNSN_E_NULL;
     if (workspace_bytes < workspace_bytes_of(pl)) return CNSN_E_WORKSPACE;
@@ -141,7 +146,7 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
     }
     {
         const WidePlan wp = wide_plan(pl, 0, false, chan_perm != nullptr);  // planes that are no whole number of vectors (7x7): channel groups in registers
-        if (wp.ok) {
+        if (wp.ok && !perm_inline) {
             st = wide_forward(pl, wp, 0, 0, x, nullptr, perm, gate_dev(g), y, saved ? saved_d : nullptr, stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
@@ -155,7 +160,7 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
     }
     {
         const MonoPlan mp = mono_cn_plan(pl, chan_perm != nullptr, 0, false);  // small planes WITH CrossNorm, the same frame
-        if (mp.ok) {
+        if (mp.ok && !perm_inline) {
             st = mono_cn_forward(pl, mp, 0, 0, x, nullptr, perm, gate_dev(g), y, saved ? saved_d : nullptr, stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
@@ -186,6 +191,7 @@ int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm,
         if (st != CNSN_E_UNSUPPORTED) return st;
     }
 
+    if (perm_inline) return CNSN_E_UNSUPPORTED;  // (the two-pass mid kernels read the device array)
     PackedGeom pg;
     if (packed_plan(pl, pg)) {  // small planes: runs of planes staged through LDS (cnsn_packed_kernels.h)
         packed_stats(pl, pg, 0, x, nullptr, mom, stream);
@@ -228,7 +234,10 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
     if (!grad_y || !x || !grad_x || !saved || !workspace) return CNSN_E_NULL;
     if ((((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)workspace) & 15u) != 0)
         return CNSN_E_ALIGN;
-    if (p.cn_active && !perm) return CNSN_E_NULL;
+    // (ABI 5) no device array: the permutation travels as a launch argument (cnsn_problem_t.perm_host) — cluster-resident
+    // kernels only; every other family below needs the array and is skipped, and the call ends CNSN_E_UNSUPPORTED
+    const bool perm_inline = p.cn_active && !perm;
+    if (perm_inline && (!p.perm_host || chan_perm || p.N > CNSN_PERM_INLINE_MAX)) return p.perm_host ? CNSN_E_UNSUPPORTED : CNSN_E_NULL;
     if (p.sn_active && (!gate_ok(g) || !gate_grad_ok(dg))) return CNSN_E_NULL;
     if (p.sn_active && p.sn_two && (!gate_ok(f) || !gate_grad_ok(df))) return CNSN_E_NULL;
     if (workspace_bytes < workspace_bytes_of(pl)) return CNSN_E_WORKSPACE;
@@ -247,7 +256,7 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
     }
     {
         const WidePlan wp = wide_plan(pl, 0, true, chan_perm != nullptr);
-        if (wp.ok) {
+        if (wp.ok && !perm_inline) {
             st = wide_backward(pl, wp, 0, 0, grad_y, x, nullptr, perm, gate_dev(g), saved_d, grad_x, gate_grad_dev(dg), stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
@@ -262,7 +271,7 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
     }
     {
         const MonoPlan mp = mono_cn_plan(pl, chan_perm != nullptr, 0, true);
-        if (mp.ok) {
+        if (mp.ok && !perm_inline) {
             st = mono_cn_backward(pl, mp, 0, 0, grad_y, x, nullptr, perm, gate_dev(g), saved_d, grad_x, gate_grad_dev(dg), stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
@@ -295,6 +304,7 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
         if (st != CNSN_E_UNSUPPORTED) return st;
     }
 
+    if (perm_inline) return CNSN_E_UNSUPPORTED;  // (the two-pass mid kernels read the device array)
     PackedGeom pg;
     if (packed_plan(pl, pg)) {
         packed_reduce(pl, pg, 0, 0, grad_y, x, nullptr, saved_d, sums, stream);

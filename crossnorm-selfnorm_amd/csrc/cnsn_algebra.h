@@ -29,7 +29,13 @@ struct GateDev {
     const float* beta;   // (C)    BatchNorm1d bias
     float* run_mean;     // (C)
     float* run_var;      // (C)
+    long long* nbt;      // BatchNorm1d.num_batches_tracked (int64 scalar) or null: the forward adds 1 in training mode
 };
+// nn.BatchNorm1d.forward's `self.num_batches_tracked.add_(1)` (models/cnsn.py:121,138 call the module): done by the ONE thread
+// of the launch that updates channel 0's running statistics
+__device__ __forceinline__ void bump_batches_tracked(long long* nbt) {
+    if (nbt) *nbt += 1;
+}
 struct GateGradDev {
     float* dw;
     float* dgamma;

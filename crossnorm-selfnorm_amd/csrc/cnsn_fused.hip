@@ -122,7 +122,10 @@ int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, c
     const cnsn_problem_t& p = pl.pr;
     if (!x || !y || !workspace) return CNSN_E_NULL;
     if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)workspace) & 15u) != 0) return CNSN_E_ALIGN;
-    if (p.cn_active && !perm) return CNSN_E_NULL;
+    // (ABI 5) no device array: the permutation travels as a launch argument (cnsn_problem_t.perm_host) — cluster-resident
+    // kernels only; every other family below needs the array and is skipped, and the call ends CNSN_E_UNSUPPORTED
+    const bool perm_inline = p.cn_active && !perm;
+    if (perm_inline && (!p.perm_host || chan_perm || p.N > CNSN_PERM_INLINE_MAX)) return p.perm_host ? CNSN_E_UNSUPPORTED : CNSN_E_NULL;
     if (p.sn_active && !gate_ok(g)) return CNSN_E_NULL;
     if (p.sn_active && p.sn_two && !gate_ok(f)) return CNSN_E_NULL;
     if (workspace_bytes < workspace_bytes_of(pl)) return CNSN_E_WORKSPACE;
@@ -140,7 +143,7 @@ int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, c
     }
     {
         const WidePlan wp = wide_plan(pl, e.add, false, chan_perm != nullptr);
-        if (wp.ok) {
+        if (wp.ok && !perm_inline) {
             st = wide_forward(pl, wp, e.add, e.relu, x, e.addend, perm, gate_dev(g), y, saved ? saved_d : nullptr, stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
@@ -154,7 +157,7 @@ int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, c
     }
     {
         const MonoPlan mp = mono_cn_plan(pl, chan_perm != nullptr, e.add, false);
-        if (mp.ok) {
+        if (mp.ok && !perm_inline) {
             st = mono_cn_forward(pl, mp, e.add, e.relu, x, e.addend, perm, gate_dev(g), y, saved ? saved_d : nullptr, stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
@@ -183,6 +186,7 @@ int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, c
         if (st != CNSN_E_UNSUPPORTED) return st;
     }
 
+    if (perm_inline) return CNSN_E_UNSUPPORTED;  // (the two-pass mid kernels read the device array)
     PackedGeom pg;
     if (packed_plan(pl, pg)) {
         packed_stats(pl, pg, e.add, x, e.addend, mom, stream);
@@ -245,7 +249,10 @@ int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, 
     if (e.add == ADD_POST && !grad_addend) return CNSN_E_NULL;
     if ((((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)grad_addend | (uintptr_t)workspace) & 15u) != 0)
         return CNSN_E_ALIGN;
-    if (p.cn_active && !perm) return CNSN_E_NULL;
+    // (ABI 5) no device array: the permutation travels as a launch argument (cnsn_problem_t.perm_host) — cluster-resident
+    // kernels only; every other family below needs the array and is skipped, and the call ends CNSN_E_UNSUPPORTED
+    const bool perm_inline = p.cn_active && !perm;
+    if (perm_inline && (!p.perm_host || chan_perm || p.N > CNSN_PERM_INLINE_MAX)) return p.perm_host ? CNSN_E_UNSUPPORTED : CNSN_E_NULL;
     if (p.sn_active && (!gate_ok(g) || !gate_grad_ok(dg))) return CNSN_E_NULL;
     if (p.sn_active && p.sn_two && (!gate_ok(f) || !gate_grad_ok(df))) return CNSN_E_NULL;
     if (workspace_bytes < workspace_bytes_of(pl)) return CNSN_E_WORKSPACE;
@@ -264,7 +271,7 @@ int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, 
     }
     {
         const WidePlan wp = wide_plan(pl, e.add, true, chan_perm != nullptr);
-        if (wp.ok) {
+        if (wp.ok && !perm_inline) {
             st = wide_backward(pl, wp, e.add, e.relu, grad_y, x, e.addend, perm, gate_dev(g), saved_d, grad_x, gate_grad_dev(dg), stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
         }
@@ -279,7 +286,7 @@ int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, 
     }
     {
         const MonoPlan mp = mono_cn_plan(pl, chan_perm != nullptr, e.add, true);
-        if (mp.ok) {
+        if (mp.ok && !perm_inline) {
             st = mono_cn_backward(pl, mp, e.add, e.relu, grad_y, x, e.addend, perm, gate_dev(g), saved_d, grad_x,
                                   gate_grad_dev(dg), stream);
             if (st != CNSN_E_UNSUPPORTED) return st;
@@ -311,6 +318,7 @@ int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, 
         if (st != CNSN_E_UNSUPPORTED) return st;
     }
 
+    if (perm_inline) return CNSN_E_UNSUPPORTED;  // (the two-pass mid kernels read the device array)
     PackedGeom pg;
     if (packed_plan(pl, pg)) {
         packed_reduce(pl, pg, e.add, e.relu, grad_y, x, e.addend, saved_d, sums, stream);

@@ -175,8 +175,8 @@ inline size_t workspace_bytes_of(const Plan& pl) {
 }
 
 inline GateDev gate_dev(const cnsn_gate_t* g) {
-    GateDev d{nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (g) d = GateDev{g->fc_weight, g->bn_weight, g->bn_bias, g->running_mean, g->running_var};
+    GateDev d{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (g) d = GateDev{g->fc_weight, g->bn_weight, g->bn_bias, g->running_mean, g->running_var, (long long*)g->num_batches_tracked};
     return d;
 }
 inline GateGradDev gate_grad_dev(const cnsn_gate_grad_t* g) {

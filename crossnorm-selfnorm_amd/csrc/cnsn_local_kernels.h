@@ -321,6 +321,10 @@ __global__ __launch_bounds__(LB) void local_fwd_kernel(LocalArgs la, const T* __
                     gf.run_mean[c] = (float)((1.0 - mom_) * q[10] + mom_ * mf);
                     gf.run_var[c] = (float)((1.0 - mom_) * q[11] + mom_ * vf * unb);
                 }
+                if (c == 0) {
+                    bump_batches_tracked(gg.nbt);
+                    if (a.sn_two) bump_batches_tracked(gf.nbt);
+                }
             }
         } else {
             rg = (double)__builtin_amdgcn_rsqf((float)q[5] + a.eps_bn);

@@ -123,6 +123,10 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
                     gf.run_mean[c] = (float)((1.0 - mom_) * gf.run_mean[c] + mom_ * mf);
                     gf.run_var[c] = (float)((1.0 - mom_) * gf.run_var[c] + mom_ * vf * unb);
                 }
+                if (c == 0) {
+                    bump_batches_tracked(gg.nbt);
+                    if (a.sn_two) bump_batches_tracked(gf.nbt);
+                }
             }
         } else {
             mg = gg.run_mean[c];

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(kMonoBlock) void mono_cn_fwd_kernel(MonoCnArgs ca, 
                     const double mom_ = a.momentum, unb = a.unbias_n;
                     gg.run_mean[c] = (float)((1.0 - mom_) * par[4] + mom_ * mg);
                     gg.run_var[c] = (float)((1.0 - mom_) * par[5] + mom_ * vg * unb);
+                    if (c == 0) bump_batches_tracked(gg.nbt);
                 }
             } else {
                 rg = (double)__builtin_amdgcn_rsqf((float)par[5] + a.eps_bn);

@@ -181,6 +181,7 @@ struct TailDev {
     const void* gz;        // backward: gradient of z
     float eps, momentum;
     int training;
+    long long* nbt;        // BatchNorm2d.num_batches_tracked or null: += 1 by the forward when training
 };
 // z-coefficients of one plane — ONE definition for the forward and the backward's mask
 __device__ __forceinline__ void tail_coefs(float g, float gamma2, float beta2, double m2, double r2, float& A, float& B) {
@@ -467,6 +468,10 @@ __global__ __launch_bounds__(kMonoBlock, TAIL ? 4 : mono_fwd_waves(RMAX * VEC * 
                 gf.run_mean[c] = (float)((1.0 - mom_) * par[10] + mom_ * mf);
                 gf.run_var[c] = (float)((1.0 - mom_) * par[11] + mom_ * vf * unb);
             }
+            if (c == 0) {
+                bump_batches_tracked(gg.nbt);
+                if (a.sn_two) bump_batches_tracked(gf.nbt);
+            }
         }
     } else {
         rg = (double)__builtin_amdgcn_rsqf((float)par[5] + a.eps_bn);
@@ -523,6 +528,7 @@ __global__ __launch_bounds__(kMonoBlock, TAIL ? 4 : mono_fwd_waves(RMAX * VEC * 
                 const double cnt = (double)N * (double)a.M, mom_ = tl.momentum;
                 tl.run_mean[c] = (float)((1.0 - mom_) * par[14] + mom_ * m2);
                 tl.run_var[c] = (float)((1.0 - mom_) * par[15] + mom_ * v2 * (cnt / (cnt - 1.0)));
+                if (c == 0) bump_batches_tracked(tl.nbt);
             }
         } else {
             m2 = par[14];

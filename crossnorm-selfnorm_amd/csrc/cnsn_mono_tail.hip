@@ -119,7 +119,7 @@ int cnsn_forward_bnrelu(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, 
     double* saved_d = saved ? (double*)saved : nullptr;
     const MonoArgs ma = make_args(pl, tp.mp);
     TailDev tl{tail->weight, tail->bias, tail->running_mean, tail->running_var, bn_stats, nullptr, nullptr, z, nullptr,
-               tail->eps, tail->momentum, tail->training ? 1 : 0};
+               tail->eps, tail->momentum, tail->training ? 1 : 0, (long long*)tail->num_batches_tracked};
     int status = CNSN_E_UNSUPPORTED;
     dispatch_tail(pl.pr.dtype, tp.mp.vec, tp.mp.lpp, tp.mp.rmax, [&](auto tt, auto vt, auto lt, auto rt) {
         using T = typename decltype(tt)::type;
@@ -151,7 +151,7 @@ int cnsn_backward_bnrelu(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi,
     hipStream_t stream = (hipStream_t)stream_;
     const MonoArgs ma = make_args(pl, tp.mp);
     TailDev tl{tail->weight, tail->bias, tail->running_mean, tail->running_var, const_cast<float*>(bn_stats), d_bn_weight,
-               d_bn_bias, nullptr, grad_z, tail->eps, tail->momentum, tail->training ? 1 : 0};
+               d_bn_bias, nullptr, grad_z, tail->eps, tail->momentum, tail->training ? 1 : 0, nullptr};
     int status = CNSN_E_UNSUPPORTED;
     dispatch_tail(pl.pr.dtype, tp.mp.vec, tp.mp.lpp, tp.mp.rmax, [&](auto tt, auto vt, auto lt, auto rt) {
         using T = typename decltype(tt)::type;

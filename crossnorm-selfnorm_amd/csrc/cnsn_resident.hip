@@ -49,6 +49,17 @@ bool resident_auto_enabled() {
 void resident_set_enabled(bool on) { g_enabled.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 namespace {
+std::atomic<int> g_wait_ms{0};  // cnsn_set_wait_ms: > 0 overrides the environment's CNSN_WAIT_MS
+}  // namespace
+void resident_set_wait_ms(int ms) { g_wait_ms.store(ms > 0 ? ms : 0, std::memory_order_relaxed); }
+long long resident_wait_ticks() {
+    const int set = g_wait_ms.load(std::memory_order_relaxed);
+    if (set > 0) return (long long)set * 100000ll;  // 100 MHz wall clock
+    const char* wm = knob(K_WAIT_MS);
+    return (wm && atoll(wm) > 0) ? atoll(wm) * 100000ll : kWaitLimitTicks;
+}
+
+namespace {
 std::mutex g_ctx_mu;
 std::unordered_map<void*, unsigned> g_ctx_epoch;  // launches counted per context (host side)
 }  // namespace

@@ -120,8 +120,7 @@ static inline ResArgs make_args(const cnsn_problem_t& p, Box cb, Box sb, const M
     ra.epoch = 0;
     ra.ctl_idle = kCtlIdle;
     ra.host_flag = resident_host_flag();
-    const char* wm = knob(K_WAIT_MS);
-    ra.wait_ticks = (wm && atoll(wm) > 0) ? atoll(wm) * 100000ll : kWaitLimitTicks;
+    ra.wait_ticks = resident_wait_ticks();  // (cnsn_set_wait_ms, else CNSN_WAIT_MS, else 5 s)
     const char* fi = knob(K_FAULT_INJECT);
     ra.fault = (fi && fi[0] == '1') ? 1 : 0;
     return ra;
@@ -217,6 +216,8 @@ int forward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidA
                  void* workspace, hipStream_t stream, bool post = false) {
     const ResPlan rp = plan_impl(p, boxed, false, false, EPI);
     if (!rp.ok) return CNSN_E_UNSUPPORTED;
+    PermInline* pin = perm_inline_scratch();
+    if (const int ps = perm_inline_fill(p, perm, pin)) return ps;
     ResArgs ra = make_args(p, cb, sb, mid, rp);
     // nothing couples the planes of a channel (inference: SelfNorm on running statistics, no CrossNorm)
     const bool solo = !boxed && !p.cn_active && !(p.sn_active && p.sn_training);
@@ -247,7 +248,7 @@ int forward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidA
             hipError_t e = hipSuccess;
             if (solo) {  // no cluster, nothing to wait for
                 kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, (const T*)addend,
-                                                    relu, nullptr, 0u);
+                                                    relu, nullptr, 0u, *pin);
             } else {
                 if (!ea.epoch && (!use_pong || pong.need_fill)) e = hipMemsetAsync(area, 0xff, fill_bytes, stream);  // 'empty' granules, idle control word
                 if (e != hipSuccess) {
@@ -255,7 +256,7 @@ int forward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidA
                     return;
                 }
                 kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, (const T*)addend,
-                                                    relu, pong.clear, pong.clear_qwords);
+                                                    relu, pong.clear, pong.clear_qwords, *pin);
             }
             e = hipGetLastError();
             status = e == hipSuccess ? CNSN_OK : (int)e;
@@ -287,6 +288,8 @@ int backward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const Mid
                   bool post = false, void* d_addend = nullptr) {
     const ResPlan rp = plan_impl(p, boxed, false, true, EPI);
     if (!rp.ok) return CNSN_E_UNSUPPORTED;
+    PermInline* pin = perm_inline_scratch();
+    if (const int ps = perm_inline_fill(p, perm, pin)) return ps;
     ResArgs ra = make_args(p, cb, sb, mid, rp);
     const int NS = boxed ? 4 : 2;
 #ifdef CNSN_PROF
@@ -318,7 +321,7 @@ int backward_impl(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const Mid
                 return;
             }
             kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)gy, (const T*)x, (T*)dx, perm, g, f, dg, df, gran,
-                                                saved, ctl, (const T*)addend, relu, (T*)d_addend, pong.clear, pong.clear_qwords);
+                                                saved, ctl, (const T*)addend, relu, (T*)d_addend, pong.clear, pong.clear_qwords, *pin);
             e = hipGetLastError();
             status = e == hipSuccess ? CNSN_OK : (int)e;
             if (use_pong && e == hipSuccess) resident_pong_commit(p, fill_bytes);

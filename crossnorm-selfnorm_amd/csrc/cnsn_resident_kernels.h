@@ -62,6 +62,18 @@ struct ResArgs {
     unsigned long long* prof;  // tuning builds (-DCNSN_PROF): [workgroup < 64][iteration < 16][8] time stamps
 };
 
+// The batch permutation as a LAUNCH ARGUMENT (cnsn_problem_t.perm_host, ABI 5): 16-bit indices in the kernarg segment, so
+// that no host-to-device copy sits in front of the launch (models/cnsn.py:62 draws it on the host: torch.randperm(N) from
+// the CPU generator).  on = 0: the kernel reads the device array `perm` as before.
+constexpr int kPermInlineMax = 1024;  // = CNSN_PERM_INLINE_MAX
+struct PermInline {
+    int on;
+    unsigned short v[kPermInlineMax];
+};
+__device__ __forceinline__ int perm_at(const int64_t* __restrict__ perm, const PermInline& pin, int n) {
+    return pin.on ? (int)pin.v[n] : (int)perm[n];
+}
+
 #ifdef CNSN_PROF
 #ifndef CNSN_PROF_SKIP
 #define CNSN_PROF_SKIP 0  // first iteration recorded
@@ -553,7 +565,8 @@ __global__ __launch_bounds__(kBlock, SPLIT ? (POST ? 2 : 3) : POST ? (data_regs(
                                                               unsigned long long* __restrict__ gran,
                                                               double* __restrict__ saved, unsigned* __restrict__ ctl,
                                                               const T* __restrict__ addend, int relu,
-                                                              unsigned long long* __restrict__ clear, unsigned clear_n) {
+                                                              unsigned long long* __restrict__ clear, unsigned clear_n,
+                                                              PermInline pin) {
     pipe_clear_other_region(clear, clear_n);
     constexpr int NG = BOXED ? 6 : 2;
     constexpr int OWN = SPLIT ? 1 : 4 * PPW;
@@ -579,7 +592,7 @@ __global__ __launch_bounds__(kBlock, SPLIT ? (POST ? 2 : 3) : POST ? (data_regs(
     const int voff = lane * VB;
 
     if (a.cn_active)
-        for (int n = threadIdx.x; n < N; n += kBlock) sperm[n] = (int)perm[n];
+        for (int n = threadIdx.x; n < N; n += kBlock) sperm[n] = perm_at(perm, pin, n);
     startup_skew(ra);
 #if CNSN_PRIO
     __builtin_amdgcn_s_setprio(2);
@@ -883,6 +896,10 @@ __global__ __launch_bounds__(kBlock, SPLIT ? (POST ? 2 : 3) : POST ? (data_regs(
                         gf.run_mean[c] = (float)((1.0 - mom_) * (double)prm[1] + mom_ * mf);
                         gf.run_var[c] = (float)((1.0 - mom_) * (double)prv[1] + mom_ * vf * unb);
                     }
+                    if (c == 0) {
+                        bump_batches_tracked(gg.nbt);
+                        if (a.sn_two) bump_batches_tracked(gf.nbt);
+                    }
                 }
             } else {
                 mg = prm[0];
@@ -1017,7 +1034,8 @@ __global__ __launch_bounds__(kBlock, SPLIT ? 2 : POST ? 2 : EPI ? bwd_waves_epi(
                                                               unsigned* __restrict__ ctl,
                                                               const T* __restrict__ addend, int relu,
                                                               T* __restrict__ d_addend,
-                                                              unsigned long long* __restrict__ clear, unsigned clear_n) {
+                                                              unsigned long long* __restrict__ clear, unsigned clear_n,
+                                                              PermInline pin) {
     pipe_clear_other_region(clear, clear_n);
     constexpr int NS = BOXED ? 4 : 2;
     constexpr int OWN = SPLIT ? 1 : 4 * PPW;
@@ -1044,7 +1062,7 @@ __global__ __launch_bounds__(kBlock, SPLIT ? 2 : POST ? 2 : EPI ? bwd_waves_epi(
     const int voff = lane * VB;
 
     if (a.cn_active)  // plane r receives the style-statistic gradient of the plane that borrowed from it
-        for (int n = threadIdx.x; n < N; n += kBlock) iperm[(int)perm[n]] = n;
+        for (int n = threadIdx.x; n < N; n += kBlock) iperm[perm_at(perm, pin, n)] = n;
     startup_skew(ra);
 #if CNSN_PRIO
     __builtin_amdgcn_s_setprio(2);
@@ -1464,9 +1482,31 @@ size_t resident_workspace_bytes(const cnsn_problem_t& p, bool boxed);
 // graph replays on one stream).  This is the only state the library keeps.
 // Host-visible word (pinned memory, allocated once per process on the first cluster launch) that the kernels bump
 // when a bounded wait ran out; NULL when it could not be allocated (e.g. first use inside a stream capture).
+// Fill the launch-argument form of the batch permutation.  perm (device) given: off.  Else from p.perm_host (N <= 1024,
+// entries checked).  Returns CNSN_OK, CNSN_E_NULL (CrossNorm armed and neither form given) or CNSN_E_SHAPE (an index out of
+// range).  `out` is a caller-provided object (2 KB: the launchers keep one per thread).
+inline int perm_inline_fill(const cnsn_problem_t& p, const int64_t* perm, PermInline* out) {
+    out->on = 0;
+    if (!p.cn_active || perm) return CNSN_OK;
+    if (!p.perm_host || p.N > kPermInlineMax) return CNSN_E_NULL;
+    for (int n = 0; n < p.N; ++n) {
+        const int64_t q = p.perm_host[n];
+        if (q < 0 || q >= p.N) return CNSN_E_SHAPE;
+        out->v[n] = (unsigned short)q;
+    }
+    out->on = 1;
+    return CNSN_OK;
+}
+inline PermInline* perm_inline_scratch() {
+    static thread_local PermInline pin{};  // (zero-initialised once; only v[0..N) is ever rewritten)
+    return &pin;
+}
+
 unsigned* resident_host_flag();
 // launches that timed out so far (0: none); after the first one AUTO stops choosing this strategy
 int resident_timeouts();
+void resident_set_wait_ms(int ms);   // cnsn_set_wait_ms
+long long resident_wait_ticks();     // bound of a cluster wait in 100 MHz ticks
 // AUTO may choose the cluster kernels: not switched off (cnsn_resident_enable(0) / CNSN_RESIDENT=0), no time-out seen
 bool resident_auto_enabled();
 void resident_set_enabled(bool on);

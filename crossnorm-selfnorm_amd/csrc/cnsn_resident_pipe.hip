@@ -80,6 +80,8 @@ int resident_pipe_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, c
     int npark = 0;
     const ResPlan rp = resident_pipe_plan(p, boxed, false, &npark);
     if (!rp.ok) return CNSN_E_UNSUPPORTED;
+    PermInline* pin = perm_inline_scratch();
+    if (const int ps = perm_inline_fill(p, perm, pin)) return ps;
     ResArgs ra = reshost::make_args(p, cb, sb, mid, rp);
     const int NG = boxed ? 6 : 2;
 #ifdef CNSN_PROF
@@ -114,7 +116,7 @@ int resident_pipe_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, c
                 return;
             }
             kern<<<grid, kBlock, lds, stream>>>(ra, npark, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, pong.clear,
-                                                pong.clear_qwords);
+                                                pong.clear_qwords, *pin);
             e = hipGetLastError();
             status = e == hipSuccess ? CNSN_OK : (int)e;
             if (use_pong && e == hipSuccess) resident_pong_commit(p, fill_bytes);
@@ -186,6 +188,8 @@ int resident_pipe_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
     int npark = 0;
     const ResPlan rp = resident_pipe_bwd_plan(p, boxed, false, &npark);
     if (!rp.ok) return CNSN_E_UNSUPPORTED;
+    PermInline* pin = perm_inline_scratch();
+    if (const int ps = perm_inline_fill(p, perm, pin)) return ps;
     ResArgs ra = reshost::make_args(p, cb, sb, mid, rp);
     const int NS = boxed ? 4 : 2;
 #ifdef CNSN_PROF
@@ -220,7 +224,7 @@ int resident_pipe_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
                 return;
             }
             kern<<<grid, kBlock, lds, stream>>>(ra, npark, (const T*)gy, (const T*)x, (T*)dx, perm, g, f, dg, df, gran, saved,
-                                                ctl, pong.clear, pong.clear_qwords);
+                                                ctl, pong.clear, pong.clear_qwords, *pin);
             e = hipGetLastError();
             status = e == hipSuccess ? CNSN_OK : (int)e;
             if (use_pong && e == hipSuccess) resident_pong_commit(p, fill_bytes);

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
                                                                       GateDev gg, GateDev gf,
                                                                       unsigned long long* __restrict__ gran,
                                                                       double* __restrict__ saved, unsigned* __restrict__ ctl,
-                                                                      unsigned long long* __restrict__ clear, unsigned clear_n) {
+                                                                      unsigned long long* __restrict__ clear, unsigned clear_n,
+                                                                      PermInline pin) {
     pipe_clear_other_region(clear, clear_n);
     constexpr int NG = BOXED ? 6 : 2;
     constexpr int OWN = 4 * PPW;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
     Raw<T, VEC>* mypark = park + (size_t)wave * NPARK * 64 + lane;  // slot i of this lane: mypark[i * 64]
 
     if (a.cn_active)
-        for (int n = threadIdx.x; n < N; n += kBlock) sperm[n] = (int)perm[n];
+        for (int n = threadIdx.x; n < N; n += kBlock) sperm[n] = perm_at(perm, pin, n);
     if (threadIdx.x == 0) *gave_up = 0;
     __syncthreads();
     startup_skew(ra);
@@ -333,6 +334,10 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
                         gf.run_mean[c] = (float)((1.0 - mom_) * (double)prm[1] + mom_ * mf);
                         gf.run_var[c] = (float)((1.0 - mom_) * (double)prv[1] + mom_ * vf * unb);
                     }
+                    if (c == 0) {
+                        bump_batches_tracked(gg.nbt);
+                        if (a.sn_two) bump_batches_tracked(gf.nbt);
+                    }
                 }
             } else {
                 mg = prm[0];
@@ -469,7 +474,8 @@ __global__ __launch_bounds__(kBlock, pipe_bwd_waves(2 * PPW * NV)) void resident
                                                                       unsigned long long* __restrict__ gran,
                                                                       const double* __restrict__ saved,
                                                                       unsigned* __restrict__ ctl,
-                                                                      unsigned long long* __restrict__ clear, unsigned clear_n) {
+                                                                      unsigned long long* __restrict__ clear, unsigned clear_n,
+                                                                      PermInline pin) {
     pipe_clear_other_region(clear, clear_n);
     constexpr int NS = BOXED ? 4 : 2;
     constexpr int OWN = 4 * PPW;
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(kBlock, pipe_bwd_waves(2 * PPW * NV)) void resident
     Raw<T, VEC>* mypark = park + (size_t)wave * NPARK * 64 + lane;  // slot i of this lane: mypark[i * 64]
 
     if (a.cn_active)  // plane r receives the style-statistic gradient of the plane that borrowed from it
-        for (int n = threadIdx.x; n < N; n += kBlock) iperm[(int)perm[n]] = n;
+        for (int n = threadIdx.x; n < N; n += kBlock) iperm[perm_at(perm, pin, n)] = n;
     if (threadIdx.x == 0) *gave_up = 0;
     __syncthreads();
     startup_skew(ra);

@@ -595,6 +595,7 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
                 const double mom_ = a.momentum;
                 ka->gg.run_mean[c] = (float)((1.0 - mom_) * (double)prm + mom_ * mg);
                 ka->gg.run_var[c] = (float)((1.0 - mom_) * (double)prv + mom_ * vg * a.unbias_n);
+                if (c == 0) bump_batches_tracked(ka->gg.nbt);
                 if (saved) {
                     const size_t P = (size_t)N * C;
                     saved[SV_ROWS * P + c] = rg;

@@ -77,6 +77,8 @@ int resident_split_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
                            double* saved, void* workspace, hipStream_t stream) {
     const ResPlan rp = resident_split_plan(p, boxed, false, add, relu, false);
     if (!rp.ok) return CNSN_E_UNSUPPORTED;
+    PermInline* pin = perm_inline_scratch();
+    if (const int ps = perm_inline_fill(p, perm, pin)) return ps;
     ResArgs ra = reshost::make_args(p, cb, sb, mid, rp);
     const bool solo = !boxed && !p.cn_active && !(p.sn_active && p.sn_training);
     const bool post = add == ADD_POST, epi = post || relu;
@@ -104,7 +106,7 @@ int resident_split_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
             hipError_t e = hipSuccess;
             if (solo) {
                 kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, (const T*)addend, relu,
-                                                    nullptr, 0u);
+                                                    nullptr, 0u, *pin);
             } else {
                 if (!ea.epoch && (!use_pong || pong.need_fill)) e = hipMemsetAsync(area, 0xff, fill_bytes, stream);
                 if (e != hipSuccess) {
@@ -112,7 +114,7 @@ int resident_split_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, 
                     return;
                 }
                 kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, (const T*)addend, relu,
-                                                    pong.clear, pong.clear_qwords);
+                                                    pong.clear, pong.clear_qwords, *pin);
                 if (use_pong && hipPeekAtLastError() == hipSuccess) resident_pong_commit(p, fill_bytes);
             }
             e = hipGetLastError();
@@ -149,6 +151,8 @@ int resident_split_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed,
                             hipStream_t stream) {
     const ResPlan rp = resident_split_plan(p, boxed, false, add, relu, true);
     if (!rp.ok) return CNSN_E_UNSUPPORTED;
+    PermInline* pin = perm_inline_scratch();
+    if (const int ps = perm_inline_fill(p, perm, pin)) return ps;
     const bool post = add == ADD_POST && relu;  // (POST without ReLU: the plain backward, grad of the addend = grad_y)
     if (post && !d_addend) return CNSN_E_UNSUPPORTED;
     ResArgs ra = reshost::make_args(p, cb, sb, mid, rp);
@@ -179,7 +183,7 @@ int resident_split_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed,
                 return;
             }
             kern<<<grid, kBlock, lds, stream>>>(ra, (const T*)gy, (const T*)x, (T*)dx, perm, g, f, dg, df, gran, saved, ctl,
-                                                (const T*)(post ? addend : nullptr), relu, (T*)d_addend, pong.clear, pong.clear_qwords);
+                                                (const T*)(post ? addend : nullptr), relu, (T*)d_addend, pong.clear, pong.clear_qwords, *pin);
             e = hipGetLastError();
             if (use_pong && e == hipSuccess) resident_pong_commit(p, fill_bytes);
             status = e == hipSuccess ? CNSN_OK : (int)e;

@@ -253,6 +253,7 @@ __global__ __launch_bounds__(kWideBlock) void wide_fwd_kernel(WideArgs wa, const
             const double mom_ = a.momentum, unb = a.unbias_n;
             gg.run_mean[c] = (float)((1.0 - mom_) * rm0 + mom_ * mg);
             gg.run_var[c] = (float)((1.0 - mom_) * rv0 + mom_ * vg * unb);
+            if (c == 0) bump_batches_tracked(gg.nbt);
         }
     } else {
         rg = (double)__builtin_amdgcn_rsqf((float)rv0 + a.eps_bn);

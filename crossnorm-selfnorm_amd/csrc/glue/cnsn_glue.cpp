@@ -89,10 +89,11 @@ struct Config {
     double eps_cn, eps_sn, eps_bn, momentum;
     int64_t strategy;
     int64_t add_mode, relu;  // residual-block epilogue (cnsn_epilogue_t)
+    int64_t perm_inline;     // the caller's plan: the permutation can ride in the launch arguments (cnsn_problem_t.perm_host)
 };
 
 Config parse_config(const std::vector<int64_t>& cfg, const std::vector<double>& fcfg) {
-    TORCH_CHECK(cfg.size() == 16 && fcfg.size() == 5, "cnsn glue: bad config vectors");
+    TORCH_CHECK(cfg.size() == 17 && fcfg.size() == 5, "cnsn glue: bad config vectors");
     Config c{};
     c.cn_active = cfg[0];
     for (int i = 0; i < 4; ++i) {
@@ -105,6 +106,7 @@ Config parse_config(const std::vector<int64_t>& cfg, const std::vector<double>& 
     c.strategy = cfg[12];
     c.add_mode = cfg[14];
     c.relu = cfg[15];
+    c.perm_inline = cfg[16];
     c.lam = fcfg[0];
     c.eps_cn = fcfg[1];
     c.eps_sn = fcfg[2];
@@ -180,7 +182,9 @@ struct GateTensors {  // float32 contiguous views/copies + where running stats m
     Tensor w, gamma, beta, rm, rv, rm_src, rv_src;
     bool direct = true;
     cnsn_gate_t c{};
-    void init(const Tensor& w_, const Tensor& g_, const Tensor& b_, const Tensor& rm_, const Tensor& rv_) {
+    // counter: nn.BatchNorm1d.num_batches_tracked when this call has to count (the forward kernel adds 1), else undefined
+    void init(const Tensor& w_, const Tensor& g_, const Tensor& b_, const Tensor& rm_, const Tensor& rv_,
+              const c10::optional<Tensor>& counter = c10::nullopt) {
         w = f32c(w_);
         gamma = f32c(g_);
         beta = f32c(b_);
@@ -195,6 +199,13 @@ struct GateTensors {  // float32 contiguous views/copies + where running stats m
         c.bn_bias = beta.data_ptr<float>();
         c.running_mean = rm.data_ptr<float>();
         c.running_var = rv.data_ptr<float>();
+        c.num_batches_tracked = nullptr;
+        if (counter.has_value() && counter->defined()) {
+            if (counter->is_cuda() && counter->scalar_type() == at::kLong && counter->numel() == 1)
+                c.num_batches_tracked = counter->data_ptr<int64_t>();
+            else
+                counter->add_(1);  // a counter the kernel cannot reach: counted here, as nn.BatchNorm1d.forward does
+        }
     }
     void write_back() {
         if (!direct) {
@@ -215,7 +226,8 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
                           const c10::optional<Tensor>& g_rv, const c10::optional<Tensor>& f_w,
                           const c10::optional<Tensor>& f_gamma, const c10::optional<Tensor>& f_beta,
                           const c10::optional<Tensor>& f_rm, const c10::optional<Tensor>& f_rv,
-                          const c10::optional<Tensor>& addend_in) {
+                          const c10::optional<Tensor>& addend_in, const c10::optional<Tensor>& g_nbt,
+                          const c10::optional<Tensor>& f_nbt) {
         TORCH_CHECK(x_in.is_cuda(), "cnsn_forward: got a ", x_in.device().type(),
                     " tensor. This implementation runs on MI355X HIP device tensors only; there is no CPU path.");
         TORCH_CHECK(x_in.dim() == 4, "expected an (N, C, H, W) tensor");
@@ -237,16 +249,24 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
         const bool has_epi = c.add_mode != CNSN_ADD_NONE || c.relu;
         const at::Device dev = x.device();
         attach_context(prob, dev, c10::hip::getCurrentHIPStream(dev.index()).stream());
-        Tensor perm, chan;
+        Tensor perm, chan, perm_host;
         if (c.cn_active) {
             TORCH_CHECK(perm_in.has_value(), "cnsn_forward: CrossNorm needs the batch permutation");
-            perm = perm_to_device(*perm_in, dev);
-            if (chan_in.has_value()) chan = perm_to_device(*chan_in, dev);
+            const bool inline_ok = c.perm_inline && !chan_in.has_value() && !perm_in->is_cuda() &&
+                                   perm_in->scalar_type() == at::kLong && perm_in->is_contiguous() &&
+                                   perm_in->numel() <= CNSN_PERM_INLINE_MAX;
+            if (inline_ok) {
+                perm_host = *perm_in;  // rides in the launch arguments: no host-to-device copy
+                prob.perm_host = perm_host.data_ptr<int64_t>();
+            } else {
+                perm = perm_to_device(*perm_in, dev);
+                if (chan_in.has_value()) chan = perm_to_device(*chan_in, dev);
+            }
         }
         GateTensors gg, gf;
         const bool two = c.sn_active && c.sn_two;
-        if (c.sn_active) gg.init(*g_w, *g_gamma, *g_beta, *g_rm, *g_rv);
-        if (two) gf.init(*f_w, *f_gamma, *f_beta, *f_rm, *f_rv);
+        if (c.sn_active) gg.init(*g_w, *g_gamma, *g_beta, *g_rm, *g_rv, c.sn_training ? g_nbt : c10::nullopt);
+        if (two) gf.init(*f_w, *f_gamma, *f_beta, *f_rm, *f_rv, c.sn_training ? f_nbt : c10::nullopt);
 
         Tensor y = at::empty_like(x);
         const bool need_bwd = cfg[13] != 0;  // decided by the caller (grad mode on and something requires grad)
@@ -256,12 +276,20 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
         if (need_bwd && ws_bytes > 0) saved = at::empty({(int64_t)cnsn_saved_floats(&prob)}, fopt);
         Tensor ws = at::empty({(int64_t)(ws_bytes / 4) + 1}, fopt);
         hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
-        const int st = cnsn_forward_fused(&prob, has_epi ? &epi : nullptr, x.data_ptr(),
-                                          c.cn_active ? perm.data_ptr<int64_t>() : nullptr,
-                                          chan.defined() ? chan.data_ptr<int64_t>() : nullptr, c.sn_active ? &gg.c : nullptr,
-                                          two ? &gf.c : nullptr, y.data_ptr(),
-                                          saved.defined() ? saved.data_ptr<float>() : nullptr, ws.data_ptr(), ws_bytes,
-                                          (void*)stream);
+        auto launch = [&]() {
+            return cnsn_forward_fused(&prob, has_epi ? &epi : nullptr, x.data_ptr(),
+                                      perm.defined() ? perm.data_ptr<int64_t>() : nullptr,
+                                      chan.defined() ? chan.data_ptr<int64_t>() : nullptr, c.sn_active ? &gg.c : nullptr,
+                                      two ? &gf.c : nullptr, y.data_ptr(), saved.defined() ? saved.data_ptr<float>() : nullptr,
+                                      ws.data_ptr(), ws_bytes, (void*)stream);
+        };
+        int st = launch();
+        if (st == CNSN_E_UNSUPPORTED && perm_host.defined()) {  // (the plan changed under the caller: upload, call again)
+            perm = perm_to_device(perm_host, dev);
+            perm_host = Tensor();
+            prob.perm_host = nullptr;
+            st = launch();
+        }
         check_status(st, "cnsn_forward");
         if (c.sn_active && c.sn_training) {
             gg.write_back();
@@ -275,6 +303,7 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
                 c.sn_active ? (int64_t)g_beta->scalar_type() : -1, two ? (int64_t)f_w->scalar_type() : -1,
                 two ? (int64_t)f_gamma->scalar_type() : -1, two ? (int64_t)f_beta->scalar_type() : -1};
             Tensor none;
+            ctx->saved_data["perm_host"] = perm_host.defined() ? c10::IValue(perm_host) : c10::IValue();
             ctx->save_for_backward({x, saved, perm.defined() ? perm : none, chan.defined() ? chan : none,
                                     c.sn_active ? gg.w : none, c.sn_active ? gg.gamma : none, c.sn_active ? gg.beta : none,
                                     c.sn_active ? gg.rm : none, c.sn_active ? gg.rv : none, two ? gf.w : none,
@@ -286,12 +315,17 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
 
     static variable_list backward(AutogradContext* ctx, variable_list grads) {
         const auto sv = ctx->get_saved_variables();
-        const Tensor &x = sv[0], &saved = sv[1], &perm = sv[2], &chan = sv[3], &addend = sv[14];
+        const Tensor &x = sv[0], &saved = sv[1], &chan = sv[3], &addend = sv[14];
+        Tensor perm = sv[2];
+        Tensor perm_host;
+        if (ctx->saved_data.count("perm_host") && ctx->saved_data["perm_host"].isTensor())
+            perm_host = ctx->saved_data["perm_host"].toTensor();
         const auto cfg = ctx->saved_data["cfg"].toIntVector();
         const auto fcfg = ctx->saved_data["fcfg"].toDoubleVector();
         const auto pd = ctx->saved_data["pd"].toIntVector();
         const Config c = parse_config(cfg, fcfg);
         cnsn_problem_t prob = make_problem(x, c);
+        if (perm_host.defined()) prob.perm_host = perm_host.data_ptr<int64_t>();
         const bool two = c.sn_active && c.sn_two;
         const at::Device dev = x.device();
         const c10::DeviceGuard device_guard(dev);
@@ -315,6 +349,7 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
             g.bn_bias = sv[base + 2].data_ptr<float>();
             g.running_mean = sv[base + 3].data_ptr<float>();
             g.running_var = sv[base + 4].data_ptr<float>();
+            g.num_batches_tracked = nullptr;
         };
         auto make_grads = [&](Tensor& flat, cnsn_gate_grad_t& d) {  // one allocation: dw (C,1,2) | dgamma (C) | dbeta (C)
             flat = at::empty({4 * Cn}, fopt);
@@ -335,11 +370,19 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
         const bool has_epi = c.add_mode != CNSN_ADD_NONE || c.relu;
         Tensor d_add;  // gradient of the addend: dx itself (PRE), grad_y behind the ReLU mask (POST)
         if (c.add_mode == CNSN_ADD_POST) d_add = c.relu ? at::empty_like(x) : gy;
-        const int st = cnsn_backward_fused(
-            &prob, has_epi ? &epi : nullptr, gy.data_ptr(), x.data_ptr(), perm.defined() ? perm.data_ptr<int64_t>() : nullptr,
-            chan.defined() ? chan.data_ptr<int64_t>() : nullptr, c.sn_active ? &gg : nullptr, two ? &gf : nullptr,
-            saved.data_ptr<float>(), dx.data_ptr(), (c.add_mode == CNSN_ADD_POST && c.relu) ? d_add.data_ptr() : nullptr,
-            c.sn_active ? &dgg : nullptr, two ? &dgf : nullptr, ws.data_ptr(), ws_bytes, (void*)stream);
+        auto launch = [&]() {
+            return cnsn_backward_fused(
+                &prob, has_epi ? &epi : nullptr, gy.data_ptr(), x.data_ptr(), perm.defined() ? perm.data_ptr<int64_t>() : nullptr,
+                chan.defined() ? chan.data_ptr<int64_t>() : nullptr, c.sn_active ? &gg : nullptr, two ? &gf : nullptr,
+                saved.data_ptr<float>(), dx.data_ptr(), (c.add_mode == CNSN_ADD_POST && c.relu) ? d_add.data_ptr() : nullptr,
+                c.sn_active ? &dgg : nullptr, two ? &dgf : nullptr, ws.data_ptr(), ws_bytes, (void*)stream);
+        };
+        int st = launch();
+        if (st == CNSN_E_UNSUPPORTED && perm_host.defined()) {  // (another strategy by now: it wants the device array)
+            perm = perm_to_device(perm_host, dev);
+            prob.perm_host = nullptr;
+            st = launch();
+        }
         if (c.add_mode == CNSN_ADD_PRE) d_add = dx;
         check_status(st, "cnsn_backward");
 
@@ -347,7 +390,7 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
             return (code >= 0 && (int64_t)t.scalar_type() != code) ? t.to((at::ScalarType)code) : t;
         };
         Tensor none;
-        variable_list out(16, none);
+        variable_list out(18, none);
         out[0] = dx;
         out[15] = d_add;
         if (c.sn_active) {
@@ -374,7 +417,8 @@ class FusedCNSNTail : public torch::autograd::Function<FusedCNSNTail> {
                                  const Tensor& g_w, const Tensor& g_gamma, const Tensor& g_beta, const Tensor& g_rm,
                                  const Tensor& g_rv, const c10::optional<Tensor>& addend_in, const Tensor& bn_w,
                                  const Tensor& bn_b, const Tensor& bn_rm, const Tensor& bn_rv, std::vector<int64_t> tcfg,
-                                 std::vector<double> tf) {
+                                 std::vector<double> tf, const c10::optional<Tensor>& g_nbt,
+                                 const c10::optional<Tensor>& bn_nbt) {
         TORCH_CHECK(x_in.is_cuda() && x_in.dim() == 4, "cnsn_forward_bnrelu: expected an (N, C, H, W) HIP device tensor");
         const Config c = parse_config(cfg, fcfg);
         const bool want_y = tcfg[0] != 0, bn_training = tcfg[1] != 0;
@@ -392,8 +436,9 @@ class FusedCNSNTail : public torch::autograd::Function<FusedCNSNTail> {
         const bool has_epi = c.add_mode != CNSN_ADD_NONE;
         const at::Device dev = x.device();
         GateTensors gg, bt;
-        gg.init(g_w, g_gamma, g_beta, g_rm, g_rv);
-        bt.init(bn_w, bn_w, bn_b, bn_rm, bn_rv);  // (w slot unused: weight / bias / running buffers of the BatchNorm2d)
+        gg.init(g_w, g_gamma, g_beta, g_rm, g_rv, c.sn_training ? g_nbt : c10::nullopt);
+        // (w slot unused: weight / bias / running buffers / counter of the BatchNorm2d)
+        bt.init(bn_w, bn_w, bn_b, bn_rm, bn_rv, bn_training ? bn_nbt : c10::nullopt);
         cnsn_bn_tail_t tail{};
         tail.struct_bytes = (int32_t)sizeof(cnsn_bn_tail_t);
         tail.training = bn_training ? 1 : 0;
@@ -403,6 +448,7 @@ class FusedCNSNTail : public torch::autograd::Function<FusedCNSNTail> {
         tail.bias = bt.beta.data_ptr<float>();
         tail.running_mean = bt.rm.data_ptr<float>();
         tail.running_var = bt.rv.data_ptr<float>();
+        tail.num_batches_tracked = bt.c.num_batches_tracked;
         Tensor y = want_y ? at::empty_like(x) : Tensor();
         Tensor z = at::empty_like(x);
         const bool need_bwd = cfg[13] != 0;
@@ -464,6 +510,7 @@ class FusedCNSNTail : public torch::autograd::Function<FusedCNSNTail> {
         gg.bn_bias = sv[6].data_ptr<float>();
         gg.running_mean = sv[7].data_ptr<float>();
         gg.running_var = sv[8].data_ptr<float>();
+        gg.num_batches_tracked = nullptr;
         cnsn_bn_tail_t tail{};
         tail.struct_bytes = (int32_t)sizeof(cnsn_bn_tail_t);
         tail.training = tcfg[1] != 0 ? 1 : 0;
@@ -473,6 +520,7 @@ class FusedCNSNTail : public torch::autograd::Function<FusedCNSNTail> {
         tail.bias = sv[10].data_ptr<float>();
         tail.running_mean = sv[11].data_ptr<float>();
         tail.running_var = sv[12].data_ptr<float>();
+        tail.num_batches_tracked = nullptr;
         const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
         const int64_t Cn = x.size(1);
         Tensor dx = at::empty_like(x);
@@ -490,8 +538,8 @@ class FusedCNSNTail : public torch::autograd::Function<FusedCNSNTail> {
         check_status(st, "cnsn_backward_bnrelu");
         auto cast = [](const Tensor& t, int64_t code) { return (int64_t)t.scalar_type() != code ? t.to((at::ScalarType)code) : t; };
         Tensor none;
-        //               x   cfg   fcfg  g_w g_gamma g_beta g_rm g_rv addend bn_w bn_b bn_rm bn_rv tcfg tf
-        variable_list out(15, none);
+        //               x   cfg   fcfg  g_w g_gamma g_beta g_rm g_rv addend bn_w bn_b bn_rm bn_rv tcfg tf g_nbt bn_nbt
+        variable_list out(17, none);
         out[0] = dx;
         out[3] = cast(flat.narrow(0, 0, 2 * Cn).view({Cn, 1, 2}), pd[0]);
         out[4] = cast(flat.narrow(0, 2 * Cn, Cn), pd[1]);
@@ -507,8 +555,10 @@ std::vector<Tensor> fused_cnsn_tail(const Tensor& x, std::vector<int64_t> cfg, s
                                     const Tensor& g_gamma, const Tensor& g_beta, const Tensor& g_rm, const Tensor& g_rv,
                                     const c10::optional<Tensor>& addend, const Tensor& bn_w, const Tensor& bn_b,
                                     const Tensor& bn_rm, const Tensor& bn_rv, std::vector<int64_t> tcfg,
-                                    std::vector<double> tf) {
-    return FusedCNSNTail::apply(x, cfg, fcfg, g_w, g_gamma, g_beta, g_rm, g_rv, addend, bn_w, bn_b, bn_rm, bn_rv, tcfg, tf);
+                                    std::vector<double> tf, const c10::optional<Tensor>& g_nbt,
+                                    const c10::optional<Tensor>& bn_nbt) {
+    return FusedCNSNTail::apply(x, cfg, fcfg, g_w, g_gamma, g_beta, g_rm, g_rv, addend, bn_w, bn_b, bn_rm, bn_rv, tcfg, tf, g_nbt,
+                                bn_nbt);
 }
 
 int64_t bnrelu_plan(const Tensor& x, std::vector<int64_t> cfg, std::vector<double> fcfg, bool backward) {
@@ -525,9 +575,10 @@ Tensor fused_cnsn(const Tensor& x, std::vector<int64_t> cfg, std::vector<double>
                   const c10::optional<Tensor>& g_rm, const c10::optional<Tensor>& g_rv, const c10::optional<Tensor>& f_w,
                   const c10::optional<Tensor>& f_gamma, const c10::optional<Tensor>& f_beta,
                   const c10::optional<Tensor>& f_rm, const c10::optional<Tensor>& f_rv,
-                  const c10::optional<Tensor>& addend) {
+                  const c10::optional<Tensor>& addend, const c10::optional<Tensor>& g_nbt,
+                  const c10::optional<Tensor>& f_nbt) {
     return FusedCNSN::apply(x, cfg, fcfg, perm, chan, g_w, g_gamma, g_beta, g_rm, g_rv, f_w, f_gamma, f_beta, f_rm, f_rv,
-                            addend);
+                            addend, g_nbt, f_nbt);
 }
 
 }  // namespace

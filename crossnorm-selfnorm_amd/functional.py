@@ -187,6 +187,9 @@ class GateParams:
     bn_bias: torch.Tensor
     running_mean: torch.Tensor
     running_var: torch.Tensor
+    # nn.BatchNorm1d.num_batches_tracked (int64 scalar, on the device) when THIS call has to count — training mode with
+    # running statistics and a fixed momentum —, else None: the forward kernel adds 1 (cnsn_gate_t.num_batches_tracked)
+    num_batches_tracked: Optional[torch.Tensor] = None
 
 
 @dataclass
@@ -234,6 +237,26 @@ def which_path(x: torch.Tensor, cfg: FusedConfig, backward: bool = False, chan_p
     return _ffi.PATHS[st]
 
 
+_perm_inline_cache = {}
+_ffi._plan_caches.append(_perm_inline_cache)
+
+
+def perm_inline_ok(x: torch.Tensor, cfg: FusedConfig, perm, chan_perm) -> bool:
+    """True when the batch permutation of this call can travel as a launch argument (cnsn_problem_t.perm_host) instead of
+    through a host-to-device copy: a host int64 vector of at most CNSN_PERM_INLINE_MAX entries, no channel permutation, and
+    BOTH directions of the call resolve to the cluster-resident kernels (remembered per problem signature)."""
+    if chan_perm is not None or not isinstance(perm, torch.Tensor) or perm.is_cuda or perm.dtype != torch.int64 \
+            or not perm.is_contiguous() or perm.numel() > _ffi.PERM_INLINE_MAX:
+        return False
+    key = (tuple(x.shape), x.dtype, x.device.index, cfg.sn_active, cfg.sn_two, cfg.sn_training, cfg.content_box is not None,
+           cfg.style_box is not None, cfg.add_mode, cfg.relu, _strategy)
+    hit = _perm_inline_cache.get(key)
+    if hit is None:
+        hit = which_path(x, cfg, False) == "resident" and which_path(x, cfg, True) == "resident"
+        _perm_inline_cache[key] = hit
+    return hit
+
+
 def sn_cluster(x: torch.Tensor, cfg: FusedConfig, backward: bool = False) -> bool:
     """True when the call runs the SelfNorm-only cluster kernels (cnsn_sn_cluster_plan)."""
     prob = _problem(x, cfg)
@@ -265,7 +288,7 @@ def _problem(x: torch.Tensor, cfg: FusedConfig) -> _ffi.Problem:
 class _GateBuffers:
     """float32 contiguous views/copies of a gate's tensors + the cnsn_gate_t that points at them."""
 
-    def __init__(self, w, gamma, beta, rm, rv):
+    def __init__(self, w, gamma, beta, rm, rv, nbt=None):
         self.src_rm, self.src_rv = rm, rv
         self.w, self.gamma, self.beta = _f32(w), _f32(gamma), _f32(beta)
         direct = rm.dtype == torch.float32 and rm.is_contiguous() and rv.dtype == torch.float32 \
@@ -273,7 +296,11 @@ class _GateBuffers:
         self.rm = rm.detach() if direct else _f32(rm)
         self.rv = rv.detach() if direct else _f32(rv)
         self.direct = direct
-        self.c = _ffi.Gate(_ptr(self.w), _ptr(self.gamma), _ptr(self.beta), _ptr(self.rm), _ptr(self.rv))
+        if nbt is not None and not (nbt.dtype == torch.int64 and nbt.is_cuda and nbt.numel() == 1):
+            nbt.add_(1)          # (a counter the kernel cannot reach: counted here, as nn.BatchNorm1d.forward does)
+            nbt = None
+        self.nbt = nbt
+        self.c = _ffi.Gate(_ptr(self.w), _ptr(self.gamma), _ptr(self.beta), _ptr(self.rm), _ptr(self.rv), _ptr(nbt))
 
     def write_back(self):
         if not self.direct:  # running buffers kept in another dtype: copy the update back
@@ -286,15 +313,15 @@ class FusedCNSN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, cfg: FusedConfig, perm, chan_perm, g_w, g_gamma, g_beta, g_rm, g_rv,
-                f_w, f_gamma, f_beta, f_rm, f_rv, addend=None):
+                f_w, f_gamma, f_beta, f_rm, f_rv, addend=None, g_nbt=None, f_nbt=None):
         _require_device(x, "cnsn_forward")
         with torch.cuda.device(x.device):
             return FusedCNSN._forward(ctx, x, cfg, perm, chan_perm, g_w, g_gamma, g_beta, g_rm, g_rv,
-                                      f_w, f_gamma, f_beta, f_rm, f_rv, addend)
+                                      f_w, f_gamma, f_beta, f_rm, f_rv, addend, g_nbt, f_nbt)
 
     @staticmethod
     def _forward(ctx, x, cfg, perm, chan_perm, g_w, g_gamma, g_beta, g_rm, g_rv,
-                 f_w, f_gamma, f_beta, f_rm, f_rv, addend):
+                 f_w, f_gamma, f_beta, f_rm, f_rv, addend, g_nbt, f_nbt):
         lib = _ffi.lib()
         _ffi.check_resident_health("cnsn_forward")
         x = _dense(x)                                              # reference cnsn.py:14
@@ -307,23 +334,37 @@ class FusedCNSN(torch.autograd.Function):
         prob = _problem(x, cfg)
         dev = x.device
         _context(prob, dev)
+        perm_host = None
         if cfg.cn_active:
-            perm = _h2d.to_device(perm, dev)
-            if chan_perm is not None:
-                chan_perm = _h2d.to_device(chan_perm, dev)
-        gate_g = _GateBuffers(g_w, g_gamma, g_beta, g_rm, g_rv) if cfg.sn_active else None
-        gate_f = _GateBuffers(f_w, f_gamma, f_beta, f_rm, f_rv) if (cfg.sn_active and cfg.sn_two) else None
+            if perm_inline_ok(x, cfg, perm, chan_perm):
+                perm_host, perm = perm, None          # the permutation rides in the launch arguments: no upload
+                prob.perm_host = perm_host.data_ptr()
+            else:
+                perm = _h2d.to_device(perm, dev)
+                if chan_perm is not None:
+                    chan_perm = _h2d.to_device(chan_perm, dev)
+        gate_g = _GateBuffers(g_w, g_gamma, g_beta, g_rm, g_rv, g_nbt if cfg.sn_training else None) if cfg.sn_active else None
+        gate_f = _GateBuffers(f_w, f_gamma, f_beta, f_rm, f_rv, f_nbt if cfg.sn_training else None) \
+            if (cfg.sn_active and cfg.sn_two) else None
         y = torch.empty_like(x)
         need_bwd = any(ctx.needs_input_grad)
         saved_floats, ws_bytes = _sizes(prob)[:2]
         saved = torch.empty(saved_floats, dtype=torch.float32, device=dev) if need_bwd else None
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
         epi = _epilogue(cfg, addend) if cfg.has_epilogue else None
-        st = lib.cnsn_forward_fused(C.byref(prob), C.byref(epi) if epi else None, _ptr(x),
-                                    _ptr(perm if cfg.cn_active else None),
-                                    _ptr(chan_perm if cfg.cn_active else None),
-                                    C.byref(gate_g.c) if gate_g else None, C.byref(gate_f.c) if gate_f else None,
-                                    _ptr(y), _ptr(saved), _ptr(ws), ws_bytes, _stream(x))
+
+        def launch():
+            return lib.cnsn_forward_fused(C.byref(prob), C.byref(epi) if epi else None, _ptr(x),
+                                          _ptr(perm if cfg.cn_active else None),
+                                          _ptr(chan_perm if cfg.cn_active else None),
+                                          C.byref(gate_g.c) if gate_g else None, C.byref(gate_f.c) if gate_f else None,
+                                          _ptr(y), _ptr(saved), _ptr(ws), ws_bytes, _stream(x))
+
+        st = launch()
+        if st == _ffi.E_UNSUPPORTED and perm_host is not None:   # (the plan changed under us: upload and call again)
+            perm, perm_host = _h2d.to_device(perm_host, dev), None
+            prob.perm_host = None
+            st = launch()
         _ffi.check(st, "cnsn_forward")
         if cfg.sn_active and cfg.sn_training:
             gate_g.write_back()
@@ -334,6 +375,7 @@ class FusedCNSN(torch.autograd.Function):
             ctx.gates = (gate_g, gate_f)
             ctx.param_dtypes = tuple(t.dtype if t is not None else None
                                      for t in (g_w, g_gamma, g_beta, f_w, f_gamma, f_beta))
+            ctx.perm_host = perm_host                  # (a CPU tensor: kept alive for the backward's launch argument)
             ctx.save_for_backward(x, saved, perm if cfg.cn_active else None,
                                   chan_perm if cfg.cn_active else None, addend)
         return y
@@ -372,12 +414,21 @@ class FusedCNSN(torch.autograd.Function):
         d_add = None
         if cfg.add_mode == "post":      # gradient of a POST addend: grad_y behind the ReLU mask
             d_add = torch.empty_like(x) if cfg.relu else gy
-        st = lib.cnsn_backward_fused(C.byref(prob), C.byref(epi) if epi else None, _ptr(gy), _ptr(x), _ptr(perm),
-                                     _ptr(chan_perm), C.byref(gate_g.c) if gate_g else None,
-                                     C.byref(gate_f.c) if gate_f else None, _ptr(saved), _ptr(dx),
-                                     _ptr(d_add) if (cfg.add_mode == "post" and cfg.relu) else None,
-                                     C.byref(gg_c) if gg_c else None, C.byref(gf_c) if gf_c else None,
-                                     _ptr(ws), ws_bytes, _stream(x))
+        perm_host = ctx.perm_host
+        prob.perm_host = perm_host.data_ptr() if perm_host is not None else None
+
+        def launch(perm_dev):
+            return lib.cnsn_backward_fused(C.byref(prob), C.byref(epi) if epi else None, _ptr(gy), _ptr(x), _ptr(perm_dev),
+                                           _ptr(chan_perm), C.byref(gate_g.c) if gate_g else None,
+                                           C.byref(gate_f.c) if gate_f else None, _ptr(saved), _ptr(dx),
+                                           _ptr(d_add) if (cfg.add_mode == "post" and cfg.relu) else None,
+                                           C.byref(gg_c) if gg_c else None, C.byref(gf_c) if gf_c else None,
+                                           _ptr(ws), ws_bytes, _stream(x))
+
+        st = launch(perm)
+        if st == _ffi.E_UNSUPPORTED and perm_host is not None:   # (another strategy by now: it wants the device array)
+            prob.perm_host = None
+            st = launch(_h2d.to_device(perm_host, dev))
         _ffi.check(st, "cnsn_backward")
         if cfg.add_mode == "pre":       # d(x + addend) reaches both terms unchanged
             d_add = dx
@@ -385,8 +436,8 @@ class FusedCNSN(torch.autograd.Function):
         out_g = [None] * 3 if gg is None else [t if t.dtype == pd[i] else t.to(pd[i]) for i, t in enumerate(gg)]
         out_f = [None] * 3 if gf is None else [t if t.dtype == pd[3 + i] else t.to(pd[3 + i])
                                                for i, t in enumerate(gf)]
-        #      x   cfg  perm  chan  g_w..g_beta   g_rm g_rv   f_w..f_beta  f_rm f_rv  addend
-        return (dx, None, None, None, *out_g, None, None, *out_f, None, None, d_add)
+        #      x   cfg  perm  chan  g_w..g_beta   g_rm g_rv   f_w..f_beta  f_rm f_rv  addend  g_nbt f_nbt
+        return (dx, None, None, None, *out_g, None, None, *out_f, None, None, d_add, None, None)
 
 
 def bnrelu_plan(x: torch.Tensor, cfg: FusedConfig, backward: bool = False) -> bool:
@@ -407,7 +458,7 @@ class FusedCNSNTail(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, cfg: FusedConfig, addend, want_y, g_w, g_gamma, g_beta, g_rm, g_rv, bn_w, bn_b, bn_rm, bn_rv,
-                bn_training, bn_eps, bn_momentum):
+                bn_training, bn_eps, bn_momentum, g_nbt=None, bn_nbt=None):
         _require_device(x, "cnsn_forward_bnrelu")
         with torch.cuda.device(x.device):
             lib = _ffi.lib()
@@ -421,14 +472,18 @@ class FusedCNSNTail(torch.autograd.Function):
                 addend = None
             prob = _problem(x, cfg)
             dev = x.device
-            gate = _GateBuffers(g_w, g_gamma, g_beta, g_rm, g_rv)
+            gate = _GateBuffers(g_w, g_gamma, g_beta, g_rm, g_rv, g_nbt if cfg.sn_training else None)
             bw, bb = _f32(bn_w), _f32(bn_b)
+            if bn_nbt is not None and not (bn_training and bn_nbt.dtype == torch.int64 and bn_nbt.is_cuda):
+                if bn_training:
+                    bn_nbt.add_(1)
+                bn_nbt = None
             direct = (bn_rm.dtype == torch.float32 and bn_rm.is_contiguous() and bn_rv.dtype == torch.float32
                       and bn_rv.is_contiguous())
             rm = bn_rm.detach() if direct else _f32(bn_rm)
             rv = bn_rv.detach() if direct else _f32(bn_rv)
             tail = _ffi.BnTail(C.sizeof(_ffi.BnTail), int(bn_training), float(bn_eps), float(bn_momentum), bw.data_ptr(),
-                               bb.data_ptr(), rm.data_ptr(), rv.data_ptr())
+                               bb.data_ptr(), rm.data_ptr(), rv.data_ptr(), _ptr(bn_nbt))
             y = torch.empty_like(x) if want_y else None
             z = torch.empty_like(x)
             need_bwd = any(ctx.needs_input_grad)
@@ -471,7 +526,7 @@ class FusedCNSNTail(torch.autograd.Function):
             bw, bb, rm, rv = ctx.bn_buffers
             tr, eps, mom = ctx.tail_cfg
             tail = _ffi.BnTail(C.sizeof(_ffi.BnTail), int(tr), eps, mom, bw.data_ptr(), bb.data_ptr(), rm.data_ptr(),
-                               rv.data_ptr())
+                               rv.data_ptr(), None)
             Cn = x.shape[1]
             dx = torch.empty_like(x)
             flat = torch.empty(6 * Cn, dtype=torch.float32, device=dev)
@@ -488,15 +543,16 @@ class FusedCNSNTail(torch.autograd.Function):
             pd = ctx.param_dtypes
             outs = [t if t.dtype == pd[i] else t.to(pd[i]) for i, t in enumerate((dw, dgam, dbet, dbw, dbb))]
             d_add = dx if cfg.add_mode == "pre" else None
-            #       x   cfg   addend want_y  g_w      g_gamma  g_beta  g_rm  g_rv  bn_w     bn_b    bn_rm bn_rv  tr   eps  mom
-            return (dx, None, d_add, None, outs[0], outs[1], outs[2], None, None, outs[3], outs[4], None, None, None, None, None)
+            #       x   cfg   addend want_y  g_w      g_gamma  g_beta  g_rm  g_rv  bn_w     bn_b    bn_rm bn_rv  tr   eps  mom  nbt nbt
+            return (dx, None, d_add, None, outs[0], outs[1], outs[2], None, None, outs[3], outs[4], None, None, None, None, None,
+                    None, None)
 
 
 def _glue_cfg(cfg: FusedConfig, need_bwd: bool):
     cb = cfg.content_box if cfg.content_box is not None else (-1, -1, -1, -1)
     sb = cfg.style_box if cfg.style_box is not None else (-1, -1, -1, -1)
     icfg = [int(cfg.cn_active), *(int(v) for v in cb), *(int(v) for v in sb), int(cfg.sn_active), int(cfg.sn_two),
-            int(cfg.sn_training), _strategy, int(need_bwd), _ADD_MODES[cfg.add_mode], int(cfg.relu)]
+            int(cfg.sn_training), _strategy, int(need_bwd), _ADD_MODES[cfg.add_mode], int(cfg.relu), 0]
     fcfg = [0.0 if cfg.lam is None else float(cfg.lam), cfg.eps_cn, cfg.eps_sn, cfg.eps_bn, cfg.momentum]
     return icfg, fcfg
 
@@ -506,13 +562,14 @@ _ffi._plan_caches.append(_tail_plan_cache)
 
 
 def fused_cnsn_tail(x, cfg: FusedConfig, addend, want_y: bool, g: GateParams, bn_w, bn_b, bn_rm, bn_rv, bn_training: bool,
-                    bn_eps: float, bn_momentum: float):
+                    bn_eps: float, bn_momentum: float, bn_nbt=None):
     """(y or None, z): FusedCNSNTail through the C++ glue when it is built (same C ABI calls, without the Python
     per-call overhead — WideResNet's step is launch-bound), else through ctypes."""
     glue = _ffi.glue()
     if glue is None:
         out = FusedCNSNTail.apply(x, cfg, addend, bool(want_y), g.fc_weight, g.bn_weight, g.bn_bias, g.running_mean,
-                                  g.running_var, bn_w, bn_b, bn_rm, bn_rv, bn_training, bn_eps, bn_momentum)
+                                  g.running_var, bn_w, bn_b, bn_rm, bn_rv, bn_training, bn_eps, bn_momentum,
+                                  g.num_batches_tracked, bn_nbt)
         return out if want_y else (None, out)
     _require_device(x, "cnsn_forward_bnrelu")
     _ffi.check_resident_health("cnsn_forward_bnrelu")
@@ -521,7 +578,8 @@ def fused_cnsn_tail(x, cfg: FusedConfig, addend, want_y: bool, g: GateParams, bn
     icfg, fcfg = _glue_cfg(cfg, need_bwd)
     out = glue.fused_cnsn_tail(x, icfg, fcfg, g.fc_weight, g.bn_weight, g.bn_bias, g.running_mean, g.running_var,
                                addend if cfg.add_mode != "none" else None, bn_w, bn_b, bn_rm, bn_rv,
-                               [int(want_y), int(bn_training)], [float(bn_eps), float(bn_momentum)])
+                               [int(want_y), int(bn_training)], [float(bn_eps), float(bn_momentum)],
+                               g.num_batches_tracked if cfg.sn_training else None, bn_nbt if bn_training else None)
     return (out[0], out[1]) if want_y else (None, out[0])
 
 
@@ -540,9 +598,11 @@ def fused_cnsn(x, cfg: FusedConfig, perm=None, chan_perm=None, g: Optional[GateP
                f: Optional[GateParams] = None, addend: Optional[torch.Tensor] = None):
     ga = (g.fc_weight, g.bn_weight, g.bn_bias, g.running_mean, g.running_var) if g else (None,) * 5
     fa = (f.fc_weight, f.bn_weight, f.bn_bias, f.running_mean, f.running_var) if f else (None,) * 5
+    g_nbt = g.num_batches_tracked if (g and cfg.sn_training) else None
+    f_nbt = f.num_batches_tracked if (f and cfg.sn_training) else None
     glue = _ffi.glue()
     if glue is None:
-        return FusedCNSN.apply(x, cfg, perm, chan_perm, *ga, *fa, addend)
+        return FusedCNSN.apply(x, cfg, perm, chan_perm, *ga, *fa, addend, g_nbt, f_nbt)
     # C++ glue: same C ABI calls, without the Python per-call overhead
     _require_device(x, "cnsn_forward")
     _ffi.check_resident_health("cnsn_forward")
@@ -552,11 +612,12 @@ def fused_cnsn(x, cfg: FusedConfig, perm=None, chan_perm=None, g: Optional[GateP
         t is not None and t.requires_grad for t in (*ga[:3], *fa[:3], addend)))
     cb = cfg.content_box if cfg.content_box is not None else (-1, -1, -1, -1)
     sb = cfg.style_box if cfg.style_box is not None else (-1, -1, -1, -1)
+    inline = cfg.cn_active and perm_inline_ok(x, cfg, perm, chan_perm)
     icfg = [int(cfg.cn_active), *(int(v) for v in cb), *(int(v) for v in sb), int(cfg.sn_active), int(cfg.sn_two),
-            int(cfg.sn_training), _strategy, int(need_bwd), _ADD_MODES[cfg.add_mode], int(cfg.relu)]
+            int(cfg.sn_training), _strategy, int(need_bwd), _ADD_MODES[cfg.add_mode], int(cfg.relu), int(inline)]
     fcfg = [0.0 if cfg.lam is None else float(cfg.lam), cfg.eps_cn, cfg.eps_sn, cfg.eps_bn, cfg.momentum]
     return glue.fused_cnsn(x, icfg, fcfg, perm if cfg.cn_active else None, chan_perm if cfg.cn_active else None,
-                           *ga, *fa, addend)
+                           *ga, *fa, addend, g_nbt, f_nbt)
 
 
 # ------------------------------------------------------------------------------------------------

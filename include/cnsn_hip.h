@@ -31,7 +31,10 @@
 extern "C" {
 #endif
 
-#define CNSN_ABI_VERSION 4
+#define CNSN_ABI_VERSION 5
+
+/* Largest batch whose permutation can travel as a launch argument (cnsn_problem_t.perm_host). */
+#define CNSN_PERM_INLINE_MAX 1024
 
 /* Element types of the activation tensors.  float64 is NOT offered (the reference's eager path accepts any float tensor,
  * models/cnsn.py:12-16): CNSN_E_DTYPE here, a TypeError naming the three supported types in the Python layer. */
@@ -86,6 +89,12 @@ typedef struct cnsn_problem {
      * through `workspace`, which costs one fill launch in front of every resident launch.                       */
     void* context;
     uint64_t context_bytes;
+    /* Optional (ABI 5): the batch permutation of `perm` (models/cnsn.py:62, torch.randperm on the CPU generator) as HOST
+     * memory — int64 (N), read before the call returns.  The cluster-resident kernels (cnsn_which_path() ==
+     * CNSN_PATH_RESIDENT, no channel permutation, N <= CNSN_PERM_INLINE_MAX) take it as a LAUNCH ARGUMENT (16-bit
+     * indices): no host-to-device copy in front of the launch.  With it `perm` may be NULL; a call that resolves to
+     * kernels which need the device array then returns CNSN_E_UNSUPPORTED and the caller uploads and calls again. */
+    const int64_t* perm_host;
 } cnsn_problem_t;
 
 /* Parameters / buffers of one SelfNorm gate: g_fc + g_bn (or f_fc + f_bn), models/cnsn.py:118-126.
@@ -96,6 +105,10 @@ typedef struct cnsn_gate {
     const float* bn_bias;   /* (C)                                         */
     float* running_mean;    /* (C) updated in place when sn_training       */
     float* running_var;     /* (C) updated in place when sn_training       */
+    /* (ABI 5) nn.BatchNorm1d.num_batches_tracked of the gate (models/cnsn.py:120,125: g_bn / f_bn), int64 scalar, or
+     * NULL: the FORWARD adds 1 to it when sn_training — what nn.BatchNorm1d.forward does per call in training mode —
+     * inside the op's own launch instead of a launch of its own.  cnsn_backward ignores it. */
+    int64_t* num_batches_tracked;
 } cnsn_gate_t;
 
 typedef struct cnsn_gate_grad {
@@ -198,6 +211,7 @@ typedef struct cnsn_bn_tail {
     const float* bias;      /* (C)                                                                   */
     float* running_mean;    /* (C) updated in place when training                                    */
     float* running_var;     /* (C) (takes the unbiased batch variance, like torch)                   */
+    int64_t* num_batches_tracked; /* (ABI 5) int64 scalar or NULL: += 1 by the forward when training          */
 } cnsn_bn_tail_t;
 
 /* 1 when a fused kernel takes the call (pure function of the problem), 0 when not, < 0 argument error */
@@ -286,6 +300,12 @@ int cnsn_resident_timeouts(void);
 /* on = 0: CNSN_STRATEGY_AUTO never chooses the resident kernels (same as the environment variable CNSN_RESIDENT=0
  * at load time); on = 1: allowed again.  CNSN_STRATEGY_RESIDENT is not affected. */
 void cnsn_resident_enable(int on);
+
+/* Bound of a cluster wait in milliseconds (default 5000; the environment variable CNSN_WAIT_MS at load time).  A process
+ * that is one rank of a data-parallel job lowers it (its peers wait with it in the next collective): the Python layer
+ * sets 2000 under an initialised process group.  ms <= 0: back to the environment's / default value. */
+void cnsn_set_wait_ms(int ms);
+int cnsn_wait_ms(void); /* the bound in force, in milliseconds */
 
 /* ---- environment knobs ---------------------------------------------------------------------------
  * The library's CNSN_* environment variables (tuning and test switches: CNSN_WAIT_MS, CNSN_RESIDENT, CNSN_PIPE, ... —

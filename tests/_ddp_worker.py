@@ -157,7 +157,7 @@ def main(out_dir, steps=3, batch=32):
                site_outputs_bit_identical=bool(same_sites), site_max_abs_diff=max(site_diff) if site_diff else None,
                grad_rel_err=grad_err, grads_bit_identical=bool(grads_equal),
                timeouts=int(_ffi.lib().cnsn_resident_timeouts()), paths=paths, loss=last_loss,
-               wait_ms=os.environ.get("CNSN_WAIT_MS"), nccl_avg_ok=avg_ok,
+               wait_ms=int(_ffi.lib().cnsn_wait_ms()), nccl_avg_ok=avg_ok,
                finite=bool(np.isfinite(last_loss)))
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
         json.dump(res, f)

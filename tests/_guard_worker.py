@@ -88,7 +88,7 @@ def main(out_dir):
                finite=all(bool(torch.isfinite(v).all()) for v in state.values()),
                counters={k: int(v) for k, v in state.items() if k.endswith("num_batches_tracked")},
                repeated_draw_equal=(len(draws) == STEPS + 1 and draws[FAULT_STEP] == draws[FAULT_STEP + 1]),
-               wait_ms=os.environ.get("CNSN_WAIT_MS"))
+               wait_ms=int(_ffi.lib().cnsn_wait_ms()))
     torch.save({k: v for k, v in state.items() if "running" not in k and "num_batches" not in k},
                os.path.join(out_dir, f"params{rank}.pt"))
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:

@@ -42,7 +42,7 @@ def test_resident_kernels_under_data_parallel_communication(tmp_path, world):
     for rep in reps:
         assert rep["world"] == world and rep["sites"] == 16
         if world == 1:
-            assert rep["backend"] == "nccl" and rep["mode"] == "ddp" and rep["wait_ms"] == "2000", rep
+            assert rep["backend"] == "nccl" and rep["mode"] == "ddp" and rep["wait_ms"] == 2000, rep
         if not rep["shared_device"]:
             assert "resident" in rep["paths"], rep             # one rank per GPU: the cluster kernels were in play
         assert rep["timeouts"] == 0, rep                       # no bounded wait ran out
