@@ -167,7 +167,7 @@ class SelfNorm(nn.Module):
         momentum = 0.0 if bn.momentum is None else float(bn.momentum)
         counter = None
         if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-            if in_kernel and bn.momentum is not None and bn.num_batches_tracked.is_cuda:
+            if in_kernel and bn.momentum is not None and bn.num_batches_tracked.is_cuda and not _F.LEGACY_LAUNCHES:
                 counter = bn.num_batches_tracked
             else:
                 bn.num_batches_tracked.add_(1)

@@ -167,6 +167,11 @@ struct ChainState {
 ChainState g_chain[16];
 }  // namespace
 
+// Round 4: the completion event is recorded WHEN A LAUNCH ARRIVES ON ANOTHER STREAM (on the stream of the previous cluster
+// launch: everything queued there so far, that launch included), not behind every launch.  An event record is a packet of
+// its own on the queue and costs the GPU about 4 us between two dependent launches (rocprofv3 timeline of the headline
+// step, profiles/r04_launches_per_step.md: 10.7 / 14.9 us gaps with two / three records in them); a training loop stays
+// on one stream and never pays it now.
 ResidentChain::ResidentChain(hipStream_t stream) : stream_(stream), dev_(0), active_(false) {
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 16) return;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -177,19 +182,29 @@ ResidentChain::ResidentChain(hipStream_t stream) : stream_(stream), dev_(0), act
     ChainState& c = g_chain[dev_];
     c.mu.lock();
     active_ = true;
-    if (c.valid && c.last != stream) (void)hipStreamWaitEvent(stream, c.ev, 0);
+    if (c.valid && c.last != stream) {
+        hipStreamCaptureStatus ls = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(c.last, &ls) != hipSuccess) {
+            // the stream of the previous cluster launch no longer exists: nothing to record on — drain the device once
+            (void)hipGetLastError();
+            (void)hipDeviceSynchronize();
+        } else if (ls == hipStreamCaptureStatusNone) {
+            if (!c.ev && hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) c.ev = nullptr;
+            if (c.ev && hipEventRecord(c.ev, c.last) == hipSuccess) {
+                (void)hipStreamWaitEvent(stream, c.ev, 0);
+            } else {
+                (void)hipGetLastError();
+                (void)hipDeviceSynchronize();
+            }
+        }  // (that stream is under capture now: its earlier, un-captured work was drained when the capture began)
+    }
 }
 
 ResidentChain::~ResidentChain() {
     if (!active_) return;
     ChainState& c = g_chain[dev_];
-    if (!c.ev && hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) c.ev = nullptr;
-    if (c.ev && hipEventRecord(c.ev, stream_) == hipSuccess) {
-        c.last = stream_;
-        c.valid = true;
-    } else {
-        c.valid = false;
-    }
+    c.last = stream_;
+    c.valid = true;
     c.mu.unlock();
 }
 

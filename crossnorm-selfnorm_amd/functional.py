@@ -239,13 +239,17 @@ def which_path(x: torch.Tensor, cfg: FusedConfig, backward: bool = False, chan_p
 
 _perm_inline_cache = {}
 _ffi._plan_caches.append(_perm_inline_cache)
+# A/B switch (profiles/r04_launches_per_step.md): CNSN_LEGACY_LAUNCHES=1 restores the two small launches in front of the op —
+# `num_batches_tracked.add_(1)` as a torch launch and the permutation as a host-to-device copy
+import os as _os  # noqa: E402
+LEGACY_LAUNCHES = _os.environ.get("CNSN_LEGACY_LAUNCHES") == "1"
 
 
 def perm_inline_ok(x: torch.Tensor, cfg: FusedConfig, perm, chan_perm) -> bool:
     """True when the batch permutation of this call can travel as a launch argument (cnsn_problem_t.perm_host) instead of
     through a host-to-device copy: a host int64 vector of at most CNSN_PERM_INLINE_MAX entries, no channel permutation, and
     BOTH directions of the call resolve to the cluster-resident kernels (remembered per problem signature)."""
-    if chan_perm is not None or not isinstance(perm, torch.Tensor) or perm.is_cuda or perm.dtype != torch.int64 \
+    if LEGACY_LAUNCHES or chan_perm is not None or not isinstance(perm, torch.Tensor) or perm.is_cuda or perm.dtype != torch.int64 \
             or not perm.is_contiguous() or perm.numel() > _ffi.PERM_INLINE_MAX:
         return False
     key = (tuple(x.shape), x.dtype, x.device.index, cfg.sn_active, cfg.sn_two, cfg.sn_training, cfg.content_box is not None,
