@@ -522,13 +522,20 @@ def model_workload(args, dist, world, rank, dev):
         r = np.random.rand(1)                                                                    # cifar.py:127-131
         return torch.nn.functional.cross_entropy(model(xb, aug=bool(r < 0.5)), y)
 
-    # forward / backward (DDP's gradient all-reduce inside) -> stream settled -> ONE 4-byte MAX all-reduce "did a cluster
-    # launch of some rank give up" -> optimizer, or every rank restores its BatchNorm buffers / RNG streams and repeats
-    # (callers.steps.StepGuard): a rank never repeats alone, so the ranks' collectives pair up whatever happens
-    guard = StepGuard(net)
+    # The time-out protocol per WINDOW of steps (warm-up window, timed window), as in the headline workload: inside a
+    # window nothing is raised and nothing synchronises the stream (a per-step `StepGuard.run` costs a stream
+    # synchronisation per step — 25 % of a launch-bound WideResNet step); every rank runs the same number of steps and
+    # DDP all-reduces; behind the window ONE 4-byte MAX all-reduce says whether any rank's cluster launch gave up, and then
+    # EVERY rank puts parameters, buffers, optimizer state and RNG streams back to the window's start (callers.steps.StepGuard
+    # with `optimizer=`), switches the cluster kernels off and runs the window again.  (`callers.steps.train_step_*` keep the
+    # per-step form: a training loop cannot replay a window of data.)
+    guard = StepGuard(net, optimizer=opt)
 
     def step():
-        guard.run(compute_loss, opt)
+        loss = compute_loss()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
 
     graphed = None
     if args.workload == "wrn40" and dist is None and not args.no_graph:
@@ -542,19 +549,42 @@ def model_workload(args, dist, world, rank, dev):
         def step():                                                                              # noqa: F811
             graphed.step(x, y, 0.5)
 
-    for _ in range(args.warmup):
-        step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    def window(k):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        with cnsn_amd._ffi.deferred_timeouts():
+            for _ in range(k):
+                step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t
+
+    def settled_window(k):
+        for _ in range(3):
+            if graphed is None:
+                guard.save()
+            t = window(k)
+            new = cnsn_amd._ffi.poll_timeouts()               # (the stream is idle: every launch of the window has run)
+            guard.local_timeouts += new
+            if dp.agree_to_repeat(new, dev) == 0:
+                return t
+            guard.repeats += k
+            if new:
+                print(f"[bench] rank {rank}: {new} cluster launch(es) gave up; all ranks repeat the window of {k} steps",
+                      file=sys.stderr)
+            dp.degrade_all()
+            if graphed is None:
+                guard.restore()
+        raise cnsn_amd.CnsnError("bench: cluster launches still time out after three windows")
+
+    if graphed is None:
+        step()                                                # (creates the optimizer's state tensors: part of every snapshot)
+    settled_window(args.warmup)
+    dt = settled_window(args.steps)
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -38,8 +38,12 @@ class StepGuard:
     (`data_parallel.degrade_all`) and repeats: the ranks issue the same collectives in the same order whatever happens.
     The reference's loops (cifar.py:136-138, imagenet.py:240-244) have no counterpart: eager PyTorch cannot time out."""
 
-    def __init__(self, *modules, group=None, restore_rng=True, max_attempts=3):
+    def __init__(self, *modules, group=None, restore_rng=True, max_attempts=3, optimizer=None):
+        """optimizer: ALSO snapshot the parameters and the optimizer's state tensors (`save` / `restore` then cover a whole
+        WINDOW of applied steps — what a launch-bound loop uses to poll once per window instead of synchronising the
+        stream in every step: bench.py's model workloads; `run()` itself never needs it, it polls before the optimizer)."""
         self.slots = [(m, name) for mod in modules for m in mod.modules() for name, b in m._buffers.items() if b is not None]
+        self.modules, self.optimizer = modules, optimizer
         self.group, self.restore_rng, self.max_attempts = group, restore_rng, max_attempts
         self.snap, self.rng = None, None
         self.repeats = 0                 # steps repeated so far (all ranks count the same)
@@ -47,12 +51,16 @@ class StepGuard:
         self._defaults_done = False
 
     def _live(self):
-        return [m._buffers[name] for m, name in self.slots]
+        live = [m._buffers[name] for m, name in self.slots]
+        if self.optimizer is not None:
+            live += [p.data for mod in self.modules for p in mod.parameters()]
+            live += [v for st in self.optimizer.state.values() for v in st.values() if torch.is_tensor(v)]
+        return live
 
     def save(self):
         live = self._live()
-        if self.snap is None or any(s.shape != b.shape or s.dtype != b.dtype or s.device != b.device
-                                    for s, b in zip(self.snap, live)):
+        if self.snap is None or len(self.snap) != len(live) or any(
+                s.shape != b.shape or s.dtype != b.dtype or s.device != b.device for s, b in zip(self.snap, live)):
             self.snap = [torch.empty_like(b) for b in live]
         if live:
             with torch.no_grad():
@@ -62,6 +70,7 @@ class StepGuard:
 
     def restore(self):
         live = self._live()
+        assert len(live) == len(self.snap), "StepGuard.restore: tensors appeared since save() (optimizer state created mid-window)"
         if live:
             with torch.no_grad():
                 torch._foreach_copy_(live, self.snap)
