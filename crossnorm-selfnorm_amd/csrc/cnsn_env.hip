@@ -13,6 +13,7 @@ const char* const kNames[K_COUNT] = {
     "CNSN_PROF",     "CNSN_MONO",     "CNSN_MONO_RELOAD", "CNSN_NO_PACKED", "CNSN_MID_TILE",   "CNSN_SNX",
     "CNSN_RESIDENT", "CNSN_CONTEXT",  "CNSN_EPOCH_START", "CNSN_KEEP",    "CNSN_PIPE",         "CNSN_WIDE",
     "CNSN_PONG",
+    "CNSN_SNXCN",
 };
 
 struct Table {

@@ -84,6 +84,7 @@ int cnsn_which_path(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int 
     if (mono_cn_plan(pl, chan, fused ? e.add : 0, bwd).ok) return CNSN_PATH_MONO;
     if (local_plan(pl, fused ? e.add : 0, bwd).ok) return CNSN_PATH_LOCAL;
     if (resident_sn_plan(p, pl.boxed, fused ? e.add : ADD_NONE, fused ? e.relu : 0, bwd).ok) return CNSN_PATH_RESIDENT;
+    if (bwd && !fused && resident_sn_cn_plan(p, pl.boxed, chan).ok) return CNSN_PATH_RESIDENT;
     if (fused ? resident_fused_plan(p, pl.boxed, chan, e.add, bwd).ok : resident_plan(p, pl.boxed, chan, bwd).ok)
         return CNSN_PATH_RESIDENT;
     if (resident_split_plan(p, pl.boxed, chan, fused ? e.add : ADD_NONE, fused ? e.relu : 0, bwd).ok) return CNSN_PATH_RESIDENT;
@@ -105,6 +106,7 @@ int cnsn_sn_cluster_plan(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi,
     if (wide_plan(pl, fused ? e.add : 0, bwd).ok || mono_plan(pl, fused ? e.add : 0, bwd).ok ||
         local_plan(pl, fused ? e.add : 0, bwd).ok)
         return 0;
+    if (bwd && !fused && resident_sn_cn_plan(pl.pr, pl.boxed, false).ok) return 1;  // (un-boxed CrossNorm in front: same family)
     return resident_sn_plan(pl.pr, pl.boxed, fused ? e.add : ADD_NONE, fused ? e.relu : 0, bwd).ok ? 1 : 0;
 }
 

@@ -23,4 +23,11 @@ int resident_sn_backward(const cnsn_problem_t& p, const MidArgs& mid, int add, i
                          const void* addend, GateDev g, const double* saved, void* dx, GateGradDev dg, void* workspace,
                          hipStream_t stream);
 
+// Round 4 — the backward of un-boxed CrossNorm + SelfNorm (models/cnsn.py:58-91 with crop='neither' in front of :130-150; no
+// channel permutation, one gate, no epilogue) in the partial-moment cluster kernels: ok only for that call.  `perm`: device
+// array or NULL with cnsn_problem_t.perm_host (launch argument).
+SnxPlan resident_sn_cn_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm);
+int resident_sn_cn_backward(const cnsn_problem_t& p, const MidArgs& mid, const void* gy, const void* x, const int64_t* perm,
+                            GateDev g, const double* saved, void* dx, GateGradDev dg, void* workspace, hipStream_t stream);
+
 }  // namespace cnsn

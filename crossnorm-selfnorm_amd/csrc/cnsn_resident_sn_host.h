@@ -59,6 +59,19 @@ constexpr int bwd_ppw(int nv, bool epi, int elem_bytes, int vb = 16) {  // (one-
                      : 1;
 }
 
+// classes of the CrossNorm-capable backward that are compiled: 16-byte vectors, planes of 7 and more register slots (40x40 fp32,
+// 56x56 in 16 bits and larger).  The smaller classes hold 4-16 planes per wave: their CrossNorm records (own rows + the
+// borrower's, 128 bytes per plane, two items) do not fit next to the parked item at three workgroups per CU, and one-slot
+// planes have the channel-in-registers kernels, which take CrossNorm themselves (cnsn_mono_cn_kernels.h)
+constexpr bool snx_cn_built(int nv, int eb, int vb) { return vb == 16 && nv >= 7 && (eb == 4 || eb == 2); }
+// AUTO rule of the CrossNorm-capable backward (plan_impl, cn): register bucket, element bytes, batch.  Same-box A/B against the
+// general (pipelined) cluster backward, HIP-event intervals of the backward call (profiles/r04_cn_partial_moments.md):
+//   fp32  40x40 (7 slots) -4 %, 56x56 (13) level at N = 256 on a box whose memory floor the general kernel already reaches,
+//         -3 % at N = 96, 64x64 (16) -6..-12 %                                   -> every fp32 class
+//   16 bit 56x56 (7 slots) -6 % at N = 256, -5 % at N = 96; 64x64 (8 slots) -9 % at N = 16 but +3..+6 % at N = 64
+//         -> 7 slots always, 8 slots for small batches; 13 / 16 slots unmeasured: the general kernels
+constexpr bool snx_cn_auto(int nv, int eb, int N) { return eb == 4 || nv == 7 || (nv == 8 && N <= 32); }
+
 // CNSN_SNX=0: never; 2: wherever instantiated (tests); default 1: AUTO rule
 inline int snx_mode() {
     const char* e = knob(K_SNX);
@@ -101,16 +114,26 @@ bool dispatch_snx(int dtype, int vec, int nv, F&& f) {
     return false;
 }
 
-inline size_t lds_bytes(int K, int own, int np, bool backward, int vb) {
-    return backward ? snx_bwd_lds_bytes(K, own, np, vb) : snx_fwd_lds_bytes(K, own, np, vb);
+inline size_t lds_bytes(int K, int own, int np, bool backward, int vb, bool cn = false, int N = 0) {
+    return backward ? snx_bwd_lds_bytes(K, own, np, vb, cn, N) : snx_fwd_lds_bytes(K, own, np, vb);
 }
 
-inline SnxPlan plan_impl(const cnsn_problem_t& p, bool boxed, int add, int relu, bool backward) {
+// CNSN_SNXCN=0: the CrossNorm-capable backward never; 2: wherever instantiated (tests); default: AUTO rule
+inline int snx_cn_mode() {
+    const char* e = knob(K_SNXCN);
+    return e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : 1;
+}
+
+// cn: the CrossNorm-capable backward (un-boxed CrossNorm in front of SelfNorm, no epilogue: round 4)
+inline SnxPlan plan_impl(const cnsn_problem_t& p, bool boxed, int add, int relu, bool backward, bool cn = false) {
     SnxPlan none{false, 0, 0, 0, 0, 0};
-    const int mode = snx_mode();
+    const int mode = cn ? (snx_mode() == 0 ? 0 : snx_cn_mode()) : snx_mode();
     if (mode == 0) return none;
     if (!(p.strategy == CNSN_STRATEGY_AUTO || p.strategy == CNSN_STRATEGY_RESIDENT)) return none;
-    if (boxed || p.cn_active || !p.sn_active || !p.sn_training || p.sn_two) return none;
+    if (boxed || (p.cn_active != 0) != cn || !p.sn_active || !p.sn_training || p.sn_two) return none;
+    if (cn && (!backward || add != ADD_NONE || relu || p.N > kPermInlineMax)) return none;
+    if (cn && (pick_vec(p.dtype, p.H * p.W) * elem_bytes(p.dtype) != 16 || (p.H * p.W / pick_vec(p.dtype, p.H * p.W) + 63) / 64 < 5))
+        return none;  // (snx_cn_built: buckets of 7 slots and more)
     if (!(add == ADD_NONE || add == ADD_PRE)) return none;
     if (resident_timeouts() > 0) return none;
     if (p.strategy == CNSN_STRATEGY_AUTO && !resident_auto_enabled()) return none;
@@ -147,7 +170,7 @@ inline SnxPlan plan_impl(const cnsn_problem_t& p, bool boxed, int add, int relu,
     int np = slots;
     if (!backward && sp.ppw == 1 && nvec % 64 != 0 && nvec % 64 <= 32) np = slots - 1;  // a last, partly filled slot stays in registers
     if (np < first_keep) np = first_keep;
-    while (np >= first_keep && lds_bytes(sp.K, own, np, backward, vb) > budget) --np;
+    while (np >= first_keep && lds_bytes(sp.K, own, np, backward, vb, cn, p.N) > budget) --np;
     if (np < first_keep) return none;
     // AUTO / forced-resident without CNSN_SNX=2: where these kernels measured faster than the general resident kernels
     // on MI355X (profiles/r03_sn_cluster.md, same-process A/B): every call WITH the residual-block epilogue (the general
@@ -158,6 +181,9 @@ inline SnxPlan plan_impl(const cnsn_problem_t& p, bool boxed, int add, int relu,
         if (!backward && eb == 4 && sp.nv == 4) return none;
         if (backward && eb == 2 && sp.nv == 7 && p.N < 128) return none;
     }
+    // the CrossNorm-capable backward, AUTO: the classes measured against the general (pipelined) cluster backward on MI355X
+    // (profiles/r04_cn_partial_moments.md)
+    if (cn && mode != 2 && !snx_cn_auto(sp.nv, eb, p.N)) return none;
     sp.npark = np;
     sp.ok = true;
     return sp;
@@ -169,9 +195,10 @@ inline ResArgs make_args(const cnsn_problem_t& p, const MidArgs& mid, const SnxP
     return reshost::make_args(p, whole, whole, mid, rp);
 }
 
-// exchange areas, in granules of 8 bytes: round A per member, round B per wave (backward only)
-inline size_t tagged_bytes(const cnsn_problem_t& p, int K, bool backward) {
-    return kCtlBytes + (size_t)p.C * K * (backward ? 4 + 8 : 4) * 8 + 1024;
+// exchange areas, in granules of 8 bytes: round A per member, round B per wave (backward only), the per-plane sums of the
+// CrossNorm-capable backward (two tagged granules per plane)
+inline size_t tagged_bytes(const cnsn_problem_t& p, int K, bool backward, bool cn = false) {
+    return kCtlBytes + (size_t)p.C * K * (backward ? 4 + 8 : 4) * 8 + 1024 + (cn ? (size_t)p.N * p.C * 2 * 8 + 256 : 0);
 }
 
 }  // namespace snxhost

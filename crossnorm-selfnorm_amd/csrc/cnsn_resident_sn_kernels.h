@@ -82,6 +82,24 @@ struct SnxBwdState {
     double mu_c, zh, dt;   // saved mean and normalised pre-activation; dL/d(pre-sigmoid)
     float g, sig_p, s1, s2;  // saved gate and std; sum G', sum G'*(X - float(mu_c))
 };
+// the CrossNorm rows of `saved` one plane's backward algebra needs (un-boxed call: cnsn_layout.h, SV_MU_P .. SV_M_IN)
+struct SnxCnRows {
+    double mu_s;
+    float mu_p, aa, a1, m_in, sig_c, M2c, sig_s;
+};
+// CN variant of the backward: the record of an own plane carries its CrossNorm rows next to the SelfNorm ones
+// ... and the rows of the plane that BORROWED this plane's statistics (same channel, instance perm^-1[n])
+struct SnxBorrower {
+    double mu_c, zh;
+    float g, sig_p, mu_p, aa, a1, m_in, sig_c, M2c;
+};
+struct SnxBwdStateCn {
+    SnxBwdState sn;
+    SnxCnRows cn;
+    SnxBorrower br;
+};
+__device__ __forceinline__ const SnxBwdState& snx_sn(const SnxBwdState& r) { return r; }
+__device__ __forceinline__ const SnxBwdState& snx_sn(const SnxBwdStateCn& r) { return r.sn; }
 
 __host__ __device__ inline size_t snx_fwd_lds_bytes(int K, int own, int parked_slots, int vec_bytes) {
     return (size_t)4 * 64 * parked_slots * vec_bytes  // parked item: [wave][slot][lane]
@@ -89,10 +107,10 @@ __host__ __device__ inline size_t snx_fwd_lds_bytes(int K, int own, int parked_s
            + (size_t)2 * own * sizeof(SnxFwdState)    // own planes of the parked item / the item in flight
            + 16;                                      // "this workgroup gave up" flag
 }
-__host__ __device__ inline size_t snx_bwd_lds_bytes(int K, int own, int parked_slots, int vec_bytes) {
+__host__ __device__ inline size_t snx_bwd_lds_bytes(int K, int own, int parked_slots, int vec_bytes, bool cn = false, int N = 0) {
     return (size_t)4 * 64 * parked_slots * vec_bytes + align16((size_t)K * kSnxVals * 4)
-           + (size_t)2 * own * sizeof(SnxBwdState)    // items t, t+1 (the rows of item t+2 wait in registers)
-           + 16;
+           + (size_t)2 * own * (cn ? sizeof(SnxBwdStateCn) : sizeof(SnxBwdState))  // items t, t+1 (the rows of item t+2 wait in registers)
+           + 16 + (cn ? align16((size_t)N * 4) : 0);  // (CN: the inverse batch permutation)
 }
 
 // Chan merge of the K members' partials of channel c: every wave does it for itself (wave-uniform result)
@@ -724,11 +742,37 @@ struct SnxBwdKargs {
     const double* saved;
     unsigned* ctl;
 };
+// CN variant: + the per-plane sums every member publishes for the plane that LENT it its statistics, the batch permutation
+// (device array, or as a launch argument: PermInline)
+template <typename T>
+struct SnxBwdKargsCn {
+    SnxBwdKargs<T> sn;
+    unsigned long long* gran_p;  // (C, N) planes x {sum G, sum G*(x - float(mu_c))}: 2 tagged granules or 1 untagged pair each
+    const int64_t* perm;
+    PermInline pin;
+};
 
-template <typename T, int VEC, int NV, int PPW, bool EPI>
+// ---- CrossNorm (un-boxed) in front of SelfNorm, backward (round 4) ------------------------------------------------------------
+// With CrossNorm a plane (n, c) takes its statistics from plane q = perm[n] of the same channel (models/cnsn.py:62-68, the
+// style source is not detached), so its gradient has a second contribution: what the plane r = perm^-1[n] that BORROWED
+// (n, c)'s statistics sends back (Emu, Esig of bwd_plane).  The general cluster kernels therefore hand every plane's two sums
+// to every member, stage the 15 `saved` rows of all N planes (30 KB per item and member: 0.5 GB of L2 reads per backward at
+// the north-star shape) and repeat the algebra of the whole channel in every member.  None of that is needed: the only
+// batch-wide quantities are still the two sums of the BatchNorm1d backward, which are sums of per-plane terms — a member
+// publishes its PARTIAL of them exactly as without CrossNorm (round A) — and the borrower's terms follow from the borrower's
+// two sums and its own `saved` rows.  So a member additionally publishes its planes' sums as point-readable granules (gran_p),
+// and lane s fetches, for plane s of its wave, the rows of the borrower (known for the whole launch: the permutation is per
+// batch) together with the item's own rows, two items ahead; after the gather it reads the borrower's granule — published
+// before the borrower's member published its partial, which the gather has just seen —, re-derives the borrower's dt and
+// runs bwd_plane a second time.  ONE exchange round, one workgroup barrier per item, no staged rows.  Same algebra functions
+// as every other strategy (cnsn_algebra.h); the batch sums are merged in another order than the general kernels do it.
+template <typename T, int VEC, int NV, int PPW, bool EPI, bool CN = false>
 __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int)sizeof(T))) void resident_sn_bwd_kernel(
-    SnxBwdKargs<T>) {
-    using KA = SnxBwdKargs<T>;
+    std::conditional_t<CN, SnxBwdKargsCn<T>, SnxBwdKargs<T>>) {
+    static_assert(!(CN && EPI), "CrossNorm with the residual-block epilogue runs the general kernels");
+    using KA = SnxBwdKargs<T>;  // (CN: the first member of the kernel's argument, at the same offsets)
+    using KAC = SnxBwdKargsCn<T>;
+    using St = std::conditional_t<CN, SnxBwdStateCn, SnxBwdState>;
 #define KA_ (kargs_now<KA>())
     constexpr int OWN = 4 * PPW;
     constexpr int SLOTS = 2 * PPW * NV;
@@ -742,8 +786,10 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
     const bool has_add = EPI && ka0->addend != nullptr;
     Raw<T, VEC>* park = (Raw<T, VEC>*)smem;
     float* vals = (float*)(smem + (size_t)4 * 64 * NPARK * VB);
-    SnxBwdState* state = (SnxBwdState*)((char*)vals + align16((size_t)K * kSnxVals * 4));  // [2][OWN]
+    St* state = (St*)((char*)vals + align16((size_t)K * kSnxVals * 4));  // [2][OWN]
     int* gave_up = (int*)(state + 2 * OWN);
+    int* iperm = gave_up + 4;  // (CN) [N]: plane iperm[n] borrowed the statistics of plane n
+    (void)iperm;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const PlaneIo<T, VEC, NV> sg(ka0->ra, N, C, lane);
@@ -768,8 +814,14 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
     } ra{ka0->ra.prof};
 #endif
 
+    if constexpr (CN) {
+        const KAC* kc = kargs_now<KAC>();
+        for (int n = threadIdx.x; n < N; n += kBlock) iperm[perm_at(kc->perm, kc->pin, n)] = n;
+    }
     if (threadIdx.x == 0) *gave_up = 0;
     __syncthreads();
+    int r_l = 0;  // (CN) lane s: the instance whose plane borrowed the statistics of plane s of this wave — the same for every item
+    if constexpr (CN) r_l = iperm[nl];
     startup_skew(ka0->ra);
     snx_set_priority();
 
@@ -810,7 +862,32 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
     auto sums_publish = [&](int item, int buf) {
         const int c = __builtin_amdgcn_readfirstlane(item);
         snx_phase_fence();
-        SnxBwdState* st = state + buf * OWN;
+        St* st = state + buf * OWN;
+        // (CN) the CrossNorm rows of this lane's plane and the rows of its borrower: issued here, used behind the sums
+        SnxCnRows cr{};
+        SnxBorrower br{};
+        if constexpr (CN) {
+            const double* saved = KA_->saved;
+            const SvRec p = sv_rec(nl, c, N), pb = sv_rec(r_l, c, N);
+            cr.mu_p = (float)saved[sv_at(p, SV_MU_P)];
+            cr.aa = (float)saved[sv_at(p, SV_A)];
+            cr.a1 = (float)saved[sv_at(p, SV_A1)];
+            cr.m_in = (float)saved[sv_at(p, SV_M_IN)];
+            cr.sig_c = (float)saved[sv_at(p, SV_SIG_C)];
+            cr.M2c = (float)saved[sv_at(p, SV_M2C)];
+            cr.mu_s = saved[sv_at(p, SV_MU_S)];
+            cr.sig_s = (float)saved[sv_at(p, SV_SIG_S)];
+            br.mu_c = saved[sv_at(pb, SV_MU_C)];
+            br.zh = saved[sv_at(pb, SV_ZH_G)];
+            br.g = (float)saved[sv_at(pb, SV_G)];
+            br.sig_p = (float)saved[sv_at(pb, SV_SIG_P)];
+            br.mu_p = (float)saved[sv_at(pb, SV_MU_P)];
+            br.aa = (float)saved[sv_at(pb, SV_A)];
+            br.a1 = (float)saved[sv_at(pb, SV_A1)];
+            br.m_in = (float)saved[sv_at(pb, SV_M_IN)];
+            br.sig_c = (float)saved[sv_at(pb, SV_SIG_C)];
+            br.M2c = (float)saved[sv_at(pb, SV_M2C)];
+        }
         const int relu = EPI ? KA_->relu : 0;
         const PlaneIo<T, VEC, NV> sg(KA_->ra, 1, 1, lane);  // (only the slot validity is used here)
         const bool has_add = EPI && KA_->addend != nullptr;
@@ -860,7 +937,10 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
             const MidArgs a = KA_->ra.mid;
             const BwdSumsT<float> sm = fix_sums<float>(a, my_s1, my_s2, 0.f, 0.f, row_mu, 0.0);
             float dtg, dtf;
-            gate_dt<float>(a, sm, 1.f, mu_l, 0.f, mu_l, g_l, 1.f, dtg, dtf);
+            if constexpr (CN)
+                gate_dt<float>(a, sm, cr.a1, cr.m_in, 0.f, cr.mu_p, g_l, 1.f, dtg, dtf);
+            else
+                gate_dt<float>(a, sm, 1.f, mu_l, 0.f, mu_l, g_l, 1.f, dtg, dtf);
             SnxBwdState r;
             r.mu_c = row_mu;
             r.zh = row_zh;
@@ -869,7 +949,23 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
             r.sig_p = (float)row_sig;
             r.s1 = my_s1;
             r.s2 = my_s2;
-            if (lane < PPW) st[wave * PPW + lane] = r;
+            if constexpr (CN) {
+                if (lane < PPW) st[wave * PPW + lane] = SnxBwdStateCn{r, cr, br};
+                // this plane's sums, point-readable for the member that owns the plane which LENT it its statistics
+                if (lane < PPW && n0 + lane < N) {
+                    const KAC* kc = kargs_now<KAC>();
+                    const unsigned epoch = kc->sn.ra.epoch;
+                    const size_t pi = (size_t)c * N + (size_t)(n0 + lane);
+                    if (epoch) {
+                        put_tagged(kc->gran_p + 2 * pi, my_s1, epoch);
+                        put_tagged(kc->gran_p + 2 * pi + 1, my_s2, epoch);
+                    } else {
+                        put_granule(kc->gran_p + pi, my_s1, my_s2);
+                    }
+                }
+            } else {
+                if (lane < PPW) st[wave * PPW + lane] = r;
+            }
         }
         __syncthreads();
         if (wave == 0) {
@@ -877,11 +973,11 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
             double sa = 0.0, sb = 0.0;
             if constexpr (OWN <= 8) {  // (wave-uniform arithmetic)
                 for (int i = 0; i < cnt; ++i) {
-                    sa += st[i].dt;
-                    sb += st[i].dt * st[i].zh;
+                    sa += snx_sn(st[i]).dt;
+                    sb += snx_sn(st[i]).dt * snx_sn(st[i]).zh;
                 }
             } else {  // lane i takes plane i of the member (OWN <= 64)
-                const SnxBwdState* ri = st + (lane < OWN ? lane : 0);
+                const SnxBwdState* ri = &snx_sn(st[lane < OWN ? lane : 0]);
                 const double di = lane < cnt ? ri->dt : 0.0;
                 sa = wave_sum_d(di);
                 sb = wave_sum_d(di * ri->zh);
@@ -978,22 +1074,87 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
             float pdw0 = 0.f, pdw1 = 0.f;
             {   // lane s < PPW takes plane s of this wave (the others repeat plane 0); the four dx coefficients stay in
                 // registers and reach the apply loop through v_readlane
-                const SnxBwdState r = state[b0 * OWN + wave * PPW + sl];
+                const St rec = state[b0 * OWN + wave * PPW + sl];
+                const SnxBwdState r = snx_sn(rec);
                 const float mu = (float)r.mu_c;
+                const bool mine = lane < nlive;  // (nlive <= PPW)
                 const BwdSumsT<float> sm = fix_sums<float>(a, r.s1, r.s2, 0.f, 0.f, r.mu_c, 0.0);
-                const BwdPlaneT<float> o =
-                    bwd_plane<float>(a, b, sm, r.dt, 0.0, r.zh, 0.0, r.g, 1.f, 1.f, 1.f, mu, mu, r.sig_p, 1.f, 0.f);
-                const BwdCoefs cf = bwd_coefs<float>(a, o, 0.f, 0.f, r.g, 1.f, mu, mu, r.mu_c, 1.f, r.mu_c, 1.f);
+                BwdPlaneT<float> o;
+                BwdCoefs cf;
+                float mu_p = mu;  // post-CrossNorm plane mean: SelfNorm's input statistic (the Conv1d tap gradient's factor)
+                if constexpr (CN) {
+                    const SnxCnRows& cr = rec.cn;
+                    const SnxBorrower& br = rec.br;
+                    mu_p = cr.mu_p;
+                    o = bwd_plane<float>(a, b, sm, r.dt, 0.0, r.zh, 0.0, r.g, 1.f, cr.aa, cr.a1, cr.m_in, cr.mu_p, r.sig_p, cr.sig_c,
+                                         cr.M2c);
+                    // the borrower's two sums: published by its member before that member's partial, which the gather has seen
+                    const KAC* kc = kargs_now<KAC>();
+                    const unsigned epoch = kc->sn.ra.epoch;
+                    const unsigned long long* gp = kc->gran_p;
+                    const size_t pi = (size_t)c * N + (size_t)r_l;
+                    float s1r = 0.f, s2r = 0.f;
+                    bool failed = false;
+                    long long t_start = 0;
+                    for (unsigned spins = 0;; ++spins) {
+                        bool ok = true;
+                        if (mine) {
+                            if (epoch) {
+                                const unsigned long long q0 = __hip_atomic_load((gu64*)(gp + 2 * pi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const unsigned long long q1 = __hip_atomic_load((gu64*)(gp + 2 * pi + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                ok = (unsigned)(q0 >> 32) == epoch && (unsigned)(q1 >> 32) == epoch;
+                                s1r = __uint_as_float((unsigned)q0);
+                                s2r = __uint_as_float((unsigned)q1);
+                            } else {
+                                const unsigned long long q0 = __hip_atomic_load((gu64*)(gp + pi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                ok = q0 != kGranuleEmpty;
+                                s1r = __uint_as_float((unsigned)q0);
+                                s2r = __uint_as_float((unsigned)(q0 >> 32));
+                            }
+                        }
+                        if (__all(ok)) break;
+                        __builtin_amdgcn_s_sleep(CNSN_POLL_SLEEP);
+                        if ((spins & 15u) == 15u) {
+                            const long long now = (long long)wall_clock64();
+                            if (t_start == 0) t_start = now;
+                            unsigned* ctl = kc->sn.ctl;
+                            const unsigned ctl_idle = kc->sn.ra.ctl_idle;
+                            const unsigned seen = __hip_atomic_load((gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (seen != ctl_idle || now - t_start > kc->sn.ra.wait_ticks) {
+                                if (seen == ctl_idle && lane == 0) {
+                                    const unsigned prev = __hip_atomic_exchange((gu32*)ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    unsigned* host_flag = kc->sn.ra.host_flag;
+                                    if (prev == ctl_idle && host_flag)
+                                        __hip_atomic_fetch_add(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                }
+                                failed = true;
+                                break;
+                            }
+                        }
+                    }
+                    const BwdSumsT<float> smr = fix_sums<float>(a, s1r, s2r, 0.f, 0.f, br.mu_c, 0.0);
+                    float dtr, dtr_f;
+                    gate_dt<float>(a, smr, br.a1, br.m_in, 0.f, br.mu_p, br.g, 1.f, dtr, dtr_f);
+                    const BwdPlaneT<float> src = bwd_plane<float>(a, b, smr, (double)dtr, 0.0, br.zh, 0.0, br.g, 1.f, br.aa, br.a1,
+                                                                  br.m_in, br.mu_p, br.sig_p, br.sig_c, br.M2c);
+                    cf = bwd_coefs<float>(a, o, src.Emu, src.Esig, r.g, cr.a1, cr.m_in, cr.mu_p, r.mu_c, cr.sig_c, cr.mu_s, cr.sig_s);
+                    if (failed) {  // the launch gives up: this wave's planes come out as NaNs, the workgroup leaves at its next gather
+                        cf.c0_in = __builtin_nanf("");
+                        if (lane == 0) *gave_up = 1;
+                    }
+                } else {
+                    o = bwd_plane<float>(a, b, sm, r.dt, 0.0, r.zh, 0.0, r.g, 1.f, 1.f, 1.f, mu, mu, r.sig_p, 1.f, 0.f);
+                    cf = bwd_coefs<float>(a, o, 0.f, 0.f, r.g, 1.f, mu, mu, r.mu_c, 1.f, r.mu_c, 1.f);
+                }
                 cG_l = cf.cG_in;
                 cX_l = cf.cX_in;
                 xr_l = cf.xr_in;
                 c0_l = cf.c0_in;
-                const bool mine = lane < nlive;  // (nlive <= PPW)
                 if constexpr (PPW == 1) {
-                    pdw0 = nlive > 0 ? o.dz_g * mu : 0.f;  // (wave-uniform)
+                    pdw0 = nlive > 0 ? o.dz_g * mu_p : 0.f;  // (wave-uniform)
                     pdw1 = nlive > 0 ? o.dz_g * r.sig_p : 0.f;
                 } else {
-                    pdw0 = wave_sum(mine ? o.dz_g * mu : 0.f);
+                    pdw0 = wave_sum(mine ? o.dz_g * mu_p : 0.f);
                     pdw1 = wave_sum(mine ? o.dz_g * r.sig_p : 0.f);
                 }
             }

@@ -266,7 +266,8 @@ enum cnsn_path {
     CNSN_PATH_MONO = 4       /* one launch, a whole channel per workgroup (registers)     */
 };
 int cnsn_which_path(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int has_chan_perm, int backward);
-/* Refinement of CNSN_PATH_RESIDENT: 1 when the call runs the SelfNorm-only cluster kernels (models/cnsn.py:130-150 with
+/* Refinement of CNSN_PATH_RESIDENT: 1 when the call runs the partial-moment cluster kernels (SelfNorm alone; since ABI 5 also the
+ * backward of un-boxed CrossNorm + SelfNorm) (models/cnsn.py:130-150 with
  * no CrossNorm armed — every ResNet-50 / WideResNet site on an idle step): the workgroups of a channel exchange PARTIAL
  * batch moments of BatchNorm1d's input (:121,138) instead of every plane's statistics.  0 otherwise, < 0 argument error. */
 int cnsn_sn_cluster_plan(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int backward);
