@@ -114,3 +114,57 @@ def test_many_channels_and_auto(forced):
     assert cnsn_amd.sn_cluster(torch.empty(256, 256, 56, 56, device=DEV, dtype=torch.bfloat16), cfg, backward=True)
     assert not cnsn_amd.sn_cluster(torch.empty(256, 256, 56, 56, device=DEV), cnsn_amd.FusedConfig(
         cn_active=True, sn_active=True, style_box=(0, 0, 9, 9)), backward=True)               # crop boxes: the general kernels
+
+
+_GIVE_UP = r'''
+import os, sys, torch, numpy as np
+sys.path.insert(0, %r)
+import cnsn_amd
+from cnsn_amd import _ffi
+cnsn_amd.follow_environ()
+from tests.golden.gen_golden_fill import fill_sn
+dev = torch.device("cuda:0")
+torch.manual_seed(0); np.random.seed(0)
+x0 = torch.randn(64, 8, 56, 56, device=dev)
+gy = torch.randn(64, 8, 56, 56, device=dev)
+perm = torch.randperm(64)
+def run(strategy, inject=False):
+    cnsn_amd.set_strategy(strategy)
+    mod = cnsn_amd.CNSN(cnsn_amd.CrossNorm("neither", 1), fill_sn(cnsn_amd.SelfNorm(8), 3, torch.float32)).to(dev).train()
+    mod.crossnorm.active = True
+    mod.crossnorm.next_draws = cnsn_amd.CNDraws(perm)
+    x = x0.clone().requires_grad_()
+    y = mod(x)
+    torch.cuda.synchronize()
+    os.environ["CNSN_FAULT_INJECT"] = "1" if inject else "0"
+    y.backward(gy)
+    torch.cuda.synchronize()
+    os.environ["CNSN_FAULT_INJECT"] = "0"
+    return x.grad
+cfg = cnsn_amd.FusedConfig(cn_active=True, sn_active=True)
+assert cnsn_amd.sn_cluster(x0, cfg, backward=True)
+ref = run("two_pass")
+good = run("auto")
+assert float((good - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+bad = run("auto", inject=True)                   # a member never publishes its partial: the launch gives up, no trap
+assert _ffi.lib().cnsn_resident_timeouts() == 1 and torch.isnan(bad).any()
+try:
+    run("auto")
+    raise SystemExit("the time-out was not reported")
+except cnsn_amd.CnsnError as e:
+    assert "timed out" in str(e)
+assert not cnsn_amd.sn_cluster(x0, cfg, backward=True)
+assert torch.equal(run("auto"), ref)
+print("CN-GIVE-UP-OK")
+'''
+
+
+def test_a_launch_that_cannot_complete_gives_up_without_trapping():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for ctx in ("1", "0"):
+        env = dict(os.environ, CNSN_WAIT_MS="200", CNSN_CONTEXT=ctx)
+        env.pop("CNSN_SNXCN", None)
+        r = subprocess.run([sys.executable, "-c", _GIVE_UP % root], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and "CN-GIVE-UP-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
