@@ -96,7 +96,6 @@ struct SnxBorrower {
 struct SnxBwdStateCn {
     SnxBwdState sn;
     SnxCnRows cn;
-    SnxBorrower br;
 };
 __device__ __forceinline__ const SnxBwdState& snx_sn(const SnxBwdState& r) { return r; }
 __device__ __forceinline__ const SnxBwdState& snx_sn(const SnxBwdStateCn& r) { return r.sn; }
@@ -865,10 +864,9 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
         St* st = state + buf * OWN;
         // (CN) the CrossNorm rows of this lane's plane and the rows of its borrower: issued here, used behind the sums
         SnxCnRows cr{};
-        SnxBorrower br{};
         if constexpr (CN) {
             const double* saved = KA_->saved;
-            const SvRec p = sv_rec(nl, c, N), pb = sv_rec(r_l, c, N);
+            const SvRec p = sv_rec(nl, c, N);
             cr.mu_p = (float)saved[sv_at(p, SV_MU_P)];
             cr.aa = (float)saved[sv_at(p, SV_A)];
             cr.a1 = (float)saved[sv_at(p, SV_A1)];
@@ -877,16 +875,6 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
             cr.M2c = (float)saved[sv_at(p, SV_M2C)];
             cr.mu_s = saved[sv_at(p, SV_MU_S)];
             cr.sig_s = (float)saved[sv_at(p, SV_SIG_S)];
-            br.mu_c = saved[sv_at(pb, SV_MU_C)];
-            br.zh = saved[sv_at(pb, SV_ZH_G)];
-            br.g = (float)saved[sv_at(pb, SV_G)];
-            br.sig_p = (float)saved[sv_at(pb, SV_SIG_P)];
-            br.mu_p = (float)saved[sv_at(pb, SV_MU_P)];
-            br.aa = (float)saved[sv_at(pb, SV_A)];
-            br.a1 = (float)saved[sv_at(pb, SV_A1)];
-            br.m_in = (float)saved[sv_at(pb, SV_M_IN)];
-            br.sig_c = (float)saved[sv_at(pb, SV_SIG_C)];
-            br.M2c = (float)saved[sv_at(pb, SV_M2C)];
         }
         const int relu = EPI ? KA_->relu : 0;
         const PlaneIo<T, VEC, NV> sg(KA_->ra, 1, 1, lane);  // (only the slot validity is used here)
@@ -950,7 +938,7 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
             r.s1 = my_s1;
             r.s2 = my_s2;
             if constexpr (CN) {
-                if (lane < PPW) st[wave * PPW + lane] = SnxBwdStateCn{r, cr, br};
+                if (lane < PPW) st[wave * PPW + lane] = SnxBwdStateCn{r, cr};
                 // this plane's sums, point-readable for the member that owns the plane which LENT it its statistics
                 if (lane < PPW && n0 + lane < N) {
                     const KAC* kc = kargs_now<KAC>();
@@ -1029,6 +1017,22 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
             pw0 = ka->gg.w[2 * c], pw1 = ka->gg.w[2 * c + 1], pgam = ka->gg.gamma[c];
             prs = ka->saved[SV_ROWS * (size_t)N * C + c];
         }
+        // (CN) lane s: the `saved` rows of the plane that borrowed the statistics of plane s of item t — in flight during the gather
+        SnxBorrower br{};
+        if constexpr (CN) {
+            const double* saved = KA_->saved;
+            const SvRec pb = sv_rec(r_l, c, N);
+            br.mu_c = saved[sv_at(pb, SV_MU_C)];
+            br.zh = saved[sv_at(pb, SV_ZH_G)];
+            br.g = (float)saved[sv_at(pb, SV_G)];
+            br.sig_p = (float)saved[sv_at(pb, SV_SIG_P)];
+            br.mu_p = (float)saved[sv_at(pb, SV_MU_P)];
+            br.aa = (float)saved[sv_at(pb, SV_A)];
+            br.a1 = (float)saved[sv_at(pb, SV_A1)];
+            br.m_in = (float)saved[sv_at(pb, SV_M_IN)];
+            br.sig_c = (float)saved[sv_at(pb, SV_SIG_C)];
+            br.M2c = (float)saved[sv_at(pb, SV_M2C)];
+        }
 
         // ---- gather round A of item t's channel
         unsigned passes_ = 0;
@@ -1084,7 +1088,6 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
                 float mu_p = mu;  // post-CrossNorm plane mean: SelfNorm's input statistic (the Conv1d tap gradient's factor)
                 if constexpr (CN) {
                     const SnxCnRows& cr = rec.cn;
-                    const SnxBorrower& br = rec.br;
                     mu_p = cr.mu_p;
                     o = bwd_plane<float>(a, b, sm, r.dt, 0.0, r.zh, 0.0, r.g, 1.f, cr.aa, cr.a1, cr.m_in, cr.mu_p, r.sig_p, cr.sig_c,
                                          cr.M2c);

@@ -4,7 +4,7 @@ set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 csrc=$root/crossnorm-selfnorm_amd/csrc
-out=$root/tools/dbg; mkdir -p $out
+out=$root/scratch; mkdir -p $out
 for u in cnsn_mono cnsn_mono_tail; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $csrc/$u.hip -o $out/${u}_$name.o &
 done
