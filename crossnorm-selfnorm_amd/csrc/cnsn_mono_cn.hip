@@ -91,7 +91,9 @@ MonoPlan mono_cn_plan(const Plan& pl, bool has_chan_perm, int add, bool backward
         // un-boxed calls the cluster kernels can take: with fewer than ~96 planes per channel one workgroup per channel is
         // under-filled and the cluster kernels win — (64,1024,14,14) bf16 0.099 vs 0.067 ms, fp32 0.107 vs 0.088 on two
         // boxes; at N = 96 / 128 the two are within noise of each other, at 256 mono leads (profiles/r02_auto_audit.md)
-        if (!pl.boxed && p.N < 96 && resident_plan(p, false, has_chan_perm, backward).ok) return mp;
+        // (round 4, tools/auto_audit.py on two boxes: at N = 96 the cluster kernels lead by 10 % in fp32 and 19 % in bf16 at
+        //  (96,1024,14,14); at N = 128 by 5 % at (128,64,16,16) fp32 — the threshold moved from 96 to 128)
+        if (!pl.boxed && p.N < 128 && resident_plan(p, false, has_chan_perm, backward).ok) return mp;
     }
     mp.vec = vec;
     mp.lpp = lpp;

@@ -202,6 +202,9 @@ static inline ResPlan plan_impl(const cnsn_problem_t& p, bool boxed, bool has_ch
             if (!ok16) return rp;
         }
         if (epi && p.dtype != CNSN_F32 && rp.nv > 8) return rp;  // (those instantiations spill registers)
+        // fp32 64x64 planes (16 slots) WITH crop boxes at small batches (segmentation: N = 16, K = 4 members per channel): two-pass
+        // is 8-16 % faster on both boxes of tools/auto_audit.py (round 4) — the boxed algebra of a 16-slot item is the cycle
+        if (!epi && boxed && p.dtype == CNSN_F32 && rp.nv == 16 && p.N <= 32) return rp;
         // POST forward of the 16-bit 56x56 class: two-pass 0.283 vs 0.304 ms at (256,256,56,56) (profiles/r02_post_add.md)
         if (post && !backward && p.dtype != CNSN_F32 && rp.nv == 7 && p.sn_training) return rp;
     }

@@ -15,7 +15,8 @@ bool resident_sn_prefers(const cnsn_problem_t& p, bool boxed, int add, int relu,
     // one-slot planes (the 14x14 class), same-process A/B against what AUTO ran before (mono up to N = 256, local beyond):
     // bf16 N = 512: forward -42 %, backward -56 %; fp32 N = 256: forward -2..-4 %, backward -17..-24 %; bf16 N <= 256: the
     // channel-in-registers kernels stay ahead (forward +20..+39 %, backward -15..+7 %)
-    return p.N >= 384 || (elem_bytes(p.dtype) == 4 && backward && p.N >= 256);
+    // round 4 (tools/auto_audit.py, two boxes): fp32 N = 256 forward too: -3.3 % / -3.5 % for the call at (256,1024,14,14)
+    return p.N >= 384 || (elem_bytes(p.dtype) == 4 && p.N >= 256);
 }
 
 size_t resident_sn_exchange_bytes(const cnsn_problem_t& p) {

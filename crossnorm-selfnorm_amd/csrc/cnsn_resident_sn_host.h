@@ -69,8 +69,9 @@ constexpr bool snx_cn_built(int nv, int eb, int vb) { return vb == 16 && nv >= 7
 //   fp32  40x40 (7 slots) -4 %, 56x56 (13) level at N = 256 on a box whose memory floor the general kernel already reaches,
 //         -3 % at N = 96, 64x64 (16) -6..-12 %                                   -> every fp32 class
 //   16 bit 56x56 (7 slots) -6 % at N = 256, -5 % at N = 96; 64x64 (8 slots) -9 % at N = 16 but +3..+6 % at N = 64
-//         -> 7 slots always, 8 slots for small batches; 13 / 16 slots unmeasured: the general kernels
-constexpr bool snx_cn_auto(int nv, int eb, int N) { return eb == 4 || nv == 7 || (nv == 8 && N <= 32); }
+//         (and level or +4..+8 % for the whole call at N = 16 in tools/auto_audit.py on another box)
+//         -> 7 slots always; 8 / 13 / 16 slots: the general kernels
+constexpr bool snx_cn_auto(int nv, int eb, int N) { return eb == 4 || nv == 7; }
 
 // CNSN_SNX=0: never; 2: wherever instantiated (tests); default 1: AUTO rule
 inline int snx_mode() {
@@ -179,7 +180,8 @@ inline SnxPlan plan_impl(const cnsn_problem_t& p, bool boxed, int add, int relu,
     // 56x56 class at small batches (N = 96: +9 %, N = 256: -7 %).  One-slot planes: see resident_sn_prefers.
     if (mode != 2 && !epi) {
         if (!backward && eb == 4 && sp.nv == 4) return none;
-        if (backward && eb == 2 && sp.nv == 7 && p.N < 128) return none;
+        // (round 3 kept the 16-bit 56x56 backward at N < 128 with the general kernels: +9 % at N = 96 then; since the launches
+        //  run back to back — round 4 — it is 7 % FASTER for the whole call on both audited boxes: the exclusion is gone)
     }
     // the CrossNorm-capable backward, AUTO: the classes measured against the general (pipelined) cluster backward on MI355X
     // (profiles/r04_cn_partial_moments.md)

@@ -23,11 +23,14 @@ TABLE = [
     ((256, 512, 28, 28), BF16, FC(**SN, **BOTH), "resident", "resident"),      # <= 4 slots: always resident
     ((256, 1024, 14, 14), BF16, FC(**SN), "mono", "mono"),                     # a channel = 100 KiB: one workgroup's registers
     ((256, 1024, 14, 14), BF16, FC(**BLOCK), "mono", "mono"),
-    ((256, 1024, 14, 14), F32, FC(**SN), "mono", "resident"),                  # fp32 backward: G and x = 128 VGPRs per lane
+    ((256, 1024, 14, 14), F32, FC(**SN), "resident", "resident"),              # fp32 N = 256: the one-slot cluster kernels, both directions (round 4 audit)
     ((96, 1024, 14, 14), BF16, FC(**SN), "mono", "mono"),
     ((256, 1024, 14, 14), BF16, FC(**SN, **CN), "mono", "mono"),               # CrossNorm inside the channel's workgroup
     ((64, 1024, 14, 14), BF16, FC(**SN, **CN), "resident", "resident"),        # fewer than 96 planes per channel, un-boxed: the cluster kernels
-    ((96, 1024, 14, 14), BF16, FC(**SN, **CN), "mono", "mono"),
+    ((96, 1024, 14, 14), BF16, FC(**SN, **CN), "resident", "resident"),        # below 128 planes per channel (round 4 audit: -19 %)
+    ((128, 1024, 14, 14), BF16, FC(**SN, **CN), "mono", "mono"),
+    ((16, 512, 64, 64), F32, FC(**SN, **BOTH), "streaming", "streaming"),      # fp32 64x64 with crop boxes at N <= 32: two-pass (round 4 audit: -8..-16 %)
+    ((64, 512, 64, 64), F32, FC(**SN, **BOTH), "resident", "resident"),
     ((64, 1024, 14, 14), BF16, FC(**SN, **BOTH), "mono", "mono"),              # with crop boxes the channel-in-registers kernels keep it
     ((256, 2048, 7, 7), F32, FC(**SN, **CN), "mono", "mono"),                  # CrossNorm without boxes: the channel-group kernels (round 3)
     ((256, 1024, 14, 14), BF16, FC(**SN, **BOTH), "mono", "mono"),             # (was packed two-pass: vectors straddle rows)

@@ -276,6 +276,6 @@ def test_auto_takes_the_resnet50_blocks():
     x = torch.empty((512, 64, 14, 14), device="cuda", dtype=torch.bfloat16)
     assert cnsn_amd.sn_cluster(x, cfg_of()) and cnsn_amd.sn_cluster(x, cfg_of("pre", True), backward=True)
     x = torch.empty((256, 64, 14, 14), device="cuda", dtype=torch.float32)
-    assert cnsn_amd.sn_cluster(x, cfg_of(), backward=True) and not cnsn_amd.sn_cluster(x, cfg_of())
+    assert cnsn_amd.sn_cluster(x, cfg_of(), backward=True) and cnsn_amd.sn_cluster(x, cfg_of())   # (forward too since round 4)
     x = torch.empty((256, 64, 14, 14), device="cuda", dtype=torch.bfloat16)
     assert not cnsn_amd.sn_cluster(x, cfg_of()) and not cnsn_amd.sn_cluster(x, cfg_of(), backward=True)
