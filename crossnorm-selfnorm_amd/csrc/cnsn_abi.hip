@@ -289,9 +289,9 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
                                   gate_grad_dev(dg), workspace, stream);
         if (st != CNSN_E_UNSUPPORTED) return st;
     }
-    if (resident_sn_cn_plan(p, pl.boxed, chan_perm != nullptr).ok) {  // un-boxed CrossNorm + SelfNorm: partial batch sums exchanged
-        st = resident_sn_cn_backward(pl.pr, pl.mid, grad_y, x, perm, gate_dev(g), saved_d, grad_x, gate_grad_dev(dg), workspace,
-                                     stream);
+    if (resident_sn_cn_plan(p, pl.boxed, chan_perm != nullptr).ok) {  // CrossNorm + SelfNorm: partial batch sums exchanged
+        st = resident_sn_cn_backward(pl.pr, pl.cb, pl.sb, pl.boxed, pl.mid, grad_y, x, perm, gate_dev(g), saved_d, grad_x,
+                                     gate_grad_dev(dg), workspace, stream);
         if (st != CNSN_E_UNSUPPORTED) return st;
     }
     if (resident_plan(p, pl.boxed, p.cn_active && chan_perm != nullptr, true).ok) {

@@ -27,7 +27,8 @@ int resident_sn_backward(const cnsn_problem_t& p, const MidArgs& mid, int add, i
 // channel permutation, one gate, no epilogue) in the partial-moment cluster kernels: ok only for that call.  `perm`: device
 // array or NULL with cnsn_problem_t.perm_host (launch argument).
 SnxPlan resident_sn_cn_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_perm);
-int resident_sn_cn_backward(const cnsn_problem_t& p, const MidArgs& mid, const void* gy, const void* x, const int64_t* perm,
-                            GateDev g, const double* saved, void* dx, GateGradDev dg, void* workspace, hipStream_t stream);
+int resident_sn_cn_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* gy, const void* x,
+                            const int64_t* perm, GateDev g, const double* saved, void* dx, GateGradDev dg, void* workspace,
+                            hipStream_t stream);
 
 }  // namespace cnsn

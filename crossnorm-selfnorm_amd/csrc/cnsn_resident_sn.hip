@@ -22,7 +22,8 @@ bool resident_sn_prefers(const cnsn_problem_t& p, bool boxed, int add, int relu,
 size_t resident_sn_exchange_bytes(const cnsn_problem_t& p) {
     // (the largest a plan can ask for: the backward with the fewest planes per workgroup)
     const int K = (p.N + 3) / 4;
-    return snxhost::tagged_bytes(p, K, true);
+    const bool cn = p.cn_active && p.sn_active;  // (the CrossNorm-capable backward: + per-plane sums, four with crop boxes)
+    return snxhost::tagged_bytes(p, K, true, cn, cn);
 }
 
 int resident_sn_forward(const cnsn_problem_t& p, const MidArgs& mid, int add, int relu, const void* x, const void* addend,

@@ -63,13 +63,14 @@ SnxPlan resident_sn_cn_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_p
     return snxhost::plan_impl(p, boxed, ADD_NONE, 0, true, true);
 }
 
-int resident_sn_cn_backward(const cnsn_problem_t& p, const MidArgs& mid, const void* gy, const void* x, const int64_t* perm,
-                            GateDev g, const double* saved, void* dx, GateGradDev dg, void* workspace, hipStream_t stream) {
-    const SnxPlan sp = snxhost::plan_impl(p, false, ADD_NONE, 0, true, true);
+int resident_sn_cn_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* gy, const void* x,
+                            const int64_t* perm, GateDev g, const double* saved, void* dx, GateGradDev dg, void* workspace,
+                            hipStream_t stream) {
+    const SnxPlan sp = snxhost::plan_impl(p, boxed, ADD_NONE, 0, true, true);
     if (!sp.ok) return CNSN_E_UNSUPPORTED;
     PermInline* pin = perm_inline_scratch();
     if (const int ps = perm_inline_fill(p, perm, pin)) return ps;
-    ResArgs ra = snxhost::make_args(p, mid, sp);
+    ResArgs ra = reshost::make_args(p, cb, sb, mid, ResPlan{true, sp.vec, sp.nv, sp.ppw, sp.K});
 #ifdef CNSN_PROF
     if (knob(K_PROF)) ra.prof = (unsigned long long*)((char*)workspace + (4u << 20));
 #endif
@@ -79,32 +80,38 @@ int resident_sn_cn_backward(const cnsn_problem_t& p, const MidArgs& mid, const v
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value, NV = decltype(nt)::value, PPW = decltype(pt)::value;
         if constexpr (snxhost::snx_cn_built(NV, (int)sizeof(T), VEC * (int)sizeof(T))) {
-            auto kern = resident_sn_bwd_kernel<T, VEC, NV, PPW, false, true>;
-            if (!allow_dynamic_lds(kern, lds)) return;
-            const int grid = reshost::grid_for(kern, lds, sp.K, ra.items);
-            if (grid < sp.K) return;
-            ResidentChain chain(stream);
-            const ExchangeArea ea = resident_exchange_area(p, snxhost::tagged_bytes(p, sp.K, true, true), workspace, stream, true);
-            ra.epoch = ea.epoch;
-            ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
-            unsigned* ctl = (unsigned*)ea.base;
-            unsigned long long* gran = (unsigned long long*)((char*)ea.base + kCtlBytes);
-            const size_t a_gran = (size_t)p.C * sp.K * (ea.epoch ? 4 : 2);
-            unsigned long long* gran_b = gran + ((a_gran + 32 + 31) & ~(size_t)31);
-            const size_t b_gran = (size_t)p.C * sp.K * 4 * (ea.epoch ? 2 : 1);
-            unsigned long long* gran_p = gran_b + ((b_gran + 31) & ~(size_t)31);  // per-plane sums behind round B
-            const size_t p_gran = (size_t)p.N * p.C * (ea.epoch ? 2 : 1);
-            hipError_t e = ea.epoch ? hipSuccess
-                                    : hipMemsetAsync(workspace, 0xff, (size_t)((char*)(gran_p + p_gran) - (char*)workspace), stream);
-            if (e != hipSuccess) {
-                status = (int)e;
-                return;
-            }
-            SnxBwdKargsCn<T> ka{{ra, sp.npark, (const T*)gy, (const T*)x, nullptr, 0, (T*)dx, g, dg, gran, gran_b, saved, ctl},
-                                gran_p, perm, *pin};
-            kern<<<grid, kBlock, lds, stream>>>(ka);
-            e = hipGetLastError();
-            status = e == hipSuccess ? CNSN_OK : (int)e;
+            auto launch = [&](auto kern) {
+                if (!allow_dynamic_lds(kern, lds)) return;
+                const int grid = reshost::grid_for(kern, lds, sp.K, ra.items);
+                if (grid < sp.K) return;
+                ResidentChain chain(stream);
+                const ExchangeArea ea =
+                    resident_exchange_area(p, snxhost::tagged_bytes(p, sp.K, true, true, boxed), workspace, stream, true);
+                ra.epoch = ea.epoch;
+                ra.ctl_idle = ea.epoch ? 0u : kCtlIdle;
+                unsigned* ctl = (unsigned*)ea.base;
+                unsigned long long* gran = (unsigned long long*)((char*)ea.base + kCtlBytes);
+                const size_t a_gran = (size_t)p.C * sp.K * (ea.epoch ? 4 : 2);
+                unsigned long long* gran_b = gran + ((a_gran + 32 + 31) & ~(size_t)31);
+                const size_t b_gran = (size_t)p.C * sp.K * 4 * (ea.epoch ? 2 : 1);
+                unsigned long long* gran_p = gran_b + ((b_gran + 31) & ~(size_t)31);  // per-plane sums behind round B
+                const size_t p_gran = (size_t)p.N * p.C * (ea.epoch ? 2 : 1) * (boxed ? 2 : 1);
+                hipError_t e = ea.epoch ? hipSuccess
+                                        : hipMemsetAsync(workspace, 0xff, (size_t)((char*)(gran_p + p_gran) - (char*)workspace), stream);
+                if (e != hipSuccess) {
+                    status = (int)e;
+                    return;
+                }
+                SnxBwdKargsCn<T> ka{{ra, sp.npark, (const T*)gy, (const T*)x, nullptr, 0, (T*)dx, g, dg, gran, gran_b, saved, ctl},
+                                    gran_p, perm, *pin};
+                kern<<<grid, kBlock, lds, stream>>>(ka);
+                e = hipGetLastError();
+                status = e == hipSuccess ? CNSN_OK : (int)e;
+            };
+            if (boxed)
+                launch(resident_sn_bwd_kernel<T, VEC, NV, PPW, false, true, true>);
+            else
+                launch(resident_sn_bwd_kernel<T, VEC, NV, PPW, false, true, false>);
         }
     });
     if (knob(K_DEBUG))

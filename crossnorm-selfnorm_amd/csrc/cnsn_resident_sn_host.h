@@ -72,6 +72,10 @@ constexpr bool snx_cn_built(int nv, int eb, int vb) { return vb == 16 && nv >= 7
 //         (and level or +4..+8 % for the whole call at N = 16 in tools/auto_audit.py on another box)
 //         -> 7 slots always; 8 / 13 / 16 slots: the general kernels
 constexpr bool snx_cn_auto(int nv, int eb, int N) { return eb == 4 || nv == 7; }
+// ... with crop boxes (profiles/r04_cn_partial_moments.md, "crop boxes"): fp32 56x56 -3 % at N = 256 (against the pipelined boxed
+// kernel), -7 % at N = 96, 40x40 level, 64x64 at N = 16 -26 % (against two-pass); 16-bit 56x56 -3 % at N = 256 against TWO-PASS
+// (3 instead of 5 tensor passes, but VALU-bound: 12 vector instructions per element in the apply), +3 % at N = 96
+constexpr bool snx_cn_boxed_auto(int nv, int eb, int N) { return eb == 4 || (nv == 7 && N >= 192); }
 
 // CNSN_SNX=0: never; 2: wherever instantiated (tests); default 1: AUTO rule
 inline int snx_mode() {
@@ -131,9 +135,10 @@ inline SnxPlan plan_impl(const cnsn_problem_t& p, bool boxed, int add, int relu,
     const int mode = cn ? (snx_mode() == 0 ? 0 : snx_cn_mode()) : snx_mode();
     if (mode == 0) return none;
     if (!(p.strategy == CNSN_STRATEGY_AUTO || p.strategy == CNSN_STRATEGY_RESIDENT)) return none;
-    if (boxed || (p.cn_active != 0) != cn || !p.sn_active || !p.sn_training || p.sn_two) return none;
+    if ((boxed && !cn) || (p.cn_active != 0) != cn || !p.sn_active || !p.sn_training || p.sn_two) return none;
     if (cn && (!backward || add != ADD_NONE || relu || p.N > kPermInlineMax)) return none;
-    if (cn && (pick_vec(p.dtype, p.H * p.W) * elem_bytes(p.dtype) != 16 || (p.H * p.W / pick_vec(p.dtype, p.H * p.W) + 63) / 64 < 5))
+    if (cn && (pick_vec(p.dtype, boxed ? p.W : p.H * p.W) * elem_bytes(p.dtype) != 16 ||
+               (p.H * p.W / pick_vec(p.dtype, boxed ? p.W : p.H * p.W) + 63) / 64 < 5))
         return none;  // (snx_cn_built: buckets of 7 slots and more)
     if (!(add == ADD_NONE || add == ADD_PRE)) return none;
     if (resident_timeouts() > 0) return none;
@@ -142,7 +147,7 @@ inline SnxPlan plan_impl(const cnsn_problem_t& p, bool boxed, int add, int relu,
     const bool epi = add != ADD_NONE || relu;
     const int M = p.H * p.W, eb = elem_bytes(p.dtype);
     SnxPlan sp = none;
-    sp.vec = pick_vec(p.dtype, M);
+    sp.vec = pick_vec(p.dtype, boxed ? p.W : M);  // (crop boxes: a vector must not straddle two rows)
     if ((size_t)p.N * p.C * M * eb >= ((size_t)1 << 31)) return none;  // one descriptor per tensor: see PlaneIo
     const int vb = sp.vec * eb;
     const int nvec = M / sp.vec;
@@ -185,7 +190,7 @@ inline SnxPlan plan_impl(const cnsn_problem_t& p, bool boxed, int add, int relu,
     }
     // the CrossNorm-capable backward, AUTO: the classes measured against the general (pipelined) cluster backward on MI355X
     // (profiles/r04_cn_partial_moments.md)
-    if (cn && mode != 2 && !snx_cn_auto(sp.nv, eb, p.N)) return none;
+    if (cn && mode != 2 && !(boxed ? snx_cn_boxed_auto(sp.nv, eb, p.N) : snx_cn_auto(sp.nv, eb, p.N))) return none;
     sp.npark = np;
     sp.ok = true;
     return sp;
@@ -199,8 +204,8 @@ inline ResArgs make_args(const cnsn_problem_t& p, const MidArgs& mid, const SnxP
 
 // exchange areas, in granules of 8 bytes: round A per member, round B per wave (backward only), the per-plane sums of the
 // CrossNorm-capable backward (two tagged granules per plane)
-inline size_t tagged_bytes(const cnsn_problem_t& p, int K, bool backward, bool cn = false) {
-    return kCtlBytes + (size_t)p.C * K * (backward ? 4 + 8 : 4) * 8 + 1024 + (cn ? (size_t)p.N * p.C * 2 * 8 + 256 : 0);
+inline size_t tagged_bytes(const cnsn_problem_t& p, int K, bool backward, bool cn = false, bool boxed = false) {
+    return kCtlBytes + (size_t)p.C * K * (backward ? 4 + 8 : 4) * 8 + 1024 + (cn ? (size_t)p.N * p.C * (boxed ? 4 : 2) * 8 + 256 : 0);
 }
 
 }  // namespace snxhost

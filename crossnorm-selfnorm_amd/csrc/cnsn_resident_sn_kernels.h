@@ -86,12 +86,13 @@ struct SnxBwdState {
 struct SnxCnRows {
     double mu_s;
     float mu_p, aa, a1, m_in, sig_c, M2c, sig_s;
+    float mu_o, s1o, s2o;  // with crop boxes: the saved mean outside the content box; sum G, sum G*(x - float(mu_o)) outside it
 };
 // CN variant of the backward: the record of an own plane carries its CrossNorm rows next to the SelfNorm ones
 // ... and the rows of the plane that BORROWED this plane's statistics (same channel, instance perm^-1[n])
 struct SnxBorrower {
     double mu_c, zh;
-    float g, sig_p, mu_p, aa, a1, m_in, sig_c, M2c;
+    float g, sig_p, mu_p, aa, a1, m_in, sig_c, M2c, mu_o;
 };
 struct SnxBwdStateCn {
     SnxBwdState sn;
@@ -765,10 +766,15 @@ struct SnxBwdKargsCn {
 // before the borrower's member published its partial, which the gather has just seen —, re-derives the borrower's dt and
 // runs bwd_plane a second time.  ONE exchange round, one workgroup barrier per item, no staged rows.  Same algebra functions
 // as every other strategy (cnsn_algebra.h); the batch sums are merged in another order than the general kernels do it.
-template <typename T, int VEC, int NV, int PPW, bool EPI, bool CN = false>
+// BOXED (round 4, CN only): crop boxes (models/cnsn.py:64-82).  Four sums per plane (inside the content box; the whole plane, from
+// which the outside follows by subtraction), a piecewise-affine dx with a third term inside the style box (11 coefficients),
+// membership of an element from one bit mask per lane and register slot (the same for every plane).
+template <typename T, int VEC, int NV, int PPW, bool EPI, bool CN = false, bool BOXED = false>
 __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int)sizeof(T))) void resident_sn_bwd_kernel(
     std::conditional_t<CN, SnxBwdKargsCn<T>, SnxBwdKargs<T>>) {
     static_assert(!(CN && EPI), "CrossNorm with the residual-block epilogue runs the general kernels");
+    static_assert(CN || !BOXED, "crop boxes belong to CrossNorm");
+    constexpr int NSP = BOXED ? 4 : 2;  // floats a plane publishes for its lender
     using KA = SnxBwdKargs<T>;  // (CN: the first member of the kernel's argument, at the same offsets)
     using KAC = SnxBwdKargsCn<T>;
     using St = std::conditional_t<CN, SnxBwdStateCn, SnxBwdState>;
@@ -821,6 +827,36 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
     __syncthreads();
     int r_l = 0;  // (CN) lane s: the instance whose plane borrowed the statistics of plane s of this wave — the same for every item
     if constexpr (CN) r_l = iperm[nl];
+    // (BOXED) bit j*VEC+q: element q of this lane's vector in register slot j lies inside the content / style box
+    constexpr int MW = BOXED ? (NV * VEC + 31) / 32 : 1;
+    unsigned cbits[MW], sbits[MW];
+#pragma unroll
+    for (int w = 0; w < MW; ++w) cbits[w] = sbits[w] = 0u;
+    if constexpr (BOXED) {
+        const Box cb = ka0->ra.cb, sb = ka0->ra.sb;
+        const int Wd = ka0->ra.Wd;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (sg.valid(j)) {
+                const int e = ((j - sg.shift) * 64 + lane) * VEC;  // VEC divides the width: one row per vector
+                const int r = e / Wd, c0 = e - r * Wd;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    const int p = j * VEC + q;
+                    cbits[p >> 5] |= (cb.has(r, c0 + q) ? 1u : 0u) << (p & 31);
+                    sbits[p >> 5] |= (sb.has(r, c0 + q) ? 1u : 0u) << (p & 31);
+                }
+            }
+    }
+    auto mask_c = [&](int j, int q) -> int {  // all-ones / all-zeros word (one v_bfe_i32)
+        const int p = j * VEC + q;
+        return (int)(cbits[p >> 5] << (31 - (p & 31))) >> 31;
+    };
+    auto in_c = [&](int j, int q) -> bool { return (cbits[(j * VEC + q) >> 5] & (1u << ((j * VEC + q) & 31))) != 0u; };
+    auto in_s = [&](int j, int q) -> bool { return (sbits[(j * VEC + q) >> 5] & (1u << ((j * VEC + q) & 31))) != 0u; };
+    (void)mask_c;
+    (void)in_c;
+    (void)in_s;
     startup_skew(ka0->ra);
     snx_set_priority();
 
@@ -875,12 +911,15 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
             cr.M2c = (float)saved[sv_at(p, SV_M2C)];
             cr.mu_s = saved[sv_at(p, SV_MU_S)];
             cr.sig_s = (float)saved[sv_at(p, SV_SIG_S)];
+            if constexpr (BOXED) cr.mu_o = (float)saved[sv_at(p, SV_MU_O)];
         }
         const int relu = EPI ? KA_->relu : 0;
         const PlaneIo<T, VEC, NV> sg(KA_->ra, 1, 1, lane);  // (only the slot validity is used here)
         const bool has_add = EPI && KA_->addend != nullptr;
         const float mu_l = (float)row_mu, g_l = (float)row_g;
         int my_s1_b = 0, my_s2_b = 0;  // lane s < PPW: the sums of this wave's plane s (v_writelane: see the forward)
+        int my_s3_b = 0, my_s4_b = 0;  // (BOXED) ... outside the content box
+        const float muo_l = BOXED ? cr.mu_o : 0.f;
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
             const float si = lane_bcast(mu_l, s);  // the saved mean of plane s, rounded as pass A' rounds it
@@ -904,29 +943,49 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
                     }
                 }
             }
-            float acc0 = 0.f, acc1 = 0.f;
+            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
                 if (sg.valid(j)) {
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
                         const float G = elem<T, VEC>(dg_[s][j], q), X = elem<T, VEC>(dx_[s][j], q);
-                        acc0 += G;
-                        acc1 = fmaf(G, X - si, acc1);
+                        if constexpr (!BOXED) {
+                            acc0 += G;
+                            acc1 = fmaf(G, X - si, acc1);
+                        } else {  // content-box sums in acc0 / acc1, whole-plane sums in acc2 / acc3, both about float(mu_c)
+                            const float Xc = X - si, Gc = keep_if(G, mask_c(j, q));
+                            acc0 += Gc;
+                            acc1 = fmaf(Gc, Xc, acc1);
+                            acc2 += G;
+                            acc3 = fmaf(G, Xc, acc3);
+                        }
                     }
                 }
-            my_s1_b = put_lane_at(wave_sum_bits(acc0), s, my_s1_b);
-            my_s2_b = put_lane_at(wave_sum_bits(acc1), s, my_s2_b);
+            if constexpr (BOXED) {  // outside the box = whole plane - box, re-centred on float(mu_o) (cnsn_resident_kernels.h)
+                const float a0 = wave_sum(acc0), a1_ = wave_sum(acc1), a2 = wave_sum(acc2), a3 = wave_sum(acc3);
+                const float so = lane_bcast(muo_l, s);
+                const float o1 = a2 - a0;
+                // (wave-uniform values computed on the vector unit: back to a scalar register for v_writelane)
+                my_s1_b = put_lane_at(__builtin_amdgcn_readfirstlane(__float_as_int(a0)), s, my_s1_b);
+                my_s2_b = put_lane_at(__builtin_amdgcn_readfirstlane(__float_as_int(a1_)), s, my_s2_b);
+                my_s3_b = put_lane_at(__builtin_amdgcn_readfirstlane(__float_as_int(o1)), s, my_s3_b);
+                my_s4_b = put_lane_at(__builtin_amdgcn_readfirstlane(__float_as_int((a3 - a1_) + (si - so) * o1)), s, my_s4_b);
+            } else {
+                my_s1_b = put_lane_at(wave_sum_bits(acc0), s, my_s1_b);
+                my_s2_b = put_lane_at(wave_sum_bits(acc1), s, my_s2_b);
+            }
         }
         {   // lane s < PPW: the gate's dt of plane s — one pass of arithmetic whatever PPW is; the whole record is written by
             // lane s and read back by the same lane, or by wave 0 behind the barrier (the lanes past PPW compute on zeros and
             // keep their results to themselves)
             const float my_s1 = __int_as_float(my_s1_b), my_s2 = __int_as_float(my_s2_b);
             const MidArgs a = KA_->ra.mid;
-            const BwdSumsT<float> sm = fix_sums<float>(a, my_s1, my_s2, 0.f, 0.f, row_mu, 0.0);
+            const float my_s3 = __int_as_float(my_s3_b), my_s4 = __int_as_float(my_s4_b);
+            const BwdSumsT<float> sm = fix_sums<float>(a, my_s1, my_s2, my_s3, my_s4, row_mu, (double)muo_l);
             float dtg, dtf;
             if constexpr (CN)
-                gate_dt<float>(a, sm, cr.a1, cr.m_in, 0.f, cr.mu_p, g_l, 1.f, dtg, dtf);
+                gate_dt<float>(a, sm, cr.a1, cr.m_in, muo_l, cr.mu_p, g_l, 1.f, dtg, dtf);
             else
                 gate_dt<float>(a, sm, 1.f, mu_l, 0.f, mu_l, g_l, 1.f, dtg, dtf);
             SnxBwdState r;
@@ -938,6 +997,8 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
             r.s1 = my_s1;
             r.s2 = my_s2;
             if constexpr (CN) {
+                cr.s1o = my_s3;
+                cr.s2o = my_s4;
                 if (lane < PPW) st[wave * PPW + lane] = SnxBwdStateCn{r, cr};
                 // this plane's sums, point-readable for the member that owns the plane which LENT it its statistics
                 if (lane < PPW && n0 + lane < N) {
@@ -945,10 +1006,15 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
                     const unsigned epoch = kc->sn.ra.epoch;
                     const size_t pi = (size_t)c * N + (size_t)(n0 + lane);
                     if (epoch) {
-                        put_tagged(kc->gran_p + 2 * pi, my_s1, epoch);
-                        put_tagged(kc->gran_p + 2 * pi + 1, my_s2, epoch);
+                        put_tagged(kc->gran_p + NSP * pi, my_s1, epoch);
+                        put_tagged(kc->gran_p + NSP * pi + 1, my_s2, epoch);
+                        if constexpr (BOXED) {
+                            put_tagged(kc->gran_p + NSP * pi + 2, my_s3, epoch);
+                            put_tagged(kc->gran_p + NSP * pi + 3, my_s4, epoch);
+                        }
                     } else {
-                        put_granule(kc->gran_p + pi, my_s1, my_s2);
+                        put_granule(kc->gran_p + (NSP / 2) * pi, my_s1, my_s2);
+                        if constexpr (BOXED) put_granule(kc->gran_p + (NSP / 2) * pi + 1, my_s3, my_s4);
                     }
                 }
             } else {
@@ -1032,6 +1098,7 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
             br.m_in = (float)saved[sv_at(pb, SV_M_IN)];
             br.sig_c = (float)saved[sv_at(pb, SV_SIG_C)];
             br.M2c = (float)saved[sv_at(pb, SV_M2C)];
+            br.mu_o = BOXED ? (float)saved[sv_at(pb, SV_MU_O)] : 0.f;
         }
 
         // ---- gather round A of item t's channel
@@ -1061,6 +1128,8 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
         // ---- batch sums of the BatchNorm backward; dx coefficients of this wave's planes; round B
         const bool reporter = k == c % K;  // the member that writes the channel's parameter gradients
         float cG_l, cX_l, xr_l, c0_l;      // lane s: the dx coefficients of this wave's plane s of item t
+        float cGo_l = 0.f, cXo_l = 0.f, xro_l = 0.f, c0o_l = 0.f, eS_l = 0.f, xs_l = 0.f, e0_l = 0.f;  // (BOXED) outside the content box; style box
+        (void)cGo_l, (void)cXo_l, (void)xro_l, (void)c0o_l, (void)eS_l, (void)xs_l, (void)e0_l;
         {
             const KA* ka = KA_;
             const MidArgs a = ka->ra.mid;
@@ -1082,7 +1151,8 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
                 const SnxBwdState r = snx_sn(rec);
                 const float mu = (float)r.mu_c;
                 const bool mine = lane < nlive;  // (nlive <= PPW)
-                const BwdSumsT<float> sm = fix_sums<float>(a, r.s1, r.s2, 0.f, 0.f, r.mu_c, 0.0);
+                BwdSumsT<float> sm = fix_sums<float>(a, r.s1, r.s2, 0.f, 0.f, r.mu_c, 0.0);
+                if constexpr (BOXED) sm = fix_sums<float>(a, r.s1, r.s2, rec.cn.s1o, rec.cn.s2o, r.mu_c, (double)rec.cn.mu_o);
                 BwdPlaneT<float> o;
                 BwdCoefs cf;
                 float mu_p = mu;  // post-CrossNorm plane mean: SelfNorm's input statistic (the Conv1d tap gradient's factor)
@@ -1096,23 +1166,36 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
                     const unsigned epoch = kc->sn.ra.epoch;
                     const unsigned long long* gp = kc->gran_p;
                     const size_t pi = (size_t)c * N + (size_t)r_l;
-                    float s1r = 0.f, s2r = 0.f;
+                    float s1r = 0.f, s2r = 0.f, s3r = 0.f, s4r = 0.f;
                     bool failed = false;
                     long long t_start = 0;
                     for (unsigned spins = 0;; ++spins) {
                         bool ok = true;
                         if (mine) {
                             if (epoch) {
-                                const unsigned long long q0 = __hip_atomic_load((gu64*)(gp + 2 * pi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                const unsigned long long q1 = __hip_atomic_load((gu64*)(gp + 2 * pi + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const unsigned long long q0 = __hip_atomic_load((gu64*)(gp + NSP * pi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const unsigned long long q1 = __hip_atomic_load((gu64*)(gp + NSP * pi + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 ok = (unsigned)(q0 >> 32) == epoch && (unsigned)(q1 >> 32) == epoch;
                                 s1r = __uint_as_float((unsigned)q0);
                                 s2r = __uint_as_float((unsigned)q1);
+                                if constexpr (BOXED) {
+                                    const unsigned long long q2 = __hip_atomic_load((gu64*)(gp + NSP * pi + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    const unsigned long long q3 = __hip_atomic_load((gu64*)(gp + NSP * pi + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    ok = ok && (unsigned)(q2 >> 32) == epoch && (unsigned)(q3 >> 32) == epoch;
+                                    s3r = __uint_as_float((unsigned)q2);
+                                    s4r = __uint_as_float((unsigned)q3);
+                                }
                             } else {
-                                const unsigned long long q0 = __hip_atomic_load((gu64*)(gp + pi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const unsigned long long q0 = __hip_atomic_load((gu64*)(gp + (NSP / 2) * pi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 ok = q0 != kGranuleEmpty;
                                 s1r = __uint_as_float((unsigned)q0);
                                 s2r = __uint_as_float((unsigned)(q0 >> 32));
+                                if constexpr (BOXED) {
+                                    const unsigned long long q1 = __hip_atomic_load((gu64*)(gp + (NSP / 2) * pi + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    ok = ok && q1 != kGranuleEmpty;
+                                    s3r = __uint_as_float((unsigned)q1);
+                                    s4r = __uint_as_float((unsigned)(q1 >> 32));
+                                }
                             }
                         }
                         if (__all(ok)) break;
@@ -1135,15 +1218,24 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
                             }
                         }
                     }
-                    const BwdSumsT<float> smr = fix_sums<float>(a, s1r, s2r, 0.f, 0.f, br.mu_c, 0.0);
+                    const BwdSumsT<float> smr = fix_sums<float>(a, s1r, s2r, s3r, s4r, br.mu_c, (double)br.mu_o);
                     float dtr, dtr_f;
-                    gate_dt<float>(a, smr, br.a1, br.m_in, 0.f, br.mu_p, br.g, 1.f, dtr, dtr_f);
+                    gate_dt<float>(a, smr, br.a1, br.m_in, br.mu_o, br.mu_p, br.g, 1.f, dtr, dtr_f);
                     const BwdPlaneT<float> src = bwd_plane<float>(a, b, smr, (double)dtr, 0.0, br.zh, 0.0, br.g, 1.f, br.aa, br.a1,
                                                                   br.m_in, br.mu_p, br.sig_p, br.sig_c, br.M2c);
                     cf = bwd_coefs<float>(a, o, src.Emu, src.Esig, r.g, cr.a1, cr.m_in, cr.mu_p, r.mu_c, cr.sig_c, cr.mu_s, cr.sig_s);
                     if (failed) {  // the launch gives up: this wave's planes come out as NaNs, the workgroup leaves at its next gather
-                        cf.c0_in = __builtin_nanf("");
+                        cf.c0_in = cf.c0_out = __builtin_nanf("");
                         if (lane == 0) *gave_up = 1;
+                    }
+                    if constexpr (BOXED) {
+                        cGo_l = cf.cG_out;
+                        cXo_l = cf.cX_out;
+                        xro_l = cf.xr_out;
+                        c0o_l = cf.c0_out;
+                        eS_l = cf.eS;
+                        xs_l = cf.xs;
+                        e0_l = cf.e0;
                     }
                 } else {
                     o = bwd_plane<float>(a, b, sm, r.dt, 0.0, r.zh, 0.0, r.g, 1.f, 1.f, 1.f, mu, mu, r.sig_p, 1.f, 0.f);
@@ -1205,6 +1297,11 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
             for (int s = 0; s < PPW; ++s) {
                 const float cG = lane_bcast(cG_l, s), cX = lane_bcast(cX_l, s), xr = lane_bcast(xr_l, s),
                             c0 = lane_bcast(c0_l, s);
+                float cGo = 0.f, cXo = 0.f, xro = 0.f, c0o = 0.f, eS = 0.f, xs = 0.f, e0 = 0.f;
+                if constexpr (BOXED) {
+                    cGo = lane_bcast(cGo_l, s), cXo = lane_bcast(cXo_l, s), xro = lane_bcast(xro_l, s), c0o = lane_bcast(c0o_l, s);
+                    eS = lane_bcast(eS_l, s), xs = lane_bcast(xs_l, s), e0 = lane_bcast(e0_l, s);
+                }
                 const unsigned doff = sg.at(span, stride_, s, nlive_);  // (a plane past the batch end drops its stores)
                 const unsigned off2 = sg.at(span2, stride_, s, nlive_);  // nothing to load: zeros, no traffic
                 const unsigned aoff2 = has_add ? off2 : sg.dead;
@@ -1216,8 +1313,16 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
                     const Raw<T, VEC> rg = parked(ig), rx = parked(ix);
                     float ov[VEC];
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q)
-                        ov[q] = fmaf(cG, elem<T, VEC>(rg, q), fmaf(cX, elem<T, VEC>(rx, q) - xr, c0));
+                    for (int q = 0; q < VEC; ++q) {
+                        const float G = elem<T, VEC>(rg, q), X = elem<T, VEC>(rx, q);
+                        if constexpr (!BOXED) {
+                            ov[q] = fmaf(cG, G, fmaf(cX, X - xr, c0));
+                        } else {
+                            float v = in_c(j, q) ? fmaf(cG, G, fmaf(cX, X - xr, c0)) : fmaf(cGo, G, fmaf(cXo, X - xro, c0o));
+                            v += in_s(j, q) ? fmaf(eS, X - xs, e0) : 0.f;
+                            ov[q] = v;
+                        }
+                    }
                     sg.store(t_dx, doff, j, pack<T, VEC>(ov));
                     if (ig < FIRST_KEEP || ig < NPARK)
                         mypark[ig * 64] = dg_[s][j];

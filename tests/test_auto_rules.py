@@ -19,7 +19,8 @@ TABLE = [
     ((256, 256, 56, 56), F32, FC(**SN, **CN), "resident", "resident"),         # the north-star workload
     ((256, 256, 56, 56), F32, FC(**SN, **BOTH), "resident", "resident"),
     ((256, 256, 56, 56), BF16, FC(**SN, **CN), "resident", "resident"),
-    ((256, 256, 56, 56), BF16, FC(**SN, **BOTH), "streaming", "streaming"),    # 16-bit boxed 56x56: two-pass
+    ((256, 256, 56, 56), BF16, FC(**SN, **BOTH), "streaming", "resident"),     # 16-bit boxed 56x56: two-pass forward; backward: partial-moment cluster kernel (round 4)
+    ((96, 256, 56, 56), BF16, FC(**SN, **BOTH), "streaming", "streaming"),     # ... at N < 192 two-pass both ways
     ((256, 512, 28, 28), BF16, FC(**SN, **BOTH), "resident", "resident"),      # <= 4 slots: always resident
     ((256, 1024, 14, 14), BF16, FC(**SN), "mono", "mono"),                     # a channel = 100 KiB: one workgroup's registers
     ((256, 1024, 14, 14), BF16, FC(**BLOCK), "mono", "mono"),
@@ -29,7 +30,7 @@ TABLE = [
     ((64, 1024, 14, 14), BF16, FC(**SN, **CN), "resident", "resident"),        # fewer than 96 planes per channel, un-boxed: the cluster kernels
     ((96, 1024, 14, 14), BF16, FC(**SN, **CN), "resident", "resident"),        # below 128 planes per channel (round 4 audit: -19 %)
     ((128, 1024, 14, 14), BF16, FC(**SN, **CN), "mono", "mono"),
-    ((16, 512, 64, 64), F32, FC(**SN, **BOTH), "streaming", "streaming"),      # fp32 64x64 with crop boxes at N <= 32: two-pass (round 4 audit: -8..-16 %)
+    ((16, 512, 64, 64), F32, FC(**SN, **BOTH), "streaming", "resident"),       # fp32 64x64 with crop boxes at N <= 32: two-pass forward (round 4 audit), partial-moment backward (-26 %)
     ((64, 512, 64, 64), F32, FC(**SN, **BOTH), "resident", "resident"),
     ((64, 1024, 14, 14), BF16, FC(**SN, **BOTH), "mono", "mono"),              # with crop boxes the channel-in-registers kernels keep it
     ((256, 2048, 7, 7), F32, FC(**SN, **CN), "mono", "mono"),                  # CrossNorm without boxes: the channel-group kernels (round 3)

@@ -45,22 +45,28 @@ def forced():
             os.environ[k] = v
 
 
-def _takes(shape, dtype):
+def _takes(shape, dtype, crop="neither"):
     x = torch.empty(shape, dtype=dtype, device=DEV)
-    cfg = cnsn_amd.FusedConfig(cn_active=True, sn_active=True)
+    cfg = cnsn_amd.FusedConfig(cn_active=True, sn_active=True,
+                               content_box=(1, 1, 5, 5) if crop in ("both", "content") else None,
+                               style_box=(0, 0, 4, 4) if crop in ("both", "style") else None)
     return cnsn_amd.sn_cluster(x, cfg, backward=True) and not cnsn_amd.sn_cluster(x, cfg, backward=False)
 
 
 @pytest.mark.parametrize("tag,nv,hw", CASES, ids=lambda v: str(v).replace(" ", ""))
 @pytest.mark.parametrize("n", [5, 37])
-def test_against_the_oracle(forced, tag, nv, hw, n):
+@pytest.mark.parametrize("crop", ["neither", "both", "style", "content"])
+def test_against_the_oracle(forced, tag, nv, hw, n, crop):
+    """crop != 'neither' (round 4, BOXED): four sums per plane, the 11-coefficient piecewise dx, bit masks per lane and slot"""
+    if crop in ("style", "content") and n == 5:
+        pytest.skip("one box alone: at N = 37 only")
     shape = (n, 4, *hw)
-    assert _takes(shape, DT[tag]), (shape, tag)
-    out = run_pair(shape, "neither", "cnsn", DT[tag], 1200 + nv + n, training=True)
-    assert_parity(out, DT[tag], ("cn-partial", tag, nv, shape))
+    assert _takes(shape, DT[tag], crop), (shape, tag, crop)
+    out = run_pair(shape, crop, "cnsn", DT[tag], 1200 + nv + n, training=True)
+    assert_parity(out, DT[tag], ("cn-partial", tag, nv, shape, crop))
 
 
-def _both(shape, dtype, seed, lam=None, device_perm=False, context=None):
+def _both(shape, dtype, seed, lam=None, device_perm=False, context=None, crop="neither"):
     torch.manual_seed(seed)
     np.random.seed(seed)
     g = torch.Generator(device=DEV).manual_seed(seed)
@@ -68,7 +74,8 @@ def _both(shape, dtype, seed, lam=None, device_perm=False, context=None):
     x = (torch.randn(shape, device=DEV, generator=g) * (torch.rand(n, c, 1, 1, device=DEV, generator=g) + 0.5)
          + torch.randn(n, c, 1, 1, device=DEV, generator=g)).to(dtype)
     gy = torch.randn(shape, device=DEV, generator=g).to(dtype)
-    perm = torch.randperm(n)
+    d = cnsn_amd.draw_cn(shape, crop, 1)
+    perm = d.perm
     res = {}
     for mode in ("2", "0"):
         os.environ["CNSN_SNXCN"] = mode
@@ -76,7 +83,7 @@ def _both(shape, dtype, seed, lam=None, device_perm=False, context=None):
             os.environ["CNSN_CONTEXT"] = context
         sn = fill_sn(cnsn_amd.SelfNorm(c), seed, torch.float32).to(DEV).train()
         kw, gp, _ = sn._fused_args()
-        cfg = cnsn_amd.FusedConfig(cn_active=True, lam=lam, **kw)
+        cfg = cnsn_amd.FusedConfig(cn_active=True, lam=lam, content_box=d.content_box, style_box=d.style_box, **kw)
         assert cnsn_amd.sn_cluster(x, cfg, backward=True) == (mode == "2")
         xg = x.clone().requires_grad_()
         y = cnsn_amd.fused_cnsn(xg, cfg, perm=perm.to(DEV) if device_perm else perm, g=gp)
@@ -90,10 +97,10 @@ def _both(shape, dtype, seed, lam=None, device_perm=False, context=None):
                                          ((70, 4, 56, 56), torch.float32), ((70, 4, 56, 56), torch.bfloat16),
                                          ((300, 2, 56, 56), torch.float32), ((19, 3, 60, 64), torch.float16)],
                          ids=lambda v: str(v).replace(" ", "").replace("torch.", ""))
-@pytest.mark.parametrize("variant", ["inline", "device_perm", "workspace", "lam"])
+@pytest.mark.parametrize("variant", ["inline", "device_perm", "workspace", "lam", "boxed", "boxed_workspace", "boxed_lam"])
 def test_against_the_general_cluster_kernels(forced, shape, dtype, variant):
-    res = _both(shape, dtype, 77, lam=0.3 if variant == "lam" else None, device_perm=variant == "device_perm",
-                context="0" if variant == "workspace" else None)
+    res = _both(shape, dtype, 77, lam=0.3 if variant.endswith("lam") else None, device_perm=variant == "device_perm",
+                context="0" if variant.endswith("workspace") else None, crop="both" if variant.startswith("boxed") else "neither")
     a, b = res["2"], res["0"]
     assert torch.equal(a[0], b[0])                                        # the same forward kernels ran
     for i, (u, v) in enumerate(zip(a[1:], b[1:])):
@@ -112,8 +119,11 @@ def test_many_channels_and_auto(forced):
     cfg = cnsn_amd.FusedConfig(cn_active=True, sn_active=True)
     assert cnsn_amd.sn_cluster(torch.empty(256, 256, 56, 56, device=DEV), cfg, backward=True)
     assert cnsn_amd.sn_cluster(torch.empty(256, 256, 56, 56, device=DEV, dtype=torch.bfloat16), cfg, backward=True)
-    assert not cnsn_amd.sn_cluster(torch.empty(256, 256, 56, 56, device=DEV), cnsn_amd.FusedConfig(
-        cn_active=True, sn_active=True, style_box=(0, 0, 9, 9)), backward=True)               # crop boxes: the general kernels
+    boxed = cnsn_amd.FusedConfig(cn_active=True, sn_active=True, style_box=(0, 0, 9, 9), content_box=(2, 2, 30, 30))
+    assert cnsn_amd.sn_cluster(torch.empty(256, 256, 56, 56, device=DEV), boxed, backward=True)       # crop boxes, fp32: every batch
+    assert cnsn_amd.sn_cluster(torch.empty(256, 256, 56, 56, device=DEV, dtype=torch.bfloat16), boxed, backward=True)
+    assert not cnsn_amd.sn_cluster(torch.empty(96, 256, 56, 56, device=DEV, dtype=torch.bfloat16), boxed, backward=True)  # two-pass
+    assert not cnsn_amd.sn_cluster(torch.empty(256, 512, 28, 28, device=DEV), cfg, backward=True)      # below 7 slots: not built
 
 
 _GIVE_UP = r'''
