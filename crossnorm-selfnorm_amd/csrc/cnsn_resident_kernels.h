@@ -367,6 +367,43 @@ __device__ __forceinline__ float elem(const Raw<T, VEC>& r, int q) {
             return (float)__builtin_bit_cast(_Float16, h);
     }
 }
+// 16-bit element types: acc + a.lo*b.lo + a.hi*b.hi straight from two packed 32-bit words (v_dot2c_f32_bf16 / v_dot2c_f32_f16:
+// fp32 accumulation of exact products, NO unpacking) — a bandwidth-bound kernel on MI355X has ~20-30 vector instructions per
+// 16-bit element to spend, and turning every element into a float first (shift / mask, then add, subtract, multiply-add) took
+// 5 of them per element and tensor in the statistics loops (ISA count, round 4: profiles/r04_dot2_sums.md)
+#ifndef CNSN_DOT2
+#define CNSN_DOT2 1
+#endif
+typedef __attribute__((ext_vector_type(2))) __bf16 cnsn_bf2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 cnsn_h2_t;
+typedef __attribute__((ext_vector_type(2))) float cnsn_f2_t;
+template <typename T>
+__device__ __forceinline__ float dot2_acc(unsigned a, unsigned b, float acc) {
+    static_assert(sizeof(T) == 2, "packed 16-bit words only");
+    if constexpr (__is_same(T, bf16_t))
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(cnsn_bf2_t, a), __builtin_bit_cast(cnsn_bf2_t, b), acc, false);
+    else
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(cnsn_h2_t, a), __builtin_bit_cast(cnsn_h2_t, b), acc, false);
+}
+template <typename T>
+__device__ __forceinline__ constexpr unsigned ones2() {  // (1, 1) as a packed word
+    return __is_same(T, bf16_t) ? 0x3f803f80u : 0x3c003c00u;
+}
+// the two elements of a packed word as a float pair (what v_pk_add_f32 / v_pk_fma_f32 work on)
+template <typename T>
+__device__ __forceinline__ cnsn_f2_t unpack2(unsigned w) {
+    cnsn_f2_t r;
+    if constexpr (__is_same(T, bf16_t)) {
+        r.x = __uint_as_float(w << 16);
+        r.y = __uint_as_float(w & 0xffff0000u);
+    } else {
+        const cnsn_h2_t h = __builtin_bit_cast(cnsn_h2_t, w);
+        r.x = (float)h.x;
+        r.y = (float)h.y;
+    }
+    return r;
+}
+
 // two floats -> one 32-bit word of two 16-bit elements (lo in bits 0..15), round to nearest even.  Converting the PAIR as
 // a vector lets the compiler pair the arithmetic that feeds it the same way (v_pk_fma_f32 on {lo, hi}) and finish with one
 // v_cvt_pk_bf16_f32 — converting element by element made it pair the even elements of two words and re-interleave the

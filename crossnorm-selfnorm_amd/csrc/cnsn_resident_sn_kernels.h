@@ -465,23 +465,45 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
                 }
             }
             float sum = 0.f;
+            if constexpr (CNSN_DOT2 && sizeof(T) == 2) {  // 16 bits: the plane sum from the packed words (no unpacking)
 #pragma unroll
-            for (int j = 0; j < NV; ++j)
+                for (int j = 0; j < NV; ++j)
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) sum += elem<T, VEC>(d[s][j], q);
+                    for (int w = 0; w < VEC / 2; ++w) sum = dot2_acc<T>((unsigned)d[s][j][w], ones2<T>(), sum);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) sum += elem<T, VEC>(d[s][j], q);
+            }
             const int tot_b = wave_sum_bits(sum);
             my_sum_b = put_lane_at(tot_b, s, my_sum_b);
             const float mean = __int_as_float(tot_b) * inv_m;  // the shift of the second pass (M2 about a point one ulp off the mean is the same number)
             float m2 = 0.f;
+            if constexpr (CNSN_DOT2 && sizeof(T) == 2) {  // ... and the second pass on element PAIRS (v_pk_add_f32 / v_pk_fma_f32)
+                cnsn_f2_t m2v = {0.f, 0.f};
+                const cnsn_f2_t mean2 = {mean, mean};
 #pragma unroll
-            for (int j = 0; j < NV; ++j)
-                if (sg.valid(j)) {
+                for (int j = 0; j < NV; ++j)
+                    if (sg.valid(j)) {
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) {
-                        const float t = elem<T, VEC>(d[s][j], q) - mean;
-                        m2 = fmaf(t, t, m2);
+                        for (int w = 0; w < VEC / 2; ++w) {
+                            const cnsn_f2_t t = unpack2<T>((unsigned)d[s][j][w]) - mean2;
+                            m2v = __builtin_elementwise_fma(t, t, m2v);
+                        }
                     }
-                }
+                m2 = m2v.x + m2v.y;
+            } else {
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+                    if (sg.valid(j)) {
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) {
+                            const float t = elem<T, VEC>(d[s][j], q) - mean;
+                            m2 = fmaf(t, t, m2);
+                        }
+                    }
+            }
             my_m2_b = put_lane_at(wave_sum_bits(m2), s, my_m2_b);
         }
         {   // lane s < PPW: the plane algebra of plane s — one pass of arithmetic whatever PPW is.  The record is written by
@@ -944,6 +966,20 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
                 }
             }
             float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+            if constexpr (CNSN_DOT2 && sizeof(T) == 2 && !BOXED) {
+                // 16 bits: sum G and sum G*X from the packed words (slots past the plane's end hold zeros), the shift by the
+                // saved mean applied to the lane's two sums: sum G*(X - si) = sum G*X - si * sum G
+                float gx = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int w = 0; w < VEC / 2; ++w) {
+                        const unsigned gw = (unsigned)dg_[s][j][w], xw = (unsigned)dx_[s][j][w];
+                        acc0 = dot2_acc<T>(gw, ones2<T>(), acc0);
+                        gx = dot2_acc<T>(gw, xw, gx);
+                    }
+                acc1 = fmaf(-si, acc0, gx);
+            } else
 #pragma unroll
             for (int j = 0; j < NV; ++j)
                 if (sg.valid(j)) {
