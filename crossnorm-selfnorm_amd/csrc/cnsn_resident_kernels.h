@@ -282,6 +282,23 @@ __device__ __forceinline__ bool sweep_granules_scalar(const unsigned long long* 
     }
 }
 
+__device__ __forceinline__ float keep_if(float v, int mask) { return __int_as_float(__float_as_int(v) & mask); }
+// a or b by an all-ones / all-zeros word, branch-free: (a & m) | (b & ~m) is one v_bfi_b32.  (`in_box ? f(x) : g(x)` with a
+// per-element predicate was compiled into an exec-masked if / else per ELEMENT — s_and_b64 / s_xor_b64 / s_mov_b64 exec /
+// s_andn2_saveexec / s_or_b64 around three instructions a branch, the 112 loop-invariant lane masks of a plane's elements kept in
+// scalar register pairs and spilled to vector lanes: two v_readlane per element — round 4, ISA of the boxed kernels.)
+__device__ __forceinline__ float pick_if(int mask, float a, float b) {
+    float r;  // spelled out: the compiler turns the C expression back into a compare + v_cndmask and hoists the compares
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
+// bit `pos` of `word` as an all-ones / all-zeros word (one v_bfe_i32), opaque to the optimiser for the same reason
+__device__ __forceinline__ int bit_mask(unsigned word, int pos) {
+    int r = (int)(word << (31 - pos)) >> 31;
+    asm("" : "+v"(r));
+    return r;
+}
+
 // static per-lane geometry of the register slots: slot j of this lane holds vector j*64+lane.
 // Kept small on purpose (the planes themselves want the registers): validity is one compare against
 // nvec, box membership is one bit per element packed into (NV*VEC+31)/32 words.
@@ -289,8 +306,8 @@ template <int VEC, int NV, bool BOXED>
 struct SlotGeom {
     static constexpr int WORDS = BOXED ? (NV * VEC + 31) / 32 : 1;
     int lane, nvec;  // (SPLIT kernels: lane carries the wave's slot offset, lane + 64 * first slot of the wave)
-    unsigned cbits[WORDS];  // bit j*VEC+q: element q of slot j is inside the content box
-    unsigned sbits[WORDS];  // ... inside the style box
+    mutable unsigned cbits[WORDS];  // bit j*VEC+q: element q of slot j is inside the content box
+    mutable unsigned sbits[WORDS];  // ... inside the style box   (mutable: forget() below)
     __device__ __forceinline__ SlotGeom(const ResArgs& ra, int lane_) : lane(lane_), nvec(ra.nvec) {
 #pragma unroll
         for (int w = 0; w < WORDS; ++w) cbits[w] = sbits[w] = 0;
@@ -320,14 +337,25 @@ struct SlotGeom {
         const int p = j * VEC + q;
         return (sbits[p >> 5] & (1u << (p & 31))) != 0u;
     }
-    // the same memberships as all-ones / all-zeros words (one v_bfe_i32): `bits(x) & mask` keeps or zeroes a float
+    // the same memberships as all-ones / all-zeros words (one v_bfe_i32): keep_if() keeps or zeroes a float by one, pick_if()
+    // chooses between two
     __device__ __forceinline__ int mask_c(int j, int q) const {
         const int p = j * VEC + q;
-        return (int)(cbits[p >> 5] << (31 - (p & 31))) >> 31;
+        return bit_mask(cbits[p >> 5], p & 31);
     }
     __device__ __forceinline__ int mask_s(int j, int q) const {
         const int p = j * VEC + q;
-        return (int)(sbits[p >> 5] << (31 - (p & 31))) >> 31;
+        return bit_mask(sbits[p >> 5], p & 31);
+    }
+    // The bit words never change, so everything derived from them is loop-invariant and would be hoisted out of the item
+    // loop: 2 x NV x VEC mask words (or lane-mask register pairs) per lane, spilled.  Called at the start of every per-plane
+    // loop that uses the masks, this makes the optimiser forget what the words hold, and an element's mask is extracted where it
+    // is used.
+    __device__ __forceinline__ void forget() const {
+        if constexpr (BOXED) {
+#pragma unroll
+            for (int w = 0; w < WORDS; ++w) asm volatile("" : "+v"(cbits[w]), "+v"(sbits[w]));
+        }
     }
 };
 
@@ -433,8 +461,6 @@ __device__ __forceinline__ Raw<T, VEC> pack(const float (&f)[VEC]) {
     }
     return r;
 }
-
-__device__ __forceinline__ float keep_if(float v, int mask) { return __int_as_float(__float_as_int(v) & mask); }
 
 // Region moments of a plane with crop boxes from ONE masked pass about a common shift k (the plane mean, from a cheap
 // unmasked pass before): sums of d = x - k and d*d over the whole plane, inside the content box and inside the style box.
@@ -700,6 +726,7 @@ __global__ __launch_bounds__(kBlock, SPLIT ? (POST ? 2 : 3) : POST ? (data_regs(
         float solo_mean[SOLO ? PPW : 1], solo_m2[SOLO ? PPW : 1];
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
+            sg.forget();
             const int n = n0 + s;
             float pub[NG];
             if constexpr (!BOXED) {
@@ -1022,6 +1049,7 @@ __global__ __launch_bounds__(kBlock, SPLIT ? (POST ? 2 : 3) : POST ? (data_regs(
         // ---- apply from registers, the only write of y
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
+            sg.forget();
             const int n = n0 + s;
             if (n < N) {
 #if CNSN_WAVE_COEF
@@ -1040,8 +1068,10 @@ __global__ __launch_bounds__(kBlock, SPLIT ? (POST ? 2 : 3) : POST ? (data_regs(
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
                         const float f = elem<T, VEC>(d[s][j], q);
-                        const bool ic = !BOXED || (sg.in_c(j, q));
-                        ov[q] = ic ? fmaf(a_in, f - xr, b_in) : fmaf(a_out, f, b_out);
+                        if constexpr (!BOXED)
+                            ov[q] = fmaf(a_in, f - xr, b_in);
+                        else  // both maps, the one of the element's region picked by its mask word (pick_if: no branches)
+                            ov[q] = pick_if(sg.mask_c(j, q), fmaf(a_in, f - xr, b_in), fmaf(a_out, f, b_out));
                         if constexpr (POST) ov[q] += elem<T, VEC>(ad[s][j], q);
                         if constexpr (EPI) ov[q] = relu ? fmaxf(ov[q], 0.f) : ov[q];
                     }
@@ -1169,6 +1199,7 @@ __global__ __launch_bounds__(kBlock, SPLIT ? 2 : POST ? 2 : EPI ? bwd_waves_epi(
         Raw<T, VEC> dg_[PPW][NV], dx_[PPW][NV];
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
+            sg.forget();
             const int n = n0 + s;
             const size_t off = ((size_t)(n < N ? n : 0) * C + c) * ra.M;
             const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;
@@ -1201,8 +1232,8 @@ __global__ __launch_bounds__(kBlock, SPLIT ? 2 : POST ? 2 : EPI ? bwd_waves_epi(
 #pragma unroll
                         for (int q = 0; q < VEC; ++q) {
                             const float X = elem<T, VEC>(dx_[s][j], q);
-                            const bool ic = !BOXED || sg.in_c(j, q);
-                            float t = ic ? fmaf(a_in, X - xr, b_in) : fmaf(a_out, X, b_out);
+                            float t = fmaf(a_in, X - xr, b_in);
+                            if constexpr (BOXED) t = pick_if(sg.mask_c(j, q), t, fmaf(a_out, X, b_out));
                             if constexpr (POST) t += elem<T, VEC>(ad[j], q);
                             gm[q] = relu_open_r<T>(t) ? elem<T, VEC>(dg_[s][j], q) : 0.f;
                         }
@@ -1217,6 +1248,7 @@ __global__ __launch_bounds__(kBlock, SPLIT ? 2 : POST ? 2 : EPI ? bwd_waves_epi(
         // ---- per-plane sums of G against x (shifted by the saved means, as pass A' does); publish
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
+            sg.forget();
             const int n = n0 + s;
             const float si = own_si[s], so = own_so[s];
             float acc[NS];
@@ -1425,6 +1457,7 @@ __global__ __launch_bounds__(kBlock, SPLIT ? 2 : POST ? 2 : EPI ? bwd_waves_epi(
         // ---- apply from registers, the only write of dx
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
+            sg.forget();
             const int n = n0 + s;
             if (n < N) {
 #if CNSN_WAVE_COEF
@@ -1454,10 +1487,9 @@ __global__ __launch_bounds__(kBlock, SPLIT ? 2 : POST ? 2 : EPI ? bwd_waves_epi(
                         if constexpr (!BOXED) {
                             v = fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i));
                         } else {
-                            const bool ic = sg.in_c(j, q), is = sg.in_s(j, q);
-                            v = ic ? fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i))
-                                   : fmaf(cG_o, G, fmaf(cX_o, X - xr_o, c0_o));
-                            v += is ? fmaf(eS, X - xs, e0) : 0.f;
+                            v = pick_if(sg.mask_c(j, q), fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i)),
+                                        fmaf(cG_o, G, fmaf(cX_o, X - xr_o, c0_o)));
+                            v += keep_if(fmaf(eS, X - xs, e0), sg.mask_s(j, q));
                         }
                         ov[q] = v;
                     }

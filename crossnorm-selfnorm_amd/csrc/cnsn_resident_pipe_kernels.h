@@ -139,6 +139,7 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
         const int c = item / ra.K, k = item - c * ra.K;
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
+            sg.forget();
             const int n = (k * 4 + wave) * PPW + s;
             float pub[NG];
             if constexpr (!BOXED) {
@@ -404,6 +405,7 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
             const int c2 = next2 / ra.K, k2 = next2 - c2 * ra.K;
 #pragma unroll
             for (int s = 0; s < PPW; ++s) {
+                sg.forget();
                 const int n = (k * 4 + wave) * PPW + s;
                 const float* o = ocoef + (wave * PPW + s) * FC_ROWS;
                 const float a_in = o[FC_A_IN], xr = o[FC_XR], b_in = o[FC_B_IN], a_out = o[FC_A_OUT], b_out = o[FC_B_OUT];
@@ -425,8 +427,10 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
                         const float f = elem<T, VEC>(v, q);
-                        const bool ic = !BOXED || (sg.in_c(j, q));
-                        ov[q] = ic ? fmaf(a_in, f - xr, b_in) : fmaf(a_out, f, b_out);
+                        if constexpr (!BOXED)
+                            ov[q] = fmaf(a_in, f - xr, b_in);
+                        else  // both maps, the one of the element's region picked by its mask word (pick_if: no branches)
+                            ov[q] = pick_if(sg.mask_c(j, q), fmaf(a_in, f - xr, b_in), fmaf(a_out, f, b_out));
                     }
                     buf_store<T, VEC>(slot_rsrc<T, VEC>(yb, pbytes, j), voff, pack<T, VEC>(ov));
                     if (i < FIRST_KEEP || i < NPARK)  // park slot i of item t+1 (garbage after the last item: never read)
@@ -534,6 +538,7 @@ __global__ __launch_bounds__(kBlock, pipe_bwd_waves(2 * PPW * NV)) void resident
         const int c = item / ra.K, k = item - c * ra.K;
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
+            sg.forget();
             const int n = (k * 4 + wave) * PPW + s;
             const float si = own_si[s], so = own_so[s];
             float acc[NS];
@@ -834,6 +839,7 @@ __global__ __launch_bounds__(kBlock, pipe_bwd_waves(2 * PPW * NV)) void resident
             const int c2 = next2 / ra.K, k2 = next2 - c2 * ra.K;
 #pragma unroll
             for (int s = 0; s < PPW; ++s) {
+                sg.forget();
                 const int n = (k * 4 + wave) * PPW + s;
                 const float* oc = ocoef + (wave * PPW + s) * BC_ROWS;
                 const float cG_i = oc[BC_CG_IN], cX_i = oc[BC_CX_IN], xr_i = oc[BC_XR_IN], c0_i = oc[BC_C0_IN];
@@ -862,9 +868,9 @@ __global__ __launch_bounds__(kBlock, pipe_bwd_waves(2 * PPW * NV)) void resident
                         if constexpr (!BOXED) {
                             v = fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i));
                         } else {
-                            const bool ic = sg.in_c(j, q), is = sg.in_s(j, q);
-                            v = ic ? fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i)) : fmaf(cG_o, G, fmaf(cX_o, X - xr_o, c0_o));
-                            v += is ? fmaf(eS, X - xs, e0) : 0.f;
+                            v = pick_if(sg.mask_c(j, q), fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i)),
+                                        fmaf(cG_o, G, fmaf(cX_o, X - xr_o, c0_o)));
+                            v += keep_if(fmaf(eS, X - xs, e0), sg.mask_s(j, q));
                         }
                         ov[q] = v;
                     }

@@ -872,13 +872,24 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
     }
     auto mask_c = [&](int j, int q) -> int {  // all-ones / all-zeros word (one v_bfe_i32)
         const int p = j * VEC + q;
-        return (int)(cbits[p >> 5] << (31 - (p & 31))) >> 31;
+        return bit_mask(cbits[p >> 5], p & 31);
     };
-    auto in_c = [&](int j, int q) -> bool { return (cbits[(j * VEC + q) >> 5] & (1u << ((j * VEC + q) & 31))) != 0u; };
-    auto in_s = [&](int j, int q) -> bool { return (sbits[(j * VEC + q) >> 5] & (1u << ((j * VEC + q) & 31))) != 0u; };
+    auto mask_s = [&](int j, int q) -> int {
+        const int p = j * VEC + q;
+        return bit_mask(sbits[p >> 5], p & 31);
+    };
+    // the bit masks are loop-invariant, and everything derived from them would be hoisted out of the item loop — 2 x NV x VEC
+    // mask words or lane-mask pairs per lane, spilled: "forgotten" at the start of every phase that uses them, so that an
+    // element's mask is extracted (one v_bfe_i32) where it is used
+    auto forget_masks = [&]() {
+        if constexpr (BOXED) {
+#pragma unroll
+            for (int w = 0; w < MW; ++w) asm volatile("" : "+v"(cbits[w]), "+v"(sbits[w]));
+        }
+    };
+    (void)mask_s;
+    (void)forget_masks;
     (void)mask_c;
-    (void)in_c;
-    (void)in_s;
     startup_skew(ka0->ra);
     snx_set_priority();
 
@@ -944,6 +955,7 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
         const float muo_l = BOXED ? cr.mu_o : 0.f;
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
+            forget_masks();
             const float si = lane_bcast(mu_l, s);  // the saved mean of plane s, rounded as pass A' rounds it
             if constexpr (EPI) {
                 if (has_add) {
@@ -1331,12 +1343,19 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
             };
 #pragma unroll
             for (int s = 0; s < PPW; ++s) {
+                forget_masks();
                 const float cG = lane_bcast(cG_l, s), cX = lane_bcast(cX_l, s), xr = lane_bcast(xr_l, s),
                             c0 = lane_bcast(c0_l, s);
                 float cGo = 0.f, cXo = 0.f, xro = 0.f, c0o = 0.f, eS = 0.f, xs = 0.f, e0 = 0.f;
+                float kG = cG, kX = cX, kr = xr, k0 = c0;  // (BOXED) the four in-box coefficients in VECTOR registers too
                 if constexpr (BOXED) {
                     cGo = lane_bcast(cGo_l, s), cXo = lane_bcast(cXo_l, s), xro = lane_bcast(xro_l, s), c0o = lane_bcast(c0o_l, s);
                     eS = lane_bcast(eS_l, s), xs = lane_bcast(xs_l, s), e0 = lane_bcast(e0_l, s);
+                    // eleven per-plane coefficients as scalar operands: a VOP3 instruction reads ONE scalar register, so the
+                    // compiler copied them to vector registers per use (v_mov) and spilled the scalar file (a quarter of the
+                    // kernel's vector instructions were v_readlane / v_writelane).  Pinned into vector registers once per plane.
+                    asm volatile("" : "+v"(kG), "+v"(kX), "+v"(kr), "+v"(k0), "+v"(cGo), "+v"(cXo), "+v"(xro), "+v"(c0o), "+v"(eS), "+v"(xs),
+                                 "+v"(e0));
                 }
                 const unsigned doff = sg.at(span, stride_, s, nlive_);  // (a plane past the batch end drops its stores)
                 const unsigned off2 = sg.at(span2, stride_, s, nlive_);  // nothing to load: zeros, no traffic
@@ -1353,10 +1372,9 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
                         const float G = elem<T, VEC>(rg, q), X = elem<T, VEC>(rx, q);
                         if constexpr (!BOXED) {
                             ov[q] = fmaf(cG, G, fmaf(cX, X - xr, c0));
-                        } else {
-                            float v = in_c(j, q) ? fmaf(cG, G, fmaf(cX, X - xr, c0)) : fmaf(cGo, G, fmaf(cXo, X - xro, c0o));
-                            v += in_s(j, q) ? fmaf(eS, X - xs, e0) : 0.f;
-                            ov[q] = v;
+                        } else {  // both affine maps, the one of the element's region picked by its mask word (no branches)
+                            const float v = pick_if(mask_c(j, q), fmaf(kG, G, fmaf(kX, X - kr, k0)), fmaf(cGo, G, fmaf(cXo, X - xro, c0o)));
+                            ov[q] = v + keep_if(fmaf(eS, X - xs, e0), mask_s(j, q));
                         }
                     }
                     sg.store(t_dx, doff, j, pack<T, VEC>(ov));
