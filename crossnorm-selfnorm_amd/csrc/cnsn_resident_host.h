@@ -194,17 +194,27 @@ static inline ResPlan plan_impl(const cnsn_problem_t& p, bool boxed, bool has_ch
         if (!resident_auto_enabled()) return rp;  // switched off, or a launch timed out earlier: degrade to two-pass
         if ((rp.nv - need) * 4 > need) return rp;
         // 16-bit (sweeps of round 1, profiles/r01_resident_tuning.md): up to 4 slots per lane (14x14 .. 44x44)
-        // always; 7/8 slots (56x56, 64x64) un-boxed only (boxed: two-pass 0.689 vs 0.725 ms at the north-star
-        // shape); 13/16 slots only the un-boxed backward
+        // always; 7/8 slots (56x56, 64x64) un-boxed always; 13/16 slots only the un-boxed backward.
+        // With crop boxes (round 4, tools/boxed_sweep.py -> profiles/r04_boxed_sweep.md, after the region select of the boxed
+        // kernels became branch-free — until then two-pass won every 16-bit boxed call of these classes): 7 slots both
+        // directions at every batch size (56x56 bf16 crop=both forward 0.254 vs 0.277 ms at N = 256, 0.038 vs 0.054 at N = 32);
+        // 8 slots the backward (64x64: -10 % at N = 256, -24 % at N = 64) and the forward of CrossNorm alone (-5..-10 %), NOT the
+        // forward with SelfNorm (two-pass 0.172 vs 0.180-0.192 at N = 256, 0.058 vs 0.062 at N = 16)
         const bool solo = !backward && !boxed && !p.cn_active && !(p.sn_active && p.sn_training);  // inference
         if (!epi && !solo && p.dtype != CNSN_F32) {
-            const bool ok16 = rp.nv <= 4 ? true : rp.nv <= 8 ? !boxed : (backward && !boxed);
+            const bool ok16 = rp.nv <= 4   ? true
+                              : rp.nv == 7 ? true
+                              : rp.nv == 8 ? (!boxed || backward || !p.sn_active)
+                                           : (backward && !boxed);
             if (!ok16) return rp;
         }
         if (epi && p.dtype != CNSN_F32 && rp.nv > 8) return rp;  // (those instantiations spill registers)
         // fp32 64x64 planes (16 slots) WITH crop boxes at small batches (segmentation: N = 16, K = 4 members per channel): two-pass
-        // is 8-16 % faster on both boxes of tools/auto_audit.py (round 4) — the boxed algebra of a 16-slot item is the cycle
-        if (!epi && boxed && p.dtype == CNSN_F32 && rp.nv == 16 && p.N <= 32) return rp;
+        // was 8-16 % faster while the boxed region select branched per element; since it is branch-free the cluster kernels win
+        // (profiles/r04_boxed_sweep.md: (16,2048,64,64) forward 0.238 vs 0.279 ms, (16,512,64,64) 0.076 vs 0.081; the rule
+        // that sent these calls to two-pass is gone.  The backward of CrossNorm alone at (16,512,64,64) measures 0.140 vs 0.115 in a
+        // loop of backwards only — x and G of the previous call still in the 256 MB cache — and 0.178 vs 0.192 for the call in a
+        // forward + backward loop, tools/auto_audit.py: the cluster kernels)
         // POST forward of the 16-bit 56x56 class: two-pass 0.283 vs 0.304 ms at (256,256,56,56) (profiles/r02_post_add.md)
         if (post && !backward && p.dtype != CNSN_F32 && rp.nv == 7 && p.sn_training) return rp;
     }

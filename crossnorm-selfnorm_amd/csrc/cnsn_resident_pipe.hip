@@ -67,10 +67,15 @@ ResPlan resident_pipe_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_pe
     // 16-bit: 20 %, 56x56: 9 %).  With crop boxes the gather is three times as long and the kernel is VALU-bound (0.53 vs
     // 0.46 ms at the north-star shape); the 8-slot class measured 4 % slower, the 16-slot class spills.
     if (mode != 2) {
-        // (round 4: with crop boxes the fp32 56x56 class at N >= 192 — three runs of tools/auto_audit.py / ab_env.sh: the call
-        //  4-5 % faster than with the plain kernels since the launches run back to back; at N = 96 it is 3 % slower)
-        if (boxed && !(rp.nv == 13 && elem_bytes(p.dtype) == 4 && p.N >= 192)) return none;
-        if (!(rp.nv == 2 || rp.nv == 4 || rp.nv == 7 || rp.nv == 13)) return none;
+        // With crop boxes (round 4, profiles/r04_boxed_sweep.md, after the branch-free region select): fp32 56x56 at every batch
+        // size (0.375 vs 0.402 ms at N = 256, 0.179 vs 0.189 at N = 128, 0.047 vs 0.053 at N = 32), fp32 64x64 from N = 64
+        // (0.234 vs 0.258 at N = 256, 0.123 vs 0.132 at N = 64; at N = 16 the plain kernel: 0.238 vs 0.304), 16-bit 56x56 at
+        // every batch size (0.254 vs 0.294, 0.128 vs 0.143, 0.038 vs 0.048); 16-bit 64x64 the plain kernel (0.158 vs 0.164).
+        if (boxed) {
+            const bool f32 = elem_bytes(p.dtype) == 4;
+            if (!((f32 && rp.nv == 13) || (f32 && rp.nv == 16 && p.N >= 64) || (!f32 && rp.nv == 7))) return none;
+        } else if (!(rp.nv == 2 || rp.nv == 4 || rp.nv == 7 || rp.nv == 13))
+            return none;
     }
     if (npark) *npark = np;
     return rp;

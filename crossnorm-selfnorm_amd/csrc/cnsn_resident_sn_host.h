@@ -74,8 +74,11 @@ constexpr bool snx_cn_built(int nv, int eb, int vb) { return vb == 16 && nv >= 7
 constexpr bool snx_cn_auto(int nv, int eb, int N) { return eb == 4 || nv == 7; }
 // ... with crop boxes (profiles/r04_cn_partial_moments.md, "crop boxes"): fp32 56x56 -3 % at N = 256 (against the pipelined boxed
 // kernel), -7 % at N = 96, 40x40 level, 64x64 at N = 16 -26 % (against two-pass); 16-bit 56x56 -3 % at N = 256 against TWO-PASS
-// (3 instead of 5 tensor passes, but VALU-bound: 12 vector instructions per element in the apply), +3 % at N = 96
-constexpr bool snx_cn_boxed_auto(int nv, int eb, int N) { return eb == 4 || (nv == 7 && N >= 192); }
+// (3 instead of 5 tensor passes, but VALU-bound: 12 vector instructions per element in the apply), +3 % at N = 96.
+// Since the region select is branch-free (profiles/r04_boxed_sweep.md): 16-bit 56x56 0.302 vs 0.354 ms at N = 256, 0.158-0.164
+// vs 0.169 (general cluster kernel) / 0.183 (two-pass) at N = 128, 0.126 vs 0.134 / 0.140 at N = 96 -> every batch size; 64x64
+// (8 slots) 0.217 vs 0.209 at N = 256, 0.121 vs 0.094 at N = 64 -> the general kernels
+constexpr bool snx_cn_boxed_auto(int nv, int eb, int N) { return eb == 4 || nv == 7; }
 
 // CNSN_SNX=0: never; 2: wherever instantiated (tests); default 1: AUTO rule
 inline int snx_mode() {

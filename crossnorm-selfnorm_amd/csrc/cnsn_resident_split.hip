@@ -63,11 +63,11 @@ ResPlan resident_split_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_p
         const int need = (nvec + 255) / 256;
         if ((rp.nv - need) * 4 > need) return rp;  // a register bucket more than 25 % too large is not worth it
         if (p.dtype != CNSN_F32 && rp.nv > 8) return rp;  // 16-bit, 16 slots: spills (not measured)
-        // 16-bit with crop boxes: VALU-bound like the one-plane-per-wave boxed kernels — (16,256,128,128) bf16 crop=both
-        // 0.256 / 0.293 ms (cn / cnsn) against 0.210 / 0.218 two-pass (profiles/r02_auto_audit.md)
-        if (p.dtype != CNSN_F32 && boxed) return rp;
+        // 16-bit with crop boxes: two-pass won while the region select branched per element (profiles/r02_auto_audit.md); since
+        // it is branch-free (profiles/r04_boxed_sweep.md, 128x128 bf16 at (16,256) and (64,64)): the backward -4..-6 %, CrossNorm
+        // alone forward -15 %; the forward with SelfNorm stays two-pass (0.094 vs 0.096-0.098 ms)
+        if (p.dtype != CNSN_F32 && boxed && !backward && p.sn_active) return rp;
     }
-    (void)backward;
     rp.ok = true;
     return rp;
 }

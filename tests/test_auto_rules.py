@@ -19,8 +19,11 @@ TABLE = [
     ((256, 256, 56, 56), F32, FC(**SN, **CN), "resident", "resident"),         # the north-star workload
     ((256, 256, 56, 56), F32, FC(**SN, **BOTH), "resident", "resident"),
     ((256, 256, 56, 56), BF16, FC(**SN, **CN), "resident", "resident"),
-    ((256, 256, 56, 56), BF16, FC(**SN, **BOTH), "streaming", "resident"),     # 16-bit boxed 56x56: two-pass forward; backward: partial-moment cluster kernel (round 4)
-    ((96, 256, 56, 56), BF16, FC(**SN, **BOTH), "streaming", "streaming"),     # ... at N < 192 two-pass both ways
+    ((256, 256, 56, 56), BF16, FC(**SN, **BOTH), "resident", "resident"),      # 16-bit boxed 56x56: pipelined forward since the region select is branch-free; backward: partial-moment cluster kernel (round 4)
+    ((32, 256, 56, 56), BF16, FC(**SN, **BOTH), "resident", "resident"),       # ... at every batch size
+    ((256, 128, 64, 64), BF16, FC(**SN, **BOTH), "streaming", "resident"),     # 16-bit boxed 64x64: the forward with SelfNorm stays two-pass
+    ((256, 128, 64, 64), BF16, FC(**CN, style_box=(0, 0, 32, 32)), "resident", "resident"),  # ... CrossNorm alone does not
+    ((96, 256, 56, 56), BF16, FC(**SN, **BOTH), "resident", "resident"),       # ... (until the branch-free region select: two-pass both ways at N < 192)
     ((256, 512, 28, 28), BF16, FC(**SN, **BOTH), "resident", "resident"),      # <= 4 slots: always resident
     ((256, 1024, 14, 14), BF16, FC(**SN), "mono", "mono"),                     # a channel = 100 KiB: one workgroup's registers
     ((256, 1024, 14, 14), BF16, FC(**BLOCK), "mono", "mono"),
@@ -30,7 +33,8 @@ TABLE = [
     ((64, 1024, 14, 14), BF16, FC(**SN, **CN), "resident", "resident"),        # fewer than 96 planes per channel, un-boxed: the cluster kernels
     ((96, 1024, 14, 14), BF16, FC(**SN, **CN), "resident", "resident"),        # below 128 planes per channel (round 4 audit: -19 %)
     ((128, 1024, 14, 14), BF16, FC(**SN, **CN), "mono", "mono"),
-    ((16, 512, 64, 64), F32, FC(**SN, **BOTH), "streaming", "resident"),       # fp32 64x64 with crop boxes at N <= 32: two-pass forward (round 4 audit), partial-moment backward (-26 %)
+    ((16, 512, 64, 64), F32, FC(**SN, **BOTH), "resident", "resident"),        # fp32 64x64 with crop boxes at N <= 32: cluster kernels again (branch-free region select), partial-moment backward (-26 %)
+    ((16, 512, 64, 64), F32, FC(**CN, style_box=(0, 0, 32, 32)), "resident", "resident"),    # ... CrossNorm alone too
     ((64, 512, 64, 64), F32, FC(**SN, **BOTH), "resident", "resident"),
     ((64, 1024, 14, 14), BF16, FC(**SN, **BOTH), "mono", "mono"),              # with crop boxes the channel-in-registers kernels keep it
     ((256, 2048, 7, 7), F32, FC(**SN, **CN), "mono", "mono"),                  # CrossNorm without boxes: the channel-group kernels (round 3)
@@ -45,7 +49,8 @@ TABLE = [
     ((16, 512, 64, 64), F32, FC(sn_active=True, add_mode="post", relu=True), "resident", "resident"),   # segmentation: SN at 'residual'
     ((16, 2048, 64, 64), BF16, FC(sn_active=True, add_mode="post", relu=True), "resident", "resident"),
     ((16, 256, 128, 128), F32, FC(sn_active=True, add_mode="post", relu=True), "resident", "resident"),  # a plane per workgroup (split)
-    ((16, 256, 128, 128), BF16, FC(**CN, style_box=(0, 0, 64, 64)), "streaming", "streaming"),          # segmentation's separate CrossNorm: 16-bit boxed = VALU-bound in the cluster kernels
+    ((16, 256, 128, 128), BF16, FC(**CN, style_box=(0, 0, 64, 64)), "resident", "resident"),            # segmentation's separate CrossNorm, 16-bit boxed: cluster kernels since the region select is branch-free
+    ((16, 256, 128, 128), BF16, FC(**SN, **BOTH), "streaming", "resident"),                               # ... with SelfNorm: the backward only
     ((16, 256, 128, 128), F32, FC(**CN, style_box=(0, 0, 64, 64)), "resident", "resident"),
     ((128, 128, 8, 8), F32, FC(**SN), "mono", "mono"),                        # 256-byte planes, 16 lanes each
     ((128, 64, 16, 16), F32, FC(**SN), "mono", "mono"),                        # WideResNet stage 2

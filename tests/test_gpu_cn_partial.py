@@ -122,7 +122,8 @@ def test_many_channels_and_auto(forced):
     boxed = cnsn_amd.FusedConfig(cn_active=True, sn_active=True, style_box=(0, 0, 9, 9), content_box=(2, 2, 30, 30))
     assert cnsn_amd.sn_cluster(torch.empty(256, 256, 56, 56, device=DEV), boxed, backward=True)       # crop boxes, fp32: every batch
     assert cnsn_amd.sn_cluster(torch.empty(256, 256, 56, 56, device=DEV, dtype=torch.bfloat16), boxed, backward=True)
-    assert not cnsn_amd.sn_cluster(torch.empty(96, 256, 56, 56, device=DEV, dtype=torch.bfloat16), boxed, backward=True)  # two-pass
+    assert cnsn_amd.sn_cluster(torch.empty(96, 256, 56, 56, device=DEV, dtype=torch.bfloat16), boxed, backward=True)   # ... 16-bit 56x56 too
+    assert not cnsn_amd.sn_cluster(torch.empty(96, 256, 64, 64, device=DEV, dtype=torch.bfloat16), boxed, backward=True)  # 8 slots: general kernels
     assert not cnsn_amd.sn_cluster(torch.empty(256, 512, 28, 28, device=DEV), cfg, backward=True)      # below 7 slots: not built
 
 

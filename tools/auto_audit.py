@@ -32,7 +32,8 @@ SHAPES = [(128, 32, 32, 32), (128, 64, 16, 16), (128, 128, 8, 8),               
 MODES = [("sn", "neither", False), ("sn-block", "neither", True), ("cnsn", "neither", False), ("cnsn", "both", False),
          ("cn", "style", False)]
 ALTS = [("two_pass", {}), ("resident", {}), ("local", {}), ("mono", {}), ("auto", {"CNSN_PIPE": "0"}), ("auto", {"CNSN_PIPE": "2"}),
-        ("auto", {"CNSN_SNX": "0"}), ("auto", {"CNSN_SNX": "2"})]
+        ("resident", {"CNSN_PIPE": "2"}), ("auto", {"CNSN_SNX": "0"}), ("auto", {"CNSN_SNX": "2"}), ("auto", {"CNSN_SNXCN": "0"}),
+        ("auto", {"CNSN_SNXCN": "2"})]
 
 
 def timeit(fn, calls, reps):
