@@ -462,6 +462,112 @@ __device__ __forceinline__ Raw<T, VEC> pack(const float (&f)[VEC]) {
     return r;
 }
 
+// ---- element PAIRS (v_pk_add_f32 / v_pk_fma_f32 do two floats an instruction at the rate of one: with crop boxes the cluster
+// kernels are bound by the vector ALU, not by HBM — 13-20 instructions per element — so the boxed statistics and apply loops
+// work on pairs; the masks stay per element (one v_bfe_i32 each))
+template <typename T, int VEC>
+__device__ __forceinline__ cnsn_f2_t elem2(const Raw<T, VEC>& r, int p) {  // elements 2p, 2p+1
+    if constexpr (sizeof(T) == 4) {
+        const cnsn_f2_t v = {__int_as_float(r[2 * p]), __int_as_float(r[2 * p + 1])};
+        return v;
+    } else {
+        return unpack2<T>((unsigned)r[p]);
+    }
+}
+__device__ __forceinline__ cnsn_f2_t splat2(float v) {
+    const cnsn_f2_t r = {v, v};
+    return r;
+}
+__device__ __forceinline__ cnsn_f2_t keep_if2(cnsn_f2_t v, int m0, int m1) {
+    const cnsn_f2_t r = {keep_if(v.x, m0), keep_if(v.y, m1)};
+    return r;
+}
+__device__ __forceinline__ cnsn_f2_t pick_if2(int m0, int m1, cnsn_f2_t a, cnsn_f2_t b) {
+    const cnsn_f2_t r = {pick_if(m0, a.x, b.x), pick_if(m1, a.y, b.y)};
+    return r;
+}
+__device__ __forceinline__ cnsn_f2_t fma2(cnsn_f2_t a, cnsn_f2_t b, cnsn_f2_t c) { return __builtin_elementwise_fma(a, b, c); }
+// pairs -> a raw vector (16-bit: one v_cvt_pk per pair)
+template <typename T, int VEC>
+__device__ __forceinline__ Raw<T, VEC> pack_pairs(const cnsn_f2_t (&f)[VEC / 2]) {
+    Raw<T, VEC> r;
+#pragma unroll
+    for (int p = 0; p < VEC / 2; ++p) {
+        if constexpr (sizeof(T) == 4) {
+            r[2 * p] = __float_as_int(f[p].x);
+            r[2 * p + 1] = __float_as_int(f[p].y);
+        } else {
+            r[p] = pack2<T>(f[p].x, f[p].y);
+        }
+    }
+    return r;
+}
+// the plain sum of a plane's register slots (slots past the plane's end hold zeros); 16 bits: straight from the packed words
+template <typename T, int VEC, int NV>
+__device__ __forceinline__ float slots_sum(const Raw<T, VEC> (&d)[NV]) {
+    float s0 = 0.f;
+    if constexpr (CNSN_DOT2 && sizeof(T) == 2) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int w = 0; w < VEC / 2; ++w) s0 = dot2_acc<T>((unsigned)d[j][w], ones2<T>(), s0);
+    } else {
+        cnsn_f2_t s2 = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int q = 0; q < VEC / 2; ++q) s2 += elem2<T, VEC>(d[j], q);
+        s0 = s2.x + s2.y;
+    }
+    return s0;
+}
+// the six region sums boxed_moments() takes (whole plane, content box, style box: sum d, sum d*d with d = x - k), this lane's part
+template <typename T, int VEC, int NV, typename SG>
+__device__ __forceinline__ void boxed_region_sums(const Raw<T, VEC> (&d)[NV], const SG& sg, float k, float (&t)[6]) {
+    cnsn_f2_t a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0;
+    const cnsn_f2_t k2 = splat2(k);
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+        if (sg.valid(j)) {
+#pragma unroll
+            for (int q = 0; q < VEC / 2; ++q) {
+                const cnsn_f2_t dd = elem2<T, VEC>(d[j], q) - k2;
+                const cnsn_f2_t dc = keep_if2(dd, sg.mask_c(j, 2 * q), sg.mask_c(j, 2 * q + 1));
+                const cnsn_f2_t ds = keep_if2(dd, sg.mask_s(j, 2 * q), sg.mask_s(j, 2 * q + 1));
+                a0 += dd;
+                a1 = fma2(dd, dd, a1);
+                a2 += dc;
+                a3 = fma2(dc, dc, a3);
+                a4 += ds;
+                a5 = fma2(ds, ds, a5);
+            }
+        }
+    t[0] = a0.x + a0.y, t[1] = a1.x + a1.y, t[2] = a2.x + a2.y, t[3] = a3.x + a3.y, t[4] = a4.x + a4.y, t[5] = a5.x + a5.y;
+}
+
+// the four backward sums of a plane with crop boxes, this lane's part: sum G and sum G*(X - si) inside the content box (acc[0..1])
+// and over the whole plane (acc[2..3]), both about the same shift si; valid(j) / mask_c(j, q) as SlotGeom's
+template <typename T, int VEC, int NV, typename VALID, typename MASK>
+__device__ __forceinline__ void boxed_bwd_sums(const Raw<T, VEC> (&g)[NV], const Raw<T, VEC> (&x)[NV], VALID valid, MASK mask_c, float si,
+                                               float (&acc)[4]) {
+    cnsn_f2_t a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    const cnsn_f2_t si2 = splat2(si);
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+        if (valid(j)) {
+#pragma unroll
+            for (int q = 0; q < VEC / 2; ++q) {
+                const cnsn_f2_t G = elem2<T, VEC>(g[j], q), Xc = elem2<T, VEC>(x[j], q) - si2;
+                const cnsn_f2_t Gc = keep_if2(G, mask_c(j, 2 * q), mask_c(j, 2 * q + 1));
+                a0 += Gc;
+                a1 = fma2(Gc, Xc, a1);
+                a2 += G;
+                a3 = fma2(G, Xc, a3);
+            }
+        }
+    acc[0] = a0.x + a0.y, acc[1] = a1.x + a1.y, acc[2] = a2.x + a2.y, acc[3] = a3.x + a3.y;
+}
+
 // Region moments of a plane with crop boxes from ONE masked pass about a common shift k (the plane mean, from a cheap
 // unmasked pass before): sums of d = x - k and d*d over the whole plane, inside the content box and inside the style box.
 // The outside-the-content-box moments follow by subtraction.  (The first version made two masked passes with three
@@ -753,30 +859,11 @@ __global__ __launch_bounds__(kBlock, SPLIT ? (POST ? 2 : 3) : POST ? (data_regs(
                 pub[0] = mean;
                 pub[1] = tq[0];
             } else {
-                float s0 = 0.f;
-#pragma unroll
-                for (int j = 0; j < NV; ++j)
-#pragma unroll
-                    for (int q = 0; q < VEC; ++q) s0 += elem<T, VEC>(d[s][j], q);  // invalid slots hold 0
-                float tot[1] = {wave_sum(s0)};
+                float tot[1] = {wave_sum(slots_sum<T, VEC, NV>(d[s]))};  // invalid slots hold 0
                 if constexpr (SPLIT) split_merge<1>(tot, xch, wave, lane);
                 const float k = tot[0] / (float)a.M;
-                float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < NV; ++j)
-                    if (sg.valid(j)) {
-#pragma unroll
-                        for (int q = 0; q < VEC; ++q) {
-                            const float dd = elem<T, VEC>(d[s][j], q) - k;
-                            const float dc = keep_if(dd, sg.mask_c(j, q)), ds = keep_if(dd, sg.mask_s(j, q));
-                            t[0] += dd;
-                            t[1] = fmaf(dd, dd, t[1]);
-                            t[2] += dc;
-                            t[3] = fmaf(dc, dc, t[3]);
-                            t[4] += ds;
-                            t[5] = fmaf(ds, ds, t[5]);
-                        }
-                    }
+                float t[6];
+                boxed_region_sums<T, VEC, NV>(d[s], sg, k, t);
 #pragma unroll
                 for (int m = 0; m < 6; ++m) t[m] = wave_sum(t[m]);
                 if constexpr (SPLIT) split_merge<6>(t, xch + 32, wave, lane);
@@ -1068,10 +1155,15 @@ __global__ __launch_bounds__(kBlock, SPLIT ? (POST ? 2 : 3) : POST ? (data_regs(
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
                         const float f = elem<T, VEC>(d[s][j], q);
-                        if constexpr (!BOXED)
+                        if constexpr (!BOXED) {
                             ov[q] = fmaf(a_in, f - xr, b_in);
-                        else  // both maps, the one of the element's region picked by its mask word (pick_if: no branches)
-                            ov[q] = pick_if(sg.mask_c(j, q), fmaf(a_in, f - xr, b_in), fmaf(a_out, f, b_out));
+                        } else if ((q & 1) == 0) {  // both maps on the element PAIR, each element's picked by its mask word
+                            const cnsn_f2_t f2 = {f, elem<T, VEC>(d[s][j], q + 1)};
+                            const cnsn_f2_t r2 = pick_if2(sg.mask_c(j, q), sg.mask_c(j, q + 1), fma2(splat2(a_in), f2 - splat2(xr), splat2(b_in)),
+                                                          fma2(splat2(a_out), f2, splat2(b_out)));
+                            ov[q] = r2.x;
+                            ov[q + 1] = r2.y;
+                        }
                         if constexpr (POST) ov[q] += elem<T, VEC>(ad[s][j], q);
                         if constexpr (EPI) ov[q] = relu ? fmaxf(ov[q], 0.f) : ov[q];
                     }
@@ -1254,22 +1346,17 @@ __global__ __launch_bounds__(kBlock, SPLIT ? 2 : POST ? 2 : EPI ? bwd_waves_epi(
             float acc[NS];
 #pragma unroll
             for (int m = 0; m < NS; ++m) acc[m] = 0.f;
+            if constexpr (BOXED) {  // whole-plane sums in acc[2..3], content-box sums in acc[0..1], both about float(mu_c)
+                boxed_bwd_sums<T, VEC, NV>(dg_[s], dx_[s], [&](int j) { return sg.valid(j); }, [&](int j, int q) { return sg.mask_c(j, q); }, si, acc);
+            } else
 #pragma unroll
             for (int j = 0; j < NV; ++j)
                 if (sg.valid(j)) {
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
                         const float G = elem<T, VEC>(dg_[s][j], q), X = elem<T, VEC>(dx_[s][j], q);
-                        if constexpr (!BOXED) {
-                            acc[0] += G;
-                            acc[1] = fmaf(G, X - si, acc[1]);
-                        } else {  // whole-plane sums in acc[2..3], content-box sums in acc[0..1], both about float(mu_c)
-                            const float Xc = X - si, Gc = keep_if(G, sg.mask_c(j, q));
-                            acc[0] += Gc;
-                            acc[1] = fmaf(Gc, Xc, acc[1]);
-                            acc[2] += G;
-                            acc[3] = fmaf(G, Xc, acc[3]);
-                        }
+                        acc[0] += G;
+                        acc[1] = fmaf(G, X - si, acc[1]);
                     }
                 }
 #pragma unroll
@@ -1487,9 +1574,16 @@ __global__ __launch_bounds__(kBlock, SPLIT ? 2 : POST ? 2 : EPI ? bwd_waves_epi(
                         if constexpr (!BOXED) {
                             v = fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i));
                         } else {
-                            v = pick_if(sg.mask_c(j, q), fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i)),
-                                        fmaf(cG_o, G, fmaf(cX_o, X - xr_o, c0_o)));
-                            v += keep_if(fmaf(eS, X - xs, e0), sg.mask_s(j, q));
+                            if ((q & 1) == 0) {  // the three affine maps on the element PAIR, then each element's by its mask words
+                                const cnsn_f2_t G2 = {G, elem<T, VEC>(dg_[s][j], q + 1)}, X2 = {X, elem<T, VEC>(dx_[s][j], q + 1)};
+                                const cnsn_f2_t vi = fma2(splat2(cG_i), G2, fma2(splat2(cX_i), X2 - splat2(xr_i), splat2(c0_i)));
+                                const cnsn_f2_t vo = fma2(splat2(cG_o), G2, fma2(splat2(cX_o), X2 - splat2(xr_o), splat2(c0_o)));
+                                const cnsn_f2_t r2 = pick_if2(sg.mask_c(j, q), sg.mask_c(j, q + 1), vi, vo) +
+                                                     keep_if2(fma2(splat2(eS), X2 - splat2(xs), splat2(e0)), sg.mask_s(j, q), sg.mask_s(j, q + 1));
+                                ov[q] = r2.x;
+                                ov[q + 1] = r2.y;
+                            }
+                            continue;
                         }
                         ov[q] = v;
                     }

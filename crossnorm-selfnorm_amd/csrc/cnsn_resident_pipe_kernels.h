@@ -162,28 +162,9 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
                 pub[0] = mean;
                 pub[1] = wave_sum(m2);
             } else {  // (one masked pass about the plane mean: boxed_moments, cnsn_resident_kernels.h)
-                float s0 = 0.f;
-#pragma unroll
-                for (int j = 0; j < NV; ++j)
-#pragma unroll
-                    for (int q = 0; q < VEC; ++q) s0 += elem<T, VEC>(d[s][j], q);  // invalid slots hold 0
-                const float k = wave_sum(s0) / (float)a.M;
-                float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < NV; ++j)
-                    if (sg.valid(j)) {
-#pragma unroll
-                        for (int q = 0; q < VEC; ++q) {
-                            const float dd = elem<T, VEC>(d[s][j], q) - k;
-                            const float dc = keep_if(dd, sg.mask_c(j, q)), ds = keep_if(dd, sg.mask_s(j, q));
-                            t[0] += dd;
-                            t[1] = fmaf(dd, dd, t[1]);
-                            t[2] += dc;
-                            t[3] = fmaf(dc, dc, t[3]);
-                            t[4] += ds;
-                            t[5] = fmaf(ds, ds, t[5]);
-                        }
-                    }
+                const float k = wave_sum(slots_sum<T, VEC, NV>(d[s])) / (float)a.M;  // invalid slots hold 0
+                float t[6];
+                boxed_region_sums<T, VEC, NV>(d[s], sg, k, t);
 #pragma unroll
                 for (int m = 0; m < 6; ++m) t[m] = wave_sum(t[m]);
                 boxed_moments(k, t, a.M, a.Mc, a.Ms, pub);
@@ -427,10 +408,15 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
                         const float f = elem<T, VEC>(v, q);
-                        if constexpr (!BOXED)
+                        if constexpr (!BOXED) {
                             ov[q] = fmaf(a_in, f - xr, b_in);
-                        else  // both maps, the one of the element's region picked by its mask word (pick_if: no branches)
-                            ov[q] = pick_if(sg.mask_c(j, q), fmaf(a_in, f - xr, b_in), fmaf(a_out, f, b_out));
+                        } else if ((q & 1) == 0) {  // both maps on the element PAIR, each element's picked by its mask word
+                            const cnsn_f2_t f2 = {f, elem<T, VEC>(v, q + 1)};
+                            const cnsn_f2_t r2 = pick_if2(sg.mask_c(j, q), sg.mask_c(j, q + 1), fma2(splat2(a_in), f2 - splat2(xr), splat2(b_in)),
+                                                          fma2(splat2(a_out), f2, splat2(b_out)));
+                            ov[q] = r2.x;
+                            ov[q + 1] = r2.y;
+                        }
                     }
                     buf_store<T, VEC>(slot_rsrc<T, VEC>(yb, pbytes, j), voff, pack<T, VEC>(ov));
                     if (i < FIRST_KEEP || i < NPARK)  // park slot i of item t+1 (garbage after the last item: never read)
@@ -544,22 +530,17 @@ __global__ __launch_bounds__(kBlock, pipe_bwd_waves(2 * PPW * NV)) void resident
             float acc[NS];
 #pragma unroll
             for (int m = 0; m < NS; ++m) acc[m] = 0.f;
+            if constexpr (BOXED) {  // whole-plane sums in acc[2..3], content-box sums in acc[0..1], both about float(mu_c)
+                boxed_bwd_sums<T, VEC, NV>(dg_[s], dx_[s], [&](int j) { return sg.valid(j); }, [&](int j, int q) { return sg.mask_c(j, q); }, si, acc);
+            } else
 #pragma unroll
             for (int j = 0; j < NV; ++j)
                 if (sg.valid(j)) {
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
                         const float G = elem<T, VEC>(dg_[s][j], q), X = elem<T, VEC>(dx_[s][j], q);
-                        if constexpr (!BOXED) {
-                            acc[0] += G;
-                            acc[1] = fmaf(G, X - si, acc[1]);
-                        } else {  // whole-plane sums in acc[2..3], content-box sums in acc[0..1], both about float(mu_c)
-                            const float Xc = X - si, Gc = keep_if(G, sg.mask_c(j, q));
-                            acc[0] += Gc;
-                            acc[1] = fmaf(Gc, Xc, acc[1]);
-                            acc[2] += G;
-                            acc[3] = fmaf(G, Xc, acc[3]);
-                        }
+                        acc[0] += G;
+                        acc[1] = fmaf(G, X - si, acc[1]);
                     }
                 }
 #pragma unroll
@@ -868,9 +849,16 @@ __global__ __launch_bounds__(kBlock, pipe_bwd_waves(2 * PPW * NV)) void resident
                         if constexpr (!BOXED) {
                             v = fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i));
                         } else {
-                            v = pick_if(sg.mask_c(j, q), fmaf(cG_i, G, fmaf(cX_i, X - xr_i, c0_i)),
-                                        fmaf(cG_o, G, fmaf(cX_o, X - xr_o, c0_o)));
-                            v += keep_if(fmaf(eS, X - xs, e0), sg.mask_s(j, q));
+                            if ((q & 1) == 0) {  // the three affine maps on the element PAIR, then each element's by its mask words
+                                const cnsn_f2_t G2 = {G, elem<T, VEC>(rg, q + 1)}, X2 = {X, elem<T, VEC>(rx, q + 1)};
+                                const cnsn_f2_t vi = fma2(splat2(cG_i), G2, fma2(splat2(cX_i), X2 - splat2(xr_i), splat2(c0_i)));
+                                const cnsn_f2_t vo = fma2(splat2(cG_o), G2, fma2(splat2(cX_o), X2 - splat2(xr_o), splat2(c0_o)));
+                                const cnsn_f2_t r2 = pick_if2(sg.mask_c(j, q), sg.mask_c(j, q + 1), vi, vo) +
+                                                     keep_if2(fma2(splat2(eS), X2 - splat2(xs), splat2(e0)), sg.mask_s(j, q), sg.mask_s(j, q + 1));
+                                ov[q] = r2.x;
+                                ov[q + 1] = r2.y;
+                            }
+                            continue;
                         }
                         ov[q] = v;
                     }

@@ -991,6 +991,10 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
                         gx = dot2_acc<T>(gw, xw, gx);
                     }
                 acc1 = fmaf(-si, acc0, gx);
+            } else if constexpr (BOXED) {  // content-box sums in acc0 / acc1, whole-plane sums in acc2 / acc3, both about float(mu_c)
+                float acc[4];
+                boxed_bwd_sums<T, VEC, NV>(dg_[s], dx_[s], [&](int j) { return sg.valid(j); }, mask_c, si, acc);
+                acc0 = acc[0], acc1 = acc[1], acc2 = acc[2], acc3 = acc[3];
             } else
 #pragma unroll
             for (int j = 0; j < NV; ++j)
@@ -998,16 +1002,8 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
                         const float G = elem<T, VEC>(dg_[s][j], q), X = elem<T, VEC>(dx_[s][j], q);
-                        if constexpr (!BOXED) {
-                            acc0 += G;
-                            acc1 = fmaf(G, X - si, acc1);
-                        } else {  // content-box sums in acc0 / acc1, whole-plane sums in acc2 / acc3, both about float(mu_c)
-                            const float Xc = X - si, Gc = keep_if(G, mask_c(j, q));
-                            acc0 += Gc;
-                            acc1 = fmaf(Gc, Xc, acc1);
-                            acc2 += G;
-                            acc3 = fmaf(G, Xc, acc3);
-                        }
+                        acc0 += G;
+                        acc1 = fmaf(G, X - si, acc1);
                     }
                 }
             if constexpr (BOXED) {  // outside the box = whole plane - box, re-centred on float(mu_o) (cnsn_resident_kernels.h)
@@ -1372,9 +1368,15 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
                         const float G = elem<T, VEC>(rg, q), X = elem<T, VEC>(rx, q);
                         if constexpr (!BOXED) {
                             ov[q] = fmaf(cG, G, fmaf(cX, X - xr, c0));
-                        } else {  // both affine maps, the one of the element's region picked by its mask word (no branches)
-                            const float v = pick_if(mask_c(j, q), fmaf(kG, G, fmaf(kX, X - kr, k0)), fmaf(cGo, G, fmaf(cXo, X - xro, c0o)));
-                            ov[q] = v + keep_if(fmaf(eS, X - xs, e0), mask_s(j, q));
+                        } else if ((q & 1) == 0) {  // the three affine maps on the element PAIR (v_pk_fma_f32), then each element's by
+                                                    // its mask words (no branches)
+                            const cnsn_f2_t G2 = {G, elem<T, VEC>(rg, q + 1)}, X2 = {X, elem<T, VEC>(rx, q + 1)};
+                            const cnsn_f2_t vi = fma2(splat2(kG), G2, fma2(splat2(kX), X2 - splat2(kr), splat2(k0)));
+                            const cnsn_f2_t vo = fma2(splat2(cGo), G2, fma2(splat2(cXo), X2 - splat2(xro), splat2(c0o)));
+                            const cnsn_f2_t r2 = pick_if2(mask_c(j, q), mask_c(j, q + 1), vi, vo) +
+                                                 keep_if2(fma2(splat2(eS), X2 - splat2(xs), splat2(e0)), mask_s(j, q), mask_s(j, q + 1));
+                            ov[q] = r2.x;
+                            ov[q + 1] = r2.y;
                         }
                     }
                     sg.store(t_dx, doff, j, pack<T, VEC>(ov));
