@@ -25,7 +25,7 @@ pmc() {  # name, command...
 }
 stats bench_f32_neither python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra
 for c in boxed_f32 boxed_bf16 neither_bf16 block_bf16 block_f32 sn_bf16; do stats $c python $R/tools/run_cases.py $c 8; done
-for c in boxed_f32 neither_bf16 block_bf16 block_f32; do pmc $c python $R/tools/run_cases.py $c 4; done
+for c in boxed_f32 boxed_bf16 neither_bf16 block_bf16 block_f32; do pmc $c python $R/tools/run_cases.py $c 4; done
 pmc bench_f32_neither python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra
 stats resnet50_step python $R/bench.py --workload resnet50 --steps 12 --warmup 4
 cd $R
