@@ -27,9 +27,12 @@ WidePlan wide_plan(const Plan& pl, int add, bool backward, bool has_chan_perm) {
     WidePlan wp{false, 0, 0, 0};
     const cnsn_problem_t& p = pl.pr;
     if (p.strategy != CNSN_STRATEGY_AUTO && p.strategy != CNSN_STRATEGY_MONO) return wp;
-    if (!p.sn_active || p.sn_two || add == ADD_POST) return wp;
-    // CrossNorm: without crop boxes and without the channel permutation (the pairing stays inside one channel)
+    if ((!p.sn_active && !p.cn_active) || (p.sn_active && p.sn_two) || add == ADD_POST) return wp;
+    // CrossNorm: without crop boxes and without the channel permutation (the pairing stays inside one channel); CrossNorm
+    // ALONE (models/cnsn.py:152-164 with selfnorm=None) runs the same kernels without a gate (round 4: it was packed two-pass,
+    // 0.203 ms at (256,2048,7,7) bf16 against 0.138 for CrossNorm+SelfNorm here)
     if (p.cn_active && (pl.boxed || has_chan_perm)) return wp;
+    if (!p.sn_active && (add != ADD_NONE)) return wp;
     int mode = 1;  // CNSN_WIDE=0: never; CNSN_WIDE=2: wherever eligible (tests: fp32 and small batches too)
     if (const char* e = knob(K_WIDE)) mode = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);
     if (mode == 0) return wp;

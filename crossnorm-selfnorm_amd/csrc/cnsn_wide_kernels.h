@@ -217,8 +217,11 @@ __global__ __launch_bounds__(kWideBlock) void wide_fwd_kernel(WideArgs wa, const
     using Rr = float;
     constexpr int PP = 2;  // pairs per thread: N * CH <= 2048
     const int k = threadIdx.x & (CH - 1), c = c0 + k;
-    const double wg0 = gg.w[2 * c], wg1 = gg.w[2 * c + 1], gam = gg.gamma[c], bet = gg.beta[c];
-    const double rm0 = gg.run_mean[c], rv0 = gg.run_var[c];
+    // (CrossNorm ALONE — sn_active 0, CN instantiations only: no gate, g = 1, nothing of `gg` is touched; models/cnsn.py:152-164
+    //  with selfnorm=None)
+    const bool sn = !CN || a.sn_active != 0;
+    const double wg0 = sn ? gg.w[2 * c] : 0.f, wg1 = sn ? gg.w[2 * c + 1] : 0.f, gam = sn ? gg.gamma[c] : 0.f, bet = sn ? gg.beta[c] : 0.f;
+    const double rm0 = sn ? gg.run_mean[c] : 0.f, rv0 = sn ? gg.run_var[c] : 1.f;
     auto plane_of = [&](int p) {  // (cheap: recomputed after the reduction instead of kept across it)
         MomentsT<Rr> o;
         o.mu_c = o.mu_s = smu[p];
@@ -243,7 +246,9 @@ __global__ __launch_bounds__(kWideBlock) void wide_fwd_kernel(WideArgs wa, const
         }
     }
     double mg = rm0, rg;
-    if (a.sn_training) {
+    if (!sn) {
+        rg = 1.0;
+    } else if (a.sn_training) {
         wide_chan_sum<2, CH>(sz, red);
         mg = sz[0] * a.inv_n;
         double vg = sz[1] * a.inv_n - mg * mg;
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(kWideBlock) void wide_fwd_kernel(WideArgs wa, const
     } else {
         rg = (double)__builtin_amdgcn_rsqf((float)rv0 + a.eps_bn);
     }
-    if (saved && threadIdx.x < CH) {
+    if (saved && sn && threadIdx.x < CH) {
         saved[SV_ROWS * P + c] = rg;
         saved[SV_ROWS * P + C + c] = 1.0;
     }
@@ -271,8 +276,8 @@ __global__ __launch_bounds__(kWideBlock) void wide_fwd_kernel(WideArgs wa, const
             const int n = p / CH;
             const FwdPlaneT<Rr> f = plane_of(p);
             const double z = wg0 * (double)f.mu_p + wg1 * (double)f.sig_p;
-            const double zhg = (z - mg) * rg;
-            const Rr gt = sigmoid_r<Rr>((Rr)(gam * zhg + bet));
+            const double zhg = sn ? (z - mg) * rg : 0.0;
+            const Rr gt = sn ? sigmoid_r<Rr>((Rr)(gam * zhg + bet)) : Rr(1);
             const FwdCoefs cf = fwd_coefs<Rr>(a, f, gt, 1.f);
             if (saved) {
                 const SvRec ps = sv_rec(n, c, N);
@@ -398,8 +403,9 @@ __global__ __launch_bounds__(kWideBlock) void wide_bwd_kernel(WideArgs wa, const
             }
         }
     }
-    const float w_g0 = gg.w[2 * c], w_g1 = gg.w[2 * c + 1], gam_g = gg.gamma[c];
-    const double rs_g = saved[SV_ROWS * P + c];
+    const bool sn = !CN || a.sn_active != 0;  // (CrossNorm alone: no gate, no gate gradients — see the forward)
+    const float w_g0 = sn ? gg.w[2 * c] : 0.f, w_g1 = sn ? gg.w[2 * c + 1] : 0.f, gam_g = sn ? gg.gamma[c] : 0.f;
+    const double rs_g = sn ? saved[SV_ROWS * P + c] : 0.0;
     __syncthreads();
 
     MRaw<T, VEC> dg_[HALF], dx_[HALF];
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(kWideBlock) void wide_bwd_kernel(WideArgs wa, const
         if constexpr (CN) {
             cr = load_cn_rows<Rr>(a, saved, ps, r_mu);
             sums = fix_sums<Rr>(a, ps1[p], ps2[p], 0.f, 0.f, r_mu, (double)cr.mu_o);
-            gate_dt<Rr>(a, sums, cr.a1, cr.m_in, cr.mu_o, (Rr)r_mup, (Rr)r_g, Rr(1), dtg, dtf);
+            if (sn) gate_dt<Rr>(a, sums, cr.a1, cr.m_in, cr.mu_o, (Rr)r_mup, (Rr)r_g, Rr(1), dtg, dtf);
         } else {
             sums = fix_sums<Rr>(a, ps1[p], ps2[p], 0.f, 0.f, r_mu, 0.0);
             gate_dt<Rr>(a, sums, Rr(1), (Rr)r_mu, Rr(0), (Rr)r_mup, (Rr)r_g, Rr(1), dtg, dtf);
@@ -561,7 +567,7 @@ __global__ __launch_bounds__(kWideBlock) void wide_bwd_kernel(WideArgs wa, const
         }
     }
     wide_chan_sum<2, CH>(sw, red);  // (also the barrier that makes Emu / Esig of every pair visible)
-    if (threadIdx.x < CH) {
+    if (sn && threadIdx.x < CH) {
         dgr.dgamma[c] = (float)s4[1];
         dgr.dbeta[c] = (float)s4[0];
         dgr.dw[2 * c] = (float)sw[0];

@@ -45,6 +45,8 @@ TABLE = [
     ((256, 2048, 7, 7), BF16, FC(**BLOCK), "mono", "mono"),
     ((96, 2048, 7, 7), BF16, FC(**SN), "local", "local"),                      # small batch: the channel-local kernels
     ((256, 2048, 7, 7), BF16, FC(**SN, **CN), "mono", "mono"),                 # CrossNorm without boxes: channel groups in registers ("wide", round 3)
+    ((256, 2048, 7, 7), BF16, FC(**CN), "mono", "mono"),                       # CrossNorm ALONE: the same kernels without a gate (round 4; was packed two-pass)
+    ((96, 2048, 7, 7), BF16, FC(**CN), "packed", "packed"),                    # ... below N = 128 the step is host-bound either way
     ((256, 2048, 7, 7), F32, FC(**SN), "mono", "mono"),                        # fp32 7x7: one element (4 B) per lane
     ((16, 512, 64, 64), F32, FC(sn_active=True, add_mode="post", relu=True), "resident", "resident"),   # segmentation: SN at 'residual'
     ((16, 2048, 64, 64), BF16, FC(sn_active=True, add_mode="post", relu=True), "resident", "resident"),

@@ -63,6 +63,28 @@ def test_crossnorm_selfnorm(shape, tag):
     assert_parity(out, DT[tag], ("wide cn", tag, shape))
 
 
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("tag", ["f32", "bf16", "f16"])
+def test_crossnorm_alone(shape, tag):
+    """CrossNorm WITHOUT SelfNorm (models/cnsn.py:152-164 with selfnorm=None; round 4): the same kernels, no gate — until then
+    the packed two-pass kernels ran it"""
+    x = torch.empty(shape, dtype=DT[tag], device="cuda")
+    cfg = cnsn_amd.FusedConfig(cn_active=True)
+    assert cnsn_amd.which_path(x, cfg, backward=False) == "mono" and cnsn_amd.which_path(x, cfg, backward=True) == "mono"
+    out = run_pair(shape, "neither", "cn", DT[tag], 75 + shape[0])
+    assert_parity(out, DT[tag], ("wide cn alone", tag, shape))
+
+
+def test_crossnorm_alone_full_size_and_auto():
+    from tests.test_gpu_full_size import check_case
+    import os
+    os.environ.pop("CNSN_WIDE", None)   # AUTO
+    cfg = cnsn_amd.FusedConfig(cn_active=True)
+    assert cnsn_amd.which_path(torch.empty((256, 2048, 7, 7), dtype=torch.bfloat16, device="cuda"), cfg) == "mono"
+    check_case((256, 2048, 7, 7), torch.bfloat16, "cn", "neither", 11)
+    check_case((256, 2048, 7, 7), torch.float32, "cn", "neither", 12)
+
+
 @pytest.mark.parametrize("shape", SHAPES[:4], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("tag", ["f32", "bf16"])
 @pytest.mark.parametrize("mode,relu", [("pre", True), ("none", True), ("pre", False)])
