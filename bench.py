@@ -807,6 +807,11 @@ def main():
             state.restore()
         raise cnsn_amd.CnsnError("bench: cluster launches still time out after three windows")
 
+    # The box's own ceilings (roofline.ceiling) are measured BEFORE the warm-up: 0.3 s of plain copies in this process.  They
+    # belong to the line either way; ahead of the timed region they also take the device out of its idle clocks — a fresh
+    # process needs ~25 headline steps to settle (profiles/r04_launches_per_step.md: 0.852 ms at steps 5-9, 0.79 from step 25),
+    # more than the W = 5 the driver passes.  W warm-up steps and exactly K timed steps follow as the contract says.
+    ceil = copy_triad_ceiling(dev) if (world == 1 and not args.no_ceiling) else None
     settled_window(args.warmup, False)
     dt = settled_window(args.steps, True)
     if dist is not None:
@@ -894,8 +899,7 @@ def main():
                     out["roofline"]["forward"]["traffic_over_bytes"] = round(live["fwd"] / need_f, 4)
             elif traffic_source is not None:
                 out["roofline"]["traffic_source"] = traffic_source + "; " + why
-        if world == 1 and not args.no_ceiling:
-            ceil = copy_triad_ceiling(dev)
+        if ceil is not None:
             out["roofline"]["ceiling"] = ceil
             if "resident_order_triad_GBps" in ceil and list(shape) == [256, 256, 56, 56] and b == 4:
                 # how close the two launches are to what their access pattern allows on THIS box
