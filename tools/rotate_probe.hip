@@ -1,0 +1,100 @@
+// tools/rotate_probe.hip — does a per-plane ROTATION of the slot order take the placement sensitivity out of the cluster
+// kernels' access order?  (measurement aid; profiles/r04_placement_sensitivity.md)
+// Plane copy as tools/pattern_bench.hip ("column" order: wave w of workgroup-item (c, k) copies plane n = 4k + w of channel c,
+// 13 x 1 KB loads then 13 x 1 KB stores), but register slot j holds memory slot (j + r) mod 13 with r a function of the plane:
+//   mode 0: r = 0 (the kernels today)   1: r = n mod 13   2: r = (5 n) mod 13   3: r = (n / 4) mod 13   4: linear order, r = 0
+// on several (x, y) buffer pairs of one process, both ways round.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef int v4i __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0 ? bytes : 0, 0x00020000);
+}
+template <int NV>
+__global__ __launch_bounds__(256, 3) void plane_copy(const float* __restrict__ x, float* __restrict__ y, int N, int C, int M, int K, int items,
+                                                     int mode) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int voff = lane * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v4i* mypark = (v4i*)smem + (size_t)wave * NV * 64 + lane;
+    v4i d[NV];
+    auto plane_of = [&](int item, int& rot) -> long {
+        if (mode == 4) { rot = 0; return (long)item * 4 + wave; }
+        const int c = item / K, k = item - c * K;
+        const int n = k * 4 + wave;
+        rot = mode == 1 ? n % NV : mode == 2 ? (5 * n) % NV : mode == 3 ? (n / 4) % NV : 0;
+        return n < N ? (long)n * C + c : -1;
+    };
+    auto slot = [&](int j, int rot) { const int t = j + rot; return t >= NV ? t - NV : t; };
+    auto load = [&](long pl, int rot) {
+        const float* pb = x + (pl < 0 ? 0 : pl) * M;
+        const int bytes = pl < 0 ? 0 : M * 4;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int jm = slot(j, rot);
+            d[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(pb + jm * 256, bytes - jm * 1024), voff, 0, 2);
+        }
+    };
+    int item = blockIdx.x;
+    if (item >= items) return;
+    int rot, nrot = 0;
+    long pl = plane_of(item, rot);
+    load(pl, rot);
+    for (;;) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) mypark[j * 64] = d[j];
+        const int next = item + gridDim.x;
+        const bool more = next < items;
+        const long npl = more ? plane_of(next, nrot) : -1;
+        float* yb = y + (pl < 0 ? 0 : pl) * M;
+        const int bytes = pl < 0 ? 0 : M * 4;
+        const float* pb = x + (npl < 0 ? 0 : npl) * M;
+        const int nbytes = npl < 0 ? 0 : M * 4;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {  // slot by slot as the pipelined kernels: store item t's slot, load item t+1's
+            const int jm = slot(j, rot), jn = slot(j, nrot);
+            v4i v = mypark[j * 64];
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc(yb + jm * 256, bytes - jm * 1024), voff, 0, 2);
+            if (more) d[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(pb + jn * 256, nbytes - jn * 1024), voff, 0, 2);
+        }
+        if (!more) break;
+        item = next;
+        pl = npl;
+        rot = nrot;
+    }
+}
+template <typename F>
+float time_ms(F&& f, int reps = 20) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) f();
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) f();
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / reps;
+}
+int main() {
+    const int N = 256, C = 256, M = 56 * 56, K = N / 4, items = C * K;
+    const size_t E = (size_t)N * C * M;
+    const int NB = 6;
+    float* buf[NB];
+    for (int i = 0; i < NB; ++i) { CK(hipMalloc(&buf[i], E * 4)); CK(hipMemset(buf[i], 0, E * 4)); }
+    const double gb = 2.0 * E * 4 / 1e9;
+    const size_t lds = (size_t)4 * 64 * 13 * 16;
+    auto kern = plane_copy<13>;
+    printf("| x | y | column r=0 | r = n %% 13 | r = 5n %% 13 | r = (n/4) %% 13 | linear |\n|---|---|---|---|---|---|---|\n");
+    const int pairs[][2] = {{0, 1}, {1, 0}, {2, 3}, {3, 2}, {4, 5}, {5, 4}, {0, 3}, {2, 5}};
+    for (auto& p : pairs) {
+        printf("| %p | %p |", (void*)buf[p[0]], (void*)buf[p[1]]);
+        for (int mode = 0; mode < 5; ++mode) {
+            float ms = time_ms([&] { kern<<<768, 256, lds>>>(buf[p[0]], buf[p[1]], N, C, M, K, items, mode); });
+            printf(" %.4f ms %.0f GB/s |", ms, gb / ms * 1e3);
+        }
+        printf("\n");
+    }
+    return 0;
+}
