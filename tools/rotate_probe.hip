@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 typedef int v4i __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base, int bytes) {
@@ -77,12 +78,61 @@ float time_ms(F&& f, int reps = 20) {
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     return ms / reps;
 }
-int main() {
+int main(int argc, char** argv) {
     const int N = 256, C = 256, M = 56 * 56, K = N / 4, items = C * K;
     const size_t E = (size_t)N * C * M;
     const int NB = 6;
     float* buf[NB];
-    for (int i = 0; i < NB; ++i) { CK(hipMalloc(&buf[i], E * 4)); CK(hipMemset(buf[i], 0, E * 4)); }
+    // argv[1] = "vmm": every buffer is a hipMemCreate'd physical allocation mapped at a virtual address aligned to argv[2] MiB
+    // (default 1024) — if what makes a placement good is the page-table FRAGMENT size (the largest power of two to which the
+    // virtual and the physical address are both aligned and contiguous), these are good every time
+    if (argc > 1 && !strcmp(argv[1], "carve")) {
+        // ONE allocation of argv[2] GiB (default 24), write targets carved out of it every argv[3] MiB (default 256): is "a good
+        // write target" a property of WHERE in the allocation (i.e. of physical regions) the plane copy's output lies?
+        const size_t total = (size_t)(argc > 2 ? atoi(argv[2]) : 24) << 30, step = (size_t)(argc > 3 ? atoi(argv[3]) : 256) << 20;
+        char* big;
+        float* src;
+        CK(hipMalloc(&src, E * 4)); CK(hipMemset(src, 0, E * 4));
+        CK(hipMalloc(&big, total)); CK(hipMemset(big, 0, total));
+        const double gb2 = 2.0 * E * 4 / 1e9;
+        auto k2 = plane_copy<13>;
+        printf("src %p big %p\n| offset MiB | column GB/s | linear GB/s | read-from-here column GB/s |\n|---|---|---|---|\n", (void*)src, (void*)big);
+        for (size_t off = 0; off + E * 4 <= total; off += step) {
+            float* dst = (float*)(big + off);
+            float m0 = time_ms([&] { k2<<<768, 256, (size_t)4 * 64 * 13 * 16>>>(src, dst, N, C, M, K, items, 0); }, 10);
+            float m4 = time_ms([&] { k2<<<768, 256, (size_t)4 * 64 * 13 * 16>>>(src, dst, N, C, M, K, items, 4); }, 10);
+            float mr = time_ms([&] { k2<<<768, 256, (size_t)4 * 64 * 13 * 16>>>(dst, src, N, C, M, K, items, 0); }, 10);
+            printf("| %zu | %.0f | %.0f | %.0f |\n", off >> 20, gb2 / m0 * 1e3, gb2 / m4 * 1e3, gb2 / mr * 1e3);
+        }
+        return 0;
+    }
+    const bool vmm = argc > 1 && !strcmp(argv[1], "vmm");
+    const size_t align = (size_t)(argc > 2 ? atoi(argv[2]) : 1024) << 20;
+    for (int i = 0; i < NB; ++i) {
+        if (!vmm) {
+            CK(hipMalloc(&buf[i], E * 4));
+        } else {
+            hipMemAllocationProp prop = {};
+            prop.type = hipMemAllocationTypePinned;
+            prop.location.type = hipMemLocationTypeDevice;
+            prop.location.id = 0;
+            size_t gran = 0;
+            CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+            const size_t sz = ((E * 4 + gran - 1) / gran) * gran;
+            hipMemGenericAllocationHandle_t h;
+            CK(hipMemCreate(&h, sz, &prop, 0));
+            void* va = nullptr;
+            CK(hipMemAddressReserve(&va, sz, align, nullptr, 0));
+            CK(hipMemMap(va, sz, 0, h, 0));
+            hipMemAccessDesc acc = {};
+            acc.location = prop.location;
+            acc.flags = hipMemAccessFlagsProtReadWrite;
+            CK(hipMemSetAccess(va, sz, &acc, 1));
+            buf[i] = (float*)va;
+            if (i == 0) printf("vmm: granularity %zu, size %zu, alignment %zu MiB\n", gran, sz, align >> 20);
+        }
+        CK(hipMemset(buf[i], 0, E * 4));
+    }
     const double gb = 2.0 * E * 4 / 1e9;
     const size_t lds = (size_t)4 * 64 * 13 * 16;
     auto kern = plane_copy<13>;
