@@ -13,7 +13,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base, int bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0 ? bytes : 0, 0x00020000);
 }
-template <int NV>
+template <int NV, int SAUX = 2>
 __global__ __launch_bounds__(256, 3) void plane_copy(const float* __restrict__ x, float* __restrict__ y, int N, int C, int M, int K, int items,
                                                      int mode) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 3) void plane_copy(const float* __restrict__ x
         for (int j = 0; j < NV; ++j) {  // slot by slot as the pipelined kernels: store item t's slot, load item t+1's
             const int jm = slot(j, rot), jn = slot(j, nrot);
             v4i v = mypark[j * 64];
-            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc(yb + jm * 256, bytes - jm * 1024), voff, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc(yb + jm * 256, bytes - jm * 1024), voff, 0, SAUX);
             if (more) d[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(pb + jn * 256, nbytes - jn * 1024), voff, 0, 2);
         }
         if (!more) break;
@@ -103,6 +103,26 @@ int main(int argc, char** argv) {
             float m4 = time_ms([&] { k2<<<768, 256, (size_t)4 * 64 * 13 * 16>>>(src, dst, N, C, M, K, items, 4); }, 10);
             float mr = time_ms([&] { k2<<<768, 256, (size_t)4 * 64 * 13 * 16>>>(dst, src, N, C, M, K, items, 0); }, 10);
             printf("| %zu | %.0f | %.0f | %.0f |\n", off >> 20, gb2 / m0 * 1e3, gb2 / m4 * 1e3, gb2 / mr * 1e3);
+        }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "aux")) {
+        // the cache policy of the STORES (aux operand of buffer_store: 0 default, 1 sc0, 2 nt, 3 sc0 nt, 16 sc1, 17 sc0 sc1, 18 sc1 nt,
+        // 19 sc0 sc1 nt) on six buffers written in turn from one source: does a policy make every buffer a good write target?
+        float* b6[7];
+        for (int i = 0; i < 7; ++i) { CK(hipMalloc(&b6[i], E * 4)); CK(hipMemset(b6[i], 0, E * 4)); }
+        const double gb2 = 2.0 * E * 4 / 1e9;
+        const size_t l2 = (size_t)4 * 64 * 13 * 16;
+        printf("| write target | aux 0 | 1 | 2 (the kernels) | 3 | 16 | 17 | 18 | 19 |\n|---|---|---|---|---|---|---|---|---|\n");
+        for (int i = 1; i < 7; ++i) {
+            printf("| %p |", (void*)b6[i]);
+            auto go = [&](auto kern) {
+                float ms = time_ms([&] { kern<<<768, 256, l2>>>(b6[0], b6[i], N, C, M, K, items, 0); }, 10);
+                printf(" %.0f |", gb2 / ms * 1e3);
+            };
+            go(plane_copy<13, 0>); go(plane_copy<13, 1>); go(plane_copy<13, 2>); go(plane_copy<13, 3>);
+            go(plane_copy<13, 16>); go(plane_copy<13, 17>); go(plane_copy<13, 18>); go(plane_copy<13, 19>);
+            printf("\n");
         }
         return 0;
     }
