@@ -36,16 +36,30 @@ Box = Tuple[int, int, int, int]
 _CROPS = ("neither", "style", "content", "both")
 
 
+def _is_f64(x) -> bool:
+    return isinstance(x, torch.Tensor) and x.dtype == torch.float64
+
+
 def calc_ins_mean_std(x, eps=1e-5):
     """Per-(n,c) mean and sqrt(unbiased variance + eps) over H*W, each shaped (N,C,1,1)
-    (reference models/cnsn.py:8-17).  Differentiable."""
+    (reference models/cnsn.py:8-17).  Differentiable.
+
+    float64 (the reference takes any floating dtype, :12-16): the parameter-free ops — this one, `instance_norm_mix`,
+    `cn_op_2ins_space_chan` / `CrossNorm` — accept it, compute on a float32 copy with the float32 kernels (whose plane
+    statistics and scalar algebra are fp32 / fp64 as for any input) and return float64: float32 ACCURACY in a float64
+    container, differentiable through the two casts.  SelfNorm's gate with float64 parameters is still refused."""
     assert x.dim() == 4
+    if _is_f64(x):
+        mean, std = _F.PlaneStats.apply(x.float(), float(eps), None, True)
+        return mean.double(), std.double()
     return _F.PlaneStats.apply(x, float(eps), None)
 
 
 def instance_norm_mix(content_feat, style_feat):
     """Give `content_feat` the plane statistics of `style_feat` (reference models/cnsn.py:20-29)."""
     assert content_feat.size()[:2] == style_feat.size()[:2]
+    if _is_f64(content_feat):
+        return instance_norm_mix(content_feat.float(), style_feat.float()).double()
     s_mean, s_std = calc_ins_mean_std(style_feat)
     c_mean, c_std = calc_ins_mean_std(content_feat)
     scale = s_std.float() / c_std.float()          # (N,C,1,1) scalars per plane; negligible work
@@ -107,6 +121,8 @@ def cn_op_2ins_space_chan(x, crop='neither', beta=1, bbx_thres=0.1, lam=None, ch
     assert crop in _CROPS
     if draws is None:
         draws = draw_cn(x.size(), crop, beta, bbx_thres, chan)
+    if _is_f64(x):   # (see calc_ins_mean_std)
+        return _F.fused_cnsn(x.float(), _cn_config(draws, lam), perm=draws.perm, chan_perm=draws.chan_perm).double()
     return _F.fused_cnsn(x, _cn_config(draws, lam), perm=draws.perm, chan_perm=draws.chan_perm)
 
 

@@ -409,8 +409,37 @@ def test_errors():
         cnsn_amd.cn_op_2ins_space_chan(torch.randn(2, 4, 8, 8, device=DEV), crop="bogus")
     with pytest.raises(AssertionError):
         cnsn_amd.calc_ins_mean_std(torch.randn(2, 4, 8, device=DEV))
-    with pytest.raises(TypeError):
-        cnsn_amd.calc_ins_mean_std(torch.randn(2, 4, 8, 8, device=DEV, dtype=torch.float64))
+    with pytest.raises(TypeError):                     # SelfNorm's gate on float64 input: not offered (float32 parameters)
+        cnsn_amd.SelfNorm(4).to(DEV).train()(torch.randn(2, 4, 8, 8, device=DEV, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("crop", ["neither", "both"])
+def test_float64_parameter_free_ops(crop):
+    """the reference takes any floating dtype (models/cnsn.py:12-16): the parameter-free ops accept float64, compute with the
+    float32 kernels and return float64 — float32 accuracy against the oracle's float64 arithmetic, gradients included"""
+    shape = (6, 5, 12, 16)
+    torch.manual_seed(3)
+    np.random.seed(3)
+    x64 = cond_input(shape, 3)
+    gy64 = torch.randn(shape, dtype=torch.float64)
+    d = orc.draw_cn(shape, crop, beta=1)
+    xr = x64.clone().requires_grad_()
+    want = orc.cn_op_2ins_space_chan(xr, crop=crop, draws=d)
+    want.backward(gy64)
+    xg = x64.clone().to(DEV).requires_grad_()
+    got = cnsn_amd.cn_op_2ins_space_chan(xg, crop=crop, draws=d)
+    assert got.dtype == torch.float64
+    got.backward(gy64.to(DEV))
+    assert xg.grad.dtype == torch.float64
+    for a, b in ((got.detach().cpu(), want.detach()), (xg.grad.cpu(), xr.grad)):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+    m, s = cnsn_amd.calc_ins_mean_std(x64.to(DEV))
+    mo, so = orc.calc_ins_mean_std(x64)
+    assert m.dtype == torch.float64 and float((m.cpu() - mo).abs().max()) <= 1e-6 * max(1.0, float(mo.abs().max()))
+    assert float((s.cpu() - so).abs().max()) <= 1e-5 * max(1.0, float(so.abs().max()))
+    mix = cnsn_amd.instance_norm_mix(x64.to(DEV), x64.flip(0).to(DEV))
+    assert mix.dtype == torch.float64
+    assert float((mix.cpu() - orc.instance_norm_mix(x64, x64.flip(0))).abs().max()) <= 2e-5 * max(1.0, float(x64.abs().max()))
 
 
 def test_crossnorm_flag_semantics():
