@@ -66,6 +66,46 @@ __global__ __launch_bounds__(256, 3) void plane_copy(const float* __restrict__ x
         rot = nrot;
     }
 }
+// column order, no software pipeline: SPLIT = 0: wave w copies plane 4k + w (13 slots); SPLIT = 1: the four waves of a workgroup
+// share EVERY plane (wave w takes slots w, w + 4, w + 8, w + 12 of each of the workgroup's four planes, one plane after the
+// other): a quarter as many planes are being written at any moment
+template <int SPLIT>
+__global__ __launch_bounds__(256, 3) void plane_copy_np(const float* __restrict__ x, float* __restrict__ y, int N, int C, int M, int K, int items) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int voff = lane * 16;
+    v4i d[16];
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int c = item / K, k = item - c * K;
+        if (!SPLIT) {
+            const long pl = (long)(k * 4 + wave) * C + c;
+            const float* pb = x + pl * M;
+            float* yb = y + pl * M;
+#pragma unroll
+            for (int j = 0; j < 13; ++j) d[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(pb + j * 256, M * 4 - j * 1024), voff, 0, 2);
+#pragma unroll
+            for (int j = 0; j < 13; ++j) __builtin_amdgcn_raw_buffer_store_b128(d[j], rsrc(yb + j * 256, M * 4 - j * 1024), voff, 0, 2);
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float* pb = x + ((long)(k * 4 + p) * C + c) * M;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int j = wave + 4 * i;
+                    d[p * 4 + i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(pb + j * 256, j < 13 ? M * 4 - j * 1024 : 0), voff, 0, 2);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float* yb = y + ((long)(k * 4 + p) * C + c) * M;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int j = wave + 4 * i;
+                    __builtin_amdgcn_raw_buffer_store_b128(d[p * 4 + i], rsrc(yb + j * 256, j < 13 ? M * 4 - j * 1024 : 0), voff, 0, 2);
+                }
+            }
+        }
+    }
+}
 template <typename F>
 float time_ms(F&& f, int reps = 20) {
     hipEvent_t a, b;
@@ -123,6 +163,19 @@ int main(int argc, char** argv) {
             go(plane_copy<13, 0>); go(plane_copy<13, 1>); go(plane_copy<13, 2>); go(plane_copy<13, 3>);
             go(plane_copy<13, 16>); go(plane_copy<13, 17>); go(plane_copy<13, 18>); go(plane_copy<13, 19>);
             printf("\n");
+        }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "split")) {
+        float* b6[7];
+        for (int i = 0; i < 7; ++i) { CK(hipMalloc(&b6[i], E * 4)); CK(hipMemset(b6[i], 0, E * 4)); }
+        const double gb2 = 2.0 * E * 4 / 1e9;
+        printf("| write target | a plane per wave | a plane per workgroup (split over its waves) | pipelined, plane per wave (the kernels) |\n|---|---|---|---|\n");
+        for (int i = 1; i < 7; ++i) {
+            float m0 = time_ms([&] { plane_copy_np<0><<<768, 256>>>(b6[0], b6[i], N, C, M, K, items); }, 10);
+            float m1 = time_ms([&] { plane_copy_np<1><<<768, 256>>>(b6[0], b6[i], N, C, M, K, items); }, 10);
+            float m2 = time_ms([&] { plane_copy<13><<<768, 256, (size_t)4 * 64 * 13 * 16>>>(b6[0], b6[i], N, C, M, K, items, 0); }, 10);
+            printf("| %p | %.0f | %.0f | %.0f |\n", (void*)b6[i], gb2 / m0 * 1e3, gb2 / m1 * 1e3, gb2 / m2 * 1e3);
         }
         return 0;
     }
