@@ -24,6 +24,9 @@ One JSON line is printed by rank 0; it also carries
                  priced on SURVEY §8(d3)'s two-pass byte count and the in-process copy / triad ceilings ride along
   cpu_baseline — the CPU oracle (a port of the reference's eager PyTorch path) timed on this
                  host's cores on a bounded slice of the same workload (rank 0, N=1 only), plus one thread
+  placement    — before the warm-up the blocks torch's allocator will hand out for y and dx are chosen by a timed write
+                 (cnsn_amd.placement: MI355X's memory has regions that take plane-strided writes 15-20 % faster,
+                 profiles/r04_memory_map.md); what was found; --no-placement leaves the allocator alone
 """
 import argparse
 import json
@@ -55,6 +58,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (crop=both, bf16)")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the copy / triad / access-order ceilings (child runs)")
+    ap.add_argument("--no-placement", action="store_true",
+                    help="do not look for output blocks in the fast-write regions of the device memory before the warm-up "
+                         "(cnsn_amd.placement, profiles/r04_memory_map.md)")
+    ap.add_argument("--placement-candidates", type=int, default=96, help="blocks of the input's size the placement step looks at")
     ap.add_argument("--workload", type=str, default="cnsn", choices=["cnsn", "resnet50", "resnet50_jsd", "wrn40"],
                     help="cnsn: the fused op at the north-star shape (headline); resnet50 / wrn40: whole "
                          "training steps of the caller backbones (images/s)")
@@ -185,10 +192,14 @@ def secondary_workloads(cnsn_amd, shape, dev, args):
     """Same shape, other modes (not the headline): CrossNorm with both crop boxes, and bf16 I/O."""
     n, c, h, w = shape
     res = {}
-    for tag, dtype, crop in (("f32_crop_both", torch.float32, "both"), ("bf16_crop_neither", torch.bfloat16, "neither"),
-                             ("bf16_crop_both", torch.bfloat16, "both"), ("f32_sn_only", torch.float32, None)):
+    placed = {torch.float32} if not args.no_placement else None    # (the headline run has placed the fp32 size already)
+    for tag, dtype, crop in (("f32_crop_both", torch.float32, "both"), ("f32_sn_only", torch.float32, None),
+                             ("bf16_crop_neither", torch.bfloat16, "neither"), ("bf16_crop_both", torch.bfloat16, "both")):
         x = conditioned(shape, dev, dtype, 31).requires_grad_()
         gy = torch.randn(shape, device=dev).to(dtype)
+        if placed is not None and dtype not in placed:              # output blocks of this size where writes are fast
+            cnsn_amd.placement.prefer_fast_write_blocks(x, keep=4, candidates=args.placement_candidates)
+            placed.add(dtype)
         mod = cnsn_amd.CNSN(cnsn_amd.CrossNorm(crop, 1) if crop else None, cnsn_amd.SelfNorm(c)).to(dev).train()
 
         def one():
@@ -373,7 +384,7 @@ def live_traffic(args, timeout_s=45):
     if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ):
         return None, "this process is itself being profiled: no nested rocprofv3 passes"
     child = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2", "--no-extra", "--no-cpu-baseline",
-             "--no-ceiling", "--shape", args.shape, "--dtype", args.dtype, "--crop", args.crop, "--kind", args.kind,
+             "--no-ceiling", "--no-placement", "--shape", args.shape, "--dtype", args.dtype, "--crop", args.crop, "--kind", args.kind,
              "--strategy", args.strategy]
     mean = {}                                              # (direction, counter) -> KiB per launch
     t0 = time.perf_counter()
@@ -812,6 +823,14 @@ def main():
     # process needs ~25 headline steps to settle (profiles/r04_launches_per_step.md: 0.852 ms at steps 5-9, 0.79 from step 25),
     # more than the W = 5 the driver passes.  W warm-up steps and exactly K timed steps follow as the contract says.
     ceil = copy_triad_ceiling(dev) if (world == 1 and not args.no_ceiling) else None
+    # Output placement (cnsn_amd.placement): the device memory has regions into which plane-strided writes run 15-20 % faster
+    # (profiles/r04_memory_map.md); y and dx are allocated per call from torch's caching allocator, which is left with free
+    # blocks of the input's size that were MEASURED to lie in such a region (a few seconds, before the warm-up; reported in the
+    # line; --no-placement switches it off).  One rank per GPU: every rank does it for its own device.
+    placement = None
+    if not args.no_placement and world <= ngpu:
+        from cnsn_amd import placement as _placement
+        placement = _placement.prefer_fast_write_blocks(x, keep=4, candidates=args.placement_candidates)
     settled_window(args.warmup, False)
     dt = settled_window(args.steps, True)
     if dist is not None:
@@ -899,6 +918,11 @@ def main():
                     out["roofline"]["forward"]["traffic_over_bytes"] = round(live["fwd"] / need_f, 4)
             elif traffic_source is not None:
                 out["roofline"]["traffic_source"] = traffic_source + "; " + why
+        if placement is not None:
+            placement["note"] = ("cnsn_amd.placement.prefer_fast_write_blocks before the warm-up: the caching allocator's free blocks "
+                                 "of the input's size (where y and dx land) were chosen among `candidates` by a timed write; "
+                                 "--no-placement for the allocator's own choice")
+            out["placement"] = placement
         if ceil is not None:
             out["roofline"]["ceiling"] = ceil
             if "resident_order_triad_GBps" in ceil and list(shape) == [256, 256, 56, 56] and b == 4:

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 typedef int v4i __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base, int bytes) {
@@ -163,6 +164,31 @@ int main(int argc, char** argv) {
             go(plane_copy<13, 0>); go(plane_copy<13, 1>); go(plane_copy<13, 2>); go(plane_copy<13, 3>);
             go(plane_copy<13, 16>); go(plane_copy<13, 17>); go(plane_copy<13, 18>); go(plane_copy<13, 19>);
             printf("\n");
+        }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "map")) {
+        // argv[2] buffers of 784 MiB (default 300 = 235 GB of the 288): every one as the WRITE target of the plane copy from buffer
+        // 0, in the kernels' order and in linear order — where in the device memory are the good targets?
+        const int nb = argc > 2 ? atoi(argv[2]) : 300;
+        const int src_i = argc > 3 ? atoi(argv[3]) : 0;  // which buffer is read
+        std::vector<float*> bs(nb, nullptr);
+        int got = 0;
+        for (int i = 0; i < nb; ++i) {
+            if (hipMalloc(&bs[i], E * 4) != hipSuccess) { (void)hipGetLastError(); break; }
+            CK(hipMemsetAsync(bs[i], 0, E * 4));
+            ++got;
+        }
+        CK(hipDeviceSynchronize());
+        const double gb2 = 2.0 * E * 4 / 1e9;
+        const size_t l2 = (size_t)4 * 64 * 13 * 16;
+        printf("%d buffers\n| # | address | column GB/s | linear GB/s | read-from-it column GB/s |\n|---|---|---|---|---|\n", got);
+        for (int i = 0; i < got; ++i) {
+            if (i == src_i) continue;
+            float m0 = time_ms([&] { plane_copy<13><<<768, 256, l2>>>(bs[src_i], bs[i], N, C, M, K, items, 0); }, 6);
+            float m4 = time_ms([&] { plane_copy<13><<<768, 256, l2>>>(bs[src_i], bs[i], N, C, M, K, items, 4); }, 6);
+            float mr = time_ms([&] { plane_copy<13><<<768, 256, l2>>>(bs[i], bs[src_i], N, C, M, K, items, 0); }, 6);
+            printf("| %d | %p | %.0f | %.0f | %.0f |\n", i, (void*)bs[i], gb2 / m0 * 1e3, gb2 / m4 * 1e3, gb2 / mr * 1e3);
         }
         return 0;
     }
