@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--no-placement", action="store_true",
                     help="do not look for output blocks in the fast-write regions of the device memory before the warm-up "
                          "(cnsn_amd.placement, profiles/r04_memory_map.md)")
-    ap.add_argument("--placement-candidates", type=int, default=96, help="blocks of the input's size the placement step looks at")
+    ap.add_argument("--placement-candidates", type=int, default=128, help="blocks of the input's size the placement step looks at")
     ap.add_argument("--workload", type=str, default="cnsn", choices=["cnsn", "resnet50", "resnet50_jsd", "wrn40"],
                     help="cnsn: the fused op at the north-star shape (headline); resnet50 / wrn40: whole "
                          "training steps of the caller backbones (images/s)")
