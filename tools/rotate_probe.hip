@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 typedef int v4i __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base, int bytes) {
@@ -189,6 +190,54 @@ int main(int argc, char** argv) {
             float m4 = time_ms([&] { plane_copy<13><<<768, 256, l2>>>(bs[src_i], bs[i], N, C, M, K, items, 4); }, 6);
             float mr = time_ms([&] { plane_copy<13><<<768, 256, l2>>>(bs[i], bs[src_i], N, C, M, K, items, 0); }, 6);
             printf("| %d | %p | %.0f | %.0f | %.0f |\n", i, (void*)bs[i], gb2 / m0 * 1e3, gb2 / m4 * 1e3, gb2 / mr * 1e3);
+        }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "mix")) {
+        // Are the fast write targets the buffers whose pages come from TWO regions?  A pool of argv[2] (default 128) physical
+        // allocations of argv[3] MiB (default 392 = half a tensor; must divide 784), and write targets MAPPED from them
+        // (hipMemAddressReserve + hipMemMap): chunks that were allocated next to each other, or far apart.
+        const int pool = argc > 2 ? atoi(argv[2]) : 128;
+        const size_t chunk = (size_t)(argc > 3 ? atoi(argv[3]) : 392) << 20;
+        const int per = (int)((E * 4) / chunk);
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = 0;
+        std::vector<hipMemGenericAllocationHandle_t> hs(pool);
+        for (int i = 0; i < pool; ++i) CK(hipMemCreate(&hs[i], chunk, &prop, 0));
+        float* src;
+        CK(hipMalloc(&src, E * 4)); CK(hipMemset(src, 0, E * 4));
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        const double gb2 = 2.0 * E * 4 / 1e9;
+        const size_t l2 = (size_t)4 * 64 * 13 * 16;
+        printf("pool %d chunks of %zu MiB, %d per tensor\n| chunks mapped | column GB/s | linear GB/s |\n|---|---|---|\n", pool, chunk >> 20, per);
+        auto run = [&](const std::vector<int>& idx) {
+            void* va = nullptr;
+            CK(hipMemAddressReserve(&va, E * 4, 0, nullptr, 0));
+            for (int q = 0; q < per; ++q) CK(hipMemMap((char*)va + q * chunk, chunk, 0, hs[idx[q]], 0));
+            CK(hipMemSetAccess(va, E * 4, &acc, 1));
+            float* dst = (float*)va;
+            float m0 = time_ms([&] { plane_copy<13><<<768, 256, l2>>>(src, dst, N, C, M, K, items, 0); }, 6);
+            float m4 = time_ms([&] { plane_copy<13><<<768, 256, l2>>>(src, dst, N, C, M, K, items, 4); }, 6);
+            printf("|");
+            for (int q = 0; q < per; ++q) printf(" %d", idx[q]);
+            printf(" | %.0f | %.0f |\n", gb2 / m0 * 1e3, gb2 / m4 * 1e3);
+            CK(hipDeviceSynchronize());
+            CK(hipMemUnmap(va, E * 4));
+            CK(hipMemAddressFree(va, E * 4));
+        };
+        for (int base = 0; base + per <= pool; base += pool / 8) {  // adjacent chunks
+            std::vector<int> idx;
+            for (int q = 0; q < per; ++q) idx.push_back(base + q);
+            run(idx);
+        }
+        for (int base = 0; base < pool / per; base += std::max(1, pool / per / 8)) {  // chunks spread over the whole pool
+            std::vector<int> idx;
+            for (int q = 0; q < per; ++q) idx.push_back(base + q * (pool / per));
+            run(idx);
         }
         return 0;
     }
