@@ -791,6 +791,9 @@ struct SnxBwdKargsCn {
 // BOXED (round 4, CN only): crop boxes (models/cnsn.py:64-82).  Four sums per plane (inside the content box; the whole plane, from
 // which the outside follows by subtraction), a piecewise-affine dx with a third term inside the style box (11 coefficients),
 // membership of an element from one bit mask per lane and register slot (the same for every plane).
+#ifndef CNSN_SNXCN_EARLY
+#define CNSN_SNXCN_EARLY 1
+#endif
 template <typename T, int VEC, int NV, int PPW, bool EPI, bool CN = false, bool BOXED = false>
 __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int)sizeof(T))) void resident_sn_bwd_kernel(
     std::conditional_t<CN, SnxBwdKargsCn<T>, SnxBwdKargs<T>>) {
@@ -1144,6 +1147,25 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
             br.M2c = (float)saved[sv_at(pb, SV_M2C)];
             br.mu_o = BOXED ? (float)saved[sv_at(pb, SV_MU_O)] : 0.f;
         }
+        // (CN) ... and a FIRST read of the borrower's granule, also in flight during the gather: its member published it before its
+        // partial, so by the time the gather has seen every partial this read has usually come back with the launch's tag — the
+        // poll loop below then starts with it instead of with a memory round trip of its own (about 1 us per item on the serial
+        // chain of the workgroup, which is what bounds the kernel once the outputs lie in fast-write memory)
+        unsigned long long pq0 = 0, pq1 = 0, pq2 = 0, pq3 = 0;
+        (void)pq0, (void)pq1, (void)pq2, (void)pq3;
+        if constexpr (CN && CNSN_SNXCN_EARLY && !BOXED) {
+            const KAC* kc = kargs_now<KAC>();
+            const unsigned long long* gp = kc->gran_p;
+            const size_t pi = (size_t)c * N + (size_t)r_l;
+            if (lane < nlive) {
+                if (kc->sn.ra.epoch) {
+                    pq0 = __hip_atomic_load((gu64*)(gp + NSP * pi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pq1 = __hip_atomic_load((gu64*)(gp + NSP * pi + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    pq0 = __hip_atomic_load((gu64*)(gp + (NSP / 2) * pi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
 
         // ---- gather round A of item t's channel
         unsigned passes_ = 0;
@@ -1216,9 +1238,10 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
                     for (unsigned spins = 0;; ++spins) {
                         bool ok = true;
                         if (mine) {
+                            const bool early = CNSN_SNXCN_EARLY && !BOXED && spins == 0;  // (the read sent off before the gather)
                             if (epoch) {
-                                const unsigned long long q0 = __hip_atomic_load((gu64*)(gp + NSP * pi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                const unsigned long long q1 = __hip_atomic_load((gu64*)(gp + NSP * pi + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const unsigned long long q0 = early ? pq0 : __hip_atomic_load((gu64*)(gp + NSP * pi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const unsigned long long q1 = early ? pq1 : __hip_atomic_load((gu64*)(gp + NSP * pi + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 ok = (unsigned)(q0 >> 32) == epoch && (unsigned)(q1 >> 32) == epoch;
                                 s1r = __uint_as_float((unsigned)q0);
                                 s2r = __uint_as_float((unsigned)q1);
@@ -1230,7 +1253,7 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
                                     s4r = __uint_as_float((unsigned)q3);
                                 }
                             } else {
-                                const unsigned long long q0 = __hip_atomic_load((gu64*)(gp + (NSP / 2) * pi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const unsigned long long q0 = early ? pq0 : __hip_atomic_load((gu64*)(gp + (NSP / 2) * pi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 ok = q0 != kGranuleEmpty;
                                 s1r = __uint_as_float((unsigned)q0);
                                 s2r = __uint_as_float((unsigned)(q0 >> 32));
