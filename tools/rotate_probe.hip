@@ -1,9 +1,16 @@
-// tools/rotate_probe.hip — does a per-plane ROTATION of the slot order take the placement sensitivity out of the cluster
-// kernels' access order?  (measurement aid; profiles/r04_placement_sensitivity.md)
-// Plane copy as tools/pattern_bench.hip ("column" order: wave w of workgroup-item (c, k) copies plane n = 4k + w of channel c,
-// 13 x 1 KB loads then 13 x 1 KB stores), but register slot j holds memory slot (j + r) mod 13 with r a function of the plane:
-//   mode 0: r = 0 (the kernels today)   1: r = n mod 13   2: r = (5 n) mod 13   3: r = (n / 4) mod 13   4: linear order, r = 0
-// on several (x, y) buffer pairs of one process, both ways round.
+// tools/rotate_probe.hip — where in the device memory is a plane-strided write fast, and why not everywhere?  (measurement aid,
+// not part of the library; build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/rotate_probe.hip -o tools/rotate_probe;
+// results: profiles/r04_placement_sensitivity.md, profiles/r04_memory_map.md.)
+// The kernel is tools/pattern_bench.hip's plane copy ("column" order: wave w of workgroup-item (c, k) copies plane n = 4k + w of
+// channel c, 13 x 1 KB loads and stores, software-pipelined through LDS like the cluster kernels; or linear order).  Modes:
+//   (none)            six 784 MiB buffers, eight (x, y) pairs both ways round; slot order of every plane rotated by r
+//                     (register slot j holds memory slot (j + r) mod 13; r = 0, n % 13, 5n % 13, (n/4) % 13) and linear order
+//   vmm [MiB]         the same on hipMemCreate + hipMemMap buffers (the alignment request is not honoured)
+//   carve [GiB] [MiB] ONE allocation, write targets carved out of it every so many MiB
+//   aux               the eight cache policies of the stores on six targets
+//   split             a plane per wave vs a plane per workgroup (split over its waves)
+//   map [n] [src]     n buffers (default 300 = 235 GB) as write targets of buffer `src`: the map of profiles/r04_memory_map.md
+//   mix [pool] [MiB]  write targets MAPPED from a pool of smaller physical allocations (adjacent chunks / chunks spread out)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
