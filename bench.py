@@ -24,9 +24,12 @@ One JSON line is printed by rank 0; it also carries
                  priced on SURVEY §8(d3)'s two-pass byte count and the in-process copy / triad ceilings ride along
   cpu_baseline — the CPU oracle (a port of the reference's eager PyTorch path) timed on this
                  host's cores on a bounded slice of the same workload (rank 0, N=1 only), plus one thread
-  placement    — before the warm-up the blocks torch's allocator will hand out for y and dx are chosen by a timed write
-                 (cnsn_amd.placement: MI355X's memory has regions that take plane-strided writes 15-20 % faster,
-                 profiles/r04_memory_map.md); what was found; --no-placement leaves the allocator alone
+  arena        — y and dx come from the library's output arena (cnsn_amd.arena: blocks of its own, a stable home; nothing
+                 is probed or timed by default).  `ms_per_step` is that default; `ms_per_step_plain_allocator` is the same
+                 K steps re-timed in the same process with the arena off (torch's caching allocator places y and dx).
+                 MI355X's memory has regions that take plane-strided writes 15-20 % faster (profiles/r04_memory_map.md):
+                 `--prospect N` lets the arena time N candidate blocks and keep the fastest (cnsn_arena_prospect) and adds
+                 `ms_per_step_prospected` — an explicit, bounded search that is OFF in the default line
 """
 import argparse
 import json
@@ -58,10 +61,15 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (crop=both, bf16)")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the copy / triad / access-order ceilings (child runs)")
+    ap.add_argument("--no-arena", action="store_true", help="y / dx from torch's caching allocator (cnsn_amd.arena off)")
+    ap.add_argument("--prospect", type=int, default=0,
+                    help="let the output arena time this many candidate blocks of the input's size and keep the 4 fastest "
+                         "(cnsn_arena_prospect); adds ms_per_step_prospected to the line.  0 (default): no search")
     ap.add_argument("--no-placement", action="store_true",
                     help="do not look for output blocks in the fast-write regions of the device memory before the warm-up "
                          "(cnsn_amd.placement, profiles/r04_memory_map.md)")
-    ap.add_argument("--placement-candidates", type=int, default=128, help="blocks of the input's size the placement step looks at")
+    ap.add_argument("--placement-candidates", type=int, default=0,
+                    help="(round 4's search through torch's allocator, cnsn_amd.placement; 0 = off, the default since round 5)")
     ap.add_argument("--workload", type=str, default="cnsn", choices=["cnsn", "resnet50", "resnet50_jsd", "wrn40"],
                     help="cnsn: the fused op at the north-star shape (headline); resnet50 / wrn40: whole "
                          "training steps of the caller backbones (images/s)")
@@ -192,17 +200,10 @@ def secondary_workloads(cnsn_amd, shape, dev, args):
     """Same shape, other modes (not the headline): CrossNorm with both crop boxes, and bf16 I/O."""
     n, c, h, w = shape
     res = {}
-    placed = {torch.float32} if not args.no_placement else None    # (the headline run has placed the fp32 size already)
     for tag, dtype, crop in (("f32_crop_both", torch.float32, "both"), ("f32_sn_only", torch.float32, None),
                              ("bf16_crop_neither", torch.bfloat16, "neither"), ("bf16_crop_both", torch.bfloat16, "both")):
         x = conditioned(shape, dev, dtype, 31).requires_grad_()
         gy = torch.randn(shape, device=dev).to(dtype)
-        if placed is not None and dtype not in placed:              # output blocks of this size where writes are fast
-            try:
-                cnsn_amd.placement.prefer_fast_write_blocks(x, keep=4, candidates=args.placement_candidates)
-            except Exception:
-                pass
-            placed.add(dtype)
         mod = cnsn_amd.CNSN(cnsn_amd.CrossNorm(crop, 1) if crop else None, cnsn_amd.SelfNorm(c)).to(dev).train()
 
         def one():
@@ -826,12 +827,16 @@ def main():
     # process needs ~25 headline steps to settle (profiles/r04_launches_per_step.md: 0.852 ms at steps 5-9, 0.79 from step 25),
     # more than the W = 5 the driver passes.  W warm-up steps and exactly K timed steps follow as the contract says.
     ceil = copy_triad_ceiling(dev) if (world == 1 and not args.no_ceiling) else None
-    # Output placement (cnsn_amd.placement): the device memory has regions into which plane-strided writes run 15-20 % faster
-    # (profiles/r04_memory_map.md); y and dx are allocated per call from torch's caching allocator, which is left with free
-    # blocks of the input's size that were MEASURED to lie in such a region (a few seconds, before the warm-up; reported in the
-    # line; --no-placement switches it off).  One rank per GPU: every rank does it for its own device.
+    # Where y and dx live.  Default: the library's output arena (cnsn_amd.arena) — blocks of its own, nothing probed, nothing
+    # timed.  --no-arena: torch's caching allocator.  After the contract's W + K steps the same K steps are timed again with
+    # the OTHER allocator (one warm-up window in front) so that the line carries both; --prospect N adds a third window
+    # after the arena has looked at N candidate blocks (profiles/r04_memory_map.md: where a block lies physically decides how
+    # fast the launches write it).  --placement-candidates N > 0 is round 4's search through torch's allocator (off).
+    from cnsn_amd import arena as _arena
     placement = None
-    if not args.no_placement and world <= ngpu:
+    if args.no_arena:
+        _arena.disable()
+    if not args.no_placement and args.placement_candidates > 0 and world <= ngpu:
         from cnsn_amd import placement as _placement
         try:
             placement = _placement.prefer_fast_write_blocks(x, keep=4, candidates=args.placement_candidates)
@@ -844,6 +849,29 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     per_rank_timeouts = dp.gather_ints(local_timeouts, dev)
+
+    # ---- the same K steps with the other allocator / after a bounded search (outside the contract's timed region)
+    alt = {}
+    if world == 1 and cnsn_amd._ffi.glue() is not None:
+        arena_stats = _arena.stats(dev) if not args.no_arena else None
+        if args.no_arena:
+            _arena.enable()
+        else:
+            _arena.disable()
+        x.grad = None
+        settled_window(max(3, args.warmup), False)
+        alt["ms_per_step_arena" if args.no_arena else "ms_per_step_plain_allocator"] = round(
+            settled_window(args.steps, False) / args.steps * 1e3, 4)
+        _arena.enable()
+        if args.prospect > 0:
+            x.grad = None
+            torch.cuda.synchronize()
+            alt["prospect"] = _arena.prospect(x, keep=4, candidates=args.prospect)
+            settled_window(max(3, args.warmup), False)
+            alt["ms_per_step_prospected"] = round(settled_window(args.steps, False) / args.steps * 1e3, 4)
+        if args.no_arena:
+            _arena.disable()
+        alt["arena"] = arena_stats if arena_stats is not None else _arena.stats(dev)
 
     fwd_ms = sum(a.elapsed_time(m_) for a, m_, _ in ev.values()) / len(ev)
     bwd_ms = sum(m_.elapsed_time(z) for _, m_, z in ev.values()) / len(ev)
@@ -924,6 +952,17 @@ def main():
                     out["roofline"]["forward"]["traffic_over_bytes"] = round(live["fwd"] / need_f, 4)
             elif traffic_source is not None:
                 out["roofline"]["traffic_source"] = traffic_source + "; " + why
+        out.update({k: v for k, v in alt.items() if k.startswith("ms_per_step")})
+        if alt:
+            out["arena"] = {"on": not args.no_arena, "min_bytes": _arena.min_bytes(), **(alt.get("arena") or {}),
+                            "note": "y / dx are tensors over blocks of the library's output arena (cnsn_amd.arena, C ABI "
+                                    "cnsn_arena_*): a stable home, nothing probed or timed; ms_per_step_plain_allocator = the "
+                                    "same K steps in this process with torch's caching allocator placing them"}
+            if "prospect" in alt:
+                out["arena"]["prospect"] = alt["prospect"]
+                if "ms_per_step_prospected" in alt:
+                    out["frac_of_hbm_peak_bytes_needed_prospected"] = round(
+                        (need_f + need_b) / (alt["ms_per_step_prospected"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if placement is not None:
             placement["note"] = ("cnsn_amd.placement.prefer_fast_write_blocks before the warm-up: the caching allocator's free blocks "
                                  "of the input's size (where y and dx land) were chosen among `candidates` by a timed write; "

@@ -13,7 +13,7 @@ CNSN_F32, CNSN_BF16, CNSN_F16 = 0, 1, 2
 STRATEGY_AUTO, STRATEGY_TWO_PASS, STRATEGY_RESIDENT, STRATEGY_LOCAL, STRATEGY_MONO = 0, 1, 2, 3, 4
 ADD_NONE, ADD_PRE, ADD_POST = 0, 1, 2
 PATHS = {0: "streaming", 1: "packed", 2: "resident", 3: "local", 4: "mono"}
-ABI_VERSION = 5
+ABI_VERSION = 6
 PERM_INLINE_MAX = 1024       # CNSN_PERM_INLINE_MAX
 E_UNSUPPORTED = -9
 
@@ -51,6 +51,13 @@ class BnTail(C.Structure):
                 ("num_batches_tracked", C.c_void_p)]
 
 
+class ArenaStats(C.Structure):
+    """cnsn_arena_stats_t"""
+    _fields_ = [("struct_bytes", C.c_int32), ("device", C.c_int32), ("chunk_bytes", C.c_uint64), ("mapped_bytes", C.c_uint64),
+                ("in_use_bytes", C.c_uint64), ("blocks", C.c_uint64), ("blocks_in_use", C.c_uint64), ("hits", C.c_uint64),
+                ("misses", C.c_uint64), ("failed", C.c_uint64)]
+
+
 class Epilogue(C.Structure):
     """cnsn_epilogue_t"""
     _fields_ = [("struct_bytes", C.c_int32), ("add_mode", C.c_int32), ("relu", C.c_int32),
@@ -68,6 +75,14 @@ SIGNATURES = {
     "cnsn_reload_env": (None, []),
     "cnsn_set_wait_ms": (None, [C.c_int]),
     "cnsn_wait_ms": (C.c_int, []),
+    "cnsn_arena_alloc": (C.c_void_p, [C.c_int, C.c_size_t, C.c_void_p]),
+    "cnsn_arena_free": (C.c_int, [C.c_void_p]),
+    "cnsn_arena_trim": (C.c_size_t, [C.c_int]),
+    "cnsn_arena_owns": (C.c_int, [C.c_void_p]),
+    "cnsn_arena_stats": (C.c_int, [C.c_int, C.POINTER(ArenaStats)]),
+    "cnsn_arena_set_chunk_bytes": (C.c_int, [C.c_size_t]),
+    "cnsn_arena_prospect": (C.c_int, [C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+    "cnsn_arena_block_gbps": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "cnsn_saved_floats": (C.c_size_t, [C.POINTER(Problem)]),
     "cnsn_workspace_bytes": (C.c_size_t, [C.POINTER(Problem)]),
     "cnsn_forward": (C.c_int, [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -294,10 +309,10 @@ def follow_environ():
 def under_process_group_defaults():
     """One process per GPU under an initialised torch.distributed group: a rank whose cluster wait runs out stalls its
     peers' collectives for as long as the bound — 2 s there instead of 5 s (`cnsn_set_wait_ms`; an explicit CNSN_WAIT_MS
-    in the environment still wins).  Called by `callers.steps.StepGuard` on its first step and by bench.py."""
+    in the environment wins, also one set later and made known through `reload_env()`).  Called by `callers.steps.StepGuard` on its first step and by bench.py."""
     try:
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and "CNSN_WAIT_MS" not in os.environ:
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and "CNSN_WAIT_MS" not in os.environ:
             lib().cnsn_set_wait_ms(2000)
     except Exception:   # pragma: no cover
         pass

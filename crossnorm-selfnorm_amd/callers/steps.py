@@ -105,18 +105,13 @@ class StepGuard:
                              "(every rank raises this together)")
 
 
-_guards = None
-
-
 def _guard_of(net):
-    """the StepGuard of a network (built on first use, kept while the network lives)"""
-    global _guards
-    if _guards is None:
-        import weakref
-        _guards = weakref.WeakKeyDictionary()
-    g = _guards.get(net)
+    """the StepGuard of a network: built on first use and kept ON the network (an attribute outside `_modules` /
+    `_buffers`, so state_dict and `.modules()` do not see it) — it dies with the network.  A dictionary keyed by the
+    network, even a weak one, would keep the network alive through the guard's own references to its modules."""
+    g = net.__dict__.get("_cnsn_step_guard")
     if g is None:
-        g = _guards[net] = StepGuard(net)
+        g = net.__dict__["_cnsn_step_guard"] = StepGuard(net)
     return g
 
 
@@ -125,7 +120,14 @@ def _apply(net, optimizer, compute_loss, guard):
     the network's `StepGuard`: gradients of a cluster launch that gave up never reach the weights, the buffers and RNG
     streams the failed attempt moved are put back, and data-parallel ranks repeat together."""
     if guard:
-        return _guard_of(net).run(compute_loss, optimizer)
+        try:
+            on_device = next(net.parameters()).is_cuda
+        except StopIteration:
+            on_device = True
+        if on_device:
+            return _guard_of(net).run(compute_loss, optimizer)
+    # (a network on the host — the step-structure tests run on host restatements of the modules — has no cluster launch that could give up:
+    #  nothing to snapshot, nothing to poll, and libcnsn_hip.so need not even be built)
     loss = compute_loss()
     optimizer.zero_grad()
     loss.backward()

@@ -29,6 +29,7 @@ enum Knob {
     K_WIDE,           // CNSN_WIDE          channel-group kernels: 0 never, 1 AUTO rule, 2 wherever eligible
     K_PONG,           // CNSN_PONG          granule regions: 0 never (fill launches), 2 also for small tensors (tests)
     K_SNXCN,          // CNSN_SNXCN         CrossNorm-capable partial-moment backward: 0 never, 1 AUTO rule, 2 wherever instantiated
+    K_ARENA_CHUNK_MB, // CNSN_ARENA_CHUNK_MB  size of the output arena's physical allocations in MiB (default 56)
     K_COUNT
 };
 

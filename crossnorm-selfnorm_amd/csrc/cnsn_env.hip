@@ -14,6 +14,7 @@ const char* const kNames[K_COUNT] = {
     "CNSN_RESIDENT", "CNSN_CONTEXT",  "CNSN_EPOCH_START", "CNSN_KEEP",    "CNSN_PIPE",         "CNSN_WIDE",
     "CNSN_PONG",
     "CNSN_SNXCN",
+    "CNSN_ARENA_CHUNK_MB",
 };
 
 struct Table {

@@ -49,14 +49,14 @@ bool resident_auto_enabled() {
 void resident_set_enabled(bool on) { g_enabled.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 namespace {
-std::atomic<int> g_wait_ms{0};  // cnsn_set_wait_ms: > 0 overrides the environment's CNSN_WAIT_MS
+std::atomic<int> g_wait_ms{0};  // cnsn_set_wait_ms: > 0 replaces the 5 s default; a CNSN_WAIT_MS knob in force still wins
 }  // namespace
 void resident_set_wait_ms(int ms) { g_wait_ms.store(ms > 0 ? ms : 0, std::memory_order_relaxed); }
 long long resident_wait_ticks() {
+    const char* wm = knob(K_WAIT_MS);  // (re-read by cnsn_reload_env: a knob set LATER than cnsn_set_wait_ms wins as well)
+    if (wm && atoll(wm) > 0) return atoll(wm) * 100000ll;  // 100 MHz wall clock
     const int set = g_wait_ms.load(std::memory_order_relaxed);
-    if (set > 0) return (long long)set * 100000ll;  // 100 MHz wall clock
-    const char* wm = knob(K_WAIT_MS);
-    return (wm && atoll(wm) > 0) ? atoll(wm) * 100000ll : kWaitLimitTicks;
+    return set > 0 ? (long long)set * 100000ll : kWaitLimitTicks;
 }
 
 namespace {

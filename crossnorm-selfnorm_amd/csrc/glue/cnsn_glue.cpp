@@ -12,7 +12,9 @@
 #include <hip/hip_runtime_api.h>
 
 #include <array>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -54,6 +56,46 @@ Tensor f32c(const Tensor& t) {
     Tensor d = t.detach();
     if (d.scalar_type() != at::kFloat) d = d.to(at::kFloat);
     return d.contiguous();
+}
+
+// ---- output arena (include/cnsn_hip.h, "output arena"): y / dx / z of at least `g_arena_min` bytes are tensors over
+// address ranges mapped from small physical allocations, where the launches' plane-strided writes are fast every time;
+// everything else, and every output while the stream is being captured into a graph, comes from torch's allocator.
+// CNSN_ARENA=0 switches it off, CNSN_ARENA_MIN_MB moves the threshold (default 32); `arena_config` does both at run time.
+std::atomic<int64_t> g_arena_min{-2};  // -2: not read yet, -1: off
+
+int64_t arena_min_bytes() {
+    int64_t v = g_arena_min.load(std::memory_order_relaxed);
+    if (v == -2) {
+        const char* on = getenv("CNSN_ARENA");
+        const char* mb = getenv("CNSN_ARENA_MIN_MB");
+        v = (on && on[0] == '0') ? -1 : (int64_t)((mb && atoll(mb) > 0) ? atoll(mb) : 32) << 20;
+        g_arena_min.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+Tensor arena_empty(at::IntArrayRef sizes, const at::TensorOptions& opt, const at::Device& dev, int64_t nbytes) {
+    hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return Tensor();
+    }
+    void* p = cnsn_arena_alloc((int)dev.index(), (size_t)nbytes, (void*)stream);
+    if (!p) return Tensor();  // (no memory / no virtual-memory support: the caller allocates as it always did)
+    return at::from_blob(p, sizes, [](void* q) { (void)cnsn_arena_free(q); }, opt, dev);
+}
+
+// `x` is dense (contiguous, aligned): a fresh tensor of its shape and type for an output of the op
+Tensor out_like(const Tensor& x) {
+    const int64_t nbytes = x.numel() * (int64_t)x.element_size();
+    const int64_t min = arena_min_bytes();
+    if (min >= 0 && nbytes >= min) {
+        Tensor t = arena_empty(x.sizes(), at::TensorOptions().dtype(x.scalar_type()).device(x.device()), x.device(), nbytes);
+        if (t.defined()) return t;
+    }
+    return at::empty_like(x);
 }
 
 // host -> device copy of the (tiny) permutation through a ring of pinned staging buffers, so that the
@@ -254,9 +296,11 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
             TORCH_CHECK(perm_in.has_value(), "cnsn_forward: CrossNorm needs the batch permutation");
             const bool inline_ok = c.perm_inline && !chan_in.has_value() && !perm_in->is_cuda() &&
                                    perm_in->scalar_type() == at::kLong && perm_in->is_contiguous() &&
-                                   perm_in->numel() <= CNSN_PERM_INLINE_MAX;
+                                   perm_in->numel() <= CNSN_PERM_INLINE_MAX && perm_in->numel() == x.size(0);
             if (inline_ok) {
-                perm_host = *perm_in;  // rides in the launch arguments: no host-to-device copy
+                // rides in the launch arguments: no host-to-device copy.  A SNAPSHOT when a backward will read it again
+                // (<= 8 KB): the caller may reuse its index buffer between the two (`randperm(out=buf)`)
+                perm_host = cfg[13] != 0 ? perm_in->clone() : *perm_in;
                 prob.perm_host = perm_host.data_ptr<int64_t>();
             } else {
                 perm = perm_to_device(*perm_in, dev);
@@ -268,7 +312,7 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
         if (c.sn_active) gg.init(*g_w, *g_gamma, *g_beta, *g_rm, *g_rv, c.sn_training ? g_nbt : c10::nullopt);
         if (two) gf.init(*f_w, *f_gamma, *f_beta, *f_rm, *f_rv, c.sn_training ? f_nbt : c10::nullopt);
 
-        Tensor y = at::empty_like(x);
+        Tensor y = out_like(x);
         const bool need_bwd = cfg[13] != 0;  // decided by the caller (grad mode on and something requires grad)
         const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
         const size_t ws_bytes = cnsn_workspace_bytes(&prob);
@@ -334,7 +378,7 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
         Tensor gy = grads[0];
         if (gy.scalar_type() != x.scalar_type()) gy = gy.to(x.scalar_type());
         gy = dense(gy);
-        Tensor dx = at::empty_like(x);
+        Tensor dx = out_like(x);
         const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
         const size_t ws_bytes = cnsn_workspace_bytes(&prob);
         Tensor ws = at::empty({(int64_t)(ws_bytes / 4) + 1}, fopt);
@@ -369,7 +413,7 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
         const cnsn_epilogue_t epi = make_epilogue(c, addend);
         const bool has_epi = c.add_mode != CNSN_ADD_NONE || c.relu;
         Tensor d_add;  // gradient of the addend: dx itself (PRE), grad_y behind the ReLU mask (POST)
-        if (c.add_mode == CNSN_ADD_POST) d_add = c.relu ? at::empty_like(x) : gy;
+        if (c.add_mode == CNSN_ADD_POST) d_add = c.relu ? out_like(x) : gy;
         auto launch = [&]() {
             return cnsn_backward_fused(
                 &prob, has_epi ? &epi : nullptr, gy.data_ptr(), x.data_ptr(), perm.defined() ? perm.data_ptr<int64_t>() : nullptr,
@@ -449,8 +493,8 @@ class FusedCNSNTail : public torch::autograd::Function<FusedCNSNTail> {
         tail.running_mean = bt.rm.data_ptr<float>();
         tail.running_var = bt.rv.data_ptr<float>();
         tail.num_batches_tracked = bt.c.num_batches_tracked;
-        Tensor y = want_y ? at::empty_like(x) : Tensor();
-        Tensor z = at::empty_like(x);
+        Tensor y = want_y ? out_like(x) : Tensor();
+        Tensor z = out_like(x);
         const bool need_bwd = cfg[13] != 0;
         const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
         const size_t ws_bytes = cnsn_workspace_bytes(&prob);
@@ -523,7 +567,7 @@ class FusedCNSNTail : public torch::autograd::Function<FusedCNSNTail> {
         tail.num_batches_tracked = nullptr;
         const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
         const int64_t Cn = x.size(1);
-        Tensor dx = at::empty_like(x);
+        Tensor dx = out_like(x);
         Tensor flat = at::empty({6 * Cn}, fopt);  // dw (C,1,2) | dgamma | dbeta | d bn weight | d bn bias
         cnsn_gate_grad_t dg{flat.data_ptr<float>(), flat.data_ptr<float>() + 2 * Cn, flat.data_ptr<float>() + 3 * Cn};
         const size_t ws_bytes = cnsn_workspace_bytes(&prob);
@@ -589,4 +633,17 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("fused_cnsn_tail", &fused_cnsn_tail, "SelfNorm + the next block's BatchNorm2d + ReLU in one launch (autograd-aware)");
     m.def("bnrelu_plan", &bnrelu_plan, "1 when a fused kernel takes the call");
     m.def("abi_version", []() { return cnsn_abi_version(); });
+    m.def("arena_config", [](int64_t min_bytes) {
+        const int64_t was = arena_min_bytes();
+        g_arena_min.store(min_bytes < 0 ? -1 : min_bytes, std::memory_order_relaxed);
+        return was;
+    }, "threshold in bytes from which the op's outputs come from the output arena (< 0: never); returns the previous value");
+    m.def("arena_min_bytes", []() { return arena_min_bytes(); });
+    m.def("arena_empty_like", [](const Tensor& x) {
+        TORCH_CHECK(x.is_cuda(), "arena_empty_like: device tensors only");
+        Tensor t = arena_empty(x.sizes(), at::TensorOptions().dtype(x.scalar_type()).device(x.device()), x.device(),
+                               x.numel() * (int64_t)x.element_size());
+        return t.defined() ? t : at::empty(x.sizes(), x.options().memory_format(at::MemoryFormat::Contiguous));
+    }, "a fresh contiguous tensor of x's shape and type over an arena block (torch's allocator when the arena cannot serve it)");
+    m.def("out_like", &out_like, "the op's output allocation for a dense x: arena from the threshold on, else torch");
 }

@@ -72,6 +72,13 @@ def _on_device_of(fn):
     return wrapped
 
 
+def _out_like(x: torch.Tensor) -> torch.Tensor:
+    """a fresh tensor for an output of the op, shaped like the dense `x`: from the output arena (arena.py) from its
+    threshold on, else from torch's allocator"""
+    g = _ffi.glue()
+    return g.out_like(x) if g is not None else torch.empty_like(x)
+
+
 def _stream(x):
     return C.c_void_p(torch._C._cuda_getCurrentRawStream(x.device.index))
 
@@ -250,7 +257,7 @@ def perm_inline_ok(x: torch.Tensor, cfg: FusedConfig, perm, chan_perm) -> bool:
     through a host-to-device copy: a host int64 vector of at most CNSN_PERM_INLINE_MAX entries, no channel permutation, and
     BOTH directions of the call resolve to the cluster-resident kernels (remembered per problem signature)."""
     if LEGACY_LAUNCHES or chan_perm is not None or not isinstance(perm, torch.Tensor) or perm.is_cuda or perm.dtype != torch.int64 \
-            or not perm.is_contiguous() or perm.numel() > _ffi.PERM_INLINE_MAX:
+            or not perm.is_contiguous() or perm.numel() > _ffi.PERM_INLINE_MAX or perm.numel() != x.shape[0]:
         return False
     key = (tuple(x.shape), x.dtype, x.device.index, cfg.sn_active, cfg.sn_two, cfg.sn_training, cfg.content_box is not None,
            cfg.style_box is not None, cfg.add_mode, cfg.relu, _strategy)
@@ -341,7 +348,9 @@ class FusedCNSN(torch.autograd.Function):
         perm_host = None
         if cfg.cn_active:
             if perm_inline_ok(x, cfg, perm, chan_perm):
-                perm_host, perm = perm, None          # the permutation rides in the launch arguments: no upload
+                # the permutation rides in the launch arguments: no upload.  A snapshot (<= 8 KB) when a backward will read
+                # it again: the caller may reuse its index buffer in between (`torch.randperm(n, out=buf)`)
+                perm_host, perm = (perm.clone() if any(ctx.needs_input_grad) else perm), None
                 prob.perm_host = perm_host.data_ptr()
             else:
                 perm = _h2d.to_device(perm, dev)
@@ -350,7 +359,7 @@ class FusedCNSN(torch.autograd.Function):
         gate_g = _GateBuffers(g_w, g_gamma, g_beta, g_rm, g_rv, g_nbt if cfg.sn_training else None) if cfg.sn_active else None
         gate_f = _GateBuffers(f_w, f_gamma, f_beta, f_rm, f_rv, f_nbt if cfg.sn_training else None) \
             if (cfg.sn_active and cfg.sn_two) else None
-        y = torch.empty_like(x)
+        y = _out_like(x)
         need_bwd = any(ctx.needs_input_grad)
         saved_floats, ws_bytes = _sizes(prob)[:2]
         saved = torch.empty(saved_floats, dtype=torch.float32, device=dev) if need_bwd else None
@@ -395,7 +404,7 @@ class FusedCNSN(torch.autograd.Function):
             gy = gy.to(x.dtype)
         gy = _dense(gy)
         dev = x.device
-        dx = torch.empty_like(x)
+        dx = _out_like(x)
         ws_bytes = _sizes(prob)[1]
         _context(prob, dev)     # (the buffer may have grown since the forward; None under graph capture)
         if torch.cuda.is_current_stream_capturing():
@@ -417,7 +426,7 @@ class FusedCNSN(torch.autograd.Function):
         epi = _epilogue(cfg, addend) if cfg.has_epilogue else None
         d_add = None
         if cfg.add_mode == "post":      # gradient of a POST addend: grad_y behind the ReLU mask
-            d_add = torch.empty_like(x) if cfg.relu else gy
+            d_add = _out_like(x) if cfg.relu else gy
         perm_host = ctx.perm_host
         prob.perm_host = perm_host.data_ptr() if perm_host is not None else None
 
@@ -488,8 +497,8 @@ class FusedCNSNTail(torch.autograd.Function):
             rv = bn_rv.detach() if direct else _f32(bn_rv)
             tail = _ffi.BnTail(C.sizeof(_ffi.BnTail), int(bn_training), float(bn_eps), float(bn_momentum), bw.data_ptr(),
                                bb.data_ptr(), rm.data_ptr(), rv.data_ptr(), _ptr(bn_nbt))
-            y = torch.empty_like(x) if want_y else None
-            z = torch.empty_like(x)
+            y = _out_like(x) if want_y else None
+            z = _out_like(x)
             need_bwd = any(ctx.needs_input_grad)
             saved_floats, ws_bytes = _sizes(prob)[:2]
             saved = torch.empty(saved_floats, dtype=torch.float32, device=dev) if need_bwd else None
@@ -532,7 +541,7 @@ class FusedCNSNTail(torch.autograd.Function):
             tail = _ffi.BnTail(C.sizeof(_ffi.BnTail), int(tr), eps, mom, bw.data_ptr(), bb.data_ptr(), rm.data_ptr(),
                                rv.data_ptr(), None)
             Cn = x.shape[1]
-            dx = torch.empty_like(x)
+            dx = _out_like(x)
             flat = torch.empty(6 * Cn, dtype=torch.float32, device=dev)
             dw, dgam, dbet = flat[:2 * Cn].view(Cn, 1, 2), flat[2 * Cn:3 * Cn], flat[3 * Cn:4 * Cn]
             dbw, dbb = flat[4 * Cn:5 * Cn], flat[5 * Cn:]
@@ -660,7 +669,7 @@ class PlaneStats(torch.autograd.Function):
         n, c, h, w = _dims(x)
         gm = _f32(gmean).view(-1)
         gs = _f32(gstd).view(-1)
-        dx = torch.empty_like(x)
+        dx = _out_like(x)
         st = lib.cnsn_plane_stats_backward(_ptr(x), _DTYPES[x.dtype], n, c, h, w,
                                            _ffi.box4(ctx.box) if ctx.box else None, _ptr(ms[0]), _ptr(ms[1]),
                                            _ptr(gm), _ptr(gs), _ptr(dx), _stream(x))
@@ -679,7 +688,7 @@ class PlaneAffine(torch.autograd.Function):
         x = _dense(x)
         n, c, h, w = _dims(x)
         sc, sh = _f32(scale).view(-1), _f32(shift).view(-1)
-        y = torch.empty_like(x)
+        y = _out_like(x)
         st = lib.cnsn_plane_affine(_ptr(x), _DTYPES[x.dtype], n, c, h, w, _ptr(sc), _ptr(sh), _ptr(y), _stream(x))
         _ffi.check(st, "cnsn_plane_affine")
         ctx.save_for_backward(x, sc)
@@ -696,7 +705,7 @@ class PlaneAffine(torch.autograd.Function):
         dt = _DTYPES[x.dtype]
         dx = dscale = dshift = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
+            dx = _out_like(x)
             zero = torch.zeros_like(sc)
             st = lib.cnsn_plane_affine(_ptr(gy), dt, n, c, h, w, _ptr(sc), _ptr(zero), _ptr(dx), _stream(x))
             _ffi.check(st, "cnsn_plane_affine(backward)")
@@ -738,7 +747,7 @@ class InstanceNorm(torch.autograd.Function):
         if bias is not None:
             shift = shift + bias.detach().float().view(1, c)
         scale, shift = scale.contiguous().view(-1), shift.contiguous().view(-1)
-        y = torch.empty_like(x)
+        y = _out_like(x)
         st = lib.cnsn_plane_affine(_ptr(x), dt, n, c, h, w, _ptr(scale), _ptr(shift), _ptr(y), _stream(x))
         _ffi.check(st, "cnsn_plane_affine")
         ctx.save_for_backward(x, mean, rstd, weight)
@@ -764,7 +773,7 @@ class InstanceNorm(torch.autograd.Function):
         wd = weight.detach().double().view(1, c) if weight is not None else torch.ones(1, c, dtype=torch.float64, device=x.device)
         rw = rstd.double() * wd
         coef = torch.stack([rw, -rw * rstd.double() * sgx / m, mean.double(), -rw * s1 / m]).float().contiguous()
-        dx = torch.empty_like(x)
+        dx = _out_like(x)
         st = lib.cnsn_plane_combine(_ptr(gy), _ptr(x), dt, n, c, h, w, _ptr(coef), _ptr(dx), _stream(x))
         _ffi.check(st, "cnsn_plane_combine")
         dweight = dbias = None

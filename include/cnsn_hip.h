@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CNSN_ABI_VERSION 5
+#define CNSN_ABI_VERSION 6
 
 /* Largest batch whose permutation can travel as a launch argument (cnsn_problem_t.perm_host). */
 #define CNSN_PERM_INLINE_MAX 1024
@@ -304,9 +304,65 @@ void cnsn_resident_enable(int on);
 
 /* Bound of a cluster wait in milliseconds (default 5000; the environment variable CNSN_WAIT_MS at load time).  A process
  * that is one rank of a data-parallel job lowers it (its peers wait with it in the next collective): the Python layer
- * sets 2000 under an initialised process group.  ms <= 0: back to the environment's / default value. */
+ * sets 2000 under an initialised process group of more than one rank.  ms <= 0: back to the default.  A CNSN_WAIT_MS
+ * knob in force (at load time or after cnsn_reload_env) takes precedence over the value set here. */
 void cnsn_set_wait_ms(int ms);
 int cnsn_wait_ms(void); /* the bound in force, in milliseconds */
+
+/* ---- output arena (ABI 6) --------------------------------------------------------------------------
+ * The reference's op returns NEW tensors (models/cnsn.py:29 `return (...) * style_std + style_mean`, :150 `return x * g`),
+ * which torch's caching allocator places.  On MI355X the single-touch launches' plane-strided writes run 10-20 % slower
+ * into four out of five large hipMalloc'ed blocks than into the fifth (profiles/r04_memory_map.md), and no allocator
+ * option chooses.  This is an allocator of the op's own for its outputs y / dx / z: blocks mapped from physical
+ * allocations the arena creates itself (hipMemCreate chunks, default 56 MiB, environment CNSN_ARENA_CHUNK_MB — the chunk
+ * size does NOT decide a block's speed, profiles/r05_arena.md), kept for the life of the process, optionally TIMED and
+ * ranked (cnsn_arena_prospect) — a stable home for the outputs instead of whatever the caching allocator splits off next.
+ * The library itself still takes caller-owned output pointers everywhere — a caller MAY get them here; the Python layer
+ * does for outputs of at least 32 MiB.
+ *
+ *   cnsn_arena_alloc   device memory of at least `bytes` (rounded up to whole chunks) on `device`, to be used first on
+ *                      `stream` (a block last used on another stream is ordered behind that stream's queued work);
+ *                      NULL when the driver has no memory or no virtual-memory support — the caller then allocates as
+ *                      it always did.  Freed blocks stay mapped on a per-size free list: in the steady state of a
+ *                      training loop a call is a mutex and a list pop (no driver call, no synchronisation).
+ *   cnsn_arena_free    give a block back (pointer as returned by cnsn_arena_alloc); work already queued on the block's
+ *                      stream may still use it — the next user is ordered behind it, like a caching allocator's.
+ *   cnsn_arena_trim    give the physical memory of every FREE block of `device` (-1: all devices) back to the driver;
+ *                      returns the bytes released.  Synchronises the streams those blocks were last used on.  The
+ *                      blocks' ADDRESS ranges stay reserved for the life of the process: a range that was unmapped is
+ *                      never mapped again (on ROCm 7.2 a re-used range was accessed through stale translations).
+ *   cnsn_arena_prospect  look for fast memory, explicitly and bounded: create `candidates` blocks for `bytes` (all alive
+ *                      at once; never more than half of the free device memory), time a plane-strided fill into each
+ *                      (~1 ms per block on `stream`, which is synchronised), leave the `keep` fastest on the free list
+ *                      and give the others back.  Returns the number kept.  `gbps_out` (candidates floats, optional)
+ *                      receives every candidate's measured write rate.  WHERE a block lies physically decides its
+ *                      write rate (about one block in five takes plane-strided writes 15-20 % faster,
+ *                      profiles/r04_memory_map.md); nothing calls this by default.
+ *   cnsn_arena_block_gbps  the rate measured for the block at `ptr` (0: never measured).
+ *   cnsn_arena_owns    1 when `ptr` lies inside a block of the arena.
+ * Not to be used while the stream is being captured into a graph (a replay needs addresses nobody else re-uses). */
+typedef struct cnsn_arena_stats {
+    int32_t struct_bytes; /* = sizeof(cnsn_arena_stats_t) */
+    int32_t device;
+    uint64_t chunk_bytes;   /* size of one physical allocation                       */
+    uint64_t mapped_bytes;  /* physical memory held by the arena on this device      */
+    uint64_t in_use_bytes;  /* ... of which handed out                               */
+    uint64_t blocks, blocks_in_use;
+    uint64_t hits;          /* requests served from the free list                    */
+    uint64_t misses;        /* requests that created and mapped a new block          */
+    uint64_t failed;        /* requests answered with NULL                           */
+} cnsn_arena_stats_t;
+void* cnsn_arena_alloc(int device, size_t bytes, void* stream);
+int cnsn_arena_free(void* ptr);
+size_t cnsn_arena_trim(int device);
+int cnsn_arena_owns(const void* ptr);
+int cnsn_arena_stats(int device, cnsn_arena_stats_t* out);
+int cnsn_arena_prospect(int device, size_t bytes, int keep, int candidates, void* stream, float* gbps_out);
+int cnsn_arena_block_gbps(const void* ptr, float* gbps);
+/* chunk size for blocks created from now on (0: back to CNSN_ARENA_CHUNK_MB / 56 MiB); blocks of another chunk size stay
+ * valid and on their free lists but no longer serve requests (cnsn_arena_trim releases them).  A measurement knob
+ * (tools/arena_probe.py, profiles/r05_arena.md). */
+int cnsn_arena_set_chunk_bytes(size_t chunk_bytes);
 
 /* ---- environment knobs ---------------------------------------------------------------------------
  * The library's CNSN_* environment variables (tuning and test switches: CNSN_WAIT_MS, CNSN_RESIDENT, CNSN_PIPE, ... —

@@ -158,3 +158,32 @@ def test_tail_counters():
     bn.eval()
     mod.forward_block_bn(x, None, "none", bn)
     assert int(bn.num_batches_tracked) == 3 and int(mod.selfnorm.g_bn.num_batches_tracked) == 4
+
+
+@pytest.mark.parametrize("ctypes_path", [False, True], ids=["glue", "ctypes"])
+def test_backward_uses_the_forward_pairing_when_the_caller_reuses_its_index_buffer(ctypes_path):
+    """The launch-argument path keeps a SNAPSHOT of the host permutation for the backward (advisor, round 4): a caller
+    that refills the same index tensor between forward and backward (`torch.randperm(n, out=buf)`) must get the gradient
+    of the forward it ran — what the reference's device copy of `perm` (models/cnsn.py:62) guarantees by construction."""
+    shape = (40, 8, 56, 56)
+    x, gy, d = _case(shape, torch.float32, "neither", 11)
+    cfg = cnsn_amd.FusedConfig(cn_active=True)
+    assert F_.perm_inline_ok(x, cfg, d.perm, None)
+    assert not F_.perm_inline_ok(x, cfg, d.perm[:-1].contiguous(), None)   # not one index per batch row: never inline
+
+    def run(mutate):
+        buf = d.perm.clone()
+        xg = x.clone().requires_grad_()
+        if ctypes_path:
+            y = F_.FusedCNSN.apply(xg, cfg, buf, None, *(None,) * 10, None, None, None)
+        else:
+            y = F_.fused_cnsn(xg, cfg, perm=buf)
+        if mutate:
+            buf.copy_(torch.roll(buf, 1))
+        y.backward(gy)
+        torch.cuda.synchronize()
+        return y.detach(), xg.grad
+
+    ya, ga = run(False)
+    yb, gb = run(True)
+    assert torch.equal(ya, yb) and torch.equal(ga, gb)
