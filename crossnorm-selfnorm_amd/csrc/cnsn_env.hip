@@ -15,6 +15,7 @@ const char* const kNames[K_COUNT] = {
     "CNSN_PONG",
     "CNSN_SNXCN",
     "CNSN_ARENA_CHUNK_MB",
+    "CNSN_XCD",
 };
 
 struct Table {

@@ -123,6 +123,8 @@ static inline ResArgs make_args(const cnsn_problem_t& p, Box cb, Box sb, const M
     ra.wait_ticks = resident_wait_ticks();  // (cnsn_set_wait_ms, else CNSN_WAIT_MS, else 5 s)
     const char* fi = knob(K_FAULT_INJECT);
     ra.fault = (fi && fi[0] == '1') ? 1 : 0;
+    const char* xc = knob(K_XCD);
+    ra.xcd = (xc && xc[0] == '1') ? 1 : 0;  // (measured slower: profiles/r05_xcd_clusters.md — off unless asked for)
     return ra;
 }
 

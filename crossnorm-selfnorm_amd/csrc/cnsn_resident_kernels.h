@@ -60,7 +60,24 @@ struct ResArgs {
     long long wait_ticks;  // bound of a cluster wait in 100 MHz ticks (default 5 s; CNSN_WAIT_MS)
     int fault;             // tests only (CNSN_FAULT_INJECT=1): the last member of channel 0's cluster never publishes
     unsigned long long* prof;  // tuning builds (-DCNSN_PROF): [workgroup < 64][iteration < 16][8] time stamps
+    int xcd;               // 1: clusters are made of workgroups of ONE XCD (cluster_block; CNSN_XCD=1, off by default)
 };
+
+// XCD-aware cluster membership (round 5).  The dispatcher hands consecutive workgroups of a grid to the 8 XCDs round-robin
+// (workgroup b runs on XCD b % 8, each XCD working through ITS workgroups in increasing order), and every XCD has its own L2.
+// A cluster of K consecutive workgroups therefore spans all 8 XCDs: every granule a member publishes is read through seven
+// other L2s, which the fabric keeps coherent at the price of a round trip past the Infinity Cache (~2 us under load) for each
+// poll.  With this numbering — workgroup b is "virtual block" (b % 8) * G/8 + b / 8 — K consecutive virtual blocks are K
+// consecutive workgroups of ONE XCD's queue: the cluster's exchange stays in one L2.  The in-order argument of DESIGN §5
+// (a cluster waits only for members that were dispatched before or with it) holds per XCD queue.  Needs a grid that is a
+// multiple of 8; clusters that straddle two XCDs (G/8 not a multiple of K) just lose the locality.
+// MEASURED SLOWER (profiles/r05_xcd_clusters.md: fp32 forward 0.300 -> 0.375 ms, everything else 1-4 % slower): with a
+// channel's 256 planes behind one L2 the chip's memory traffic of the moment goes through one XCD's fabric port per
+// channel instead of all eight.  Kept as an A/B knob, off by default.
+__device__ __forceinline__ int cluster_block(int xcd_on) {
+    const unsigned b = blockIdx.x, G = gridDim.x;
+    return (xcd_on && (G & 7u) == 0u) ? (int)((b & 7u) * (G >> 3) + (b >> 3)) : (int)b;
+}
 
 // The batch permutation as a LAUNCH ARGUMENT (cnsn_problem_t.perm_host, ABI 5): 16-bit indices in the kernarg segment, so
 // that no host-to-device copy sits in front of the launch (models/cnsn.py:62 draws it on the host: torch.randperm(N) from
@@ -106,7 +123,7 @@ __device__ __forceinline__ int perm_at(const int64_t* __restrict__ perm, const P
 // its memory system during every exchange.  Skewing the start by a fraction of the period lets one
 // cluster's exchange overlap another's loads and stores.
 __device__ __forceinline__ void startup_skew(const ResArgs& ra) {
-    const int steps = ((blockIdx.x / ra.K) & 3) * ra.stagger;
+    const int steps = ((cluster_block(ra.xcd) / ra.K) & 3) * ra.stagger;
     for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
 }
 
@@ -768,7 +785,7 @@ __global__ __launch_bounds__(kBlock, SPLIT ? (POST ? 2 : 3) : POST ? (data_regs(
 #endif
 
     int iter_ = -1;
-    for (int item = blockIdx.x; item < ra.items; item += gridDim.x) {
+    for (int item = cluster_block(ra.xcd); item < ra.items; item += gridDim.x) {
         const int c = item / ra.K, k = item - c * ra.K;
         const int n0 = SPLIT ? k : (k * 4 + wave) * PPW;
         ++iter_;
@@ -1228,7 +1245,7 @@ __global__ __launch_bounds__(kBlock, SPLIT ? 2 : POST ? 2 : EPI ? bwd_waves_epi(
 #endif
 
     int iter_ = -1;
-    for (int item = blockIdx.x; item < ra.items; item += gridDim.x) {
+    for (int item = cluster_block(ra.xcd); item < ra.items; item += gridDim.x) {
         const int c = item / ra.K, k = item - c * ra.K;
         const int n0 = SPLIT ? k : (k * 4 + wave) * PPW;
         ++iter_;

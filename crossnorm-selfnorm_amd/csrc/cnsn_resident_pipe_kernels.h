@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
             }
     };
 
-    int item = blockIdx.x;
+    int item = cluster_block(ra.xcd);
     if (item >= ra.items) return;  // (the grid never exceeds the items)
     int iter_ = 0;
     (void)iter_;
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(kBlock, pipe_bwd_waves(2 * PPW * NV)) void resident
         for (int n = threadIdx.x + kBlock; n < N; n += kBlock) stage_row(n, rows_of(c, n));
     };
 
-    int item = blockIdx.x;
+    int item = cluster_block(ra.xcd);
     if (item >= ra.items) return;
     int iter_ = 0;
     (void)iter_;

@@ -403,7 +403,8 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
     const __amdgpu_buffer_rsrc_t rx = sg.tensor(ka0->x), ry = sg.tensor(ka0->y), radd = sg.tensor(has_add ? ka0->addend : ka0->x);
     Raw<T, VEC>* mypark = park + (size_t)wave * NPARK * 64 + lane;  // slot i of this lane: mypark[i * 64]
     // this workgroup is member k of cluster q_ (fixed); an "item" below is the channel the cluster works on
-    const int q_ = (int)blockIdx.x / K, k = (int)blockIdx.x - q_ * K, nq = (int)gridDim.x / K;
+    const int vb_ = cluster_block(ka0->ra.xcd);  // (XCD-aware numbering: the cluster's members share one L2)
+    const int q_ = vb_ / K, k = vb_ - q_ * K, nq = (int)gridDim.x / K;
     auto static_channel = [&](int seq) {
         const long long ch = (long long)q_ + (long long)seq * nq;
         return ch < (long long)C ? (int)ch : kNoChan;
@@ -827,7 +828,8 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
                                  t_add = sg.tensor(has_add ? ka0->addend : ka0->x);
     Raw<T, VEC>* mypark = park + (size_t)wave * NPARK * 64 + lane;
     // this workgroup is member k of cluster q_ (fixed); an "item" below is the channel the cluster works on
-    const int q_ = (int)blockIdx.x / K, k = (int)blockIdx.x - q_ * K, nq = (int)gridDim.x / K;
+    const int vb_ = cluster_block(ka0->ra.xcd);  // (XCD-aware numbering: the cluster's members share one L2)
+    const int q_ = vb_ / K, k = vb_ - q_ * K, nq = (int)gridDim.x / K;
     auto static_channel = [&](int seq) {
         const long long ch = (long long)q_ + (long long)seq * nq;
         return ch < (long long)C ? (int)ch : kNoChan;
