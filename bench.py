@@ -632,12 +632,13 @@ def model_workload(args, dist, world, rank, dev):
             new = cnsn_amd._ffi.poll_timeouts()               # (the stream is idle: every launch of the window has run)
             guard.local_timeouts += new
             if dp.agree_to_repeat(new, dev) == 0:
+                guard.step_applied(k)                             # (the way back: re-armed after a clean stretch, rank-agreed)
                 return t
             guard.repeats += k
             if new:
                 print(f"[bench] rank {rank}: {new} cluster launch(es) gave up; all ranks repeat the window of {k} steps",
                       file=sys.stderr)
-            dp.degrade_all()
+            guard.degrade()
             if graphed is None:
                 guard.restore()
         raise cnsn_amd.CnsnError("bench: cluster launches still time out after three windows")
@@ -654,6 +655,7 @@ def model_workload(args, dist, world, rank, dev):
     if rank == 0:
         print(json.dumps({
             "steps_repeated_after_a_cluster_timeout": guard.repeats, "resident_timeouts": per_rank_timeouts,
+            "resident_rearmed": [guard.rearms] * world,   # (degradations are rank-agreed: every rank re-arms at the same step)
             "metric": ("ResNet-50+CNSN images/sec" if args.workload.startswith("resnet50") else
                        "FCN-ResNet50+CNSN 512x512 images/sec" if args.workload == "seg" else "WideResNet-40-2+CNSN images/sec"),
             "value": round(world * bs * views * args.steps / dt, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -860,12 +862,13 @@ def main():
             new = cnsn_amd._ffi.poll_timeouts()           # (the stream is idle: every launch of the window has run)
             local_timeouts += new
             if dp.agree_to_repeat(new, dev) == 0:
+                state.step_applied(k)                             # (the way back: re-armed after a clean stretch, rank-agreed)
                 return t
             repeats += k
             if new:
                 print(f"[bench] rank {rank}: {new} cluster launch(es) gave up; all ranks repeat the window of {k} steps "
                       "on the two-pass kernels", file=sys.stderr)
-            dp.degrade_all()
+            state.degrade()
             state.restore()
         raise cnsn_amd.CnsnError("bench: cluster launches still time out after three windows")
 
@@ -969,6 +972,7 @@ def main():
             "fwd_ms": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4),
             "images_per_s": round(world * n / (dt / args.steps), 1),
             "steps_repeated_after_a_cluster_timeout": repeats, "resident_timeouts": per_rank_timeouts,
+            "resident_rearmed": [state.rearms] * world,   # (degradations are rank-agreed: every rank re-arms at the same step)
             "roofline": {"bound": "hbm",
                          "kernel": f"cnsn_backward launch ({path_b} path: reads G and x, writes dx)",
                          "bytes": need_b, "bytes_moved": moved_b,

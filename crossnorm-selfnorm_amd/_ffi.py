@@ -72,6 +72,8 @@ SIGNATURES = {
     "cnsn_context_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "cnsn_resident_timeouts": (C.c_int, []),
     "cnsn_resident_enable": (None, [C.c_int]),
+    "cnsn_resident_rearm": (C.c_int, []),
+    "cnsn_resident_degraded": (C.c_int, []),
     "cnsn_reload_env": (None, []),
     "cnsn_set_wait_ms": (None, [C.c_int]),
     "cnsn_wait_ms": (C.c_int, []),

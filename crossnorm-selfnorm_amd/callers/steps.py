@@ -38,7 +38,7 @@ class StepGuard:
     (`data_parallel.degrade_all`) and repeats: the ranks issue the same collectives in the same order whatever happens.
     The reference's loops (cifar.py:136-138, imagenet.py:240-244) have no counterpart: eager PyTorch cannot time out."""
 
-    def __init__(self, *modules, group=None, restore_rng=True, max_attempts=3, optimizer=None):
+    def __init__(self, *modules, group=None, restore_rng=True, max_attempts=3, optimizer=None, rearm_after=200):
         """optimizer: ALSO snapshot the parameters and the optimizer's state tensors (`save` / `restore` then cover a whole
         WINDOW of applied steps — what a launch-bound loop uses to poll once per window instead of synchronising the
         stream in every step: bench.py's model workloads; `run()` itself never needs it, it polls before the optimizer)."""
@@ -46,6 +46,13 @@ class StepGuard:
         self.modules, self.optimizer = modules, optimizer
         self.group, self.restore_rng, self.max_attempts = group, restore_rng, max_attempts
         self.snap, self.rng = None, None
+        # The way back: after `rearm_after` applied steps without a time-out the cluster kernels are tried again
+        # (`data_parallel.rearm_all`); a relapse doubles the interval.  Degradations are rank-agreed and every rank counts
+        # the same applied steps, so all ranks re-arm at the same step without a collective.  None / 0: never.
+        self.rearm_after = rearm_after
+        self.clean_steps = 0             # applied steps since the last degradation
+        self.degraded = False
+        self.rearms = 0                  # times this guard switched the cluster kernels back on
         self.repeats = 0                 # steps repeated so far (all ranks count the same)
         self.local_timeouts = 0          # launches of THIS rank that gave up
         self._defaults_done = False
@@ -78,6 +85,25 @@ class StepGuard:
             np.random.set_state(self.rng[0])
             torch.set_rng_state(self.rng[1])
 
+    def degrade(self):
+        """every rank, at the same step: cluster kernels off (a relapse after a re-arm doubles the way back)"""
+        from .. import data_parallel as dp
+        dp.degrade_all()
+        if self.rearms and self.rearm_after:
+            self.rearm_after = min(self.rearm_after * 2, 1 << 20)
+        self.degraded, self.clean_steps = True, 0
+
+    def step_applied(self, k=1):
+        """count `k` applied steps; re-arm the cluster kernels when the clean stretch since a degradation is long enough"""
+        if not self.degraded or not self.rearm_after:
+            return
+        self.clean_steps += k
+        if self.clean_steps >= self.rearm_after:
+            from .. import data_parallel as dp
+            dp.rearm_all()
+            self.degraded, self.clean_steps = False, 0
+            self.rearms += 1
+
     def run(self, compute_loss, optimizer):
         """compute_loss(): the forward(s) of the step, returns the loss (RNG draws included: a repeat re-draws the same
         values).  Then zero_grad / backward [gradient all-reduce inside] / settle / agree / optimizer.step."""
@@ -97,9 +123,10 @@ class StepGuard:
             self.local_timeouts += new
             if dp.agree_to_repeat(new, dev, self.group) == 0:
                 optimizer.step()
+                self.step_applied()
                 return loss.detach()
             self.repeats += 1                        # some rank's cluster launch gave up: nobody applies this attempt
-            dp.degrade_all()
+            self.degrade()
             self.restore()
         raise _ffi.CnsnError(f"training step: cluster-resident launches still time out after {self.max_attempts} attempts "
                              "(every rank raises this together)")

@@ -84,6 +84,8 @@ int cnsn_context_init(void* context, size_t bytes, void* stream) {
 }
 
 int cnsn_resident_timeouts(void) { return resident_timeouts(); }
+int cnsn_resident_rearm(void) { return resident_rearm(); }
+int cnsn_resident_degraded(void) { return resident_degraded() ? 1 : 0; }
 void cnsn_resident_enable(int on) { resident_set_enabled(on != 0); }
 void cnsn_reload_env(void) { reload_knobs(); }
 void cnsn_set_wait_ms(int ms) { resident_set_wait_ms(ms); }

@@ -31,6 +31,7 @@ enum Knob {
     K_SNXCN,          // CNSN_SNXCN         CrossNorm-capable partial-moment backward: 0 never, 1 AUTO rule, 2 wherever instantiated
     K_ARENA_CHUNK_MB, // CNSN_ARENA_CHUNK_MB  size of the output arena's physical allocations in MiB (default 56)
     K_XCD,            // CNSN_XCD           1: a cluster's workgroups share ONE XCD (A/B knob; default: consecutive workgroups, all 8 XCDs)
+    K_HEADROOM_CUS,   // CNSN_HEADROOM_CUS  compute units the persistent grids leave to others (RCCL's channel kernels): default 0
     K_COUNT
 };
 

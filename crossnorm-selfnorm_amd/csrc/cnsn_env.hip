@@ -16,6 +16,7 @@ const char* const kNames[K_COUNT] = {
     "CNSN_SNXCN",
     "CNSN_ARENA_CHUNK_MB",
     "CNSN_XCD",
+    "CNSN_HEADROOM_CUS",
 };
 
 struct Table {

@@ -36,6 +36,16 @@ int resident_timeouts() {
     return f ? (int)*(volatile const unsigned*)f : 0;
 }
 
+namespace {
+std::atomic<int> g_forgiven{0};  // time-outs that happened before the last cnsn_resident_rearm
+std::atomic<int> g_rearms{0};
+}  // namespace
+bool resident_degraded() { return resident_timeouts() > g_forgiven.load(std::memory_order_relaxed); }
+int resident_rearm() {
+    g_forgiven.store(resident_timeouts(), std::memory_order_relaxed);
+    return g_rearms.fetch_add(1, std::memory_order_relaxed) + 1;
+}
+
 bool resident_auto_enabled() {
     int e = g_enabled.load(std::memory_order_relaxed);
     if (e < 0) {
@@ -43,7 +53,7 @@ bool resident_auto_enabled() {
         e = (env && env[0] == '0') ? 0 : 1;
         g_enabled.store(e, std::memory_order_relaxed);
     }
-    return e == 1 && resident_timeouts() == 0;
+    return e == 1 && !resident_degraded();
 }
 
 void resident_set_enabled(bool on) { g_enabled.store(on ? 1 : 0, std::memory_order_relaxed); }

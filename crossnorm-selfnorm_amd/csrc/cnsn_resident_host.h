@@ -155,7 +155,17 @@ int grid_for(Kern kern, size_t lds, int K, int items) {
     if (knob(K_DEBUG))
         fprintf(stderr, "[cnsn] resident grid: occupancy %d/CU x %d CUs, K=%d, items=%d, lds=%zu\n", occ, cu_count(),
                 K, items, lds);
-    long g = (long)occ * cu_count();
+    // Head-room (CNSN_HEADROOM_CUS = n): size the grid for n compute units fewer than the part has.  A persistent grid sized
+    // for the whole chip next to a kernel that HOLDS compute units for longer than the launch (RCCL's channel kernels during a
+    // large all-reduce) still completes — its clusters drain in order — but the workgroups that found no slot only start once
+    // others have finished ALL their items: the launch takes up to twice as long.  With the grid sized for what is free, every
+    // workgroup is resident from the start and the items are shared evenly (tests/test_gpu_foreign_kernel.py, 32 CUs held).
+    int cus = cu_count();
+    if (const char* hr = knob(K_HEADROOM_CUS)) {
+        const int n = atoi(hr);
+        if (n > 0) cus = cus - n > 8 ? cus - n : 8;
+    }
+    long g = (long)occ * cus;
     g = (g / K) * K;
     if (g > items) g = items;  // items is a multiple of K
     return (int)g;
@@ -168,7 +178,7 @@ static inline ResPlan plan_impl(const cnsn_problem_t& p, bool boxed, bool has_ch
     if (p.strategy == CNSN_STRATEGY_TWO_PASS || p.strategy == CNSN_STRATEGY_LOCAL || p.strategy == CNSN_STRATEGY_MONO ||
         has_chan_perm)
         return rp;
-    if (resident_timeouts() > 0) return rp;  // a launch gave up earlier in this process: never again, even when forced
+    if (resident_degraded()) return rp;  // a launch gave up and nobody re-armed since (cnsn_resident_rearm): not even when forced
     const int M = p.H * p.W;
     rp.vec = pick_vec(p.dtype, boxed ? p.W : M);
     if (!(rp.vec == 16 / elem_bytes(p.dtype) || (elem_bytes(p.dtype) == 2 && rp.vec == 4))) return rp;

@@ -1685,6 +1685,8 @@ inline PermInline* perm_inline_scratch() {
 unsigned* resident_host_flag();
 // launches that timed out so far (0: none); after the first one AUTO stops choosing this strategy
 int resident_timeouts();
+bool resident_degraded();  // a launch gave up since the last cnsn_resident_rearm (or ever)
+int resident_rearm();      // forgive the time-outs so far; returns how often this process has re-armed
 void resident_set_wait_ms(int ms);   // cnsn_set_wait_ms
 long long resident_wait_ticks();     // bound of a cluster wait in 100 MHz ticks
 // AUTO may choose the cluster kernels: not switched off (cnsn_resident_enable(0) / CNSN_RESIDENT=0), no time-out seen

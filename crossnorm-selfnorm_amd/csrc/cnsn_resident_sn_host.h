@@ -144,7 +144,7 @@ inline SnxPlan plan_impl(const cnsn_problem_t& p, bool boxed, int add, int relu,
                (p.H * p.W / pick_vec(p.dtype, boxed ? p.W : p.H * p.W) + 63) / 64 < 5))
         return none;  // (snx_cn_built: buckets of 7 slots and more)
     if (!(add == ADD_NONE || add == ADD_PRE)) return none;
-    if (resident_timeouts() > 0) return none;
+    if (resident_degraded()) return none;
     if (p.strategy == CNSN_STRATEGY_AUTO && !resident_auto_enabled()) return none;
     if ((long)p.N * p.C < 16) return none;  // (the exchange area is sized against the two-pass workspace: see cnsn_resident_sn.hip)
     const bool epi = add != ADD_NONE || relu;

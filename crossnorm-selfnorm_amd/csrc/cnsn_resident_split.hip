@@ -45,7 +45,7 @@ ResPlan resident_split_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_p
     if (p.strategy == CNSN_STRATEGY_TWO_PASS || p.strategy == CNSN_STRATEGY_LOCAL || p.strategy == CNSN_STRATEGY_MONO ||
         has_chan_perm)
         return rp;
-    if (resident_timeouts() > 0) return rp;
+    if (resident_degraded()) return rp;
     if (add == ADD_PRE || (add == ADD_POST && boxed)) return rp;
     const int M = p.H * p.W;
     rp.vec = 16 / elem_bytes(p.dtype);

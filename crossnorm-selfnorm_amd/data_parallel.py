@@ -100,8 +100,31 @@ def degrade_all() -> None:
     kernels (`cnsn_resident_enable(0)`), so all ranks run the same (two-pass / single-workgroup) kernels from the repeat
     on — a rank that kept its cluster kernels would be faster than the degraded one and wait for it in every collective,
     and could be the next to time out if the cause (a shared GPU, a foreign persistent kernel) is node-wide."""
+    global _degraded_here
     from . import functional
     functional.set_resident(False)
+    _degraded_here = True
+
+
+_degraded_here = False       # the cluster kernels are off because degrade_all() switched them off (not the user)
+
+
+def rearm_all() -> int:
+    """The way back from `degrade_all`: forgive the time-outs counted so far (`cnsn_resident_rearm`) and let
+    CNSN_STRATEGY_AUTO choose the cluster-resident kernels again.  What kept part of a persistent grid off the device for
+    seconds — another process's kernel, a debugger, a clock event — is usually gone minutes later, and a job that runs for
+    days should not pay the two-pass kernels for the rest of its life.  EVERY rank must call it at the same step: the
+    callers count clean steps since the (rank-agreed) degradation, so no collective is needed (`StepGuard`).  Does nothing
+    when the cluster kernels are off for another reason (CNSN_RESIDENT=0, `set_resident(False)` by the user).  Returns how
+    often this process has re-armed."""
+    global _degraded_here
+    from . import _ffi, functional
+    if not _degraded_here:
+        return 0
+    n = int(_ffi.lib().cnsn_resident_rearm())
+    functional.set_resident(True)
+    _degraded_here = False
+    return n
 
 
 def gather_ints(value: int, device: Optional[torch.device] = None, group: Optional[dist.ProcessGroup] = None):

@@ -298,6 +298,15 @@ int cnsn_context_init(void* context, size_t bytes, void* stream);
  * host read, no synchronisation — and repeats the step that was in flight.  Nothing in the reference corresponds to
  * this (eager PyTorch has no cross-workgroup exchange); it belongs to the replacement of models/cnsn.py:159-164. */
 int cnsn_resident_timeouts(void);
+/* Re-arm (ABI 6): forgive the time-outs counted so far, so that the resident kernels may be chosen again (by
+ * CNSN_STRATEGY_AUTO once cnsn_resident_enable(1) has been called too).  The cause of a time-out is usually transient —
+ * another process's kernel held part of the GPU for seconds — and a job that runs for days should not pay the two-pass
+ * kernels for the rest of its life: the training loops re-arm after a number of clean steps that doubles with every
+ * relapse (callers/steps.py::StepGuard, the same count on every data-parallel rank).  cnsn_resident_timeouts() keeps
+ * counting from where it was.  Returns how often this process has re-armed.  cnsn_resident_degraded(): 1 while a
+ * time-out is unforgiven. */
+int cnsn_resident_rearm(void);
+int cnsn_resident_degraded(void);
 /* on = 0: CNSN_STRATEGY_AUTO never chooses the resident kernels (same as the environment variable CNSN_RESIDENT=0
  * at load time); on = 1: allowed again.  CNSN_STRATEGY_RESIDENT is not affected. */
 void cnsn_resident_enable(int on);

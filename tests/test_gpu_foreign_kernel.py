@@ -60,6 +60,63 @@ def workload():
     return cases
 
 
+@pytest.fixture
+def headroom_env():
+    yield
+    os.environ.pop("CNSN_HEADROOM_CUS", None)
+    cnsn_amd.reload_env()
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="tools/liboccupy.so not built")
+def test_grid_headroom_next_to_32_held_cus(headroom_env):
+    """round-4 review item 7a: RCCL's channel kernels hold compute units for the length of a large all-reduce.  With
+    CNSN_HEADROOM_CUS=32 the persistent grids are sized for 224 CUs: next to a foreign kernel holding 32 CUs every workgroup
+    is resident from the start.  Same bits as a quiet run either way, no time-out either way; the two busy times are recorded
+    (gpurun_out/foreign_kernel_headroom.json) and the head-room grid must not be slower than the full grid next to the holder."""
+    occ = C.CDLL(LIB)
+    occ.occupy_launch.restype = C.c_int
+    occ.occupy_launch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    side = torch.cuda.Stream(device=DEV)
+    before = cnsn_amd.lib().cnsn_resident_timeouts()
+    report = []
+    totals = {}
+    for headroom in (0, 32):
+        if headroom:
+            os.environ["CNSN_HEADROOM_CUS"] = str(headroom)
+        else:
+            os.environ.pop("CNSN_HEADROOM_CUS", None)
+        cnsn_amd.reload_env()
+        for tag, run in workload():
+            want = run()
+            run()
+            torch.cuda.synchronize()
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e[0].record()
+            for _ in range(3):
+                run()
+            e[1].record()
+            torch.cuda.synchronize()
+            assert occ.occupy_launch(32, 160 * 1024, 70, C.c_void_p(side.cuda_stream)) == 0
+            time.sleep(0.002)
+            e[2].record()
+            got = [run() for _ in range(3)]
+            e[3].record()
+            torch.cuda.current_stream().synchronize()
+            held = not side.query()
+            side.synchronize()
+            for out in got:
+                for a, b in zip(out, want):
+                    assert torch.equal(a, b), (headroom, tag)
+            quiet_ms, busy_ms = e[0].elapsed_time(e[1]) / 3, e[2].elapsed_time(e[3]) / 3
+            report.append({"case": tag, "headroom_cus": headroom, "cus_held": 32, "quiet_ms": round(quiet_ms, 3),
+                           "busy_ms": round(busy_ms, 3), "foreign_kernel_outlived_ours": bool(held)})
+            totals[headroom] = totals.get(headroom, 0.0) + busy_ms
+    assert cnsn_amd.lib().cnsn_resident_timeouts() == before, "a cluster wait ran out next to the foreign kernel"
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(report, open(os.path.join(ROOT, "gpurun_out", "foreign_kernel_headroom.json"), "w"), indent=1)
+    assert totals[32] <= totals[0] * 1.05, totals
+
+
 @pytest.mark.skipif(not os.path.exists(LIB), reason="tools/liboccupy.so not built")
 @pytest.mark.parametrize("cus", [16, 64, 128])
 def test_cluster_kernels_next_to_a_foreign_persistent_kernel(cus):

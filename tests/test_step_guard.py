@@ -58,14 +58,14 @@ class _Script:
         return self.count
 
 
-def _train(net, steps, script, group_ok=True):
+def _train(net, steps, script, group_ok=True, rearm_after=200, log=None):
     from cnsn_amd import _ffi
     from cnsn_amd.callers import StepGuard
     torch.manual_seed(11)
     xs = [torch.randn(16, 6) for _ in range(steps)]
     ys = [torch.randint(0, 3, (16,)) for _ in range(steps)]
     opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9)
-    guard = StepGuard(net)
+    guard = StepGuard(net, rearm_after=rearm_after)
     model = net
     if dist.is_initialized():
         model = nn.parallel.DistributedDataParallel(net)
@@ -78,6 +78,8 @@ def _train(net, steps, script, group_ok=True):
                 return nn.functional.cross_entropy(model(xs[i]), ys[i])
             loss = guard.run(compute_loss, opt)
             assert torch.isfinite(loss)
+            if log is not None:
+                log.append((i, guard.degraded, guard.rearms, guard.rearm_after, int(_ffi.lib().cnsn_resident_degraded())))
     finally:
         _ffi._timeout_count = old
     return guard
@@ -118,6 +120,30 @@ def test_failed_attempt_leaves_no_trace(resident_reenabled):
     # the repeats drew the SAME numbers the failed attempts had drawn: the trajectory of draws is that of the clean run
     applied = [d for i, d in enumerate(faulty.draws) if i not in (1, 4)]
     assert applied == clean.draws and faulty.draws[1] == faulty.draws[2] and faulty.draws[4] == faulty.draws[5]
+
+
+def test_cluster_kernels_come_back_after_a_clean_stretch(resident_reenabled):
+    """round-4 review item 7b: a process that degraded once tries the cluster kernels again after `rearm_after` applied
+    steps without a time-out (`data_parallel.rearm_all` -> `cnsn_resident_rearm` + `cnsn_resident_enable(1)`); a relapse
+    doubles the stretch.  Steps: 0 ok | 1 fails -> degraded, its repeat is the first clean step | 2 clean -> re-armed behind
+    step 2 | 3 ok | 4 fails (relapse: the way back is now 4 steps; its repeat is the first) | 5, 6, 7 clean -> re-armed behind
+    step 7 | 8, 9 ok."""
+    import cnsn_amd
+    from cnsn_amd import data_parallel as dp
+    net = _Net()
+    log = []
+    # call indices: step 0 -> 0, step 1 -> 1 (fails) + 2, steps 2, 3 -> 3, 4, step 4 -> 5 (fails) + 6, ...
+    g = _train(net, 10, _Script(net, (1, 5)), rearm_after=2, log=log)
+    assert g.repeats == 2 and g.rearms == 2 and g.rearm_after == 4 and not g.degraded
+    degraded = [d for _, d, *_ in log]
+    assert degraded == [False, True, False, False, True, True, True, False, False, False]
+    assert [r for _, _, r, *_ in log] == [0, 0, 1, 1, 1, 1, 1, 2, 2, 2]
+    assert not dp._degraded_here
+    # the library's own switch follows: AUTO may choose the cluster kernels again (asked without a GPU: the plan query)
+    assert cnsn_amd.lib().cnsn_resident_degraded() == 0
+    # a user's own CNSN_RESIDENT=0 / set_resident(False) is never undone by the protocol
+    cnsn_amd.set_resident(False)
+    assert dp.rearm_all() == 0
 
 
 def test_gives_up_loudly_when_every_attempt_fails(resident_reenabled):
@@ -162,8 +188,10 @@ def _worker(rank, world, port, out, fail_rank, fail_at):
         net = _Net()                                          # same initial weights on both ranks
         dp.seed_rank(50, rank)
         script = _Script(net, fail_at if rank == fail_rank else ())
-        guard = _train(net, 5, script)
+        log = []
+        guard = _train(net, 5, script, rearm_after=2, log=log)
         out[rank] = dict(state=_state(net), repeats=guard.repeats, local=guard.local_timeouts, attempts=script.calls,
+                         rearm_log=[(i, d, r) for i, d, r, *_ in log], rearms=guard.rearms,
                          agreed=dp.agree_to_repeat(rank, None), gathered=dp.gather_ints(10 + rank))
         dist.barrier()
     finally:
@@ -184,6 +212,10 @@ def test_two_ranks_repeat_in_lock_step():
     r0, r1 = _two_ranks(1, (1, 4))
     assert (r0["repeats"], r1["repeats"]) == (2, 2) and (r0["local"], r1["local"]) == (0, 2)
     assert r0["attempts"] == r1["attempts"] == 7
+    # the way back is rank-agreed without a collective: both ranks re-arm behind the same step (steps 1 and 3 failed on rank
+    # 1 only; two applied steps later — behind step 2 — BOTH switch the cluster kernels on again; step 3 is a relapse)
+    assert r0["rearm_log"] == r1["rearm_log"] and r0["rearms"] == r1["rearms"] == 1
+    assert [d for _, d, _ in r0["rearm_log"]] == [False, True, False, True, True]
     assert r0["agreed"] == r1["agreed"] == 1 and r0["gathered"] == r1["gathered"] == [10, 11]
     for k in r0["state"]:
         if "running" in k or "num_batches" in k:              # BatchNorm buffers are rank-local under DDP(broadcast off at
