@@ -323,16 +323,17 @@ template <int VEC, int NV, bool BOXED>
 struct SlotGeom {
     static constexpr int WORDS = BOXED ? (NV * VEC + 31) / 32 : 1;
     int lane, nvec;  // (SPLIT kernels: lane carries the wave's slot offset, lane + 64 * first slot of the wave)
+    int shift;       // slots are RIGHT-aligned by this many (PlaneIo's layout: slot j holds vector (j - shift) * 64 + lane); 0 = left-aligned
     mutable unsigned cbits[WORDS];  // bit j*VEC+q: element q of slot j is inside the content box
     mutable unsigned sbits[WORDS];  // ... inside the style box   (mutable: forget() below)
-    __device__ __forceinline__ SlotGeom(const ResArgs& ra, int lane_) : lane(lane_), nvec(ra.nvec) {
+    __device__ __forceinline__ SlotGeom(const ResArgs& ra, int lane_, int shift_ = 0) : lane(lane_), nvec(ra.nvec), shift(shift_) {
 #pragma unroll
         for (int w = 0; w < WORDS; ++w) cbits[w] = sbits[w] = 0;
         if constexpr (BOXED) {
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                const int i = j * 64 + lane;
-                if (i < ra.nvec) {
+                const int i = (j - shift) * 64 + lane;
+                if (j >= shift && i < ra.nvec) {
                     const int e = i * VEC;  // VEC divides the width: one row per vector
                     const int r = e / ra.Wd, c = e - r * ra.Wd;
 #pragma unroll
@@ -345,7 +346,7 @@ struct SlotGeom {
             }
         }
     }
-    __device__ __forceinline__ bool valid(int j) const { return j * 64 + lane < nvec; }
+    __device__ __forceinline__ bool valid(int j) const { return j >= shift && (j - shift) * 64 + lane < nvec; }
     __device__ __forceinline__ bool in_c(int j, int q) const {
         const int p = j * VEC + q;
         return (cbits[p >> 5] & (1u << (p & 31))) != 0u;

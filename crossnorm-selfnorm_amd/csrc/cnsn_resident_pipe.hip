@@ -3,6 +3,8 @@
 // of 7+ register slots (40x40 fp32 / 56x56 16-bit and larger) — the classes whose items are large enough (>= 25 KB per
 // workgroup) for the exposed cluster wait to be the bottleneck.
 #include "cnsn_resident_host.h"
+
+#include <cstring>
 #include "cnsn_env.h"
 #include "cnsn_resident_pipe_kernels.h"
 
@@ -51,6 +53,7 @@ ResPlan resident_pipe_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_pe
     if (!boxed && !p.cn_active && !(p.sn_active && p.sn_training)) return none;  // inference: nothing to wait for
     const int vb = rp.vec * elem_bytes(p.dtype);
     if (vb != 16 || rp.nv < 2) return none;
+    if ((size_t)p.N * p.C * p.H * p.W * elem_bytes(p.dtype) >= ((size_t)1 << 31)) return none;  // one descriptor per tensor: see PlaneIo
     const int slots = rp.ppw * rp.nv, nvec = p.H * p.W / rp.vec;
     const int wg_per_cu = pipe_fwd_waves(slots);
     const int grid_max = (wg_per_cu * reshost::cu_count() / rp.K) * rp.K;
@@ -122,8 +125,10 @@ int resident_pipe_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, c
                 status = (int)e;
                 return;
             }
-            kern<<<grid, kBlock, lds, stream>>>(ra, npark, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, pong.clear,
-                                                pong.clear_qwords, *pin);
+            PipeFwdKargs<T> ka{ra, npark, (const T*)x, (T*)y, perm, g, f, gran, saved, ctl, pong.clear, pong.clear_qwords, {}};
+            ka.pin.on = pin->on;  // (the index table only when it is in use: 2 KB of kernel arguments)
+            if (pin->on) memcpy(ka.pin.v, pin->v, sizeof(unsigned short) * (size_t)p.N);
+            kern<<<grid, kBlock, lds, stream>>>(ka);
             e = hipGetLastError();
             status = e == hipSuccess ? CNSN_OK : (int)e;
             if (use_pong && e == hipSuccess) resident_pong_commit(p, fill_bytes);

@@ -15,6 +15,7 @@
 // Same arithmetic, same published numbers, same `saved` rows as the plain kernel: results are bit-identical.
 #pragma once
 #include "cnsn_resident_kernels.h"
+#include "cnsn_resident_io.h"
 
 #ifndef CNSN_PIPE_PRIO
 #define CNSN_PIPE_PRIO 0
@@ -82,65 +83,114 @@ __host__ __device__ inline size_t pipe_lds_bytes(int N, int NG, int own, int par
 constexpr int kPipeKeep = 6;
 // workgroups per CU the forward is compiled for: small items (8 slots = 32 data registers) want more neighbours
 constexpr int pipe_fwd_waves(int slots) { return slots <= 8 ? 4 : 3; }
+// Kernel arguments travel as ONE struct and are re-read from the kernarg segment where they are used (cnsn_resident_io.h):
+// the kernel has far more wave-uniform state than a wave has SGPRs (ResArgs alone is ~50 dwords), and what the compiler keeps
+// resident it spills to VGPR lanes — until round 5 a fifth of this kernel's instructions were v_readlane / v_writelane.
+template <typename T>
+struct PipeFwdKargs {
+    ResArgs ra;
+    int npark;
+    const T* x;
+    T* y;
+    const int64_t* perm;
+    GateDev gg, gf;
+    unsigned long long* gran;
+    double* saved;
+    unsigned* ctl;
+    unsigned long long* clear;
+    unsigned clear_n;
+    PermInline pin;
+};
+
+// geometry the boxed statistics helpers ask for: slot validity from the tensor-descriptor layout, region masks from SlotGeom
+template <typename IO, typename SG>
+struct PipeGeom {
+    const IO& io;
+    const SG& sg;
+    __device__ __forceinline__ bool valid(int j) const { return io.valid(j); }
+    __device__ __forceinline__ int mask_c(int j, int q) const { return sg.mask_c(j, q); }
+    __device__ __forceinline__ int mask_s(int j, int q) const { return sg.mask_s(j, q); }
+};
+
 template <typename T, int VEC, int NV, int PPW, bool BOXED>
-__global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd_pipe_kernel(ResArgs ra, int npark, const T* __restrict__ x,
-                                                                      T* __restrict__ y, const int64_t* __restrict__ perm,
-                                                                      GateDev gg, GateDev gf,
-                                                                      unsigned long long* __restrict__ gran,
-                                                                      double* __restrict__ saved, unsigned* __restrict__ ctl,
-                                                                      unsigned long long* __restrict__ clear, unsigned clear_n,
-                                                                      PermInline pin) {
-    pipe_clear_other_region(clear, clear_n);
+__global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd_pipe_kernel(PipeFwdKargs<T>) {
+    using KA = PipeFwdKargs<T>;
+#define PKA_ (kargs_now<KA>())
+    {
+        const KA* ka = PKA_;
+        pipe_clear_other_region(ka->clear, ka->clear_n);
+    }
     constexpr int NG = BOXED ? 6 : 2;
     constexpr int OWN = 4 * PPW;
     constexpr int SLOTS = PPW * NV;
     constexpr int KEEP = SLOTS < kPipeKeep ? SLOTS : kPipeKeep, FIRST_KEEP = SLOTS - KEEP;  // slots below FIRST_KEEP: always parked
     constexpr int VB = VEC * (int)sizeof(T);
-    const int NPARK = __builtin_amdgcn_readfirstlane(npark);  // FIRST_KEEP <= NPARK <= SLOTS
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const MidArgs a = ra.mid;
-    const int N = a.N, C = a.C;
+    // resident for the whole kernel: the geometry, two tensor descriptors, the item bookkeeping
+    const KA* ka0 = PKA_;
+    const int NPARK = __builtin_amdgcn_readfirstlane(ka0->npark);  // FIRST_KEEP <= NPARK <= SLOTS
+    const int N = ka0->ra.mid.N, C = ka0->ra.mid.C, K = ka0->ra.K, items = ka0->ra.items;
+    const bool cn_on = ka0->ra.mid.cn_active != 0;
     Raw<T, VEC>* park = (Raw<T, VEC>*)smem;
     float* vals = (float*)(smem + (size_t)4 * 64 * NPARK * VB);
     int* sperm = (int*)((char*)vals + align16((size_t)N * NG * 4));
-    float* ocoef = (float*)((char*)sperm + (a.cn_active ? align16((size_t)N * 4) : 0));
+    float* ocoef = (float*)((char*)sperm + (cn_on ? align16((size_t)N * 4) : 0));
     double* red = (double*)((char*)ocoef + align16((size_t)OWN * FC_ROWS * 4));
     int* gave_up = (int*)(red + 4 * 4);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t P = (size_t)N * C;
-    const SlotGeom<VEC, NV, BOXED> sg(ra, lane);
-    const int voff = lane * VB;
+    const PlaneIo<T, VEC, NV> io(ka0->ra, N, C, lane);
+    const SlotGeom<VEC, NV, BOXED> sg(ka0->ra, lane, io.shift);
+    const PipeGeom<PlaneIo<T, VEC, NV>, SlotGeom<VEC, NV, BOXED>> geo{io, sg};
+    const __amdgpu_buffer_rsrc_t rx = io.tensor(ka0->x), ry = io.tensor(ka0->y);
+    const unsigned stride = (unsigned)C * (unsigned)ka0->ra.M * (unsigned)sizeof(T);  // plane (n, c) -> plane (n + 1, c)
     Raw<T, VEC>* mypark = park + (size_t)wave * NPARK * 64 + lane;  // slot i of this lane: mypark[i * 64]
+#ifdef CNSN_PROF
+    struct {
+        unsigned long long* prof;
+    } ra{ka0->ra.prof};
+#endif
 
-    if (a.cn_active)
-        for (int n = threadIdx.x; n < N; n += kBlock) sperm[n] = perm_at(perm, pin, n);
+    if (cn_on) {
+        const KA* ka = PKA_;
+        for (int n = threadIdx.x; n < N; n += kBlock) sperm[n] = perm_at(ka->perm, ka->pin, n);
+    }
     if (threadIdx.x == 0) *gave_up = 0;
     __syncthreads();
-    startup_skew(ra);
+    startup_skew(ka0->ra);
 
     Raw<T, VEC> d[PPW][NV];                        // the item being loaded / whose statistics are being taken
     Raw<T, VEC> keep[KEEP];                        // slots of the parked item that did not go to LDS
 
-    auto load_item = [&](int item) {
-        const int c = item / ra.K, k = item - c * ra.K;
+    // this wave's planes of item (c, k): n0 .. n0 + PPW - 1, the first `nlive` of them inside the batch
+    auto first_plane = [&](int k) { return (k * 4 + wave) * PPW; };
+    auto live_planes = [&](int n0) { return N - n0 < 0 ? 0 : (N - n0 > PPW ? PPW : N - n0); };
+
+    auto load_item = [&](int item, bool exists) {
+        const int c = item / K, k = item - c * K;
+        const int n0 = first_plane(k), nl = live_planes(n0);
+        const unsigned span = io.span(n0 < N ? n0 : 0, exists ? c : 0, C, (int)(stride / ((unsigned)C * (unsigned)sizeof(T))), exists);
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
-            const int n = (k * 4 + wave) * PPW + s;
-            const T* pb = x + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
-            const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;  // past the batch end: every lane reads zeros
+            const unsigned off = io.at(span, stride, s, nl);  // past the batch end / no such item: every lane reads zeros
 #pragma unroll
-            for (int j = 0; j < NV; ++j) d[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(pb, pbytes, j), voff);
+            for (int j = 0; j < NV; ++j) d[s][j] = io.load(rx, off, j);
         }
     };
 
     // exact two-pass statistics of the planes in d, published to the cluster
     auto stats_publish = [&](int item) {
-        const int c = item / ra.K, k = item - c * ra.K;
+        snx_phase_fence();
+        const KA* ka = PKA_;
+        const int c = item / K, k = item - c * K;
+        const int M = ka->ra.M;
+        const unsigned epoch = ka->ra.epoch;
+        const bool fault = ka->ra.fault && item == K - 1;
+        unsigned long long* gran = ka->gran;
 #pragma unroll
         for (int s = 0; s < PPW; ++s) {
             sg.forget();
-            const int n = (k * 4 + wave) * PPW + s;
+            const int n = first_plane(k) + s;
             float pub[NG];
             if constexpr (!BOXED) {
                 float sum = 0.f;
@@ -148,11 +198,11 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
                 for (int j = 0; j < NV; ++j)
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) sum += elem<T, VEC>(d[s][j], q);
-                const float mean = wave_sum(sum) / (float)ra.M;
+                const float mean = wave_sum(sum) / (float)M;
                 float m2 = 0.f;
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
-                    if (sg.valid(j)) {
+                    if (io.valid(j)) {
 #pragma unroll
                         for (int q = 0; q < VEC; ++q) {
                             const float t = elem<T, VEC>(d[s][j], q) - mean;
@@ -162,21 +212,22 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
                 pub[0] = mean;
                 pub[1] = wave_sum(m2);
             } else {  // (one masked pass about the plane mean: boxed_moments, cnsn_resident_kernels.h)
-                const float k = wave_sum(slots_sum<T, VEC, NV>(d[s])) / (float)a.M;  // invalid slots hold 0
+                const MidArgs a = ka->ra.mid;
+                const float kk = wave_sum(slots_sum<T, VEC, NV>(d[s])) / (float)a.M;  // invalid slots hold 0
                 float t[6];
-                boxed_region_sums<T, VEC, NV>(d[s], sg, k, t);
+                boxed_region_sums<T, VEC, NV>(d[s], geo, kk, t);
 #pragma unroll
                 for (int m = 0; m < 6; ++m) t[m] = wave_sum(t[m]);
-                boxed_moments(k, t, a.M, a.Mc, a.Ms, pub);
+                boxed_moments(kk, t, a.M, a.Mc, a.Ms, pub);
             }
-            if (ra.epoch) {  // persistent context: lane m publishes pub[m] with the launch's tag
-                if (n < N && lane < NG && !(ra.fault && item == ra.K - 1)) {
+            if (epoch) {  // persistent context: lane m publishes pub[m] with the launch's tag
+                if (n < N && lane < NG && !fault) {
                     float v = pub[0];
 #pragma unroll
                     for (int m = 1; m < NG; ++m) v = (lane == m) ? pub[m] : v;
-                    put_tagged(gran + ((size_t)c * N + n) * NG + lane, v, ra.epoch);
+                    put_tagged(gran + ((size_t)c * N + n) * NG + lane, v, epoch);
                 }
-            } else if (n < N && lane < NG / 2 && !(ra.fault && item == ra.K - 1)) {  // lane m: (pub[2m], pub[2m+1])
+            } else if (n < N && lane < NG / 2 && !fault) {  // lane m: (pub[2m], pub[2m+1])
                 float lo = pub[0], hi = pub[1];
 #pragma unroll
                 for (int m = 1; m < NG / 2; ++m) {
@@ -201,23 +252,29 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
             }
     };
 
-    int item = cluster_block(ra.xcd);
-    if (item >= ra.items) return;  // (the grid never exceeds the items)
+    const int grid = (int)gridDim.x;
+    int item = cluster_block(ka0->ra.xcd);
+    if (item >= items) return;  // (the grid never exceeds the items)
     int iter_ = 0;
     (void)iter_;
     CNSN_STAMP(0);
-    load_item(item);
+    load_item(item, true);
     stats_publish(item);
     park_item();
-    if (item + (int)gridDim.x < ra.items) load_item(item + (int)gridDim.x);
+    load_item(item + grid, item + grid < items);
 
     for (;;) {
-        const int c = item / ra.K, k = item - c * ra.K;
-        const int next = item + (int)gridDim.x, next2 = next + (int)gridDim.x;
-        const bool more = next < ra.items, more2 = next2 < ra.items;  // workgroup-uniform
+        const int c = item / K, k = item - c * K;
+        const int next = item + grid, next2 = next + grid;
+        const bool more = next < items, more2 = next2 < items;  // workgroup-uniform
         CNSN_STAMP(1);
+        snx_phase_fence();
 
         // ---- per-channel parameters of item t (scalar loads: in flight during the gather)
+        const KA* ka = PKA_;
+        const MidArgs a = ka->ra.mid;
+        const GateDev gg = ka->gg, gf = ka->gf;
+        double* saved = ka->saved;
         float pw[4] = {0.f, 0.f, 0.f, 0.f}, pgam[2] = {0.f, 0.f}, pbet[2] = {0.f, 0.f}, prm[2] = {0.f, 0.f},
               prv[2] = {1.f, 1.f};
         if (a.sn_active) {
@@ -240,18 +297,21 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
         // ---- gather item t's channel
         unsigned passes_ = 0;
         {
-            const bool got = ra.epoch ? sweep_tagged_scalar(gran + (size_t)c * N * NG, N * NG, vals, ctl, ra.host_flag,
-                                                            ra.wait_ticks, wave, ra.epoch, passes_)
-                                      : sweep_granules_scalar(gran + (size_t)c * N * (NG / 2), N * NG, vals, ctl, ra.host_flag,
-                                                              ra.wait_ticks, wave, passes_);
+            const unsigned epoch = ka->ra.epoch;
+            const bool got = epoch ? sweep_tagged_scalar(ka->gran + (size_t)c * N * NG, N * NG, vals, ka->ctl, ka->ra.host_flag,
+                                                         ka->ra.wait_ticks, wave, epoch, passes_)
+                                   : sweep_granules_scalar(ka->gran + (size_t)c * N * (NG / 2), N * NG, vals, ka->ctl,
+                                                           ka->ra.host_flag, ka->ra.wait_ticks, wave, passes_);
             if (lane == 0 && !got) *gave_up = 1;
         }
         __syncthreads();
         if (*gave_up) {  // (workgroup-uniform) timed out: see sweep_granules; the planes still owed are marked with NaNs
+            T* y = PKA_->y;
+            const int M = PKA_->ra.M;
 #pragma unroll
             for (int s = 0; s < PPW; ++s) {
-                const int n = (k * 4 + wave) * PPW + s;
-                if (n < N && lane == 0) poison_plane<T, VEC>(y + ((size_t)n * C + c) * ra.M);
+                const int n = first_plane(k) + s;
+                if (n < N && lane == 0) poison_plane<T, VEC>(y + ((size_t)n * C + c) * M);
             }
             return;
         }
@@ -280,6 +340,7 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
         };
 
         // ---- SelfNorm gate statistics over the batch (every member computes them redundantly)
+        const size_t P = (size_t)N * C;
         double mg = 0, mf = 0, rg = 1, rf = 1, wg0 = 0, wg1 = 0, wf0 = 0, wf1 = 0;
         if (a.sn_active) {
             wg0 = pw[0];
@@ -378,24 +439,25 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
         //      exchange travels while this workgroup stores
         if (more) stats_publish(next);
         CNSN_STAMP(4);
+        snx_phase_fence();
 
         // ---- slot by slot: apply item t from LDS (the only write of y), park item t+1's slot in its place, send the
         //      load of item t+2's slot (the only read of x) after it: item t's stores and item t+2's loads reach the
         //      memory system interleaved, and the loads are under way a whole apply phase earlier
         {
-            const int c2 = next2 / ra.K, k2 = next2 - c2 * ra.K;
+            const int c2 = next2 / K, k2 = next2 - c2 * K;
+            const int M_ = (int)(stride / ((unsigned)C * (unsigned)sizeof(T)));
+            const int n0 = first_plane(k), n02 = first_plane(k2);
+            const unsigned span_y = io.span(n0 < N ? n0 : 0, c, C, M_, true);
+            const unsigned span_x2 = io.span(n02 < N ? n02 : 0, more2 ? c2 : 0, C, M_, more2);
+            const int nl = live_planes(n0), nl2 = live_planes(n02);
 #pragma unroll
             for (int s = 0; s < PPW; ++s) {
                 sg.forget();
-                const int n = (k * 4 + wave) * PPW + s;
                 const float* o = ocoef + (wave * PPW + s) * FC_ROWS;
                 const float a_in = o[FC_A_IN], xr = o[FC_XR], b_in = o[FC_B_IN], a_out = o[FC_A_OUT], b_out = o[FC_B_OUT];
-                T* yb = y + ((size_t)(n < N ? n : 0) * C + c) * ra.M;
-                const int pbytes = n < N ? ra.M * (int)sizeof(T) : 0;  // (a plane past the batch end drops its stores)
-                const int n2 = (k2 * 4 + wave) * PPW + s;
-                const bool live2 = more2 && n2 < N;
-                const T* xb2 = x + ((size_t)(live2 ? n2 : 0) * C + (more2 ? c2 : 0)) * ra.M;
-                const int pbytes2 = live2 ? ra.M * (int)sizeof(T) : 0;  // nothing to load: zeros, no traffic
+                const unsigned off_y = io.at(span_y, stride, s, nl);      // (a plane past the batch end drops its stores)
+                const unsigned off_x2 = io.at(span_x2, stride, s, nl2);   // nothing to load: zeros, no traffic
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
                     const int i = s * NV + j;
@@ -418,12 +480,12 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
                             ov[q + 1] = r2.y;
                         }
                     }
-                    buf_store<T, VEC>(slot_rsrc<T, VEC>(yb, pbytes, j), voff, pack<T, VEC>(ov));
+                    io.store(ry, off_y, j, pack<T, VEC>(ov));
                     if (i < FIRST_KEEP || i < NPARK)  // park slot i of item t+1 (garbage after the last item: never read)
                         mypark[i * 64] = d[s][j];
                     else
                         keep[i - FIRST_KEEP] = d[s][j];
-                    d[s][j] = buf_load<T, VEC>(slot_rsrc<T, VEC>(xb2, pbytes2, j), voff);
+                    d[s][j] = io.load(rx, off_x2, j);
                 }
             }
         }
@@ -432,6 +494,7 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
         item = next;
         ++iter_;
     }
+#undef PKA_
 }
 
 // ================================================================================================

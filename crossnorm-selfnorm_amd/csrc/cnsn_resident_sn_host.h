@@ -175,7 +175,7 @@ inline SnxPlan plan_impl(const cnsn_problem_t& p, bool boxed, int add, int relu,
     const long grid_max = ((long)wg_per_cu * reshost::cu_count() / sp.K) * sp.K;
     if (grid_max < sp.K) return none;
     const size_t budget = (kLdsPerCu / wg_per_cu) & ~(size_t)511;
-    const int first_keep = slots - (backward ? snx_bwd_keep(slots, epi, vb) : snx_fwd_keep(slots, vb));
+    const int first_keep = slots - (backward ? snx_bwd_keep(slots, epi, vb, cn, cn && boxed) : snx_fwd_keep(slots, vb, epi && eb == 2));
     int np = slots;
     if (!backward && sp.ppw == 1 && nvec % 64 != 0 && nvec % 64 <= 32) np = slots - 1;  // a last, partly filled slot stays in registers
     if (np < first_keep) np = first_keep;
