@@ -1033,7 +1033,7 @@ def main():
             out["extra"]["inference"] = inference_workloads(cnsn_amd, shape, dev)
             out["roofline_bf16"] = roofline_bf16(cnsn_amd, dev)
             out["extra"]["resnet50_bs256_bf16"] = model_line("resnet50", 12, 4, 200)
-            out["extra"]["seg_bs16_512"] = {"f32": model_line("seg", 8, 3, 150), "bf16": model_line("seg", 8, 3, 150, ("--dtype", "bf16"))}
+            out["extra"]["seg_bs16_512"] = {"f32": model_line("seg", 5, 2, 150), "bf16": model_line("seg", 5, 2, 150, ("--dtype", "bf16"))}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shape, args.crop, args.kind, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -13,6 +13,10 @@ DEV = torch.device("cuda:0")
 
 
 def test_probe_and_kept_blocks_are_what_the_allocator_hands_out_next():
+    import gc
+    gc.collect()                                                    # (blocks of this size other tests left cached would be
+    torch.cuda.synchronize()                                        #  handed out before the kept ones)
+    torch.cuda.empty_cache()
     x = torch.randn(64, 64, 56, 56, device=DEV)                     # 51 MB blocks
     y = torch.empty_like(x)
     assert cnsn_amd.placement.probe_write_ms(x, y) > 0.0
