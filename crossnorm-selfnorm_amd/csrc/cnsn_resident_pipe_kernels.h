@@ -81,6 +81,12 @@ __host__ __device__ inline size_t pipe_lds_bytes(int N, int NG, int own, int par
 // a launch argument — the host parks as many slots as let three workgroups share a CU's 160 KB (at 56x56 fp32 the 13th
 // slot, a quarter full, stays: 12 slots = 48 KB).
 constexpr int kPipeKeep = 6;
+// (one place for the host and the kernel; a knob for instantiations that spill)
+constexpr int pipe_fwd_keep(int slots, int elem_bytes, bool boxed) {
+    (void)elem_bytes;
+    (void)boxed;
+    return slots < kPipeKeep ? slots : kPipeKeep;
+}
 // workgroups per CU the forward is compiled for: small items (8 slots = 32 data registers) want more neighbours
 constexpr int pipe_fwd_waves(int slots) { return slots <= 8 ? 4 : 3; }
 // Kernel arguments travel as ONE struct and are re-read from the kernarg segment where they are used (cnsn_resident_io.h):
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
     constexpr int NG = BOXED ? 6 : 2;
     constexpr int OWN = 4 * PPW;
     constexpr int SLOTS = PPW * NV;
-    constexpr int KEEP = SLOTS < kPipeKeep ? SLOTS : kPipeKeep, FIRST_KEEP = SLOTS - KEEP;  // slots below FIRST_KEEP: always parked
+    constexpr int KEEP = pipe_fwd_keep(SLOTS, (int)sizeof(T), BOXED), FIRST_KEEP = SLOTS - KEEP;  // slots below FIRST_KEEP: always parked
     constexpr int VB = VEC * (int)sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // resident for the whole kernel: the geometry, two tensor descriptors, the item bookkeeping
@@ -294,7 +300,9 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
             }
         }
 
-        // ---- gather item t's channel
+        // ---- gather item t's channel.  (Round 5 tried reading the granules EARLY with a vector load issued a third of the way
+        //      through the previous apply loop — counted vmcnt wait, no extra latency: profiles/r05_early_gather.md.  It misses
+        //      80-100 % of the time: what this wait waits for is the slowest of the cluster's members, not a round trip.)
         unsigned passes_ = 0;
         {
             const unsigned epoch = ka->ra.epoch;
