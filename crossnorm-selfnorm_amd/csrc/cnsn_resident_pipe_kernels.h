@@ -18,7 +18,7 @@
 #include "cnsn_resident_io.h"
 
 #ifndef CNSN_PIPE_PRIO
-#define CNSN_PIPE_PRIO 0
+#define CNSN_PIPE_PRIO 2  // 0: none, 1: the algebra, 2: the whole serial section at wave priority 3 (profiles/r05_serial_priority.md: -1 ... -4 %)
 #endif
 
 namespace cnsn {
@@ -274,6 +274,9 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
         const int next = item + grid, next2 = next + grid;
         const bool more = next < items, more2 = next2 < items;  // workgroup-uniform
         CNSN_STAMP(1);
+#if CNSN_PIPE_PRIO == 2
+        __builtin_amdgcn_s_setprio(3);  // (A/B: the WHOLE serial section — gather, algebra, statistics of t+1 — ahead of the neighbours' apply loops)
+#endif
         snx_phase_fence();
 
         // ---- per-channel parameters of item t (scalar loads: in flight during the gather)
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
             return;
         }
         CNSN_STAMP(2);
-#if CNSN_PIPE_PRIO
+#if CNSN_PIPE_PRIO == 1
         __builtin_amdgcn_s_setprio(3);  // the algebra is the short serial section of the cycle: ahead of the neighbours' bulk loops
 #endif
         CNSN_NOTE(6, passes_);
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
             }
         }
         __syncthreads();
-#if CNSN_PIPE_PRIO
+#if CNSN_PIPE_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
 #endif
         CNSN_STAMP(3);
@@ -446,6 +449,9 @@ __global__ __launch_bounds__(kBlock, pipe_fwd_waves(PPW * NV)) void resident_fwd
         // ---- item t+1 has arrived long ago: its statistics go out BEFORE item t is applied — the cluster's next
         //      exchange travels while this workgroup stores
         if (more) stats_publish(next);
+#if CNSN_PIPE_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
         CNSN_STAMP(4);
         snx_phase_fence();
 

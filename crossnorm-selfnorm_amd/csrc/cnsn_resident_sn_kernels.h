@@ -197,6 +197,15 @@ constexpr int snx_bwd_keep(int slots2, bool epi, int vb = 16, bool cn = false, b
 #ifndef SNX_PRIO_MODE
 #define SNX_PRIO_MODE 0
 #endif
+// the serial section of an item (gather, algebra, sums of t+1) at wave priority 3, ahead of the neighbours' apply loops — where it
+// measured faster (profiles/r05_serial_priority.md): the fp32 forward (-2 %) and the backward with crop boxes (-6 %); the 16-bit
+// forward got 5 % SLOWER with it
+#ifndef SNX_SERIAL_PRIO
+#define SNX_SERIAL_PRIO 1
+#endif
+template <typename T>
+constexpr bool snx_fwd_serial_prio() { return SNX_SERIAL_PRIO && sizeof(T) == 4; }
+constexpr bool snx_bwd_serial_prio(bool boxed) { return SNX_SERIAL_PRIO && boxed; }
 __device__ __forceinline__ void snx_set_priority() {
 #if SNX_PRIO_MODE == 1
     const int rank = (int)blockIdx.x / 256;  // (256 CUs: the r-th workgroup to arrive on its CU)
@@ -490,6 +499,7 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
     if (next != kNoChan) load_item(next);
 
     for (;;) {
+        if constexpr (snx_fwd_serial_prio<T>()) __builtin_amdgcn_s_setprio(3);  // the serial section ahead of the neighbours' apply loops
         const int c = __builtin_amdgcn_readfirstlane(item);
         const bool more = next != kNoChan;  // workgroup-uniform
         CNSN_STAMP(0);
@@ -582,6 +592,7 @@ __global__ __launch_bounds__(kBlock, snx_fwd_waves(PPW * NV, EPI, (int)sizeof(T)
         const bool more2 = next2 != kNoChan;
         CNSN_STAMP(2);
         if (more) stats_publish(next, buf ^ 1, more2);
+        if constexpr (snx_fwd_serial_prio<T>()) __builtin_amdgcn_s_setprio(0);
         CNSN_STAMP(3);
 
         // ---- slot by slot: apply item t (the only write of y), park item t+1's slot in its place, send the loads of
@@ -1021,6 +1032,7 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
     if (next != kNoChan) load_item(next);
 
     for (;;) {
+        if constexpr (snx_bwd_serial_prio(BOXED)) __builtin_amdgcn_s_setprio(3);  // the serial section ahead of the neighbours' apply loops
         const int c = __builtin_amdgcn_readfirstlane(item);
         const bool more = next != kNoChan;  // workgroup-uniform
         const int next2 = __builtin_amdgcn_readfirstlane(more ? static_channel(iter_ + 2) : kNoChan);
@@ -1242,6 +1254,7 @@ __global__ __launch_bounds__(kBlock, snx_bwd_waves(2 * PPW * NV, EPI, VEC * (int
         // ---- item t+1 has arrived long ago: its partial sums go out BEFORE item t is applied
         CNSN_STAMP(2);
         if (more) sums_publish(next, b0 ^ 1);
+        if constexpr (snx_bwd_serial_prio(BOXED)) __builtin_amdgcn_s_setprio(0);
         CNSN_STAMP(3);
 
         // ---- slot by slot: apply item t (the only write of dx), park item t+1's slots in its place, send the loads of
