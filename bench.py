@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--prospect", type=int, default=12,
                     help="let the output arena time this many candidate blocks of the input's size and keep the 4 fastest "
                          "(cnsn_arena_prospect); adds ms_per_step_prospected to the line (never the headline).  0: no search")
+    ap.add_argument("--no-alt", action="store_true",
+                    help="only the contract's W + K steps: no second window with the other allocator, no prospecting (rocprofv3 "
+                         "passes: the kernel averages then belong to ONE placement)")
     ap.add_argument("--no-placement", action="store_true",
                     help="do not look for output blocks in the fast-write regions of the device memory before the warm-up "
                          "(cnsn_amd.placement, profiles/r04_memory_map.md)")
@@ -398,7 +401,7 @@ def live_traffic(args, timeout_s=45):
     if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ):
         return None, "this process is itself being profiled: no nested rocprofv3 passes"
     child = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2", "--no-extra", "--no-cpu-baseline",
-             "--no-ceiling", "--no-placement", "--shape", args.shape, "--dtype", args.dtype, "--crop", args.crop, "--kind", args.kind,
+             "--no-ceiling", "--no-placement", "--no-alt", "--shape", args.shape, "--dtype", args.dtype, "--crop", args.crop, "--kind", args.kind,
              "--strategy", args.strategy]
     mean = {}                                              # (direction, counter) -> KiB per launch
     t0 = time.perf_counter()
@@ -902,7 +905,7 @@ def main():
 
     # ---- the same K steps with the other allocator / after a bounded search (outside the contract's timed region)
     alt = {}
-    if world == 1 and cnsn_amd._ffi.glue() is not None:
+    if world == 1 and cnsn_amd._ffi.glue() is not None and not args.no_alt:
         arena_stats = _arena.stats(dev) if not args.no_arena else None
         if args.no_arena:
             _arena.enable()

@@ -23,16 +23,17 @@ pmc() {  # name, command...
   done
   echo "pmc $name: $(wc -l < $OUT/${name}_pmc.txt) rows"
 }
-stats bench_f32_neither python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra
+stats bench_f32_neither python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-alt
 for c in boxed_f32 boxed_bf16 neither_bf16 block_bf16 block_f32 sn_bf16; do stats $c python $R/tools/run_cases.py $c 8; done
-for c in boxed_f32 boxed_bf16 neither_bf16 block_bf16 block_f32; do pmc $c python $R/tools/run_cases.py $c 4; done
-pmc bench_f32_neither python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra
+for c in boxed_f32 boxed_bf16 neither_bf16 block_bf16; do pmc $c python $R/tools/run_cases.py $c 4; done
+pmc bench_f32_neither python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra --no-alt
 stats resnet50_step python $R/bench.py --workload resnet50 --steps 12 --warmup 4
 cd $R
 timeout 200 tools/pattern_bench 256 256 > $OUT/pattern_bench.txt 2>&1
 timeout 600 python bench.py --sweep > $OUT/shape_sweep.md 2> /dev/null
-timeout 400 python bench.py --steps 50 --warmup 10 > $OUT/bench_n1.json 2> $OUT/bench_n1.err
-for w in resnet50 resnet50_jsd wrn40; do timeout 300 python bench.py --workload $w --steps 30 --warmup 8 2>/dev/null | tail -1 >> $OUT/model_workloads.jsonl; done
+timeout 600 python bench.py --steps 50 --warmup 10 > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_style.json 2> $OUT/bench_driver_style.err
+for w in resnet50 resnet50_jsd wrn40 seg; do timeout 300 python bench.py --workload $w --steps 30 --warmup 8 2>/dev/null | tail -1 >> $OUT/model_workloads.jsonl; done
 timeout 300 python bench.py --workload wrn40 --steps 60 --warmup 15 --no-graph 2>/dev/null | tail -1 >> $OUT/model_workloads.jsonl
 CNSN_FUSE_TAIL=0 timeout 300 python bench.py --workload wrn40 --steps 60 --warmup 15 --no-graph 2>/dev/null | tail -1 > $OUT/wrn40_eager_no_tail.json
 ls -la $OUT
