@@ -210,13 +210,15 @@ static inline ResPlan plan_impl(const cnsn_problem_t& p, bool boxed, bool has_ch
         // With crop boxes (round 4, tools/boxed_sweep.py -> profiles/r04_boxed_sweep.md, after the region select of the boxed
         // kernels became branch-free — until then two-pass won every 16-bit boxed call of these classes): 7 slots both
         // directions at every batch size (56x56 bf16 crop=both forward 0.254 vs 0.277 ms at N = 256, 0.038 vs 0.054 at N = 32);
-        // 8 slots the backward (64x64: -10 % at N = 256, -24 % at N = 64) and the forward of CrossNorm alone (-5..-10 %), NOT the
-        // forward with SelfNorm (two-pass 0.172 vs 0.180-0.192 at N = 256, 0.058 vs 0.062 at N = 16)
+        // 8 slots the backward (64x64: -10 % at N = 256, -24 % at N = 64) and the forward of CrossNorm alone (-5..-10 %); the
+        // forward with SelfNorm was left to two-pass in round 4 (0.172 vs 0.180-0.192 ms at N = 256 in a loop of forwards only)
         const bool solo = !backward && !boxed && !p.cn_active && !(p.sn_active && p.sn_training);  // inference
         if (!epi && !solo && p.dtype != CNSN_F32) {
             const bool ok16 = rp.nv <= 4   ? true
                               : rp.nv == 7 ? true
-                              : rp.nv == 8 ? (!boxed || backward || !p.sn_active)
+                              : rp.nv == 8 ? true  // (round 5, tools/auto_audit.py: the forward with crop boxes AND SelfNorm too —
+                                                   //  (16,2048,64,64) bf16 crop=both 0.354 -> 0.318 ms per call, (16,512,64,64)
+                                                   //  0.118 -> 0.103: config 5's mode is single-touch in both directions now)
                                            : (backward && !boxed);
             if (!ok16) return rp;
         }

@@ -76,9 +76,11 @@ ResPlan resident_pipe_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_pe
         // every batch size (0.254 vs 0.294, 0.128 vs 0.143, 0.038 vs 0.048); 16-bit 64x64 the plain kernel (0.158 vs 0.164).
         if (boxed) {
             const bool f32 = elem_bytes(p.dtype) == 4;
-            if (!((f32 && rp.nv == 13) || (f32 && rp.nv == 16 && p.N >= 64) || (!f32 && rp.nv == 7))) return none;
-        } else if (!(rp.nv == 2 || rp.nv == 4 || rp.nv == 7 || rp.nv == 13))
-            return none;
+            // (fp32 28x28 — 4 slots — too since round 5: -3.4 / -4.1 % per call at (256,512,28,28) and (96,512,28,28) on both audited boxes)
+            if (!((f32 && rp.nv == 13) || (f32 && rp.nv == 16 && p.N >= 64) || (f32 && rp.nv == 4) || (!f32 && rp.nv == 7))) return none;
+        } else if (!(rp.nv == 2 || rp.nv == 4 || rp.nv == 7 || rp.nv == 13 || (rp.nv == 8 && elem_bytes(p.dtype) == 2)))
+            return none;  // (8 slots in 16 bits: round 5, after the forward's register pass — (16,512,64,64) bf16 0.105 -> 0.093 ms per
+                          //  call, (16,2048,64,64) 0.321 -> 0.300: tools/auto_audit.py)
     }
     if (npark) *npark = np;
     return rp;

@@ -21,7 +21,8 @@ TABLE = [
     ((256, 256, 56, 56), BF16, FC(**SN, **CN), "resident", "resident"),
     ((256, 256, 56, 56), BF16, FC(**SN, **BOTH), "resident", "resident"),      # 16-bit boxed 56x56: pipelined forward since the region select is branch-free; backward: partial-moment cluster kernel (round 4)
     ((32, 256, 56, 56), BF16, FC(**SN, **BOTH), "resident", "resident"),       # ... at every batch size
-    ((256, 128, 64, 64), BF16, FC(**SN, **BOTH), "streaming", "resident"),     # 16-bit boxed 64x64: the forward with SelfNorm stays two-pass
+    ((256, 128, 64, 64), BF16, FC(**SN, **BOTH), "resident", "resident"),      # 16-bit boxed 64x64 WITH SelfNorm: single-touch forward too since round 5 (config 5's mode)
+    ((16, 2048, 64, 64), BF16, FC(**SN, **BOTH), "resident", "resident"),
     ((256, 128, 64, 64), BF16, FC(**CN, style_box=(0, 0, 32, 32)), "resident", "resident"),  # ... CrossNorm alone does not
     ((96, 256, 56, 56), BF16, FC(**SN, **BOTH), "resident", "resident"),       # ... (until the branch-free region select: two-pass both ways at N < 192)
     ((256, 512, 28, 28), BF16, FC(**SN, **BOTH), "resident", "resident"),      # <= 4 slots: always resident
