@@ -24,8 +24,8 @@ One JSON line is printed by rank 0; it also carries
                  priced on SURVEY §8(d3)'s two-pass byte count and the in-process copy / triad ceilings ride along
   cpu_baseline — the CPU oracle (a port of the reference's eager PyTorch path) timed on this
                  host's cores on a bounded slice of the same workload (rank 0, N=1 only), plus one thread
-  arena        — y and dx come from the library's output arena (cnsn_amd.arena: blocks of its own, a stable home; nothing
-                 is probed or timed by default).  `ms_per_step` is that default; `ms_per_step_plain_allocator` is the same
+  arena        — y and dx come from the library's output arena (cnsn_amd.arena: blocks of its own, a stable home; a NEW block
+                 is the fastest of 4 candidates timed when it is created — during the warm-up here).  `ms_per_step` is that default; `ms_per_step_plain_allocator` is the same
                  K steps re-timed in the same process with the arena off (torch's caching allocator places y and dx).
                  MI355X's memory has regions that take plane-strided writes 15-20 % faster (profiles/r04_memory_map.md):
                  `--prospect N` lets the arena time N candidate blocks and keep the fastest (cnsn_arena_prospect) and adds
@@ -1010,8 +1010,10 @@ def main():
         if alt:
             out["arena"] = {"on": not args.no_arena, "min_bytes": _arena.min_bytes(), **(alt.get("arena") or {}),
                             "note": "y / dx are tensors over blocks of the library's output arena (cnsn_amd.arena, C ABI "
-                                    "cnsn_arena_*): a stable home, nothing probed or timed; ms_per_step_plain_allocator = the "
-                                    "same K steps in this process with torch's caching allocator placing them"}
+                                    "cnsn_arena_*): a stable home; every NEW block is the fastest of `tries` candidates timed "
+                                    "with a plane-strided fill when it is created (the allocator's standing policy, during the "
+                                    "warm-up here); ms_per_step_plain_allocator = the same K steps in this process with torch's "
+                                    "caching allocator placing them"}
             if "prospect" in alt:
                 out["arena"]["prospect"] = alt["prospect"]
                 if "ms_per_step_prospected" in alt:

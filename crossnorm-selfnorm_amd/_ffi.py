@@ -55,7 +55,7 @@ class ArenaStats(C.Structure):
     """cnsn_arena_stats_t"""
     _fields_ = [("struct_bytes", C.c_int32), ("device", C.c_int32), ("chunk_bytes", C.c_uint64), ("mapped_bytes", C.c_uint64),
                 ("in_use_bytes", C.c_uint64), ("blocks", C.c_uint64), ("blocks_in_use", C.c_uint64), ("hits", C.c_uint64),
-                ("misses", C.c_uint64), ("failed", C.c_uint64)]
+                ("misses", C.c_uint64), ("failed", C.c_uint64), ("probed", C.c_uint64), ("tries", C.c_uint64)]
 
 
 class Epilogue(C.Structure):
@@ -85,6 +85,7 @@ SIGNATURES = {
     "cnsn_arena_set_chunk_bytes": (C.c_int, [C.c_size_t]),
     "cnsn_arena_prospect": (C.c_int, [C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "cnsn_arena_block_gbps": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "cnsn_arena_set_tries": (C.c_int, [C.c_int]),
     "cnsn_saved_floats": (C.c_size_t, [C.POINTER(Problem)]),
     "cnsn_workspace_bytes": (C.c_size_t, [C.POINTER(Problem)]),
     "cnsn_forward": (C.c_int, [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p,

@@ -5,8 +5,10 @@ MI355X that decides 7-10 % of the single-touch launches' time: their plane-strid
 large `hipMalloc` block in five and 10-20 % below it into the rest (profiles/r04_memory_map.md).  Address ranges MAPPED from
 physical allocations of the arena's own give the outputs a home that does not change from step to step: the op's outputs of at
 least `min_bytes` (default 32 MiB; `CNSN_ARENA_MIN_MB`) are tensors over such ranges — `at::from_blob` views whose deleter
-hands the block back to the arena's per-size free list.  By default nothing is probed and nothing is timed; in the steady
-state of a training loop an allocation is a mutex and a list pop.
+hands the block back to the arena's per-size free list.  A NEW block is the fastest of four candidates created together and
+timed with a plane-strided fill (~1 ms each, `set_tries` / `CNSN_ARENA_TRIES`; where a block lies physically decides how
+fast it is written, and about one in four lies well) — paid in the first steps of a job, for EVERY output block of the job; in
+the steady state of a training loop an allocation is a mutex and a list pop.
 
 What a user may want to know:
   * on by default (`CNSN_ARENA=0` or `arena.disable()` switch it off); outputs under graph capture and small outputs come
@@ -27,7 +29,7 @@ import torch
 
 from . import _ffi
 
-__all__ = ["enable", "disable", "enabled", "min_bytes", "stats", "trim", "empty_like", "set_chunk_mb", "prospect", "block_gbps"]
+__all__ = ["enable", "disable", "enabled", "min_bytes", "stats", "trim", "empty_like", "set_chunk_mb", "prospect", "block_gbps", "set_tries"]
 
 
 def _glue():
@@ -106,6 +108,12 @@ def block_gbps(t: torch.Tensor) -> float:
     """the write rate measured for the arena block under `t` (0.0: never measured / not an arena tensor)"""
     v = C.c_float(0.0)
     return float(v.value) if _ffi.lib().cnsn_arena_block_gbps(C.c_void_p(t.data_ptr()), C.byref(v)) == 0 else 0.0
+
+
+def set_tries(tries: int) -> int:
+    """candidates the arena creates and times per NEW block, keeping the fastest (default 4, `CNSN_ARENA_TRIES`; 1: none);
+    returns the previous value"""
+    return int(_ffi.lib().cnsn_arena_set_tries(int(tries)))
 
 
 def set_chunk_mb(mb: float) -> None:

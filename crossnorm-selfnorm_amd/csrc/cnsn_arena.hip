@@ -60,7 +60,7 @@ struct Block {
 
 struct DeviceArena {
     std::multimap<size_t, Block*> free_by_size;
-    uint64_t mapped = 0, in_use = 0, blocks = 0, blocks_in_use = 0, hits = 0, misses = 0, failed = 0;
+    uint64_t mapped = 0, in_use = 0, blocks = 0, blocks_in_use = 0, hits = 0, misses = 0, failed = 0, probed = 0;
 };
 
 struct Arena {
@@ -70,6 +70,7 @@ struct Arena {
     size_t chunk = 0;       // resolved on first use
     size_t granularity = 0;
     bool broken = false;    // the driver refused the virtual-memory calls once: never try again
+    int tries = -1;         // candidates per new block (cnsn_arena_set_tries; -1: CNSN_ARENA_TRIES, default 4)
 };
 
 Arena& arena() {
@@ -78,6 +79,16 @@ Arena& arena() {
 }
 
 size_t round_up(size_t v, size_t to) { return (v + to - 1) / to * to; }
+
+int resolve_tries() {  // (under the arena's mutex)
+    Arena& a = arena();
+    if (a.tries < 0) {
+        const char* e = knob(K_ARENA_TRIES);
+        a.tries = (e && atoi(e) > 0) ? atoi(e) : 4;
+        if (a.tries > 32) a.tries = 32;
+    }
+    return a.tries;
+}
 
 size_t resolve_chunk(Arena& a, int device) {
     if (a.chunk) return a.chunk;
@@ -243,7 +254,36 @@ void* cnsn_arena_alloc(int device, size_t bytes, void* stream) {
         int cur = -1;
         (void)hipGetDevice(&cur);
         if (cur != device) (void)hipSetDevice(device);
-        b = create_block(a, device, need);
+        // Best of `tries`: WHERE a block lies physically decides how fast it is written (about one in four is of the fast
+        // kind), so a new block is chosen among a few candidates created together — distinct physical memory —, each timed
+        // with the plane-strided fill (~1 ms), the losers' memory handed back at once.  Happens when a block is CREATED (the
+        // first steps of a job), costs `tries` x the block's size transiently, never more than a quarter of what is free.
+        int tries = resolve_tries();
+        if (tries > 1) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                tries = (int)std::max<size_t>(1, std::min<size_t>((size_t)tries, free_b / 4 / need));
+            else
+                (void)hipGetLastError();
+        }
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;  // (never time anything on a capturing stream)
+        if (tries > 1 && (hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)) {
+            (void)hipGetLastError();
+            tries = 1;
+        }
+        std::vector<Block*> cand;
+        for (int i = 0; i < tries; ++i) {
+            Block* c = create_block(a, device, need);
+            if (!c) break;
+            cand.push_back(c);
+        }
+        if (cand.size() > 1) {
+            for (Block* c : cand) c->gbps = measure_block(c, (hipStream_t)stream);
+            std::sort(cand.begin(), cand.end(), [](const Block* x, const Block* y) { return x->gbps > y->gbps; });
+            for (size_t i = 1; i < cand.size(); ++i) release_block(cand[i]);  // (measure_block left the stream idle)
+            d.probed += cand.size();
+        }
+        b = cand.empty() ? nullptr : cand[0];
         if (cur != device && cur >= 0) (void)hipSetDevice(cur);
         if (!b) {
             ++d.failed;
@@ -392,7 +432,17 @@ int cnsn_arena_stats(int device, cnsn_arena_stats_t* out) {
     out->hits = d.hits;
     out->misses = d.misses;
     out->failed = d.failed;
+    out->probed = d.probed;
+    out->tries = (uint64_t)(a.tries < 0 ? 0 : a.tries);
     return CNSN_OK;
+}
+
+int cnsn_arena_set_tries(int tries) {
+    Arena& a = arena();
+    std::lock_guard<std::mutex> lock(a.mu);
+    const int was = resolve_tries();
+    a.tries = tries < 1 ? -1 : (tries > 32 ? 32 : tries);
+    return was;
 }
 
 int cnsn_arena_set_chunk_bytes(size_t chunk_bytes) {

@@ -32,6 +32,7 @@ enum Knob {
     K_ARENA_CHUNK_MB, // CNSN_ARENA_CHUNK_MB  size of the output arena's physical allocations in MiB (default 56)
     K_XCD,            // CNSN_XCD           1: a cluster's workgroups share ONE XCD (A/B knob; default: consecutive workgroups, all 8 XCDs)
     K_HEADROOM_CUS,   // CNSN_HEADROOM_CUS  compute units the persistent grids leave to others (RCCL's channel kernels): default 0
+    K_ARENA_TRIES,    // CNSN_ARENA_TRIES   candidates the output arena times per new block (default 4; 1: none)
     K_COUNT
 };
 

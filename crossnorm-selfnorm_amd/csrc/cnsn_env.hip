@@ -17,6 +17,7 @@ const char* const kNames[K_COUNT] = {
     "CNSN_ARENA_CHUNK_MB",
     "CNSN_XCD",
     "CNSN_HEADROOM_CUS",
+    "CNSN_ARENA_TRIES",
 };
 
 struct Table {

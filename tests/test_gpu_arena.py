@@ -28,6 +28,7 @@ def default_arena():
     yield
     _ffi.glue().arena_config(was)
     arena.set_chunk_mb(0)
+    arena.set_tries(0)
     gc.collect()
     if os.environ.get("CNSN_TEST_NO_TRIM") != "1":
         arena.trim()
@@ -100,6 +101,28 @@ def test_trimmed_address_ranges_are_never_mapped_again():
         assert arena.trim(DEV) > 0
 
 
+def test_a_new_block_is_the_fastest_of_four_candidates():
+    """the arena's standing policy (cnsn_arena_set_tries, default 4): candidates created together, each timed with the
+    plane-strided fill, the fastest kept, the others' memory back to the driver at once"""
+    arena.trim()
+    assert arena.set_tries(0) in (1, 2, 3, 4, 6, 8, 32) and arena.set_tries(0) == 4      # (0: back to the default, which is 4)
+    x = torch.randn(64, 64, 56, 56, device=DEV)                                # 51 MB
+    s0 = arena.stats(DEV)
+    a = arena.empty_like(x)
+    s1 = arena.stats(DEV)
+    assert s1["probed"] == s0["probed"] + 4 and s1["blocks"] == s0["blocks"] + 1 and s1["misses"] == s0["misses"] + 1
+    assert s1["mapped_bytes"] - s0["mapped_bytes"] == 56 << 20                 # the three losers are gone
+    assert arena.block_gbps(a) > 100.0
+    del a
+    gc.collect()
+    b = arena.empty_like(x)                                                    # steady state: a list pop, nothing timed
+    assert arena.stats(DEV)["probed"] == s1["probed"] and arena.stats(DEV)["hits"] == s1["hits"] + 1
+    arena.set_tries(1)
+    c = arena.empty_like(x)
+    assert arena.stats(DEV)["probed"] == s1["probed"] and arena.block_gbps(c) == 0.0
+    del b, c
+
+
 def test_prospect_keeps_the_fastest_blocks_on_the_free_list():
     arena.trim()
     x = torch.randn(64, 64, 56, 56, device=DEV)                                # 51 MB
@@ -113,7 +136,8 @@ def test_prospect_keeps_the_fastest_blocks_on_the_free_list():
     assert arena.stats(DEV)["misses"] == s1["misses"]
     ga, gb = arena.block_gbps(a), arena.block_gbps(b)
     assert ga >= gb > 0 and round(ga, 1) == rep["GBps_fill"][0] and round(gb, 1) == rep["GBps_fill"][1]
-    c = arena.empty_like(x)                                                    # a third one: created, never measured
+    arena.set_tries(1)
+    c = arena.empty_like(x)                                                    # a third one: created with one try, never measured
     assert arena.block_gbps(c) == 0.0
     del a
     gc.collect()
