@@ -228,13 +228,6 @@ int resident_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const 
     return reshost::forward_impl<false>(p, cb, sb, boxed, mid, x, nullptr, 0, perm, g, f, y, saved, workspace, stream);
 }
 
-int resident_backward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, const MidArgs& mid, const void* gy,
-                      const void* x, const int64_t* perm, GateDev g, GateDev f, const double* saved, void* dx,
-                      GateGradDev dg, GateGradDev df, void* workspace, hipStream_t stream) {
-    return reshost::backward_impl<false>(p, cb, sb, boxed, mid, gy, x, nullptr, 0, perm, g, f, saved, dx, dg, df,
-                                         workspace, stream);
-}
-
 size_t resident_workspace_bytes(const cnsn_problem_t& p, bool boxed) {
     return kCtlBytes + (size_t)p.N * p.C * (boxed ? 6 : 2) * 8 + 256;  // (+ 256: whole 256-byte groups are read)
 }
