@@ -970,8 +970,12 @@ def main():
                        "algorithmic_bytes_per_step": step_bytes,
                        "parallelism": f"dp{world} (independent minibatches; grads of 4C SN params all-reduced)",
                        "world_size": world, "devices": ngpu, "backend": backend},
-            "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
+            # READ THIS ONE FIRST: the whole step on the bytes it physically has to move (5*E*b: x in + y out, G and x in + dx out)
             "frac_of_hbm_peak_bytes_needed": round((need_f + need_b) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "value_note": "value = 8*E*b per step / time — SURVEY §8(d3) prices the op as a two-pass algorithm (BASELINE's metric); "
+                          "this implementation touches every tensor once (5*E*b), so value can exceed the 8 TB/s peak without "
+                          "anything being skipped: frac_of_hbm_peak_bytes_needed is the physical fraction",
+            "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
             "fwd_ms": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4),
             "images_per_s": round(world * n / (dt / args.steps), 1),
             "steps_repeated_after_a_cluster_timeout": repeats, "resident_timeouts": per_rank_timeouts,
