@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("CNSN_LIB_PATH") or os.path.join(_HERE, "libcnsn_hip.s
 CNSN_F32, CNSN_BF16, CNSN_F16 = 0, 1, 2
 STRATEGY_AUTO, STRATEGY_TWO_PASS, STRATEGY_RESIDENT, STRATEGY_LOCAL, STRATEGY_MONO = 0, 1, 2, 3, 4
 ADD_NONE, ADD_PRE, ADD_POST = 0, 1, 2
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 PATHS = {0: "streaming", 1: "packed", 2: "resident", 3: "local", 4: "mono"}
 ABI_VERSION = 6
 PERM_INLINE_MAX = 1024       # CNSN_PERM_INLINE_MAX
@@ -27,7 +28,7 @@ class Problem(C.Structure):
         ("lam", C.c_float), ("eps_cn", C.c_float),
         ("sn_active", C.c_int32), ("sn_two", C.c_int32), ("sn_training", C.c_int32),
         ("eps_sn", C.c_float), ("eps_bn", C.c_float), ("momentum", C.c_float),
-        ("strategy", C.c_int32), ("reserved", C.c_int32),
+        ("strategy", C.c_int32), ("layout", C.c_int32),
         ("context", C.c_void_p), ("context_bytes", C.c_uint64),
         ("perm_host", C.c_void_p),
     ]

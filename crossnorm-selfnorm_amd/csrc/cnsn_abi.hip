@@ -10,6 +10,7 @@
 
 #include "cnsn_device.h"
 #include "cnsn_host_plan.h"
+#include "cnsn_nhwc.h"
 #include "cnsn_local.h"
 #include "cnsn_mid_kernels.h"
 #include "cnsn_mono.h"
@@ -116,12 +117,16 @@ size_t cnsn_saved_floats(const cnsn_problem_t* prob) {
 size_t cnsn_workspace_bytes(const cnsn_problem_t* prob) {
     Plan pl;
     if (make_plan(prob, pl) != CNSN_OK) return 0;
+    if (pl.pr.layout == CNSN_LAYOUT_NHWC)  // (+ the pixel chunks' partial sums and the plane-order rows: cnsn_nhwc.hip)
+        return nhwc_supported(pl, false) ? ((workspace_bytes_of(pl) + 255) & ~(size_t)255) + nhwc_extra_bytes(pl) : 0;
     return workspace_bytes_of(pl);
 }
 
 int cnsn_forward(const cnsn_problem_t* prob, const void* x, const int64_t* perm, const int64_t* chan_perm,
                  const cnsn_gate_t* g, const cnsn_gate_t* f, void* y, float* saved, void* workspace,
                  size_t workspace_bytes, void* stream_) {
+    if (prob && prob->layout == CNSN_LAYOUT_NHWC)  // channels-last: one entry point for every epilogue (cnsn_fused.hip)
+        return cnsn_forward_fused(prob, nullptr, x, perm, chan_perm, g, f, y, saved, workspace, workspace_bytes, stream_);
     Plan pl;
     int st = make_plan(prob, pl);
     if (st) return st;
@@ -229,6 +234,9 @@ int cnsn_backward(const cnsn_problem_t* prob, const void* grad_y, const void* x,
                   const int64_t* chan_perm, const cnsn_gate_t* g, const cnsn_gate_t* f, const float* saved,
                   void* grad_x, const cnsn_gate_grad_t* dg, const cnsn_gate_grad_t* df, void* workspace,
                   size_t workspace_bytes, void* stream_) {
+    if (prob && prob->layout == CNSN_LAYOUT_NHWC)
+        return cnsn_backward_fused(prob, nullptr, grad_y, x, perm, chan_perm, g, f, saved, grad_x, nullptr, dg, df, workspace,
+                                   workspace_bytes, stream_);
     Plan pl;
     int st = make_plan(prob, pl);
     if (st) return st;

@@ -8,6 +8,7 @@
 #include "cnsn_host_plan.h"
 #include "cnsn_local.h"
 #include "cnsn_mono.h"
+#include "cnsn_nhwc.h"
 #include "cnsn_wide.h"
 #include "cnsn_packed.h"
 #include "cnsn_resident_fused.h"
@@ -76,6 +77,7 @@ int cnsn_which_path(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int 
     const cnsn_problem_t& p = pl.pr;
     const bool chan = p.cn_active && has_chan_perm;
     const bool bwd = backward != 0;
+    if (p.layout == CNSN_LAYOUT_NHWC) return (chan || !nhwc_supported(pl, false)) ? CNSN_E_UNSUPPORTED : CNSN_PATH_STREAMING;
     // the backward of an epilogue without ReLU and without PRE add is the plain backward
     const bool fused = bwd ? (e.relu || e.add == ADD_PRE) : (e.relu || e.add != ADD_NONE);
     if (resident_sn_prefers(p, pl.boxed, fused ? e.add : ADD_NONE, fused ? e.relu : 0, bwd)) return CNSN_PATH_RESIDENT;
@@ -101,6 +103,7 @@ int cnsn_sn_cluster_plan(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi,
     if (st) return st;
     const bool bwd = backward != 0;
     const bool fused = bwd ? (e.relu || e.add == ADD_PRE) : (e.relu || e.add != ADD_NONE);
+    if (pl.pr.layout == CNSN_LAYOUT_NHWC) return 0;  // (channels-last: the two-pass kernels of cnsn_nhwc.hip)
     // (the small-plane strategies come first in every entry point, unless this family is known to be faster)
     if (resident_sn_prefers(pl.pr, pl.boxed, fused ? e.add : ADD_NONE, fused ? e.relu : 0, bwd)) return 1;
     if (wide_plan(pl, fused ? e.add : 0, bwd).ok || mono_plan(pl, fused ? e.add : 0, bwd).ok ||
@@ -116,6 +119,18 @@ int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, c
     EpiPlan e;
     int st = parse_epilogue(epi, e);
     if (st) return st;
+    if (prob && prob->layout == CNSN_LAYOUT_NHWC) {  // channels-last tensors: the two-pass kernels of cnsn_nhwc.hip, every epilogue
+        Plan pl;
+        st = make_plan(prob, pl);
+        if (st) return st;
+        if (!x || !y || !workspace) return CNSN_E_NULL;
+        if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)workspace) & 15u) != 0) return CNSN_E_ALIGN;
+        if (chan_perm || !nhwc_supported(pl, false)) return CNSN_E_UNSUPPORTED;
+        if (pl.pr.sn_active && !gate_ok(g)) return CNSN_E_NULL;
+        if (pl.pr.sn_active && pl.pr.sn_two && !gate_ok(f)) return CNSN_E_NULL;
+        return nhwc_forward(pl, e.add, e.relu, x, e.addend, perm, gate_dev(g), gate_dev(f), y, saved, workspace, workspace_bytes,
+                            (hipStream_t)stream_);
+    }
     if (e.add == ADD_NONE && !e.relu)
         return cnsn_forward(prob, x, perm, chan_perm, g, f, y, saved, workspace, workspace_bytes, stream_);
     Plan pl;
@@ -239,6 +254,19 @@ int cnsn_backward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, 
     EpiPlan e;
     int st = parse_epilogue(epi, e);
     if (st) return st;
+    if (prob && prob->layout == CNSN_LAYOUT_NHWC) {
+        Plan pl;
+        st = make_plan(prob, pl);
+        if (st) return st;
+        if (!grad_y || !x || !grad_x || !saved || !workspace) return CNSN_E_NULL;
+        if ((((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)grad_addend | (uintptr_t)workspace) & 15u) != 0)
+            return CNSN_E_ALIGN;
+        if (chan_perm || !nhwc_supported(pl, false)) return CNSN_E_UNSUPPORTED;
+        if (pl.pr.sn_active && (!gate_ok(g) || !gate_grad_ok(dg))) return CNSN_E_NULL;
+        if (pl.pr.sn_active && pl.pr.sn_two && (!gate_ok(f) || !gate_grad_ok(df))) return CNSN_E_NULL;
+        return nhwc_backward(pl, e.add, e.relu, grad_y, x, e.addend, perm, gate_dev(g), gate_dev(f), saved, grad_x, grad_addend,
+                             gate_grad_dev(dg), gate_grad_dev(df), workspace, workspace_bytes, (hipStream_t)stream_);
+    }
     // without a ReLU the gradient of a POST addend is grad_y itself and nothing else changes
     if (!e.relu && e.add != ADD_PRE)
         return cnsn_backward(prob, grad_y, x, perm, chan_perm, g, f, saved, grad_x, dg, df, workspace, workspace_bytes,

@@ -75,7 +75,7 @@ int64_t arena_min_bytes() {
     return v;
 }
 
-Tensor arena_empty(at::IntArrayRef sizes, const at::TensorOptions& opt, const at::Device& dev, int64_t nbytes) {
+Tensor arena_empty(at::IntArrayRef sizes, at::IntArrayRef strides, const at::TensorOptions& opt, const at::Device& dev, int64_t nbytes) {
     hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
@@ -84,18 +84,39 @@ Tensor arena_empty(at::IntArrayRef sizes, const at::TensorOptions& opt, const at
     }
     void* p = cnsn_arena_alloc((int)dev.index(), (size_t)nbytes, (void*)stream);
     if (!p) return Tensor();  // (no memory / no virtual-memory support: the caller allocates as it always did)
-    return at::from_blob(p, sizes, [](void* q) { (void)cnsn_arena_free(q); }, opt, dev);
+    return at::from_blob(p, sizes, strides, [](void* q) { (void)cnsn_arena_free(q); }, opt, dev);
 }
 
-// `x` is dense (contiguous, aligned): a fresh tensor of its shape and type for an output of the op
+// `x` is dense (contiguous in NCHW or channels-last order, aligned): a fresh tensor of its shape, type AND memory order for an
+// output of the op
 Tensor out_like(const Tensor& x) {
     const int64_t nbytes = x.numel() * (int64_t)x.element_size();
     const int64_t min = arena_min_bytes();
     if (min >= 0 && nbytes >= min) {
-        Tensor t = arena_empty(x.sizes(), at::TensorOptions().dtype(x.scalar_type()).device(x.device()), x.device(), nbytes);
+        Tensor t = arena_empty(x.sizes(), x.strides(), at::TensorOptions().dtype(x.scalar_type()).device(x.device()), x.device(),
+                               nbytes);
         if (t.defined()) return t;
     }
     return at::empty_like(x);
+}
+
+// Channels-last calls the library computes where the tensor lies (cnsn_problem_t.layout = CNSN_LAYOUT_NHWC, include/cnsn_hip.h):
+// strictly channels-last strides, un-boxed, no channel permutation, a channel count that is a whole number of 16-byte vectors.
+// Everything else is copied to NCHW like the reference's `.contiguous()` (models/cnsn.py:14).  CNSN_NHWC=0 switches it off.
+bool nhwc_call(const Tensor& x, const int64_t* cbox, const int64_t* sbox, bool has_chan) {
+    static const bool on = [] {
+        const char* e = getenv("CNSN_NHWC");
+        return !(e && e[0] == '0');
+    }();
+    if (!on || x.dim() != 4 || has_chan || cbox[0] >= 0 || sbox[0] >= 0) return false;
+    if (x.is_contiguous() || !x.is_contiguous(at::MemoryFormat::ChannelsLast)) return false;
+    const int64_t vec = 16 / (int64_t)x.element_size();
+    return x.size(1) % vec == 0 && x.size(2) * x.size(3) >= 2 && (reinterpret_cast<uintptr_t>(x.data_ptr()) & 15u) == 0;
+}
+Tensor dense_cl(const Tensor& t) {  // channels-last contiguous AND 16-byte aligned
+    Tensor d = t.contiguous(at::MemoryFormat::ChannelsLast);
+    if ((reinterpret_cast<uintptr_t>(d.data_ptr()) & 15u) != 0) d = d.clone(at::MemoryFormat::ChannelsLast);
+    return d;
 }
 
 // host -> device copy of the (tiny) permutation through a ring of pinned staging buffers, so that the
@@ -278,15 +299,17 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
         // tensor's device's: make that device current (a model on cuda:1 must not need set_device(1))
         const c10::DeviceGuard device_guard(x_in.device());
 
-        const Tensor x = dense(x_in);  // reference cnsn.py:14
+        const bool nhwc = nhwc_call(x_in, c.cbox, c.sbox, c.cn_active && chan_in.has_value());
+        const Tensor x = nhwc ? x_in : dense(x_in);  // reference cnsn.py:14 (a channels-last call is computed where it lies)
         Tensor addend;
         if (c.add_mode != CNSN_ADD_NONE) {
             TORCH_CHECK(addend_in.has_value() && addend_in->is_cuda() && addend_in->sizes() == x.sizes() &&
                             addend_in->scalar_type() == x.scalar_type(),
                         "cnsn_forward: the addend must be a device tensor of x's shape and dtype");
-            addend = dense(*addend_in);
+            addend = nhwc ? dense_cl(*addend_in) : dense(*addend_in);
         }
         cnsn_problem_t prob = make_problem(x, c);
+        prob.layout = nhwc ? CNSN_LAYOUT_NHWC : CNSN_LAYOUT_NCHW;
         const cnsn_epilogue_t epi = make_epilogue(c, addend);
         const bool has_epi = c.add_mode != CNSN_ADD_NONE || c.relu;
         const at::Device dev = x.device();
@@ -294,7 +317,7 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
         Tensor perm, chan, perm_host;
         if (c.cn_active) {
             TORCH_CHECK(perm_in.has_value(), "cnsn_forward: CrossNorm needs the batch permutation");
-            const bool inline_ok = c.perm_inline && !chan_in.has_value() && !perm_in->is_cuda() &&
+            const bool inline_ok = !nhwc && c.perm_inline && !chan_in.has_value() && !perm_in->is_cuda() &&
                                    perm_in->scalar_type() == at::kLong && perm_in->is_contiguous() &&
                                    perm_in->numel() <= CNSN_PERM_INLINE_MAX && perm_in->numel() == x.size(0);
             if (inline_ok) {
@@ -369,6 +392,8 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
         const auto pd = ctx->saved_data["pd"].toIntVector();
         const Config c = parse_config(cfg, fcfg);
         cnsn_problem_t prob = make_problem(x, c);
+        const bool nhwc = nhwc_call(x, c.cbox, c.sbox, chan.defined());  // (the saved x: the forward's decision again)
+        prob.layout = nhwc ? CNSN_LAYOUT_NHWC : CNSN_LAYOUT_NCHW;
         if (perm_host.defined()) prob.perm_host = perm_host.data_ptr<int64_t>();
         const bool two = c.sn_active && c.sn_two;
         const at::Device dev = x.device();
@@ -377,7 +402,7 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
 
         Tensor gy = grads[0];
         if (gy.scalar_type() != x.scalar_type()) gy = gy.to(x.scalar_type());
-        gy = dense(gy);
+        gy = nhwc ? dense_cl(gy) : dense(gy);
         Tensor dx = out_like(x);
         const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
         const size_t ws_bytes = cnsn_workspace_bytes(&prob);
@@ -641,8 +666,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("arena_min_bytes", []() { return arena_min_bytes(); });
     m.def("arena_empty_like", [](const Tensor& x) {
         TORCH_CHECK(x.is_cuda(), "arena_empty_like: device tensors only");
-        Tensor t = arena_empty(x.sizes(), at::TensorOptions().dtype(x.scalar_type()).device(x.device()), x.device(),
-                               x.numel() * (int64_t)x.element_size());
+        Tensor t = arena_empty(x.sizes(), at::detail::defaultStrides(x.sizes()), at::TensorOptions().dtype(x.scalar_type()).device(x.device()),
+                               x.device(), x.numel() * (int64_t)x.element_size());
         return t.defined() ? t : at::empty(x.sizes(), x.options().memory_format(at::MemoryFormat::Contiguous));
     }, "a fresh contiguous tensor of x's shape and type over an arena block (torch's allocator when the arena cannot serve it)");
     m.def("out_like", &out_like, "the op's output allocation for a dense x: arena from the threshold on, else torch");

@@ -57,6 +57,32 @@ def _dense(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+NHWC = None
+
+
+def _nhwc_call(x: torch.Tensor, cfg, chan_perm) -> bool:
+    """True when this call is computed where a channels-last tensor lies (`cnsn_problem_t.layout = CNSN_LAYOUT_NHWC`): strictly
+    channels-last strides, no crop boxes, no channel permutation, a channel count that is a whole number of 16-byte vectors.
+    Everything else is copied to NCHW, like the reference's `.contiguous()` (models/cnsn.py:14).  CNSN_NHWC=0 switches it off."""
+    global NHWC
+    if NHWC is None:
+        import os
+        NHWC = os.environ.get("CNSN_NHWC") != "0"
+    if not NHWC or x.dim() != 4 or chan_perm is not None or cfg.content_box is not None or cfg.style_box is not None:
+        return False
+    if x.is_contiguous() or not x.is_contiguous(memory_format=torch.channels_last):
+        return False
+    vec = 16 // x.element_size()
+    return x.shape[1] % vec == 0 and x.shape[2] * x.shape[3] >= 2 and x.data_ptr() % 16 == 0
+
+
+def _dense_cl(t: torch.Tensor) -> torch.Tensor:
+    t = t.contiguous(memory_format=torch.channels_last)
+    if t.data_ptr() % 16:
+        t = t.clone(memory_format=torch.channels_last)
+    return t
+
+
 def _on_device_of(fn):
     """Run a Function.forward/backward with the tensor's device current: the library sizes grids, orders its
     persistent launches and sets kernel attributes for the CURRENT device, and the stream handed over belongs
@@ -106,7 +132,7 @@ _ffi._plan_caches.append(_size_cache)
 
 def _sizes(prob):
     key = (prob.dtype, prob.N, prob.C, prob.H, prob.W, prob.cn_active, prob.sn_active, prob.sn_two,
-           prob.sn_training, prob.content_box[0] >= 0, prob.style_box[0] >= 0, prob.strategy)
+           prob.sn_training, prob.content_box[0] >= 0, prob.style_box[0] >= 0, prob.strategy, prob.layout)
     hit = _size_cache.get(key)
     if hit is None:
         lib = _ffi.lib()
@@ -237,6 +263,8 @@ def which_path(x: torch.Tensor, cfg: FusedConfig, backward: bool = False, chan_p
     """'streaming' | 'packed' | 'resident' | 'local' | 'mono': the kernels a call with this tensor / configuration would run
     under the current strategy setting (cnsn_which_path; nothing is launched)."""
     prob = _problem(x, cfg)
+    if _nhwc_call(x, cfg, True if chan_perm else None):
+        prob.layout = _ffi.LAYOUT_NHWC
     epi = _epilogue(cfg, None) if cfg.has_epilogue else None
     st = _ffi.lib().cnsn_which_path(C.byref(prob), C.byref(epi) if epi else None, int(chan_perm), int(backward))
     if st < 0:
@@ -335,19 +363,21 @@ class FusedCNSN(torch.autograd.Function):
                  f_w, f_gamma, f_beta, f_rm, f_rv, addend, g_nbt, f_nbt):
         lib = _ffi.lib()
         _ffi.check_resident_health("cnsn_forward")
-        x = _dense(x)                                              # reference cnsn.py:14
+        nhwc = _nhwc_call(x, cfg, chan_perm if cfg.cn_active else None)
+        x = x if nhwc else _dense(x)                               # reference cnsn.py:14 (a channels-last call is computed where it lies)
         if cfg.add_mode != "none":
             _require_device(addend, "cnsn_forward(addend)")
             assert addend.shape == x.shape and addend.dtype == x.dtype, "addend must match x"
-            addend = _dense(addend)
+            addend = _dense_cl(addend) if nhwc else _dense(addend)
         else:
             addend = None
         prob = _problem(x, cfg)
+        prob.layout = _ffi.LAYOUT_NHWC if nhwc else _ffi.LAYOUT_NCHW
         dev = x.device
         _context(prob, dev)
         perm_host = None
         if cfg.cn_active:
-            if perm_inline_ok(x, cfg, perm, chan_perm):
+            if not nhwc and perm_inline_ok(x, cfg, perm, chan_perm):
                 # the permutation rides in the launch arguments: no upload.  A snapshot (<= 8 KB) when a backward will read
                 # it again: the caller may reuse its index buffer in between (`torch.randperm(n, out=buf)`)
                 perm_host, perm = (perm.clone() if any(ctx.needs_input_grad) else perm), None
@@ -363,7 +393,7 @@ class FusedCNSN(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad)
         saved_floats, ws_bytes = _sizes(prob)[:2]
         saved = torch.empty(saved_floats, dtype=torch.float32, device=dev) if need_bwd else None
-        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+        ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=dev)
         epi = _epilogue(cfg, addend) if cfg.has_epilogue else None
 
         def launch():
@@ -402,14 +432,14 @@ class FusedCNSN(torch.autograd.Function):
         gate_g, gate_f = ctx.gates
         if gy.dtype != x.dtype:
             gy = gy.to(x.dtype)
-        gy = _dense(gy)
+        gy = _dense_cl(gy) if prob.layout == _ffi.LAYOUT_NHWC else _dense(gy)
         dev = x.device
         dx = _out_like(x)
         ws_bytes = _sizes(prob)[1]
         _context(prob, dev)     # (the buffer may have grown since the forward; None under graph capture)
         if torch.cuda.is_current_stream_capturing():
             prob.context, prob.context_bytes = None, 0
-        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+        ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=dev)
         Cn = x.shape[1]
 
         def grads():  # one allocation, three views: d_fc_weight (C,1,2), d_bn_weight (C), d_bn_bias (C)

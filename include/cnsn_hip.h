@@ -53,6 +53,14 @@ enum cnsn_status {
     CNSN_E_UNSUPPORTED = -9 /* valid request this build cannot run (e.g. N too large)      */
 };
 
+/* Memory order of the activation tensors (ABI 6).  The reference takes any layout through `.contiguous()` (models/cnsn.py:14,16:
+ * a channels-last tensor is COPIED to NCHW there).  CNSN_LAYOUT_NHWC: element (n, c, h, w) lives at ((n*H + h)*W + w)*C + c — what
+ * torch.channels_last tensors and MIOpen's NHWC convolutions use; the op is computed where the tensor lies (two-pass kernels around
+ * the same per-plane algebra; `saved`, parameter gradients and running statistics as in NCHW).  Un-boxed calls whose channel count
+ * is a whole number of 16-byte vectors (C % 4 == 0 in fp32, C % 8 == 0 in 16 bits), no channel permutation; everything else
+ * returns CNSN_E_UNSUPPORTED and the caller converts to NCHW as the reference does.  cnsn_workspace_bytes() is layout-dependent. */
+enum cnsn_layout { CNSN_LAYOUT_NCHW = 0, CNSN_LAYOUT_NHWC = 1 };
+
 enum cnsn_strategy {
     CNSN_STRATEGY_AUTO = 0,
     CNSN_STRATEGY_TWO_PASS = 1, /* stats kernel -> mid kernel -> apply kernel (3 / 5 tensor passes) */
@@ -83,7 +91,7 @@ typedef struct cnsn_problem {
     float eps_bn;         /* BatchNorm1d eps, 1e-5                                           */
     float momentum;       /* BatchNorm1d momentum, 0.1                                       */
     int32_t strategy;     /* enum cnsn_strategy                                              */
-    int32_t reserved;     /* 0                                                               */
+    int32_t layout;       /* enum cnsn_layout: memory order of x / y / addend / grad tensors (ABI 6; was `reserved`, 0)   */
     /* Optional persistent exchange context of the cluster-resident kernels (see cnsn_context_init): device memory
      * the caller allocates ONCE per device and passes with every call.  NULL / too small: the kernels exchange
      * through `workspace`, which costs one fill launch in front of every resident launch.                       */

@@ -99,7 +99,9 @@ def _oracle_side(shape, kind, crop, mode, relu, dtype, seed, mask):
     return out
 
 
-def run_case(shape, kind, crop, mode, relu, dtype, seed):
+def run_case(shape, kind, crop, mode, relu, dtype, seed, channels_last=False):
+    """channels_last: x / addend / grad_y handed over in torch.channels_last order (tests/test_gpu_nhwc.py) — same values, so
+    the oracle side is the same"""
     from tests._memo import memo
     n, c = shape[:2]
     case = (tuple(shape), kind, crop, str(dtype), seed)
@@ -108,11 +110,16 @@ def run_case(shape, kind, crop, mode, relu, dtype, seed):
     # device
     mod = build(cnsn_amd, kind, crop, c, seed, torch.float32).to(DEV)
     _arm(mod, to_draws(d) if d else None)
-    xg = x64.detach().clone().to(dtype).to(DEV).requires_grad_()
-    bg = b64.detach().clone().to(dtype).to(DEV).requires_grad_() if mode != "none" else None
+    fmt = torch.channels_last if channels_last else torch.contiguous_format
+    xg = x64.detach().clone().to(dtype).to(DEV).contiguous(memory_format=fmt).requires_grad_()
+    bg = b64.detach().clone().to(dtype).to(DEV).contiguous(memory_format=fmt).requires_grad_() if mode != "none" else None
     yg = mod.forward_block(xg, bg, add_mode=mode, relu=relu)
-    yg.backward(gy64.to(dtype).to(DEV))
+    if channels_last:      # computed where the tensors lie: the output comes back in the same memory order
+        assert yg.is_contiguous(memory_format=torch.channels_last) and yg.shape == xg.shape
+    yg.backward(gy64.to(dtype).to(DEV).contiguous(memory_format=fmt))
     torch.cuda.synchronize()
+    if channels_last:
+        assert xg.grad.is_contiguous(memory_format=torch.channels_last)
     assert mod.crossnorm is None or mod.crossnorm.active is False
     hip = dict(y=yg.detach().cpu(), dx=xg.grad.cpu(), db=bg.grad.cpu() if bg is not None else None,
                pg={k: v.grad.cpu() for k, v in mod.named_parameters()},

@@ -1,0 +1,136 @@
+"""Channels-last ("NHWC") calls are computed where the tensor lies (`cnsn_problem_t.layout = CNSN_LAYOUT_NHWC`, round 5).
+
+The reference takes any layout through `.contiguous()` (models/cnsn.py:14,16) — values do not depend on the memory order.  So a
+channels-last call must give what the oracle gives for the same VALUES (north_star's tolerances: 1e-5 fp32, 1e-2 bf16), outputs and
+gradients must come back channels-last (the next convolution's layout), and calls the channels-last kernels do not take (crop
+boxes, a channel count that is no whole number of vectors) must fall back to the NCHW copy silently."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import cnsn_amd  # noqa: E402
+from cnsn_amd import _ffi  # noqa: E402
+from cnsn_amd import functional as F_  # noqa: E402
+from tests.golden.gen_golden_fill import fill_sn  # noqa: E402
+from tests.test_gpu_fused_block import check, run_case  # noqa: E402
+from tests.test_gpu_parity import DEV, seed_of  # noqa: E402
+
+CL = torch.channels_last
+SHAPES = [(4, 8, 8, 8),        # one column block, many rows per workgroup
+          (6, 16, 9, 11),      # odd plane, pixel tail
+          (5, 64, 28, 28),     # several pixel chunks
+          (37, 8, 56, 56),     # the north-star plane, odd batch
+          (9, 2048, 7, 7),     # stage-4 site: 512 (fp32) / 256 (16-bit) vector columns -> column blocks
+          (3, 520, 6, 5)]      # a channel count that is no power of two (130 / 65 vector columns)
+EPILOGUES = [("pre", True), ("pre", False), ("post", True), ("post", False), ("none", True), ("none", False)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("kind", ["sn", "cnsn", "cn"])
+@pytest.mark.parametrize("mode,relu", EPILOGUES)
+def test_channels_last_block_fp32(shape, kind, mode, relu):
+    seed = seed_of(shape, kind, "neither", mode, relu)
+    check(run_case(shape, kind, "neither", mode, relu, torch.float32, seed, channels_last=True), torch.float32, relu,
+          (shape, kind, mode, relu, "channels_last"))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(8, 16, 28, 28), (5, 64, 14, 14), (9, 2048, 7, 7)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("kind", ["sn", "cnsn"])
+@pytest.mark.parametrize("mode,relu", [("pre", True), ("post", True), ("none", False)])
+def test_channels_last_block_16bit(dtype, shape, kind, mode, relu):
+    seed = seed_of(shape, kind, "neither", mode, relu, str(dtype))
+    check(run_case(shape, kind, "neither", mode, relu, dtype, seed, channels_last=True), dtype, relu,
+          (shape, kind, mode, relu, dtype, "channels_last"))
+
+
+@pytest.mark.parametrize("ctypes_path", [False, True], ids=["glue", "ctypes"])
+def test_channels_last_equals_the_nchw_path_and_reports_its_kernels(ctypes_path):
+    """the same values in both memory orders: outputs / gradients agree to rounding, parameter gradients and running statistics
+    too; which_path says 'streaming' for the channels-last call; both glue paths"""
+    shape = (16, 64, 28, 28)
+    torch.manual_seed(2)
+    x = torch.randn(shape, device=DEV) * 1.4 + 0.3
+    add = torch.randn(shape, device=DEV) * 0.5
+    gy = torch.randn(shape, device=DEV)
+
+    def run(fmt):
+        sn = fill_sn(cnsn_amd.SelfNorm(64), 4, torch.float32).to(DEV).train()
+        xg = x.detach().clone(memory_format=fmt).requires_grad_()
+        ag = add.detach().clone(memory_format=fmt).requires_grad_()
+        kw, g, f = sn._fused_args()
+        cfg = cnsn_amd.FusedConfig(add_mode="pre", relu=True, **kw)
+        if ctypes_path:
+            y = F_.FusedCNSN.apply(xg, cfg, None, None, g.fc_weight, g.bn_weight, g.bn_bias, g.running_mean, g.running_var,
+                                   *(None,) * 5, ag, g.num_batches_tracked, None)
+        else:
+            y = F_.fused_cnsn(xg, cfg, g=g, addend=ag)
+        y.backward(gy.contiguous(memory_format=fmt))
+        torch.cuda.synchronize()
+        return y.detach(), xg.grad, ag.grad, [p.grad for p in sn.parameters()], sn.g_bn.running_var.clone(), int(sn.g_bn.num_batches_tracked)
+
+    a, b = run(torch.contiguous_format), run(CL)
+    assert b[0].is_contiguous(memory_format=CL) and b[1].is_contiguous(memory_format=CL) and not b[0].is_contiguous()
+    assert float((a[0] - b[0]).abs().max()) <= 1e-5 * max(1.0, float(a[0].abs().max()))
+    same = (a[0] > 0) == (b[0] > 0)            # (the ReLU masks may differ where the pre-activation is rounding noise around zero)
+    assert float(same.float().mean()) > 0.9999
+    for u, v in zip(a[1:3], b[1:3]):
+        assert float(((u - v).abs() * same).max()) <= 1e-5 * max(1.0, float(u.abs().max()))
+    for u, v in zip(a[3], b[3]):
+        assert float((u - v).abs().max()) <= 1e-4 * max(1.0, float(u.abs().max()))
+    assert float((a[4] - b[4]).abs().max()) <= 1e-6 and a[5] == b[5] == 1
+    cfg = cnsn_amd.FusedConfig(sn_active=True, add_mode="pre", relu=True)
+    assert cnsn_amd.which_path(x.contiguous(memory_format=CL), cfg) == "streaming"
+    assert cnsn_amd.which_path(x, cfg) != "streaming"
+
+
+def test_calls_the_channels_last_kernels_do_not_take_fall_back_to_a_copy():
+    shape = (6, 16, 12, 12)
+    torch.manual_seed(3)
+    np.random.seed(3)
+    x = (torch.randn(shape, device=DEV) + 0.2).contiguous(memory_format=CL)
+    d = cnsn_amd.draw_cn(shape, "both", 1)
+    boxed = cnsn_amd.cn_op_2ins_space_chan(x, draws=d)                        # crop boxes: NCHW kernels on a copy
+    want = cnsn_amd.cn_op_2ins_space_chan(x.contiguous(), draws=d)
+    assert torch.equal(boxed.contiguous(), want)
+    odd = (torch.randn(4, 6, 8, 8, device=DEV)).contiguous(memory_format=CL)   # 6 channels: no whole 16-byte vector
+    sn = fill_sn(cnsn_amd.SelfNorm(6), 1, torch.float32).to(DEV).eval()
+    with torch.no_grad():
+        assert torch.equal(sn(odd).contiguous(), sn(odd.contiguous()))
+    # the C ABI says so itself: the workspace query answers 0, the call CNSN_E_UNSUPPORTED
+    prob = F_._problem(odd, cnsn_amd.FusedConfig(sn_active=True, sn_training=False))
+    prob.layout = _ffi.LAYOUT_NHWC
+    assert cnsn_amd.lib().cnsn_workspace_bytes(C.byref(prob)) == 0
+
+
+def test_full_size_channels_last_against_the_nchw_kernels():
+    """(256,256,56,56) bf16 block — BASELINE config 3's layer-1 site: the channels-last kernels against the cluster kernels on
+    the same values"""
+    shape, dt = (256, 256, 56, 56), torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(shape, device=DEV, dtype=dt, generator=g)
+    b = torch.randn(shape, device=DEV, dtype=dt, generator=g) * 0.5
+    gy = torch.randn(shape, device=DEV, dtype=dt, generator=g)
+    outs = []
+    for fmt in (torch.contiguous_format, CL):
+        m = cnsn_amd.CNSN(None, fill_sn(cnsn_amd.SelfNorm(256), 7, torch.float32)).to(DEV).train()
+        xg, bg = x.detach().clone(memory_format=fmt).requires_grad_(), b.detach().clone(memory_format=fmt).requires_grad_()
+        y = m.forward_block(xg, bg, add_mode="pre", relu=True)
+        y.backward(gy.contiguous(memory_format=fmt))
+        outs.append((y.detach().float(), xg.grad.float(), [p.grad for p in m.parameters()], m.selfnorm.g_bn.running_mean.clone()))
+        del xg, bg, y
+    (y0, g0, p0, r0), (y1, g1, p1, r1) = outs
+    assert float((y0 - y1).abs().max()) <= 1e-2 * float(y0.abs().max())
+    same = (y0 > 0) == (y1 > 0)
+    assert float(same.float().mean()) > 0.999
+    assert float(((g0 - g1).abs() * same).max()) <= 2e-2 * float(g0.abs().max())
+    for u, v in zip(p0, p1):
+        assert float((u - v).abs().max()) <= 1e-3 * max(float(u.abs().max()), 1e-3)
+    assert float((r0 - r1).abs().max()) <= 1e-5
