@@ -83,6 +83,11 @@ def parse():
                          "7.11 ms per step; off by default)")
     ap.add_argument("--no-graph", action="store_true",
                     help="wrn40: run the steps whose CrossNorm sites are idle eagerly instead of replaying them from a HIP graph")
+    ap.add_argument("--channels-last", action="store_true",
+                    help="model workloads: the network and its input in torch.channels_last (MIOpen's NHWC convolutions; the op is "
+                         "computed where the activations lie: cnsn_problem_t.layout = CNSN_LAYOUT_NHWC).  The default of the "
+                         "ResNet-50 workloads since round 5 (4 057 -> 5 408 img/s, profiles/r05_nhwc.md)")
+    ap.add_argument("--nchw", action="store_true", help="ResNet-50 workloads in torch's default NCHW order (what rounds 1-4 measured)")
     ap.add_argument("--sweep", action="store_true", help="print the SURVEY d1 shape sweep as a markdown table and exit")
     return ap.parse_args()
 
@@ -538,6 +543,11 @@ def model_workload(args, dist, world, rank, dev):
         net = WideResNetCNSN(40, ncls, 2, active_num=2, pos="post", beta=1, crop="both", cnsn_type="cnsn").to(dev)
         name = "WideResNet-40-2+CNSN(post, crop=both, 2 of 18 sites armed with p=0.5), fp32"
     net.train()
+    if args.workload in ("resnet50", "resnet50_jsd") and not args.nchw:
+        args.channels_last = True
+    if args.channels_last:
+        net = net.to(memory_format=torch.channels_last)
+        name += "; channels-last"
     model = net
     if dist is not None:
         if dist.get_backend() == "nccl":
@@ -556,6 +566,9 @@ def model_workload(args, dist, world, rank, dev):
 
     if views == 3:
         x = torch.cat([x, x + 0.1 * torch.randn_like(x), x + 0.1 * torch.randn_like(x)], 0)   # clean + two "augmented"
+    cl = (lambda t: t.contiguous(memory_format=torch.channels_last)) if args.channels_last else (lambda t: t)
+    if args.workload not in ("resnet50", "resnet50_jsd"):
+        x = cl(x)            # (the image-space CrossNorm of the ResNet workloads runs on the loader's NCHW batch first)
 
     fault = FaultPlan(rank)
 
@@ -563,13 +576,13 @@ def model_workload(args, dist, world, rank, dev):
         fault.before_step()
         xb = x
         if views == 3:
-            xb = image_space_crossnorm(x, 0.5, 1, "neither", cnsn_amd.cn_op_2ins_space_chan)   # imagenet.py:352-358
+            xb = cl(image_space_crossnorm(x, 0.5, 1, "neither", cnsn_amd.cn_op_2ins_space_chan))   # imagenet.py:352-358
             with torch.autocast("cuda", dtype=amp):
                 logits = model(xb).float()
             l_clean, l_a1, l_a2 = torch.split(logits, bs)
             return torch.nn.functional.cross_entropy(l_clean, y) + 12.0 * jsd_consistency(l_clean, l_a1, l_a2)
         if args.workload == "resnet50":
-            xb = image_space_crossnorm(x, 0.5, 1, "neither", cnsn_amd.cn_op_2ins_space_chan)   # imagenet.py:211-215
+            xb = cl(image_space_crossnorm(x, 0.5, 1, "neither", cnsn_amd.cn_op_2ins_space_chan))   # imagenet.py:211-215
             with torch.autocast("cuda", dtype=amp):
                 return torch.nn.functional.cross_entropy(model(xb).float(), y)
         if args.workload == "seg":                                                               # train_cnsn.py:302-313
@@ -1041,7 +1054,8 @@ def main():
             out["extra"]["residual_block_add_cnsn_relu"] = residual_block_workloads(cnsn_amd, shape, dev)
             out["extra"]["inference"] = inference_workloads(cnsn_amd, shape, dev)
             out["roofline_bf16"] = roofline_bf16(cnsn_amd, dev)
-            out["extra"]["resnet50_bs256_bf16"] = model_line("resnet50", 12, 4, 200)
+            out["extra"]["resnet50_bs256_bf16"] = model_line("resnet50", 12, 4, 200)          # channels-last (the default)
+            out["extra"]["resnet50_bs256_bf16_nchw"] = model_line("resnet50", 12, 4, 200, ("--nchw",))
             out["extra"]["seg_bs16_512"] = {"f32": model_line("seg", 5, 2, 150), "bf16": model_line("seg", 5, 2, 150, ("--dtype", "bf16"))}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shape, args.crop, args.kind, args.cpu_seconds)
