@@ -28,8 +28,8 @@ One JSON line is printed by rank 0; it also carries
                  is the fastest of 4 candidates timed when it is created — during the warm-up here).  `ms_per_step` is that default; `ms_per_step_plain_allocator` is the same
                  K steps re-timed in the same process with the arena off (torch's caching allocator places y and dx).
                  MI355X's memory has regions that take plane-strided writes 15-20 % faster (profiles/r04_memory_map.md):
-                 `--prospect N` lets the arena time N candidate blocks and keep the fastest (cnsn_arena_prospect) and adds
-                 `ms_per_step_prospected` — an explicit, bounded search that is OFF in the default line
+                 `--prospect N` lets the arena time N more candidate blocks and keep the fastest (cnsn_arena_prospect) and
+                 adds `ms_per_step_prospected` — an explicit, bounded search that is OFF in the default line
 """
 import argparse
 import json
@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (crop=both, bf16)")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the copy / triad / access-order ceilings (child runs)")
     ap.add_argument("--no-arena", action="store_true", help="y / dx from torch's caching allocator (cnsn_amd.arena off)")
-    ap.add_argument("--prospect", type=int, default=12,
+    ap.add_argument("--prospect", type=int, default=0,
                     help="let the output arena time this many candidate blocks of the input's size and keep the 4 fastest "
                          "(cnsn_arena_prospect); adds ms_per_step_prospected to the line (never the headline).  0: no search")
     ap.add_argument("--no-alt", action="store_true",
@@ -1054,9 +1054,11 @@ def main():
             out["extra"]["residual_block_add_cnsn_relu"] = residual_block_workloads(cnsn_amd, shape, dev)
             out["extra"]["inference"] = inference_workloads(cnsn_amd, shape, dev)
             out["roofline_bf16"] = roofline_bf16(cnsn_amd, dev)
-            out["extra"]["resnet50_bs256_bf16"] = model_line("resnet50", 12, 4, 200)          # channels-last (the default)
-            out["extra"]["resnet50_bs256_bf16_nchw"] = model_line("resnet50", 12, 4, 200, ("--nchw",))
-            out["extra"]["seg_bs16_512"] = {"f32": model_line("seg", 5, 2, 150), "bf16": model_line("seg", 5, 2, 150, ("--dtype", "bf16"))}
+            # (channels-last, the workload's default since round 5; `--workload resnet50 --nchw`: 4 030-4 074 img/s, profiles/r05_nhwc.md)
+            out["extra"]["resnet50_bs256_bf16"] = model_line("resnet50", 12, 4, 200)
+            out["extra"]["seg_bs16_512"] = {"bf16": model_line("seg", 5, 2, 150, ("--dtype", "bf16")),
+                                               "f32_note": "fp32: 102-106 img/s (`--workload seg`, profiles/r05h_seg_f32.json); left out of the "
+                                                           "default line to keep it within minutes (a child process per model line)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shape, args.crop, args.kind, args.cpu_seconds)
         print(json.dumps(out), flush=True)
