@@ -259,12 +259,14 @@ void* cnsn_arena_alloc(int device, size_t bytes, void* stream) {
         // with the plane-strided fill (~1 ms), the losers' memory handed back at once.  Happens when a block is CREATED (the
         // first steps of a job), costs `tries` x the block's size transiently, never more than a quarter of what is free.
         int tries = resolve_tries();
-        if (tries > 1) {
+        {
             size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-                tries = (int)std::max<size_t>(1, std::min<size_t>((size_t)tries, free_b / 4 / need));
-            else
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                if (need > free_b) tries = 0;  // (no point in creating thousands of chunks to find that out)
+                else if (tries > 1) tries = (int)std::max<size_t>(1, std::min<size_t>((size_t)tries, free_b / 4 / need));
+            } else {
                 (void)hipGetLastError();
+            }
         }
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;  // (never time anything on a capturing stream)
         if (tries > 1 && (hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)) {

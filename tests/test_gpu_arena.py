@@ -54,6 +54,11 @@ def test_c_abi_alloc_free_reuse_and_trim():
     q = lib.cnsn_arena_alloc(0, 90 << 20, stream)                               # same number of chunks: the block comes back
     assert q == p and arena.stats(DEV)["hits"] == s1["hits"] + 1
     assert lib.cnsn_arena_alloc(0, 0, stream) is None
+    failed = arena.stats(DEV)["failed"]
+    assert lib.cnsn_arena_alloc(0, 400 << 30, stream) is None                   # more than the part has: NULL, the caller falls back
+    assert arena.stats(DEV)["failed"] == failed + 1
+    again = lib.cnsn_arena_alloc(0, 10 << 20, stream)                           # ... and the arena goes on serving
+    assert again and lib.cnsn_arena_free(C.c_void_p(again)) == 0
     lib.cnsn_arena_free(C.c_void_p(q))
     freed = arena.trim(DEV)
     assert freed >= 2 * (56 << 20) and arena.stats(DEV)["mapped_bytes"] == arena.stats(DEV)["in_use_bytes"]
