@@ -273,8 +273,32 @@ void* cnsn_arena_alloc(int device, size_t bytes, void* stream) {
             (void)hipGetLastError();
             tries = 1;
         }
+        // CNSN_ARENA_SPREAD_GB (A/B knob, default 0): candidates created one after the other are neighbours in physical memory,
+        // and the fast regions are tens of GB wide — with this many GB of physical allocations held BETWEEN the candidates (never
+        // mapped, given back with the losers) they sample different stretches of the device memory
         std::vector<Block*> cand;
+        std::vector<hipMemGenericAllocationHandle_t> spacers;
+        size_t spacer_each = 0;
+        if (tries > 1) {
+            if (const char* e = knob(K_ARENA_SPREAD_GB))
+                if (atof(e) > 0) spacer_each = (size_t)(atof(e) * 1073741824.0) / (size_t)(tries - 1);
+        }
+        hipMemAllocationProp sprop{};
+        sprop.type = hipMemAllocationTypePinned;
+        sprop.location.type = hipMemLocationTypeDevice;
+        sprop.location.id = device;
         for (int i = 0; i < tries; ++i) {
+            if (i > 0 && spacer_each) {
+                const size_t piece = round_up(size_t(1) << 30, a.granularity ? a.granularity : 2 * kMiB);
+                for (size_t got = 0; got < spacer_each; got += piece) {
+                    hipMemGenericAllocationHandle_t h;
+                    if (hipMemCreate(&h, piece, &sprop, 0) != hipSuccess) {
+                        (void)hipGetLastError();
+                        break;
+                    }
+                    spacers.push_back(h);
+                }
+            }
             Block* c = create_block(a, device, need);
             if (!c) break;
             cand.push_back(c);
@@ -285,6 +309,7 @@ void* cnsn_arena_alloc(int device, size_t bytes, void* stream) {
             for (size_t i = 1; i < cand.size(); ++i) release_block(cand[i]);  // (measure_block left the stream idle)
             d.probed += cand.size();
         }
+        for (auto h : spacers) (void)hipMemRelease(h);
         b = cand.empty() ? nullptr : cand[0];
         if (cur != device && cur >= 0) (void)hipSetDevice(cur);
         if (!b) {

@@ -33,6 +33,7 @@ enum Knob {
     K_XCD,            // CNSN_XCD           1: a cluster's workgroups share ONE XCD (A/B knob; default: consecutive workgroups, all 8 XCDs)
     K_HEADROOM_CUS,   // CNSN_HEADROOM_CUS  compute units the persistent grids leave to others (RCCL's channel kernels): default 0
     K_ARENA_TRIES,    // CNSN_ARENA_TRIES   candidates the output arena times per new block (default 4; 1: none)
+    K_ARENA_SPREAD_GB,// CNSN_ARENA_SPREAD_GB  GB of physical memory held between an arena block's candidates (A/B knob, default 0)
     K_COUNT
 };
 

@@ -18,6 +18,7 @@ const char* const kNames[K_COUNT] = {
     "CNSN_XCD",
     "CNSN_HEADROOM_CUS",
     "CNSN_ARENA_TRIES",
+    "CNSN_ARENA_SPREAD_GB",
 };
 
 struct Table {
