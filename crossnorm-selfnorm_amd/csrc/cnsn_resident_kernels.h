@@ -311,6 +311,10 @@ __device__ __forceinline__ float pick_if(int mask, float a, float b) {
 }
 // bit `pos` of `word` as an all-ones / all-zeros word (one v_bfe_i32), opaque to the optimiser for the same reason
 __device__ __forceinline__ int bit_mask(unsigned word, int pos) {
+#if defined(CNSN_FAKE_MASKS)  // timing experiment only (WRONG results): what the kernels would gain if an element's mask cost nothing
+    (void)pos;
+    return (int)word;
+#endif
     int r = (int)(word << (31 - pos)) >> 31;
     asm("" : "+v"(r));
     return r;
