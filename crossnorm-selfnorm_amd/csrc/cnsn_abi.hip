@@ -25,31 +25,56 @@ using namespace cnsn;
 
 namespace cnsn {
 
-// channels per workgroup of the mid kernels: tiles of 8 once there are enough channels to fill the chip with tiles
-// (measured at C = 2048, N = 256: mid_fwd 115 -> see profiles/r01_small_planes.md); CNSN_MID_TILE=1 disables
+// channels per workgroup of the mid kernels: tiles once there are enough channels to fill the chip with tiles (measured at
+// C = 2048, N = 256: mid_fwd 115 -> see profiles/r01_small_planes.md) — 8 from C = 2048 on, 4 between 512 and 2048 so that those
+// calls still start 128-256 workgroups (profiles/r05_mid_blocks.md); CNSN_MID_TILE=1 disables, =8 restores the single tile size
 static int mid_tile(const cnsn_problem_t& p) {
-    if (const char* e = knob(K_MID_TILE))
+    int only8 = 0;
+    if (const char* e = knob(K_MID_TILE)) {
         if (e[0] == '1') return 1;
-    return (p.C >= 512 && p.C % 8 == 0) ? 8 : 1;
+        only8 = e[0] == '8';
+    }
+    if (p.C >= 512 && p.C % 8 == 0 && (p.C >= 2048 || only8)) return 8;
+    return (p.C >= 512 && p.C % 4 == 0) ? 4 : 1;
 }
+
+// threads per workgroup of the channel kernels: 1024 once a thread of a 256-thread workgroup would walk more than two instances
+// per sweep (CNSN_MID_BLOCK=256 keeps the small workgroups)
+static int mid_block(const cnsn_problem_t& p, int tile) {
+    if (const char* e = knob(K_MID_BLOCK))
+        if (atoi(e) == 256) return 256;
+    return (long long)p.N * tile > 2 * kBlock ? 1024 : kBlock;
+}
+
+#define CNSN_MID_DISPATCH(KERNEL, ...)                                                               \
+    do {                                                                                             \
+        const int tile = mid_tile(pl.pr), blk = mid_block(pl.pr, tile);                              \
+        if (tile == 8 && blk == 1024)                                                                \
+            KERNEL<8, 1024><<<pl.pr.C / 8, 1024, 0, stream>>>(__VA_ARGS__);                          \
+        else if (tile == 8)                                                                          \
+            KERNEL<8, kBlock><<<pl.pr.C / 8, kBlock, 0, stream>>>(__VA_ARGS__);                      \
+        else if (tile == 4 && blk == 1024)                                                           \
+            KERNEL<4, 1024><<<pl.pr.C / 4, 1024, 0, stream>>>(__VA_ARGS__);                          \
+        else if (tile == 4)                                                                          \
+            KERNEL<4, kBlock><<<pl.pr.C / 4, kBlock, 0, stream>>>(__VA_ARGS__);                      \
+        else if (blk == 1024)                                                                        \
+            KERNEL<1, 1024><<<pl.pr.C, 1024, 0, stream>>>(__VA_ARGS__);                              \
+        else                                                                                         \
+            KERNEL<1, kBlock><<<pl.pr.C, kBlock, 0, stream>>>(__VA_ARGS__);                          \
+    } while (0)
 
 void launch_mid_fwd(const Plan& pl, const double* mom, const int64_t* perm, const int64_t* chan_perm, GateDev g,
                     GateDev f, float* coef, double* saved, hipStream_t stream) {
-    if (mid_tile(pl.pr) == 8)
-        mid_fwd_kernel<8><<<pl.pr.C / 8, kBlock, 0, stream>>>(pl.mid, mom, perm, chan_perm, g, f, coef, saved);
-    else
-        mid_fwd_kernel<1><<<pl.pr.C, kBlock, 0, stream>>>(pl.mid, mom, perm, chan_perm, g, f, coef, saved);
+    CNSN_MID_DISPATCH(mid_fwd_kernel, pl.mid, mom, perm, chan_perm, g, f, coef, saved);
 }
 
 void launch_mid_bwd(const Plan& pl, const float* sums, const double* saved, const int64_t* perm,
                     const int64_t* chan_perm, GateDev g, GateDev f, GateGradDev dg, GateGradDev df, double* tmp,
                     float* coef, hipStream_t stream) {
-    if (mid_tile(pl.pr) == 8)
-        mid_bwd_a_kernel<8><<<pl.pr.C / 8, kBlock, 0, stream>>>(pl.mid, sums, saved, perm, chan_perm, g, f, dg, df, tmp);
-    else
-        mid_bwd_a_kernel<1><<<pl.pr.C, kBlock, 0, stream>>>(pl.mid, sums, saved, perm, chan_perm, g, f, dg, df, tmp);
+    CNSN_MID_DISPATCH(mid_bwd_a_kernel, pl.mid, sums, saved, perm, chan_perm, g, f, dg, df, tmp);
     mid_bwd_b_kernel<<<(int)((pl.P + kBlock - 1) / kBlock), kBlock, 0, stream>>>(pl.mid, saved, tmp, coef);
 }
+#undef CNSN_MID_DISPATCH
 
 }  // namespace cnsn
 

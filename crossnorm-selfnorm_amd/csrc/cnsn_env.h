@@ -19,7 +19,7 @@ enum Knob {
     K_MONO,           // CNSN_MONO          0: AUTO never takes the channel-in-registers kernels
     K_MONO_RELOAD,    // CNSN_MONO_RELOAD   0: no part-wise backward (A/B runs)
     K_NO_PACKED,      // CNSN_NO_PACKED     1: no packed two-pass kernels
-    K_MID_TILE,       // CNSN_MID_TILE      1: one channel per workgroup in the mid kernels
+    K_MID_TILE,       // CNSN_MID_TILE      1: one channel per workgroup in the mid kernels, 8: tiles of 8 channels only (A/B)
     K_SNX,            // CNSN_SNX           SelfNorm-only cluster kernels: 0 never, 1 AUTO rule, 2 wherever instantiated
     K_RESIDENT,       // CNSN_RESIDENT      0: AUTO never takes a cluster-resident kernel
     K_CONTEXT,        // CNSN_CONTEXT       0: exchange through the workspace, 1: through the context at every size
@@ -34,6 +34,7 @@ enum Knob {
     K_HEADROOM_CUS,   // CNSN_HEADROOM_CUS  compute units the persistent grids leave to others (RCCL's channel kernels): default 0
     K_ARENA_TRIES,    // CNSN_ARENA_TRIES   candidates the output arena times per new block (default 4; 1: none)
     K_ARENA_SPREAD_GB,// CNSN_ARENA_SPREAD_GB  GB of physical memory held between an arena block's candidates (A/B knob, default 0)
+    K_MID_BLOCK,      // CNSN_MID_BLOCK     256: the mid kernels never take 1024-thread workgroups (A/B knob)
     K_COUNT
 };
 

@@ -19,6 +19,7 @@ const char* const kNames[K_COUNT] = {
     "CNSN_HEADROOM_CUS",
     "CNSN_ARENA_TRIES",
     "CNSN_ARENA_SPREAD_GB",
+    "CNSN_MID_BLOCK",
 };
 
 struct Table {

@@ -13,11 +13,14 @@ namespace cnsn {
 // small, the bound of the whole two-pass path when the planes are tiny (C = 2048, 7x7: 250 of 420 us).  With TC > 1 a
 // workgroup takes TC adjacent channels: thread t works on channel c0 + t % TC and instances t / TC, t / TC + 256/TC, ...
 // so that the TC planes of one instance form one contiguous piece of every side array.
-template <int NACC, int TC>
+// BLK threads per workgroup: a thread walks N / (BLK / TC) instances in each of the three sweeps, one dependent chain of loads,
+// double-precision algebra and stores per instance — at TC = 8, N = 256 and 256 threads that is 24 such steps and the kernel
+// takes 32 us whatever C is (profiles/r05_mid_blocks.md); 1024 threads make it 6.
+template <int NACC, int TC, int BLK>
 __device__ __forceinline__ void tile_sum_d(double (&acc)[NACC], double* lds) {
-    if constexpr (TC == 1) {
+    if constexpr (TC == 1 && BLK == kBlock) {
         block_sum_d<NACC>(acc, lds);
-    } else {  // sum over the threads that share threadIdx.x % TC; lds: (kBlock/64) * TC * NACC doubles
+    } else {  // sum over the threads that share threadIdx.x % TC; lds: (BLK/64) * TC * NACC doubles
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
         for (int k = 0; k < NACC; ++k) {
@@ -36,19 +39,19 @@ __device__ __forceinline__ void tile_sum_d(double (&acc)[NACC], double* lds) {
 #pragma unroll
         for (int k = 0; k < NACC; ++k) {
             double t = 0.0;
-            for (int w = 0; w < kBlock / 64; ++w) t += lds[(w * TC + cl) * NACC + k];
+            for (int w = 0; w < BLK / 64; ++w) t += lds[(w * TC + cl) * NACC + k];
             acc[k] = t;
         }
     }
 }
 
-template <int TC>
-__global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double* __restrict__ mom,
+template <int TC, int BLK>
+__global__ __launch_bounds__(BLK) void mid_fwd_kernel(MidArgs a, const double* __restrict__ mom,
                                                          const int64_t* __restrict__ perm,
                                                          const int64_t* __restrict__ chan_perm, GateDev gg, GateDev gf,
                                                          float* __restrict__ coef, double* __restrict__ saved) {
-    __shared__ double red[(kBlock / 64) * 2 * TC];
-    constexpr int NSTEP = kBlock / TC;                 // instances per sweep step
+    __shared__ double red[(BLK / 64) * 2 * TC];
+    constexpr int NSTEP = BLK / TC;                    // instances per sweep step
     const int n0 = threadIdx.x / TC;                   // first instance of this thread
     const bool lead = n0 == 0;                         // the thread that writes its channel's per-channel results
     const int c = blockIdx.x * TC + threadIdx.x % TC;  // (C is a multiple of TC)
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
     if (a.sn_active) {
         if (a.sn_training) {
             // ---- BatchNorm1d batch statistics over N (biased variance for normalising, :138)
-            tile_sum_d<2, TC>(sz, red);
+            tile_sum_d<2, TC, BLK>(sz, red);
             mg = sz[0] / a.N;
             mf = sz[1] / a.N;
             double sv[2] = {0.0, 0.0};
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
                 sv[0] += dg * dg;
                 sv[1] += df * df;
             }
-            tile_sum_d<2, TC>(sv, red);
+            tile_sum_d<2, TC, BLK>(sv, red);
             const double vg = sv[0] / a.N, vf = sv[1] / a.N;
             rg = 1.0 / sqrt(vg + (double)a.eps_bn);
             rf = 1.0 / sqrt(vf + (double)a.eps_bn);
@@ -179,14 +182,14 @@ __global__ __launch_bounds__(kBlock) void mid_fwd_kernel(MidArgs a, const double
 
 // per channel: gate / BatchNorm backward, parameter gradients, statistic gradients per plane;
 // scatters the style-statistic gradients to the planes that lent their statistics.
-template <int TC>
-__global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const float* __restrict__ sums,
+template <int TC, int BLK>
+__global__ __launch_bounds__(BLK) void mid_bwd_a_kernel(MidArgs a, const float* __restrict__ sums,
                                                            const double* __restrict__ saved,
                                                            const int64_t* __restrict__ perm,
                                                            const int64_t* __restrict__ chan_perm, GateDev gg, GateDev gf,
                                                            GateGradDev dg, GateGradDev df, double* __restrict__ tmp) {
-    __shared__ double red[(kBlock / 64) * 4 * TC];
-    constexpr int NSTEP = kBlock / TC;
+    __shared__ double red[(BLK / 64) * 4 * TC];
+    constexpr int NSTEP = BLK / TC;
     const int n0 = threadIdx.x / TC;
     const bool lead = n0 == 0;
     const int c = blockIdx.x * TC + threadIdx.x % TC;
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
             tmp[BT_DT_G * P + p] = dtg;
             tmp[BT_DT_F * P + p] = dtf;
         }
-        tile_sum_d<4, TC>(s, red);
+        tile_sum_d<4, TC, BLK>(s, red);
         if (lead) {
             dg.dgamma[c] = (float)s[1];
             dg.dbeta[c] = (float)s[0];
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void mid_bwd_a_kernel(MidArgs a, const floa
         }
     }
     if (a.sn_active) {
-        tile_sum_d<4, TC>(sw, red);
+        tile_sum_d<4, TC, BLK>(sw, red);
         if (lead) {
             dg.dw[2 * c] = (float)sw[0];
             dg.dw[2 * c + 1] = (float)sw[1];
