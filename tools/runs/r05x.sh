@@ -1,21 +1,19 @@
 cd /tmp && export TMPDIR=/tmp
-for blk in 1024; do
-echo "== CNSN_MID_BLOCK=$blk"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_sites_$blk -- python $GRAFT_REPO_ROOT/tools/nhwc_sites.py bf16 > /tmp/sites.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_sites -- python $GRAFT_REPO_ROOT/tools/nhwc_sites.py bf16 > /tmp/sites.log 2>&1
 grep "^|" /tmp/sites.log
-g=$(find /tmp/rp_sites_$blk -name "*kernel_trace.csv" | head -1); python3 - $g <<'PY'
+g=$(find /tmp/rp_sites -name "*kernel_trace.csv" | head -1); python3 - $g <<'PY'
 import csv,sys,collections
-rows=list(csv.DictReader(open(sys.argv[1])))
-agg=collections.OrderedDict()
+rows=sorted(csv.DictReader(open(sys.argv[1])), key=lambda r:int(r['Start_Timestamp']))
+by=collections.OrderedDict()
 for r in rows:
-    k=(r['Kernel_Name'][:60], r.get('Grid_Size_X') or r.get('Grid_Size'), r.get('Workgroup_Size_X') or r.get('Workgroup_Size'))
-    d=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
-    a=agg.setdefault(k,[0,0.0]); a[0]+=1; a[1]+=d
-for k,(n,t) in agg.items():
-    if 'mid_' in k[0]:
-        print(f"{k[0]:60s} grid {k[1]:>9} wg {k[2]:>5} n {n:4d} avg us {t/n:8.1f}")
+    n=r['Kernel_Name']
+    if 'nhwc' not in n: continue
+    by.setdefault(n[:70],[]).append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)
+sites=["56x56 C256 (411 MB)","28x28 C512 (206 MB)","14x14 C1024 (103 MB)","7x7 C2048 (51 MB)"]
+for n,d in by.items():
+    k=len(d)//4
+    print(n, len(d))
+    for i,s in enumerate(sites):
+        ch=d[i*k:(i+1)*k][4*(k//14):]
+        print(f"    {s:24s} avg us {sum(ch)/len(ch):8.1f}  (n {len(ch)})")
 PY
-done
-cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_nhwc.py -q -m gpu -x 2>&1 | tail -2
-python -m pytest tests -q -m gpu -x -k "two_pass or twopass or stream or strategy or parity" 2>&1 | tail -2
