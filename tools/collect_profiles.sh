@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/collect_profiles.sh <outdir>: the rocprofv3 passes behind profiles/r03_* (run on the GPU box through gpurun).
 # Every rocprofv3 call is bounded by `timeout`; counters are collected in their own passes (--pmc without --stats).
-OUT=$1; mkdir -p $OUT
+OUT=$(realpath -m $1); mkdir -p $OUT   # (absolute: the rocprofv3 passes run from /tmp)
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 python -c "import torch" > /dev/null 2>&1
