@@ -1027,7 +1027,7 @@ def main():
         if alt:
             out["arena"] = {"on": not args.no_arena, "min_bytes": _arena.min_bytes(), **(alt.get("arena") or {}),
                             "note": "y / dx are tensors over blocks of the library's output arena (cnsn_amd.arena, C ABI "
-                                    "cnsn_arena_*): a stable home; every NEW block is the fastest of `tries` candidates timed "
+                                    "cnsn_arena_*): a stable home; every NEW block of 384 MiB or more is the fastest of `tries` candidates timed "
                                     "with a plane-strided fill when it is created (the allocator's standing policy, during the "
                                     "warm-up here); ms_per_step_plain_allocator = the same K steps in this process with torch's "
                                     "caching allocator placing them"}

@@ -5,10 +5,11 @@ MI355X that decides 7-10 % of the single-touch launches' time: their plane-strid
 large `hipMalloc` block in five and 10-20 % below it into the rest (profiles/r04_memory_map.md).  Address ranges MAPPED from
 physical allocations of the arena's own give the outputs a home that does not change from step to step: the op's outputs of at
 least `min_bytes` (default 32 MiB; `CNSN_ARENA_MIN_MB`) are tensors over such ranges — `at::from_blob` views whose deleter
-hands the block back to the arena's per-size free list.  A NEW block is the fastest of four candidates created together and
-timed with a plane-strided fill (~1 ms each, `set_tries` / `CNSN_ARENA_TRIES`; where a block lies physically decides how
-fast it is written, and about one in four lies well) — paid in the first steps of a job, for EVERY output block of the job; in
-the steady state of a training loop an allocation is a mutex and a list pop.
+hands the block back to the arena's per-size free list.  A NEW block of 384 MiB or more is the fastest of eight candidates
+created together and timed with a plane-strided fill (~1 ms each, `set_tries` / `CNSN_ARENA_TRIES`; where a block lies
+physically decides how fast it is written, and about one in five lies well; smaller blocks are never timed — the Infinity
+Cache absorbs a write of that size) — paid in the first steps of a job, for EVERY large output block of the job; in the
+steady state of a training loop an allocation is a mutex and a list pop.
 
 What a user may want to know:
   * on by default (`CNSN_ARENA=0` or `arena.disable()` switch it off); outputs under graph capture and small outputs come

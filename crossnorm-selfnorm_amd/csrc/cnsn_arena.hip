@@ -46,6 +46,11 @@ namespace {
 
 constexpr size_t kMiB = size_t(1) << 20;
 constexpr size_t kDefaultChunk = 56 * kMiB;
+constexpr int kDefaultTries = 8;
+// Blocks below this size are never timed: a write of up to ~256 MB is absorbed by the Infinity Cache and says nothing about the
+// memory behind it (392 single 56 MiB chunks all 5.9 TB/s, 112 blocks of 224 MiB all 7.8 TB/s, 784 MiB blocks 5.3 or 6.8:
+// profiles/r05_arena.md section 5)
+constexpr size_t kTimedFrom = 384 * kMiB;
 
 struct Block {
     void* va = nullptr;
@@ -70,7 +75,7 @@ struct Arena {
     size_t chunk = 0;       // resolved on first use
     size_t granularity = 0;
     bool broken = false;    // the driver refused the virtual-memory calls once: never try again
-    int tries = -1;         // candidates per new block (cnsn_arena_set_tries; -1: CNSN_ARENA_TRIES, default 4)
+    int tries = -1;         // candidates per new block (cnsn_arena_set_tries; -1: CNSN_ARENA_TRIES, default 8)
 };
 
 Arena& arena() {
@@ -84,7 +89,7 @@ int resolve_tries() {  // (under the arena's mutex)
     Arena& a = arena();
     if (a.tries < 0) {
         const char* e = knob(K_ARENA_TRIES);
-        a.tries = (e && atoi(e) > 0) ? atoi(e) : 4;
+        a.tries = (e && atoi(e) > 0) ? atoi(e) : kDefaultTries;
         if (a.tries > 32) a.tries = 32;
     }
     return a.tries;
@@ -254,11 +259,12 @@ void* cnsn_arena_alloc(int device, size_t bytes, void* stream) {
         int cur = -1;
         (void)hipGetDevice(&cur);
         if (cur != device) (void)hipSetDevice(device);
-        // Best of `tries`: WHERE a block lies physically decides how fast it is written (about one in four is of the fast
-        // kind), so a new block is chosen among a few candidates created together — distinct physical memory —, each timed
-        // with the plane-strided fill (~1 ms), the losers' memory handed back at once.  Happens when a block is CREATED (the
-        // first steps of a job), costs `tries` x the block's size transiently, never more than a quarter of what is free.
-        int tries = resolve_tries();
+        // Best of `tries`: WHERE a block lies physically decides how fast it is written (about one candidate in five is of the
+        // fast kind), so a new block of kTimedFrom bytes or more is chosen among a few candidates created together — distinct
+        // physical memory —, each timed with the plane-strided fill (~1 ms), the losers' memory handed back at once.  Happens
+        // when a block is CREATED (the first steps of a job), costs `tries` x the block's size transiently, never more than a
+        // quarter of what is free.
+        int tries = need >= kTimedFrom ? resolve_tries() : 1;
         {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -306,6 +312,8 @@ void* cnsn_arena_alloc(int device, size_t bytes, void* stream) {
         if (cand.size() > 1) {
             for (Block* c : cand) c->gbps = measure_block(c, (hipStream_t)stream);
             std::sort(cand.begin(), cand.end(), [](const Block* x, const Block* y) { return x->gbps > y->gbps; });
+            // (keeping a fast runner-up for the next request of the size was tried: the second-best of eight is slower than the best
+            // of the next eight — 0.766-0.772 against 0.759 ms per headline step on one box; not kept)
             for (size_t i = 1; i < cand.size(); ++i) release_block(cand[i]);  // (measure_block left the stream idle)
             d.probed += cand.size();
         }

@@ -32,7 +32,7 @@ enum Knob {
     K_ARENA_CHUNK_MB, // CNSN_ARENA_CHUNK_MB  size of the output arena's physical allocations in MiB (default 56)
     K_XCD,            // CNSN_XCD           1: a cluster's workgroups share ONE XCD (A/B knob; default: consecutive workgroups, all 8 XCDs)
     K_HEADROOM_CUS,   // CNSN_HEADROOM_CUS  compute units the persistent grids leave to others (RCCL's channel kernels): default 0
-    K_ARENA_TRIES,    // CNSN_ARENA_TRIES   candidates the output arena times per new block (default 4; 1: none)
+    K_ARENA_TRIES,    // CNSN_ARENA_TRIES   candidates the output arena times per new block of 384 MiB or more (default 8; 1: none)
     K_ARENA_SPREAD_GB,// CNSN_ARENA_SPREAD_GB  GB of physical memory held between an arena block's candidates (A/B knob, default 0)
     K_MID_BLOCK,      // CNSN_MID_BLOCK     256: the mid kernels never take 1024-thread workgroups (A/B knob)
     K_COUNT

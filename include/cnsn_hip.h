@@ -339,8 +339,8 @@ int cnsn_wait_ms(void); /* the bound in force, in milliseconds */
  *
  *   cnsn_arena_alloc   device memory of at least `bytes` (rounded up to whole chunks) on `device`, to be used first on
  *                      `stream` (a block last used on another stream is ordered behind that stream's queued work).  A NEW
- *                      block is the fastest of cnsn_arena_set_tries() candidates timed on `stream` (which is synchronised,
- *                      ~1 ms per candidate; not while the stream is being captured);
+ *                      block of 384 MiB or more is the fastest of cnsn_arena_set_tries() candidates timed on `stream` (which
+ *                      is synchronised, ~1 ms per candidate; not while the stream is being captured);
  *                      NULL when the driver has no memory or no virtual-memory support — the caller then allocates as
  *                      it always did.  Freed blocks stay mapped on a per-size free list: in the steady state of a
  *                      training loop a call is a mutex and a list pop (no driver call, no synchronisation).
@@ -379,10 +379,10 @@ size_t cnsn_arena_trim(int device);
 int cnsn_arena_owns(const void* ptr);
 int cnsn_arena_stats(int device, cnsn_arena_stats_t* out);
 int cnsn_arena_prospect(int device, size_t bytes, int keep, int candidates, void* stream, float* gbps_out);
-/* candidates per NEW block (default 4, environment CNSN_ARENA_TRIES; 1: take what the driver gives): a block is chosen as the
- * fastest of that many created together and timed with the plane-strided fill, the others handed back at once — the arena's
- * standing policy, paid when a block is created (the first steps of a job).  Returns the previous value; < 1: back to the
- * environment's / default. */
+/* candidates per NEW block of 384 MiB or more (default 8, environment CNSN_ARENA_TRIES; 1: take what the driver gives): a block
+ * is chosen as the fastest of that many created together and timed with the plane-strided fill, the others handed back at once
+ * — the arena's standing policy, paid when a block is created (the first steps of a job).  Smaller blocks are never timed: the Infinity Cache absorbs a write of that size.
+ * Returns the previous value; < 1: back to the environment's / default. */
 int cnsn_arena_set_tries(int tries);
 int cnsn_arena_block_gbps(const void* ptr, float* gbps);
 /* chunk size for blocks created from now on (0: back to CNSN_ARENA_CHUNK_MB / 56 MiB); blocks of another chunk size stay
