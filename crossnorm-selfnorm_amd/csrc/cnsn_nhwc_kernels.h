@@ -17,6 +17,10 @@
 #pragma once
 #include "cnsn_fused_stream_kernels.h"
 
+#ifndef CNSN_NHWC_UB
+#define CNSN_NHWC_UB 2  // pixels of a thread's column in flight at once in the backward passes (A/B: profiles/r05_nhwc.md)
+#endif
+
 namespace cnsn {
 
 struct NhwcGeom {
@@ -50,6 +54,25 @@ struct NhwcThread {
     __device__ __forceinline__ size_t elem(const NhwcGeom& g, int p) const { return ((size_t)n * g.M + p) * g.C + (size_t)vc * VEC; }
 };
 
+// VEC adjacent per-plane floats (the planes of one pixel vector's channels) with 16-byte accesses.  Written as a loop over
+// `p[j]` the backward passes compiled to one 4-byte load per channel and row — 56 loads a thread whose lanes lie 32 bytes apart,
+// four times the cache-line requests of the tensor loads themselves (ISA of round 5's first version: profiles/r05_nhwc.md).
+// p is 16-byte aligned: side arrays start on 256-byte boundaries and C is a whole number of vectors.
+template <int VEC>
+__device__ __forceinline__ void load_planes(const float* __restrict__ p, float (&o)[VEC]) {
+    static_assert(VEC % 4 == 0, "whole float4s");
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
+        o[4 * q] = v.x, o[4 * q + 1] = v.y, o[4 * q + 2] = v.z, o[4 * q + 3] = v.w;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void store_planes(float* __restrict__ p, const float (&o)[VEC]) {
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) *reinterpret_cast<float4*>(p + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+}
+
 // rows of a block -> one value per (column, channel-in-vector, accumulator), fixed order; lds: [NACC][rows][tcb*VEC] floats
 template <int VEC, int NACC>
 __device__ __forceinline__ void nhwc_rows_sum(const NhwcGeom& g, const NhwcThread<VEC>& t, float (&acc)[NACC][VEC], float* lds,
@@ -65,13 +88,15 @@ __device__ __forceinline__ void nhwc_rows_sum(const NhwcGeom& g, const NhwcThrea
     if (t.r == 0 && t.active) {
         const size_t p = t.plane0(g);
 #pragma unroll
-        for (int k = 0; k < NACC; ++k)
+        for (int k = 0; k < NACC; ++k) {
+            float v[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                float v = 0.f;
-                for (int q = 0; q < g.rows; ++q) v += lds[((size_t)k * g.rows + q) * width + col * VEC + j];
-                part[((size_t)t.s * NACC + k) * g.P + p + j] = v;
+                v[j] = 0.f;
+                for (int q = 0; q < g.rows; ++q) v[j] += lds[((size_t)k * g.rows + q) * width + col * VEC + j];
             }
+            store_planes<VEC>(part + ((size_t)t.s * NACC + k) * g.P + p, v);
+        }
     }
 }
 
@@ -128,8 +153,7 @@ __global__ __launch_bounds__(kBlock) void nhwc_stats_kernel(const T* __restrict_
         }
         if (t.s == 0 && t.r == 0) {
             const size_t pl = t.plane0(g);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) kshift[pl + j] = K[j];
+            store_planes<VEC>(kshift + pl, K);
         }
     }
     nhwc_rows_sum<VEC, 2>(g, t, acc, lds, part);
@@ -174,12 +198,9 @@ __global__ __launch_bounds__(kBlock) void nhwc_apply_fwd_kernel(const T* __restr
     if (!t.active) return;
     const size_t pl = t.plane0(g);
     float a_in[VEC], xr[VEC], b_in[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        a_in[j] = cf.a_in[pl + j];
-        xr[j] = cf.xr[pl + j];
-        b_in[j] = cf.b_in[pl + j];
-    }
+    load_planes<VEC>(cf.a_in + pl, a_in);
+    load_planes<VEC>(cf.xr + pl, xr);
+    load_planes<VEC>(cf.b_in + pl, b_in);
     constexpr int U = ADD == ADD_NONE ? 4 : 2;
     auto emit = [&](const Vec<T, VEC>& va, const Vec<T, VEC>& vb, size_t e) {
         Vec<T, VEC> o;
@@ -259,16 +280,13 @@ __global__ __launch_bounds__(kBlock) void nhwc_bwd_reduce_kernel(const T* __rest
     for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = si[j] = a_in[j] = xr[j] = b_in[j] = 0.f;
     if (t.active) {
         const size_t pl = t.plane0(g);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            si[j] = rows[pl + j];
-            if (relu) {
-                a_in[j] = rows[g.P + pl + j];
-                xr[j] = rows[2 * g.P + pl + j];
-                b_in[j] = rows[3 * g.P + pl + j];
-            }
+        load_planes<VEC>(rows + pl, si);
+        if (relu) {
+            load_planes<VEC>(rows + g.P + pl, a_in);
+            load_planes<VEC>(rows + 2 * g.P + pl, xr);
+            load_planes<VEC>(rows + 3 * g.P + pl, b_in);
         }
-        constexpr int U = 2;
+        constexpr int U = CNSN_NHWC_UB;
         auto eat = [&](const Vec<T, VEC>& vg, const Vec<T, VEC>& vx, const Vec<T, VEC>& vb) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
@@ -315,15 +333,16 @@ __global__ __launch_bounds__(kBlock) void nhwc_apply_bwd_kernel(const T* __restr
     if (!t.active) return;
     const size_t pl = t.plane0(g), P = g.P;
     float cG[VEC], cX[VEC], xri[VEC], c0[VEC], a_in[VEC], xr[VEC], b_in[VEC];
+    load_planes<VEC>(coef + pl, cG);
+    load_planes<VEC>(coef + P + pl, cX);
+    load_planes<VEC>(coef + 2 * P + pl, xri);
+    load_planes<VEC>(coef + 3 * P + pl, c0);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        cG[j] = coef[pl + j];
-        cX[j] = coef[P + pl + j];
-        xri[j] = coef[2 * P + pl + j];
-        c0[j] = coef[3 * P + pl + j];
-        a_in[j] = relu ? rows[P + pl + j] : 0.f;
-        xr[j] = relu ? rows[2 * P + pl + j] : 0.f;
-        b_in[j] = relu ? rows[3 * P + pl + j] : 0.f;
+    for (int j = 0; j < VEC; ++j) a_in[j] = xr[j] = b_in[j] = 0.f;
+    if (relu) {
+        load_planes<VEC>(rows + P + pl, a_in);
+        load_planes<VEC>(rows + 2 * P + pl, xr);
+        load_planes<VEC>(rows + 3 * P + pl, b_in);
     }
     auto emit = [&](const Vec<T, VEC>& vg, const Vec<T, VEC>& vx, const Vec<T, VEC>& vb, size_t e) {
         Vec<T, VEC> o, om;
@@ -339,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void nhwc_apply_bwd_kernel(const T* __restr
             if (d_addend) store_vec_nt<T, VEC>(d_addend + e, om);
         }
     };
-    constexpr int U = 2;
+    constexpr int U = CNSN_NHWC_UB;
     int p = t.p0 + t.r;
     for (; p + (U - 1) * g.rows < t.p1; p += U * g.rows) {
         Vec<T, VEC> vg[U], vx[U], vb[U];
