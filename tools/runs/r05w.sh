@@ -1,13 +1,6 @@
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-python - <<'PY'
-import time
-t=time.time(); import torch; print("import torch s", round(time.time()-t,2))
-t=time.time(); import cnsn_amd; cnsn_amd.lib(); print("dlopen s", round(time.time()-t,3))
-import cnsn_amd.functional as F
-from cnsn_amd import SelfNorm
-m=SelfNorm(64).cuda().train()
-x=torch.randn(8,64,32,32,device="cuda:0",requires_grad=True)
-torch.cuda.synchronize(); t=time.time(); y=m(x); y.sum().backward(); torch.cuda.synchronize(); print("first call s", round(time.time()-t,3))
-t=time.time(); y=m(x); y.sum().backward(); torch.cuda.synchronize(); print("second call s", round(time.time()-t,4))
-PY
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_arena.py -q -m gpu -x 2>&1 | tail -2
+python -m pytest tests -q -m gpu -x 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+for w in resnet50 resnet50_jsd; do timeout 300 python bench.py --workload $w --steps 30 --warmup 8 2>/dev/null | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print(d['config']['workload'][:70], d['value'], d['unit'], d['ms_per_step'])"; done
+python tools/nhwc_sites.py bf16 2>/dev/null | grep "^|"
