@@ -71,8 +71,9 @@ void launch_mid_fwd(const Plan& pl, const double* mom, const int64_t* perm, cons
 void launch_mid_bwd(const Plan& pl, const float* sums, const double* saved, const int64_t* perm,
                     const int64_t* chan_perm, GateDev g, GateDev f, GateGradDev dg, GateGradDev df, double* tmp,
                     float* coef, hipStream_t stream) {
-    CNSN_MID_DISPATCH(mid_bwd_a_kernel, pl.mid, sums, saved, perm, chan_perm, g, f, dg, df, tmp);
-    mid_bwd_b_kernel<<<(int)((pl.P + kBlock - 1) / kBlock), kBlock, 0, stream>>>(pl.mid, saved, tmp, coef);
+    CNSN_MID_DISPATCH(mid_bwd_a_kernel, pl.mid, sums, saved, perm, chan_perm, g, f, dg, df, tmp, coef);
+    if (pl.mid.cn_active)  // (without CrossNorm mid_bwd_a has written the coefficients itself)
+        mid_bwd_b_kernel<<<(int)((pl.P + kBlock - 1) / kBlock), kBlock, 0, stream>>>(pl.mid, saved, tmp, coef);
 }
 #undef CNSN_MID_DISPATCH
 

@@ -187,7 +187,8 @@ __global__ __launch_bounds__(BLK) void mid_bwd_a_kernel(MidArgs a, const float* 
                                                            const double* __restrict__ saved,
                                                            const int64_t* __restrict__ perm,
                                                            const int64_t* __restrict__ chan_perm, GateDev gg, GateDev gf,
-                                                           GateGradDev dg, GateGradDev df, double* __restrict__ tmp) {
+                                                           GateGradDev dg, GateGradDev df, double* __restrict__ tmp,
+                                                           float* __restrict__ coef) {
     __shared__ double red[(BLK / 64) * 4 * TC];
     constexpr int NSTEP = BLK / TC;
     const int n0 = threadIdx.x / TC;
@@ -259,8 +260,28 @@ __global__ __launch_bounds__(BLK) void mid_bwd_a_kernel(MidArgs a, const float* 
         sw[1] += o.dz_g * sig_p;
         sw[2] += o.dz_f * mu_p;
         sw[3] += o.dz_f * sig_p;
-        tmp[BT_DMU_P * P + p] = o.dmu_p;
-        tmp[BT_K * P + p] = o.k;
+        if (!a.cn_active) {
+            // no plane lends statistics to another one: the coefficients of dx are complete here, mid_bwd_b_kernel is not launched
+            // (launch_mid_bwd) and the two scratch rows it would read are not written
+            const BwdCoefs k = bwd_coefs<double>(a, o, 0.0, 0.0, saved[sv_at(ps, SV_G)], cr.a1, cr.m_in, mu_p, saved[sv_at(ps, SV_MU_C)],
+                                                 cr.sig_c, cr.mu_s, cr.sig_s);
+            coef[BC_CG_IN * P + p] = k.cG_in;
+            coef[BC_CX_IN * P + p] = k.cX_in;
+            coef[BC_XR_IN * P + p] = k.xr_in;
+            coef[BC_C0_IN * P + p] = k.c0_in;
+            if (a.boxed) {
+                coef[BC_CG_OUT * P + p] = k.cG_out;
+                coef[BC_CX_OUT * P + p] = k.cX_out;
+                coef[BC_XR_OUT * P + p] = k.xr_out;
+                coef[BC_C0_OUT * P + p] = k.c0_out;
+                coef[BC_ES * P + p] = k.eS;
+                coef[BC_XS * P + p] = k.xs;
+                coef[BC_E0 * P + p] = k.e0;
+            }
+        } else {
+            tmp[BT_DMU_P * P + p] = o.dmu_p;
+            tmp[BT_K * P + p] = o.k;
+        }
         if (a.cn_active) {
             tmp[BT_DMU_C * P + p] = o.Dmu_c;
             tmp[BT_DSIG_C * P + p] = o.Dsig_c;

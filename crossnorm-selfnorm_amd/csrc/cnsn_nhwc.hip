@@ -103,6 +103,8 @@ int nhwc_forward(Plan& pl, int add, int relu, const void* x, const void* addend,
         else
             nhwc_stats_kernel<T, VEC, ADD_NONE><<<blocks, kBlock, lds, stream>>>((const T*)x, nullptr, ng, part, kshift);
     });
+    // (merging the pixel chunks inside the mid kernel instead of by this launch was measured: the finishing kernel takes 5-7 us on
+    // all compute units, the same loads inside mid_fwd_kernel's 128-256 workgroups cost it 5-13 us: profiles/r05_mid_blocks.md)
     nhwc_finish_stats_kernel<<<pblocks, kBlock, 0, stream>>>(part, kshift, ng.S, P, ng.M, mom);
     launch_mid_fwd(pl, mom, perm, nullptr, g, f, coef, saved_d, stream);
     ApplyCoef cf{coef + FC_A_IN * P, coef + FC_XR * P, coef + FC_B_IN * P, coef + FC_A_OUT * P, coef + FC_B_OUT * P};
