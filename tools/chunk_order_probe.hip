@@ -46,6 +46,49 @@ __global__ __launch_bounds__(256) void linear_fill(char* base, size_t runs) {
     }
 }
 
+__global__ __launch_bounds__(256) void linear_read(char* base, size_t runs) {  // reads everything, writes (almost) nothing
+    const int lane = threadIdx.x & 63;
+    const size_t waves = (size_t)gridDim.x * 4, w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    unsigned acc = 0;
+    for (size_t r = w; r < runs; r += waves) {
+        const uint4* p = (const uint4*)(base + r * kRun) + lane;
+#pragma unroll
+        for (int j = 0; j < kRun / 1024; ++j) {
+            const uint4 v = p[j * 64];
+            acc += v.x ^ v.y ^ v.z ^ v.w;
+        }
+    }
+    if (acc == 0x12345678u) ((unsigned*)base)[0] = acc;
+}
+__global__ __launch_bounds__(256) void linear_copy(char* dst, const char* src, size_t runs) {
+    const int lane = threadIdx.x & 63;
+    const size_t waves = (size_t)gridDim.x * 4, w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (size_t r = w; r < runs; r += waves) {
+        const uint4* p = (const uint4*)(src + r * kRun) + lane;
+        uint4* q = (uint4*)(dst + r * kRun) + lane;
+#pragma unroll
+        for (int j = 0; j < kRun / 1024; ++j) q[j * 64] = p[j * 64];
+    }
+}
+float copy_rate(char* dst, const char* src, size_t bytes) {  // TB/s of bytes moved (read + written)
+    const size_t runs = bytes / kRun;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    linear_copy<<<2048, 256>>>(dst, src, runs);
+    float best = 0.f;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        linear_copy<<<2048, 256>>>(dst, src, runs);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::max(best, (float)(2.0 * runs * kRun / 1e9 / (ms * 1e-3)));
+    }
+    return best;
+}
+
 template <typename K>
 float rate(K kernel, char* va, size_t bytes) {
     const size_t runs = bytes / kRun;
@@ -121,5 +164,31 @@ int main(int argc, char** argv) {
         CK(hipDeviceSynchronize());
         for (int i = 0; i < per; ++i) CK(hipMemUnmap((char*)va + (size_t)i * chunk, chunk));
     }
+    // reads: every block mapped once more in creation order, all at the same time
+    std::vector<char*> vas(nblocks);
+    std::vector<float> wr(nblocks), rd(nblocks);
+    for (int bi = 0; bi < nblocks; ++bi) {
+        void* va = nullptr;
+        CK(hipMemAddressReserve(&va, bytes, 0, nullptr, 0));
+        for (int i = 0; i < per; ++i) CK(hipMemMap((char*)va + (size_t)i * chunk, chunk, 0, blocks[bi][i], 0));
+        CK(hipMemSetAccess(va, bytes, &acc, 1));
+        vas[bi] = (char*)va;
+    }
+    printf("write / read TB/s per block:\n");
+    for (int bi = 0; bi < nblocks; ++bi) {
+        wr[bi] = rate(linear_fill, vas[bi], bytes) / 1000;
+        rd[bi] = rate(linear_read, vas[bi], bytes) / 1000;
+        printf("  block %2d: write %.2f read %.2f\n", bi, wr[bi], rd[bi]);
+    }
+    int fast = -1, fast2 = -1, slow = -1, slow2 = -1;
+    std::vector<int> idx(nblocks);
+    for (int i = 0; i < nblocks; ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int x, int y) { return wr[x] > wr[y]; });
+    fast = idx[0], fast2 = idx[1], slow = idx[nblocks - 1], slow2 = idx[nblocks - 2];
+    printf("copies (TB/s of bytes moved): fast %d,%d slow %d,%d\n", fast, fast2, slow, slow2);
+    printf("  fast -> fast %.2f\n", copy_rate(vas[fast2], vas[fast], bytes) / 1000);
+    printf("  slow -> fast %.2f\n", copy_rate(vas[fast], vas[slow], bytes) / 1000);
+    printf("  fast -> slow %.2f\n", copy_rate(vas[slow], vas[fast], bytes) / 1000);
+    printf("  slow -> slow %.2f\n", copy_rate(vas[slow2], vas[slow], bytes) / 1000);
     return 0;
 }
