@@ -112,8 +112,8 @@ def block_gbps(t: torch.Tensor) -> float:
 
 
 def set_tries(tries: int) -> int:
-    """candidates the arena creates and times per NEW block, keeping the fastest (default 4, `CNSN_ARENA_TRIES`; 1: none);
-    returns the previous value"""
+    """candidates the arena creates and times per NEW block of 384 MiB or more, keeping the fastest (default 8,
+    `CNSN_ARENA_TRIES`; 1: none; smaller blocks are never timed); returns the previous value"""
     return int(_ffi.lib().cnsn_arena_set_tries(int(tries)))
 
 
