@@ -94,6 +94,10 @@ MonoPlan mono_cn_plan(const Plan& pl, bool has_chan_perm, int add, bool backward
         // (round 4, tools/auto_audit.py on two boxes: at N = 96 the cluster kernels lead by 10 % in fp32 and 19 % in bf16 at
         //  (96,1024,14,14); at N = 128 by 5 % at (128,64,16,16) fp32 — the threshold moved from 96 to 128)
         if (!pl.boxed && p.N < 128 && resident_plan(p, false, has_chan_perm, backward).ok) return mp;
+        // (round 5, three audits on three boxes: with 64 channels — 64 workgroups for 256 compute units — the cluster kernels lead
+        //  at N = 128 too, with and without crop boxes, in fp32: (128,64,16,16) 0.065-0.068 vs 0.072-0.073 ms un-boxed, 0.078-0.079
+        //  vs 0.085-0.088 boxed; in bf16 the two are level)
+        if (p.dtype == CNSN_F32 && p.C <= 64 && p.N <= 128 && resident_plan(p, pl.boxed, has_chan_perm, backward).ok) return mp;
     }
     mp.vec = vec;
     mp.lpp = lpp;

@@ -57,7 +57,12 @@ ResPlan resident_pipe_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_pe
     const int slots = rp.ppw * rp.nv, nvec = p.H * p.W / rp.vec;
     const int wg_per_cu = pipe_fwd_waves(slots);
     const int grid_max = (wg_per_cu * reshost::cu_count() / rp.K) * rp.K;
-    if (grid_max < rp.K || (mode != 2 && (long)p.C * rp.K < 3l * grid_max)) return none;  // fewer than three items per workgroup: no pipeline to fill
+    // fewer than three items per workgroup: no pipeline to fill — except 16-bit 2-slot planes with crop boxes, where this kernel's
+    // boxed code is simply the better one: (128,32,32,32) bf16 crop=both 0.077 against 0.086 / 0.104 / 0.077 ms with the plain
+    // cluster kernel on three audits (profiles/r04_auto_audit_after.md, r05_auto_audit_box1.md, r05_auto_audit_box2_after.md)
+    const bool few_items = (long)p.C * rp.K < 3l * grid_max;
+    const bool small_boxed16 = boxed && elem_bytes(p.dtype) == 2 && rp.nv == 2;
+    if (grid_max < rp.K || (mode != 2 && few_items && !small_boxed16)) return none;
     // slots worth parking: the full ones of every plane held (a last, partly filled slot may as well stay in registers)
     const int keep_max = slots < kPipeKeep ? slots : kPipeKeep;
     const size_t budget = (kLdsPerCu / wg_per_cu) & ~(size_t)511;
@@ -77,7 +82,9 @@ ResPlan resident_pipe_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_pe
         if (boxed) {
             const bool f32 = elem_bytes(p.dtype) == 4;
             // (fp32 28x28 — 4 slots — too since round 5: -3.4 / -4.1 % per call at (256,512,28,28) and (96,512,28,28) on both audited boxes)
-            if (!((f32 && rp.nv == 13) || (f32 && rp.nv == 16 && p.N >= 64) || (f32 && rp.nv == 4) || (!f32 && rp.nv == 7))) return none;
+            if (!((f32 && rp.nv == 13) || (f32 && rp.nv == 16 && p.N >= 64) || (f32 && rp.nv == 4) || (!f32 && rp.nv == 7) ||
+                  (small_boxed16 && few_items)))
+                return none;
         } else if (!(rp.nv == 2 || rp.nv == 4 || rp.nv == 7 || rp.nv == 13 || (rp.nv == 8 && elem_bytes(p.dtype) == 2)))
             return none;  // (8 slots in 16 bits: round 5, after the forward's register pass — (16,512,64,64) bf16 0.105 -> 0.093 ms per
                           //  call, (16,2048,64,64) 0.321 -> 0.300: tools/auto_audit.py)

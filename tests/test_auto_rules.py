@@ -57,6 +57,10 @@ TABLE = [
     ((16, 256, 128, 128), F32, FC(**CN, style_box=(0, 0, 64, 64)), "resident", "resident"),
     ((128, 128, 8, 8), F32, FC(**SN), "mono", "mono"),                        # 256-byte planes, 16 lanes each
     ((128, 64, 16, 16), F32, FC(**SN), "mono", "mono"),                        # WideResNet stage 2
+    ((128, 64, 16, 16), F32, FC(**SN, **CN), "resident", "resident"),          # ... armed site, fp32: 64 channels leave 3 CUs in 4 idle with one workgroup per channel (round 5, three audits)
+    ((128, 64, 16, 16), F32, FC(**SN, **BOTH), "resident", "resident"),        # ... with crop boxes too
+    ((128, 64, 16, 16), BF16, FC(**SN, **BOTH), "mono", "mono"),               # ... in 16 bits the two are level: unchanged
+    ((256, 64, 16, 16), F32, FC(**SN, **CN), "mono", "resident"),              # ... above N = 128 the forward stays with the channel-in-registers kernels (the backward never fitted them)
     ((128, 32, 32, 32), F32, FC(**SN, **BOTH), "resident", "resident"),        # WideResNet stage 1
     ((768, 3, 224, 224), F32, FC(**CN), "streaming", "streaming"),             # image-level CrossNorm: 12544 vectors
     ((16, 256, 128, 128), F32, FC(**SN), "resident", "resident"),              # 4096 vectors: split over the workgroup's waves
