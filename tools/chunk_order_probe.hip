@@ -1,8 +1,8 @@
-// tools/chunk_order_probe.hip — measurement aid (profiles/r05_chunk_order.md): is the write rate of a 784 MiB block a property of
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/chunk_order_probe.hip -o tools/chunk_order_probe; run: tools/chunk_order_probe [blocks] [random orders] [chunk MiB]
+// tools/chunk_order_probe.hip — measurement aid (profiles/r05_arena.md section 5): is the write rate of a 784 MiB block a property of
 // the physical chunks it is made of, or of the ORDER in which they are mapped?  Creates blocks of 14 x 56 MiB hipMemCreate chunks,
 // times a plane-strided fill (the arena's probe pattern) and a linear fill into each, then maps the SAME chunks into fresh address
 // ranges in other orders and times again.  Address ranges are never reused (ROCm 7.2 stale translations, csrc/cnsn_arena.hip).
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/chunk_order_probe.hip -o tools/chunk_order_probe; run: tools/chunk_order_probe [blocks] [random orders] [chunk MiB]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
