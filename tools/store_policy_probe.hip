@@ -1,4 +1,4 @@
-// tools/store_policy_probe.hip — measurement aid (profiles/r05_arena.md section 7): does the cache policy of the stores change what
+// tools/store_policy_probe.hip — measurement aid (profiles/r05_arena.md section 5): does the cache policy of the stores change what
 // the two kinds of memory do?  784 MiB blocks of 14 x 56 MiB hipMemCreate chunks, linear fill with every combination of the
 // gfx950 store modifiers sc0 / sc1 / nt, TB/s per block.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/store_policy_probe.hip -o tools/store_policy_probe; run: tools/store_policy_probe [blocks]
