@@ -68,11 +68,6 @@ def parse():
     ap.add_argument("--no-alt", action="store_true",
                     help="only the contract's W + K steps: no second window with the other allocator, no prospecting (rocprofv3 "
                          "passes: the kernel averages then belong to ONE placement)")
-    ap.add_argument("--no-placement", action="store_true",
-                    help="do not look for output blocks in the fast-write regions of the device memory before the warm-up "
-                         "(cnsn_amd.placement, profiles/r04_memory_map.md)")
-    ap.add_argument("--placement-candidates", type=int, default=0,
-                    help="(round 4's search through torch's allocator, cnsn_amd.placement; 0 = off, the default since round 5)")
     ap.add_argument("--workload", type=str, default="cnsn", choices=["cnsn", "resnet50", "resnet50_jsd", "wrn40", "seg"],
                     help="cnsn: the fused op at the north-star shape (headline); resnet50 / wrn40: whole "
                          "training steps of the caller backbones (images/s)")
@@ -406,7 +401,7 @@ def live_traffic(args, timeout_s=45):
     if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ):
         return None, "this process is itself being profiled: no nested rocprofv3 passes"
     child = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2", "--no-extra", "--no-cpu-baseline",
-             "--no-ceiling", "--no-placement", "--no-alt", "--shape", args.shape, "--dtype", args.dtype, "--crop", args.crop, "--kind", args.kind,
+             "--no-ceiling", "--no-alt", "--shape", args.shape, "--dtype", args.dtype, "--crop", args.crop, "--kind", args.kind,
              "--strategy", args.strategy]
     mean = {}                                              # (direction, counter) -> KiB per launch
     t0 = time.perf_counter()
@@ -897,17 +892,10 @@ def main():
     # timed.  --no-arena: torch's caching allocator.  After the contract's W + K steps the same K steps are timed again with
     # the OTHER allocator (one warm-up window in front) so that the line carries both; --prospect N adds a third window
     # after the arena has looked at N candidate blocks (profiles/r04_memory_map.md: where a block lies physically decides how
-    # fast the launches write it).  --placement-candidates N > 0 is round 4's search through torch's allocator (off).
+    # fast the launches write it).
     from cnsn_amd import arena as _arena
-    placement = None
     if args.no_arena:
         _arena.disable()
-    if not args.no_placement and args.placement_candidates > 0 and world <= ngpu:
-        from cnsn_amd import placement as _placement
-        try:
-            placement = _placement.prefer_fast_write_blocks(x, keep=4, candidates=args.placement_candidates)
-        except Exception as exc:      # an aid: the bench runs without it (and says so)
-            placement = {"error": f"{type(exc).__name__}: {exc}"[:300], "kept": 0}
     settled_window(args.warmup, False)
     dt = settled_window(args.steps, True)
     if dist is not None:
@@ -1036,11 +1024,6 @@ def main():
                 if "ms_per_step_prospected" in alt:
                     out["frac_of_hbm_peak_bytes_needed_prospected"] = round(
                         (need_f + need_b) / (alt["ms_per_step_prospected"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        if placement is not None:
-            placement["note"] = ("cnsn_amd.placement.prefer_fast_write_blocks before the warm-up: the caching allocator's free blocks "
-                                 "of the input's size (where y and dx land) were chosen among `candidates` by a timed write; "
-                                 "--no-placement for the allocator's own choice")
-            out["placement"] = placement
         if ceil is not None:
             out["roofline"]["ceiling"] = ceil
             if "resident_order_triad_GBps" in ceil and list(shape) == [256, 256, 56, 56] and b == 4:

@@ -8,8 +8,8 @@ from .cnsn import (CNSN, CNDraws, CrossNorm, SelfNorm, calc_ins_mean_std, cn_op_
                    cn_rand_bbox, draw_cn, instance_norm_mix)
 from .functional import FusedConfig, GateParams, fused_cnsn, set_resident, set_strategy, sn_cluster, which_path
 from ._ffi import LIB_PATH, CnsnError, follow_environ, lib, reload_env
-from . import arena, placement
+from . import arena
 
 __all__ = ["CNSN", "CrossNorm", "SelfNorm", "calc_ins_mean_std", "instance_norm_mix", "cn_rand_bbox",
            "cn_op_2ins_space_chan", "CNDraws", "draw_cn", "FusedConfig", "GateParams", "fused_cnsn",
-           "set_strategy", "set_resident", "which_path", "sn_cluster", "lib", "LIB_PATH", "CnsnError", "reload_env", "follow_environ", "placement", "arena"]
+           "set_strategy", "set_resident", "which_path", "sn_cluster", "lib", "LIB_PATH", "CnsnError", "reload_env", "follow_environ", "arena"]

@@ -14,7 +14,7 @@ STRATEGY_AUTO, STRATEGY_TWO_PASS, STRATEGY_RESIDENT, STRATEGY_LOCAL, STRATEGY_MO
 ADD_NONE, ADD_PRE, ADD_POST = 0, 1, 2
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 PATHS = {0: "streaming", 1: "packed", 2: "resident", 3: "local", 4: "mono"}
-ABI_VERSION = 6
+ABI_VERSION = 7
 PERM_INLINE_MAX = 1024       # CNSN_PERM_INLINE_MAX
 E_UNSUPPORTED = -9
 
@@ -56,7 +56,8 @@ class ArenaStats(C.Structure):
     """cnsn_arena_stats_t"""
     _fields_ = [("struct_bytes", C.c_int32), ("device", C.c_int32), ("chunk_bytes", C.c_uint64), ("mapped_bytes", C.c_uint64),
                 ("in_use_bytes", C.c_uint64), ("blocks", C.c_uint64), ("blocks_in_use", C.c_uint64), ("hits", C.c_uint64),
-                ("misses", C.c_uint64), ("failed", C.c_uint64), ("probed", C.c_uint64), ("tries", C.c_uint64)]
+                ("misses", C.c_uint64), ("failed", C.c_uint64), ("probed", C.c_uint64), ("tries", C.c_uint64),
+                ("evicted", C.c_uint64), ("limit_bytes", C.c_uint64), ("broken", C.c_uint64)]
 
 
 class Epilogue(C.Structure):
@@ -78,7 +79,13 @@ SIGNATURES = {
     "cnsn_reload_env": (None, []),
     "cnsn_set_wait_ms": (None, [C.c_int]),
     "cnsn_wait_ms": (C.c_int, []),
+    "cnsn_set_headroom_cus": (None, [C.c_int]),
+    "cnsn_headroom_cus": (C.c_int, []),
+    "cnsn_arena_map": (C.c_void_p, [C.c_size_t, C.c_int, C.c_void_p]),
+    "cnsn_arena_unmap": (None, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "cnsn_arena_alloc": (C.c_void_p, [C.c_int, C.c_size_t, C.c_void_p]),
+    "cnsn_arena_record_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cnsn_arena_set_limit": (C.c_int, [C.c_int, C.c_uint64]),
     "cnsn_arena_free": (C.c_int, [C.c_void_p]),
     "cnsn_arena_trim": (C.c_size_t, [C.c_int]),
     "cnsn_arena_owns": (C.c_int, [C.c_void_p]),
@@ -310,16 +317,39 @@ def follow_environ():
     os.putenv, os.unsetenv = putenv, unsetenv
 
 
-def under_process_group_defaults():
-    """One process per GPU under an initialised torch.distributed group: a rank whose cluster wait runs out stalls its
-    peers' collectives for as long as the bound — 2 s there instead of 5 s (`cnsn_set_wait_ms`; an explicit CNSN_WAIT_MS
-    in the environment wins, also one set later and made known through `reload_env()`).  Called by `callers.steps.StepGuard` on its first step and by bench.py."""
+def default_headroom_cus() -> int:
+    """compute units the persistent grids leave to RCCL under a process group: two per channel RCCL may open —
+    `NCCL_MAX_NCHANNELS` when the job sets it, else 16 channels (what an 8-GPU all-reduce ring of this stack's RCCL uses per
+    direction pair; `profiles/r05_exchange_hardening.md` measured the 32-CU case) —, never more than a quarter of the part.
+    `CNSN_HEADROOM_CUS` in the environment overrides it (0: none)."""
+    try:
+        ch = int(os.environ.get("NCCL_MAX_NCHANNELS", "") or 16)
+    except ValueError:
+        ch = 16
+    return max(0, min(2 * ch, 64))
+
+
+def under_process_group_defaults() -> dict:
+    """One process per GPU under an initialised torch.distributed group of more than one rank.  (1) A rank whose cluster wait
+    runs out stalls its peers' collectives for as long as the bound — 2 s there instead of 5 s (`cnsn_set_wait_ms`; an explicit
+    CNSN_WAIT_MS in the environment wins, also one set later and made known through `reload_env()`).  (2) RCCL's channel
+    kernels HOLD compute units for the length of an all-reduce: a persistent grid sized for the whole part next to them runs
+    1.5-1.7 x its quiet time (profiles/r05_exchange_hardening.md), so the grids leave `default_headroom_cus()` compute units
+    free (`cnsn_set_headroom_cus`; CNSN_HEADROOM_CUS in the environment wins).  Called by `callers.steps.StepGuard` on its
+    first step, by `data_parallel` and by bench.py; returns what is in force ({} outside a process group)."""
     try:
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and "CNSN_WAIT_MS" not in os.environ:
-            lib().cnsn_set_wait_ms(2000)
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return {}
+        handle = lib()
+        if "CNSN_WAIT_MS" not in os.environ:
+            handle.cnsn_set_wait_ms(2000)
+        if "CNSN_HEADROOM_CUS" not in os.environ:
+            handle.cnsn_set_headroom_cus(default_headroom_cus())
+            forget_plans()
+        return {"wait_ms": int(handle.cnsn_wait_ms()), "headroom_cus": int(handle.cnsn_headroom_cus())}
     except Exception:   # pragma: no cover
-        pass
+        return {}
 
 
 def check(status: int, what: str):

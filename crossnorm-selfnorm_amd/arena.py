@@ -2,25 +2,24 @@
 
 The reference's op returns new tensors (models/cnsn.py:29,150) and torch's caching allocator decides where they lie.  On
 MI355X that decides 7-10 % of the single-touch launches' time: their plane-strided writes run at the copy rate into one
-large `hipMalloc` block in five and 10-20 % below it into the rest (profiles/r04_memory_map.md).  Address ranges MAPPED from
-physical allocations of the arena's own give the outputs a home that does not change from step to step: the op's outputs of at
-least `min_bytes` (default 32 MiB; `CNSN_ARENA_MIN_MB`) are tensors over such ranges — `at::from_blob` views whose deleter
-hands the block back to the arena's per-size free list.  A NEW block of 384 MiB or more is the fastest of eight candidates
-created together and timed with a plane-strided fill (~1 ms each, `set_tries` / `CNSN_ARENA_TRIES`; where a block lies
-physically decides how fast it is written, and about one in five lies well; smaller blocks are never timed — the Infinity
-Cache absorbs a write of that size) — paid in the first steps of a job, for EVERY large output block of the job; in the
-steady state of a training loop an allocation is a mutex and a list pop.
+large `hipMalloc` block in five and 10-20 % below it into the rest (profiles/r04_memory_map.md).  The library can create
+blocks it chooses among — address ranges mapped from physical allocations of its own, a NEW block of 384 MiB or more the
+fastest of eight candidates created together and timed with a plane-strided fill (~1 ms each, `set_tries` /
+`CNSN_ARENA_TRIES`; smaller blocks are never timed — the Infinity Cache absorbs a write of that size).
 
-What a user may want to know:
-  * on by default (`CNSN_ARENA=0` or `arena.disable()` switch it off); outputs under graph capture and small outputs come
-    from torch's allocator as before; if the driver cannot map memory the call falls back silently (`stats()['failed']`);
-  * WHERE a block lies physically decides how fast it is written, not what it is composed of (profiles/r05_arena.md):
-    the arena gives the outputs a STABLE home, and `prospect()` is the explicit, bounded way to look for fast blocks;
-  * blocks the arena holds are NOT visible to torch's allocator (`torch.cuda.memory_allocated` does not count them,
-    `torch.cuda.empty_cache()` does not free them): `arena.stats()` / `arena.trim()` are the counterparts;
-  * stream semantics are a caching allocator's: a block is re-used at once on the stream it was last used on, and behind an
-    event on any other stream.  A tensor handed to ANOTHER stream and freed there needs the care `record_stream` asks for
-    with torch's allocator (keep a reference until that stream is done).
+Since round 6 those blocks belong to TORCH's allocator: the arena is a `torch.cuda.MemPool` (one per device, `use_on_oom`)
+whose segments come from `cnsn_arena_map` / `cnsn_arena_unmap`, and the op's outputs of at least `min_bytes` (default
+32 MiB; `CNSN_ARENA_MIN_MB`) are ordinary tensors allocated while that pool is active for the calling thread.  So:
+  * `torch.cuda.memory_allocated` / `memory_reserved` / `memory_snapshot` count them; `Tensor.record_stream` orders their
+    re-use across streams like any tensor's (round 5's `at::from_blob` tensors were invisible to both);
+  * the pool's free blocks are split and re-used by the caching allocator (a last, smaller batch does not pin a second
+    full-size set), released by its out-of-memory path, and LENT to any other allocation of the process that would
+    otherwise fail (`use_on_oom`): a model that fits with the reference's plain allocation fits with the arena on;
+  * `trim()` releases the pool's free blocks (`torch.cuda.empty_cache()` leaves user pools alone);
+  * on by default (`CNSN_ARENA=0` or `disable()` switch it off); outputs under graph capture and small outputs come from
+    torch's default pool as before; if the driver cannot map memory the allocation falls back to it (`stats()['broken']`).
+`prospect()` and the `cnsn_arena_alloc` family remain the C ABI's own caching layer (for callers without torch); the Python
+layer no longer uses it for the op's outputs.
 """
 from __future__ import annotations
 
@@ -30,7 +29,8 @@ import torch
 
 from . import _ffi
 
-__all__ = ["enable", "disable", "enabled", "min_bytes", "stats", "trim", "empty_like", "set_chunk_mb", "prospect", "block_gbps", "set_tries"]
+__all__ = ["enable", "disable", "enabled", "min_bytes", "stats", "trim", "empty_like", "set_chunk_mb", "prospect", "block_gbps",
+           "set_tries", "set_limit_mb", "pool_id"]
 
 
 def _glue():
@@ -68,11 +68,19 @@ def out_like(x: torch.Tensor) -> torch.Tensor:
 
 
 def empty_like(x: torch.Tensor) -> torch.Tensor:
-    """a contiguous tensor of x's shape and type over an arena block, whatever its size"""
+    """a contiguous tensor of x's shape and type from the arena's pool, whatever its size"""
     return _glue().arena_empty_like(x)
 
 
+def pool_id(device=None):
+    """id of the `torch.cuda.MemPool` behind the arena on `device` — `torch.cuda.memory_snapshot(pool_id())` lists its
+    segments; (0, 0) when the pool could not be created"""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    return tuple(int(v) for v in _glue().arena_pool_id(int(dev)))
+
+
 def stats(device=None) -> dict:
+    """the library's counters for `device` (blocks it created and still holds for torch's pool or its own cache)"""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     st = _ffi.ArenaStats()
     st.struct_bytes = C.sizeof(_ffi.ArenaStats)
@@ -81,15 +89,30 @@ def stats(device=None) -> dict:
 
 
 def trim(device=None) -> int:
-    """unmap and release every free block (all devices when `device` is None); returns the bytes released"""
-    return int(_ffi.lib().cnsn_arena_trim(-1 if device is None else int(torch.device(device).index)))
+    """release every free block — of the torch pool (`emptyCache(pool)`) and of the C ABI's own cache — on `device` (all
+    devices when None); returns the bytes of physical memory given back to the driver"""
+    devs = range(torch.cuda.device_count()) if device is None else [torch.device(device).index]
+    before = sum(stats(d)["mapped_bytes"] for d in devs)
+    g = _ffi.glue()
+    if g is not None:
+        g.arena_trim(-1 if device is None else int(torch.device(device).index))
+    _ffi.lib().cnsn_arena_trim(-1 if device is None else int(torch.device(device).index))
+    return before - sum(stats(d)["mapped_bytes"] for d in devs)
+
+
+def set_limit_mb(mb: float, device=None) -> None:
+    """cap on what the C ABI's own caching layer (`cnsn_arena_alloc`) holds on `device`; 0: the default (CNSN_ARENA_MAX_MB, else
+    half of the device memory).  The torch pool is bounded by torch's allocator, not by this."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    _ffi.check(_ffi.lib().cnsn_arena_set_limit(int(dev), int(mb * (1 << 20))), "cnsn_arena_set_limit")
 
 
 def prospect(like, keep: int = 4, candidates: int = 12) -> dict:
-    """Look for fast memory, explicitly and bounded (`cnsn_arena_prospect`): create `candidates` blocks of `like`'s size (a
-    tensor, or a byte count), time a plane-strided fill into each, keep the `keep` fastest on the arena's free list — the
-    next outputs of that size are written there — and give the rest back.  Transient memory: candidates x size, never more
-    than half of what is free.  A job calls it once per large output size after building its model, or not at all."""
+    """Look for fast memory, explicitly and bounded (`cnsn_arena_prospect`, the C ABI's own cache): create `candidates` blocks
+    of `like`'s size (a tensor, or a byte count), time a plane-strided fill into each, keep the `keep` fastest on the free list
+    of `cnsn_arena_alloc` and give the rest back.  Transient memory: candidates x size, never more than half of what is free.
+    A measurement aid since round 6 (the op's outputs come from the torch pool, whose new blocks are the best of
+    `set_tries()` candidates each)."""
     if isinstance(like, torch.Tensor):
         nbytes, dev = like.numel() * like.element_size(), like.device
     else:
@@ -118,6 +141,5 @@ def set_tries(tries: int) -> int:
 
 
 def set_chunk_mb(mb: float) -> None:
-    """size of the physical allocations NEW blocks are mapped from (measurement knob; 0: default); blocks of the previous
-    size stop serving requests — `trim()` releases the free ones"""
+    """size of the physical allocations NEW blocks are mapped from (measurement knob; 0: default)"""
     _ffi.check(_ffi.lib().cnsn_arena_set_chunk_bytes(int(mb * (1 << 20))), "cnsn_arena_set_chunk_bytes")

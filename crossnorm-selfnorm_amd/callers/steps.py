@@ -38,7 +38,7 @@ class StepGuard:
     (`data_parallel.degrade_all`) and repeats: the ranks issue the same collectives in the same order whatever happens.
     The reference's loops (cifar.py:136-138, imagenet.py:240-244) have no counterpart: eager PyTorch cannot time out."""
 
-    def __init__(self, *modules, group=None, restore_rng=True, max_attempts=3, optimizer=None, rearm_after=200):
+    def __init__(self, *modules, group=None, restore_rng=True, max_attempts=3, optimizer=None, rearm_after=20):
         """optimizer: ALSO snapshot the parameters and the optimizer's state tensors (`save` / `restore` then cover a whole
         WINDOW of applied steps — what a launch-bound loop uses to poll once per window instead of synchronising the
         stream in every step: bench.py's model workloads; `run()` itself never needs it, it polls before the optimizer)."""
@@ -47,7 +47,8 @@ class StepGuard:
         self.group, self.restore_rng, self.max_attempts = group, restore_rng, max_attempts
         self.snap, self.rng = None, None
         # The way back: after `rearm_after` applied steps without a time-out the cluster kernels are tried again
-        # (`data_parallel.rearm_all`); a relapse doubles the interval.  Degradations are rank-agreed and every rank counts
+        # (`data_parallel.rearm_all`; 20 by default — a degraded step costs 1.3-1.6 x a healthy one, so the way back should be
+        # short; round 5 waited 200); a relapse doubles the interval.  Degradations are rank-agreed and every rank counts
         # the same applied steps, so all ranks re-arm at the same step without a collective.  None / 0: never.
         self.rearm_after = rearm_after
         self.clean_steps = 0             # applied steps since the last degradation
@@ -56,6 +57,16 @@ class StepGuard:
         self.repeats = 0                 # steps repeated so far (all ranks count the same)
         self.local_timeouts = 0          # launches of THIS rank that gave up
         self._defaults_done = False
+
+    # The guard lives in the network's __dict__ (`_guard_of`): `copy.deepcopy(net)` (EMA / SWA copies) and `torch.save(net)`
+    # would otherwise drag along the snapshot clones of every buffer (and of the parameters and optimizer state when an
+    # optimizer was passed) and the process-group handle, which does not pickle.  A copy gets no guard; `_guard_of` builds it
+    # a fresh one on its first step.
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
 
     def _live(self):
         live = [m._buffers[name] for m, name in self.slots]

@@ -117,6 +117,8 @@ void cnsn_resident_enable(int on) { resident_set_enabled(on != 0); }
 void cnsn_reload_env(void) { reload_knobs(); }
 void cnsn_set_wait_ms(int ms) { resident_set_wait_ms(ms); }
 int cnsn_wait_ms(void) { return (int)(resident_wait_ticks() / 100000ll); }
+void cnsn_set_headroom_cus(int n) { resident_set_headroom_cus(n); }
+int cnsn_headroom_cus(void) { return resident_headroom_cus(); }
 
 const char* cnsn_status_string(int status) {
     switch (status) {

@@ -70,6 +70,15 @@ long long resident_wait_ticks() {
 }
 
 namespace {
+std::atomic<int> g_headroom_cus{0};  // cnsn_set_headroom_cus; a CNSN_HEADROOM_CUS knob in force wins
+}  // namespace
+void resident_set_headroom_cus(int n) { g_headroom_cus.store(n > 0 ? n : 0, std::memory_order_relaxed); }
+int resident_headroom_cus() {
+    if (const char* hr = knob(K_HEADROOM_CUS)) return atoi(hr) > 0 ? atoi(hr) : 0;  // ("0" in the environment: none, whatever was set)
+    return g_headroom_cus.load(std::memory_order_relaxed);
+}
+
+namespace {
 std::mutex g_ctx_mu;
 std::unordered_map<void*, unsigned> g_ctx_epoch;  // launches counted per context (host side)
 }  // namespace

@@ -155,16 +155,13 @@ int grid_for(Kern kern, size_t lds, int K, int items) {
     if (knob(K_DEBUG))
         fprintf(stderr, "[cnsn] resident grid: occupancy %d/CU x %d CUs, K=%d, items=%d, lds=%zu\n", occ, cu_count(),
                 K, items, lds);
-    // Head-room (CNSN_HEADROOM_CUS = n): size the grid for n compute units fewer than the part has.  A persistent grid sized
+    // Head-room (cnsn_set_headroom_cus(n) / CNSN_HEADROOM_CUS = n; the Python layer sets it under a process group): size the grid for n compute units fewer than the part has.  A persistent grid sized
     // for the whole chip next to a kernel that HOLDS compute units for longer than the launch (RCCL's channel kernels during a
     // large all-reduce) still completes — its clusters drain in order — but the workgroups that found no slot only start once
     // others have finished ALL their items: the launch takes up to twice as long.  With the grid sized for what is free, every
     // workgroup is resident from the start and the items are shared evenly (tests/test_gpu_foreign_kernel.py, 32 CUs held).
     int cus = cu_count();
-    if (const char* hr = knob(K_HEADROOM_CUS)) {
-        const int n = atoi(hr);
-        if (n > 0) cus = cus - n > 8 ? cus - n : 8;
-    }
+    if (const int n = resident_headroom_cus()) cus = cus - n > 8 ? cus - n : 8;
     long g = (long)occ * cus;
     g = (g / K) * K;
     if (g > items) g = items;  // items is a multiple of K

@@ -1693,6 +1693,8 @@ int resident_timeouts();
 bool resident_degraded();  // a launch gave up since the last cnsn_resident_rearm (or ever)
 int resident_rearm();      // forgive the time-outs so far; returns how often this process has re-armed
 void resident_set_wait_ms(int ms);   // cnsn_set_wait_ms
+void resident_set_headroom_cus(int n);  // cnsn_set_headroom_cus
+int resident_headroom_cus();            // compute units the persistent grids leave free (CNSN_HEADROOM_CUS wins over the setter)
 long long resident_wait_ticks();     // bound of a cluster wait in 100 MHz ticks
 // AUTO may choose the cluster kernels: not switched off (cnsn_resident_enable(0) / CNSN_RESIDENT=0), no time-out seen
 bool resident_auto_enabled();

@@ -7,15 +7,20 @@
 // network made of many small CNSN sites (WideResNet-40-2: 18 sites at 32x32 and below).
 #include <torch/extension.h>
 
+#include <ATen/hip/MemPool.h>
 #include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPCachingAllocator.h>
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
+#include <torch/csrc/cuda/CUDAPluggableAllocator.h>
 
 #include <array>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -58,9 +63,15 @@ Tensor f32c(const Tensor& t) {
     return d.contiguous();
 }
 
-// ---- output arena (include/cnsn_hip.h, "output arena"): y / dx / z of at least `g_arena_min` bytes are tensors over
-// address ranges mapped from small physical allocations, where the launches' plane-strided writes are fast every time;
-// everything else, and every output while the stream is being captured into a graph, comes from torch's allocator.
+// ---- output arena (include/cnsn_hip.h, "output arena"): y / dx / z of at least `g_arena_min` bytes come from a torch MemPool
+// whose blocks the LIBRARY creates (cnsn_arena_map: address ranges mapped from physical allocations of its own, a new block of
+// 384 MiB or more the fastest of several candidates timed when it is created — where a block lies physically decides how fast
+// the single-touch launches write it, profiles/r05_arena.md).  Everything else about those blocks is the caching allocator's:
+// it caches and splits them, `torch.cuda.memory_allocated` counts them, `Tensor.record_stream` orders their re-use across
+// streams, its out-of-memory path releases them, and (`use_on_oom`) an allocation ANYWHERE in the process that would otherwise
+// fail may use the pool's free blocks.  Round 5 handed out at::from_blob tensors over a cache of the library's own, which
+// torch could neither see, trim nor order (review of round 5, both findings).  Outputs below the threshold, and every output
+// while the stream is being captured into a graph, come from torch's default pool.
 // CNSN_ARENA=0 switches it off, CNSN_ARENA_MIN_MB moves the threshold (default 32); `arena_config` does both at run time.
 std::atomic<int64_t> g_arena_min{-2};  // -2: not read yet, -1: off
 
@@ -75,16 +86,80 @@ int64_t arena_min_bytes() {
     return v;
 }
 
-Tensor arena_empty(at::IntArrayRef sizes, at::IntArrayRef strides, const at::TensorOptions& opt, const at::Device& dev, int64_t nbytes) {
+namespace hca = c10::hip::HIPCachingAllocator;
+
+struct ArenaPools {
+    std::mutex mu;
+    std::shared_ptr<hca::HIPAllocator> allocator;
+    std::unordered_map<int, at::cuda::MemPool*> by_device;  // (leaked on purpose: tensors outlive static destructors)
+    bool unusable = false;  // this torch build refused the pool once: torch's default pool from then on
+};
+ArenaPools& arena_pools() {
+    static ArenaPools* p = new ArenaPools;
+    return *p;
+}
+
+// the pool of `device` (created on first use with that device current), or nullptr
+at::cuda::MemPool* arena_pool(int device) {
+    ArenaPools& ps = arena_pools();
+    std::lock_guard<std::mutex> lock(ps.mu);
+    if (ps.unusable) return nullptr;
+    auto it = ps.by_device.find(device);
+    if (it != ps.by_device.end()) return it->second;
+    try {
+        if (!ps.allocator)
+            ps.allocator = torch::cuda::CUDAPluggableAllocator::createCustomAllocator(
+                [](size_t bytes, int dev, hipStream_t stream) { return cnsn_arena_map(bytes, dev, (void*)stream); },
+                [](void* ptr, size_t bytes, int dev, hipStream_t stream) { cnsn_arena_unmap(ptr, bytes, dev, (void*)stream); });
+        c10::DeviceGuard guard(c10::Device(c10::DeviceType::CUDA, (c10::DeviceIndex)device));
+        auto* pool = new at::cuda::MemPool(ps.allocator.get(), /*is_user_created=*/true, /*use_on_oom=*/true);
+        ps.by_device.emplace(device, pool);
+        return pool;
+    } catch (const c10::Error&) {
+        ps.unusable = true;
+        return nullptr;
+    }
+}
+
+// allocations of THIS thread on `device` go to the arena's pool while one of these is alive (torch.cuda.use_mem_pool's steps)
+struct ToArenaPool {
+    c10::DeviceIndex dev;
+    c10::MempoolId_t id;
+    ToArenaPool(int device, at::cuda::MemPool* pool) : dev((c10::DeviceIndex)device), id(pool->id()) {
+        const auto tid = std::this_thread::get_id();
+        hca::beginAllocateToPool(dev, id, [tid](hipStream_t) { return std::this_thread::get_id() == tid; });
+    }
+    ~ToArenaPool() {
+        hca::endAllocateToPool(dev, id);
+        hca::releasePool(dev, id);
+    }
+};
+
+Tensor arena_empty(at::IntArrayRef sizes, at::IntArrayRef strides, const at::TensorOptions& opt, const at::Device& dev, int64_t /*nbytes*/) {
     hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
         return Tensor();
     }
-    void* p = cnsn_arena_alloc((int)dev.index(), (size_t)nbytes, (void*)stream);
-    if (!p) return Tensor();  // (no memory / no virtual-memory support: the caller allocates as it always did)
-    return at::from_blob(p, sizes, strides, [](void* q) { (void)cnsn_arena_free(q); }, opt, dev);
+    at::cuda::MemPool* pool = arena_pool((int)dev.index());
+    if (!pool) return Tensor();
+    ToArenaPool scope((int)dev.index(), pool);
+    // (out of memory: the caching allocator has by now released its own caches AND this pool's; the error is the one the
+    // reference's plain allocation would raise)
+    return at::empty_strided(sizes, strides, opt.device(dev));
+}
+
+// bytes the pool of `device` gives back to the driver (free cached blocks; `torch.cuda.empty_cache()` leaves user pools alone)
+void arena_pool_trim(int device) {
+    ArenaPools& ps = arena_pools();
+    std::vector<c10::MempoolId_t> ids;
+    {
+        std::lock_guard<std::mutex> lock(ps.mu);
+        for (auto& kv : ps.by_device)
+            if (device < 0 || kv.first == device) ids.push_back(kv.second->id());
+    }
+    for (auto id : ids) hca::emptyCache(id);
 }
 
 // `x` is dense (contiguous in NCHW or channels-last order, aligned): a fresh tensor of its shape, type AND memory order for an
@@ -670,5 +745,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                                x.device(), x.numel() * (int64_t)x.element_size());
         return t.defined() ? t : at::empty(x.sizes(), x.options().memory_format(at::MemoryFormat::Contiguous));
     }, "a fresh contiguous tensor of x's shape and type over an arena block (torch's allocator when the arena cannot serve it)");
+    m.def("arena_trim", [](int64_t device) { arena_pool_trim((int)device); },
+          "release the free cached blocks of the arena's torch pool (device < 0: every device)");
+    m.def("arena_pool_id", [](int64_t device) {
+        at::cuda::MemPool* p = arena_pool((int)device);
+        return p ? std::make_pair((int64_t)p->id().first, (int64_t)p->id().second) : std::make_pair((int64_t)0, (int64_t)0);
+    }, "id of the torch MemPool behind the arena on `device` ((0, 0): none) — for torch.cuda.memory_snapshot(id)");
     m.def("out_like", &out_like, "the op's output allocation for a dense x: arena from the threshold on, else torch");
 }

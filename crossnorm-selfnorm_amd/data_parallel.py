@@ -100,13 +100,16 @@ def degrade_all() -> None:
     kernels (`cnsn_resident_enable(0)`), so all ranks run the same (two-pass / single-workgroup) kernels from the repeat
     on — a rank that kept its cluster kernels would be faster than the degraded one and wait for it in every collective,
     and could be the next to time out if the cause (a shared GPU, a foreign persistent kernel) is node-wide."""
-    global _degraded_here
+    global _degraded_here, _allowed_before
     from . import functional
+    if not _degraded_here:
+        _allowed_before = functional.resident_allowed()
     functional.set_resident(False)
     _degraded_here = True
 
 
 _degraded_here = False       # the cluster kernels are off because degrade_all() switched them off (not the user)
+_allowed_before = True       # ... and what the user's switch said at that moment (CNSN_RESIDENT=0 / set_resident(False))
 
 
 def rearm_all() -> int:
@@ -115,14 +118,14 @@ def rearm_all() -> int:
     seconds — another process's kernel, a debugger, a clock event — is usually gone minutes later, and a job that runs for
     days should not pay the two-pass kernels for the rest of its life.  EVERY rank must call it at the same step: the
     callers count clean steps since the (rank-agreed) degradation, so no collective is needed (`StepGuard`).  Does nothing
-    when the cluster kernels are off for another reason (CNSN_RESIDENT=0, `set_resident(False)` by the user).  Returns how
+    when this module did not switch them off; puts the user's switch (CNSN_RESIDENT=0, `set_resident(False)`) back as it was.  Returns how
     often this process has re-armed."""
     global _degraded_here
     from . import _ffi, functional
     if not _degraded_here:
         return 0
     n = int(_ffi.lib().cnsn_resident_rearm())
-    functional.set_resident(True)
+    functional.set_resident(_allowed_before)      # (back to what the switch said: a job started with CNSN_RESIDENT=0 stays off)
     _degraded_here = False
     return n
 

@@ -31,8 +31,20 @@ def set_strategy(name: str):
 def set_resident(enabled: bool):
     """Allow (default) or forbid CNSN_STRATEGY_AUTO to choose the cluster-resident kernels (cnsn_resident_enable);
     the environment variable CNSN_RESIDENT=0 does the same from process start."""
+    global _resident_set
     _ffi.lib().cnsn_resident_enable(int(bool(enabled)))
+    _resident_set = bool(enabled)
     _ffi.forget_plans()
+
+
+_resident_set = None        # what set_resident() last asked for (None: never called — the environment decides)
+
+
+def resident_allowed() -> bool:
+    """whether CNSN_STRATEGY_AUTO may currently choose the cluster kernels as far as the SWITCH goes (`set_resident`, else
+    CNSN_RESIDENT at load); a degradation after a time-out is separate (`cnsn_resident_degraded`)"""
+    import os
+    return _resident_set if _resident_set is not None else os.environ.get("CNSN_RESIDENT", "1") != "0"
 
 
 def _require_device(x: torch.Tensor, what: str):

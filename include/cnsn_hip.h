@@ -10,11 +10,22 @@
  *   - Plain C: pointers, sizes, PODs.  No C++ types, no torch types.
  *   - Every pointer is a DEVICE pointer unless it says "host".  Activations are NCHW, contiguous,
  *     16-byte aligned, element type `dtype`.  All per-plane / per-channel side arrays are float32.
- *   - The caller owns every buffer (inputs, outputs, `saved`, `workspace`).  The library allocates
- *     nothing on the device, is re-entrant, never synchronises the host, never throws; the only state it keeps
- *     is a per-device event that orders its persistent launches across streams and one pinned host word that
- *     counts timed-out cluster launches (cnsn_resident_timeouts).
- *     All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *   - The caller owns every buffer the op's entry points take (inputs, outputs, `saved`, `workspace`, `context`); those
+ *     entry points enqueue their work on `stream` (a hipStream_t passed as void*; NULL = default stream), never
+ *     synchronise the host and never throw.  What the library DOES own, allocate and keep — all of it outside the
+ *     numerical path, listed here once (ABI 5-7; SURVEY b2 asked for none of it, DESIGN.md section 1 says why each exists):
+ *       allocates   nothing on the device inside the op's calls.  The OUTPUT ARENA (cnsn_arena_*, below) allocates device
+ *                   memory — hipMemCreate / hipMemMap — but only when a caller asks it for a block;
+ *       synchronises  the op's calls: never.  The arena: the requesting stream when a NEW block of 384 MiB or more is timed
+ *                   (~1 ms per candidate, at creation only), the streams of the blocks it releases (cnsn_arena_trim, the cap);
+ *       keeps, per process   which stream the last persistent ("cluster") launch of each device went to (a launch on another
+ *                   stream waits for it: one event recorded at that moment); a launch counter and two granule regions per
+ *                   exchange context; ONE pinned host word counting cluster launches that gave up (cnsn_resident_timeouts)
+ *                   and the count forgiven by cnsn_resident_rearm; the wait bound (cnsn_set_wait_ms), the grid head-room
+ *                   (cnsn_set_headroom_cus) and the strategy switches (cnsn_resident_enable); the CNSN_* environment as of
+ *                   load; the arena's blocks, free lists and counters.
+ *     The op's calls are safe from several host threads on different streams and devices; the setters above are
+ *     process-wide and meant for start-up.
  *   - Randomness stays on the host: the batch permutation, channel permutation and boxes are
  *     INPUTS (the reference draws them with torch.randperm / numpy, models/cnsn.py:62,65,71,76).
  *   - Return value: 0 on success, <0 argument error (CNSN_E_*), >0 a hipError_t from the launch.
@@ -31,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CNSN_ABI_VERSION 6
+#define CNSN_ABI_VERSION 7
 
 /* Largest batch whose permutation can travel as a launch argument (cnsn_problem_t.perm_host). */
 #define CNSN_PERM_INLINE_MAX 1024
@@ -326,26 +337,50 @@ void cnsn_resident_enable(int on);
 void cnsn_set_wait_ms(int ms);
 int cnsn_wait_ms(void); /* the bound in force, in milliseconds */
 
-/* ---- output arena (ABI 6) --------------------------------------------------------------------------
+/* Grid head-room (ABI 7): the persistent ("cluster") grids are sized for `n` compute units fewer than the part has (n <= 0:
+ * the whole part).  Next to a kernel that HOLDS compute units for longer than a launch — RCCL's channel kernels during a
+ * large all-reduce — a full-size persistent grid still completes, in order, but takes 1.5-1.7 x its quiet time; a grid sized for
+ * what is free takes its quiet time (profiles/r05_exchange_hardening.md).  The Python layer sets it under an initialised
+ * process group of more than one rank (two compute units per RCCL channel, NCCL_MAX_NCHANNELS or 16 of them).  A
+ * CNSN_HEADROOM_CUS knob in force takes precedence.  Nothing in the reference corresponds to this. */
+void cnsn_set_headroom_cus(int n);
+int cnsn_headroom_cus(void); /* the head-room in force */
+
+/* ---- output arena (ABI 6; torch-visible since ABI 7) ------------------------------------------------
  * The reference's op returns NEW tensors (models/cnsn.py:29 `return (...) * style_std + style_mean`, :150 `return x * g`),
  * which torch's caching allocator places.  On MI355X the single-touch launches' plane-strided writes run 10-20 % slower
  * into four out of five large hipMalloc'ed blocks than into the fifth (profiles/r04_memory_map.md), and no allocator
- * option chooses.  This is an allocator of the op's own for its outputs y / dx / z: blocks mapped from physical
- * allocations the arena creates itself (hipMemCreate chunks, default 56 MiB, environment CNSN_ARENA_CHUNK_MB — the chunk
- * size does NOT decide a block's speed, profiles/r05_arena.md), kept for the life of the process, optionally TIMED and
- * ranked (cnsn_arena_prospect) — a stable home for the outputs instead of whatever the caching allocator splits off next.
- * The library itself still takes caller-owned output pointers everywhere — a caller MAY get them here; the Python layer
- * does for outputs of at least 32 MiB.
+ * option chooses.  The arena creates blocks it can choose among: address ranges mapped from physical allocations of its
+ * own (hipMemCreate chunks, default 56 MiB, environment CNSN_ARENA_CHUNK_MB, plus one tail chunk — the chunk size does NOT
+ * decide a block's speed, profiles/r05_arena.md); a NEW block of 384 MiB or more is the fastest of cnsn_arena_set_tries()
+ * candidates created together and timed with a plane-strided fill on the requesting stream (which is synchronised, ~1 ms per
+ * candidate; not while the stream is being captured), the others' memory handed back at once.
+ * The library itself still takes caller-owned output pointers everywhere — a caller MAY get them here.
  *
- *   cnsn_arena_alloc   device memory of at least `bytes` (rounded up to whole chunks) on `device`, to be used first on
- *                      `stream` (a block last used on another stream is ordered behind that stream's queued work).  A NEW
- *                      block of 384 MiB or more is the fastest of cnsn_arena_set_tries() candidates timed on `stream` (which
- *                      is synchronised, ~1 ms per candidate; not while the stream is being captured);
- *                      NULL when the driver has no memory or no virtual-memory support — the caller then allocates as
- *                      it always did.  Freed blocks stay mapped on a per-size free list: in the steady state of a
- *                      training loop a call is a mutex and a list pop (no driver call, no synchronisation).
+ * Two ways in.
+ *  (1) cnsn_arena_map / cnsn_arena_unmap (ABI 7): create / release ONE block; nothing is cached by the library.  The pair has
+ *      the signature of a torch pluggable allocator (alloc(size, device, stream), free(ptr, size, device, stream)): the Python
+ *      layer's arena is a `torch.cuda.MemPool` over it, so the caching allocator caches, splits, counts
+ *      (`memory_allocated`), orders across streams (`record_stream`) and — out of memory anywhere in the process — releases
+ *      these blocks like its own.  cnsn_arena_map returns NULL when the device has no memory (torch then frees its caches and
+ *      asks again) or the driver has no virtual-memory support (remembered per device).  cnsn_arena_unmap gives the physical
+ *      memory back; the caller has ordered it behind every use of the block.
+ *  (2) cnsn_arena_alloc / cnsn_arena_free: the same blocks behind a caching layer of the library's own, for callers without an
+ *      allocator to plug into.
+ *   cnsn_arena_alloc   device memory of at least `bytes` (rounded up to the driver's granularity, 2 MiB) on `device`, to be
+ *                      used first on `stream`.  Served from the free lists when a block of that size — or the smallest one
+ *                      within an eighth above it — is free (a mutex and a list operation; a block last used on other streams
+ *                      is ordered behind their queued work); else a new block is created, after evicting the least recently
+ *                      used free blocks if the arena would exceed its cap (cnsn_arena_set_limit).  When the device is out of
+ *                      memory every free block is released and the request repeated once.  NULL: no memory, cap reached with
+ *                      everything in use, or no virtual-memory support — the caller allocates as it always did.
  *   cnsn_arena_free    give a block back (pointer as returned by cnsn_arena_alloc); work already queued on the block's
  *                      stream may still use it — the next user is ordered behind it, like a caching allocator's.
+ *   cnsn_arena_record_stream  `ptr` (from cnsn_arena_alloc, not yet freed) is also used on `stream`: whoever gets the block
+ *                      next is ordered behind that stream's work as well (Tensor.record_stream's contract).
+ *   cnsn_arena_set_limit  cap in bytes on what the caching layer holds on `device` (in use + free); 0: back to the default
+ *                      (environment CNSN_ARENA_MAX_MB, else half of the device memory).  Free blocks above a new cap are
+ *                      released at once.
  *   cnsn_arena_trim    give the physical memory of every FREE block of `device` (-1: all devices) back to the driver;
  *                      returns the bytes released.  Synchronises the streams those blocks were last used on.  The
  *                      blocks' ADDRESS ranges stay reserved for the life of the process: a range that was unmapped is
@@ -357,24 +392,31 @@ int cnsn_wait_ms(void); /* the bound in force, in milliseconds */
  *                      receives every candidate's measured write rate.  WHERE a block lies physically decides its
  *                      write rate (about one block in five takes plane-strided writes 15-20 % faster,
  *                      profiles/r04_memory_map.md); nothing calls this by default.
- *   cnsn_arena_block_gbps  the rate measured for the block at `ptr` (0: never measured).
- *   cnsn_arena_owns    1 when `ptr` lies inside a block of the arena.
+ *   cnsn_arena_block_gbps  the rate measured for the block that contains `ptr` (0: never measured).
+ *   cnsn_arena_owns    1 when `ptr` lies inside a block of the arena (either way in).
  * Not to be used while the stream is being captured into a graph (a replay needs addresses nobody else re-uses). */
 typedef struct cnsn_arena_stats {
     int32_t struct_bytes; /* = sizeof(cnsn_arena_stats_t) */
     int32_t device;
     uint64_t chunk_bytes;   /* size of one physical allocation                       */
-    uint64_t mapped_bytes;  /* physical memory held by the arena on this device      */
-    uint64_t in_use_bytes;  /* ... of which handed out                               */
+    uint64_t mapped_bytes;  /* physical memory held by the arena on this device (both ways in) */
+    uint64_t in_use_bytes;  /* ... of which handed out (a mapped block counts as handed out to its cache) */
     uint64_t blocks, blocks_in_use;
     uint64_t hits;          /* requests served from the free list                    */
     uint64_t misses;        /* requests that created and mapped a new block          */
     uint64_t failed;        /* requests answered with NULL                           */
     uint64_t probed;        /* candidate blocks timed when blocks were created       */
     uint64_t tries;         /* candidates per new block in force (0: not resolved)   */
+    uint64_t evicted;       /* free blocks released because of the cap / a full device (ABI 7) */
+    uint64_t limit_bytes;   /* the caching layer's cap in force (0: not resolved yet)  (ABI 7) */
+    uint64_t broken;        /* 1: the driver refused the virtual-memory calls on this device (ABI 7) */
 } cnsn_arena_stats_t;
+void* cnsn_arena_map(size_t bytes, int device, void* stream);
+void cnsn_arena_unmap(void* ptr, size_t bytes, int device, void* stream);
 void* cnsn_arena_alloc(int device, size_t bytes, void* stream);
 int cnsn_arena_free(void* ptr);
+int cnsn_arena_record_stream(void* ptr, void* stream);
+int cnsn_arena_set_limit(int device, uint64_t bytes);
 size_t cnsn_arena_trim(int device);
 int cnsn_arena_owns(const void* ptr);
 int cnsn_arena_stats(int device, cnsn_arena_stats_t* out);

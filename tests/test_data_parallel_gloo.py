@@ -44,11 +44,16 @@ def _worker(rank, world, port, out):
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        from cnsn_amd import _ffi
         from cnsn_amd import data_parallel as dp
+        # what a rank of a process group gets WITHOUT asking (review of round 5, item 3): a 2 s bound on cluster waits and
+        # persistent grids that leave RCCL's channel kernels their compute units
+        before = (int(_ffi.lib().cnsn_wait_ms()), int(_ffi.lib().cnsn_headroom_cus()))
+        defaults = _ffi.under_process_group_defaults()
         mod, y, d = _local_step(rank, world)
         local = [p.grad.clone() for p in mod.parameters()]
         dp.allreduce_gradients(mod.parameters())
-        out[rank] = dict(y=y, perm=d.perm, box=d.content_box, local=local,
+        out[rank] = dict(y=y, perm=d.perm, box=d.content_box, local=local, before=before, defaults=defaults,
                          reduced=[p.grad.clone() for p in mod.parameters()])
         dist.barrier()
     finally:
@@ -61,6 +66,8 @@ def test_two_rank_data_parallel_gloo():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     r0, r1 = out[0], out[1]
+    for r in (r0, r1):
+        assert r["before"] == (5000, 0) and r["defaults"] == {"wait_ms": 2000, "headroom_cus": 32}, (r["before"], r["defaults"])
     # ranks drew different permutations / boxes (per-rank seed offset)
     assert not (torch.equal(r0["perm"], r1["perm"]) and r0["box"] == r1["box"])
     # the all-reduce averaged exactly the two local gradients, identically on both ranks
@@ -71,6 +78,29 @@ def test_two_rank_data_parallel_gloo():
     for rank, r in ((0, r0), (1, r1)):
         _, y_single, _ = _local_step(rank, world)
         assert torch.equal(r["y"], y_single)
+
+
+def test_process_group_defaults_follow_the_environment(monkeypatch):
+    from cnsn_amd import _ffi
+    assert _ffi.under_process_group_defaults() == {}                 # no process group: nothing changes
+    assert _ffi.default_headroom_cus() == 32
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "8")
+    assert _ffi.default_headroom_cus() == 16
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "64")
+    assert _ffi.default_headroom_cus() == 64                         # never more than a quarter of the part
+    lib = _ffi.lib()
+    try:
+        lib.cnsn_set_headroom_cus(24)
+        assert lib.cnsn_headroom_cus() == 24
+        monkeypatch.setenv("CNSN_HEADROOM_CUS", "0")                 # the environment wins over the setter
+        lib.cnsn_reload_env()
+        assert lib.cnsn_headroom_cus() == 0
+        monkeypatch.delenv("CNSN_HEADROOM_CUS")
+        lib.cnsn_reload_env()
+        assert lib.cnsn_headroom_cus() == 24
+    finally:
+        lib.cnsn_set_headroom_cus(0)
+        lib.cnsn_reload_env()
 
 
 def test_shard_batch_covers_everything():

@@ -1,5 +1,5 @@
 """cnsn_amd.arena — the op's outputs live in address ranges mapped from small physical allocations (C ABI `cnsn_arena_*`,
-include/cnsn_hip.h; why: profiles/r04_memory_map.md, profiles/r05_arena.md).  The reference's op returns new tensors
+include/cnsn_hip.h; why: profiles/r04_memory_map.md, profiles/r05_arena.md), handed out through a torch MemPool since round 6.  The reference's op returns new tensors
 (models/cnsn.py:29,150): WHERE they lie must be invisible in the results and in the tensors' behaviour."""
 import ctypes as C
 import gc
@@ -39,6 +39,7 @@ def _owned(t):
 
 
 def test_c_abi_alloc_free_reuse_and_trim():
+    """the C ABI's own caching layer (callers without a torch allocator to plug into)"""
     lib = cnsn_amd.lib()
     arena.trim()
     s0 = arena.stats(DEV)
@@ -47,25 +48,65 @@ def test_c_abi_alloc_free_reuse_and_trim():
     assert p and p % 16 == 0 and lib.cnsn_arena_owns(C.c_void_p(p)) == 1 and lib.cnsn_arena_owns(C.c_void_p(p + (100 << 20) - 1)) == 1
     s1 = arena.stats(DEV)
     assert s1["misses"] == s0["misses"] + 1 and s1["blocks_in_use"] == s0["blocks_in_use"] + 1
-    assert s1["chunk_bytes"] == 56 << 20 and s1["in_use_bytes"] - s0["in_use_bytes"] == 2 * (56 << 20)      # whole chunks
+    # one 56 MiB chunk + a 44 MiB tail chunk: what is held is the request rounded to the driver's granularity, not whole chunks
+    assert s1["chunk_bytes"] == 56 << 20 and s1["in_use_bytes"] - s0["in_use_bytes"] == 100 << 20
+    assert lib.cnsn_arena_record_stream(C.c_void_p(p), stream) == 0
     assert lib.cnsn_arena_free(C.c_void_p(p)) == 0
     assert lib.cnsn_arena_free(C.c_void_p(p)) < 0                               # not handed out: refused, nothing corrupted
+    assert lib.cnsn_arena_record_stream(C.c_void_p(p), stream) < 0
     assert lib.cnsn_arena_free(C.c_void_p(12345)) < 0
-    q = lib.cnsn_arena_alloc(0, 90 << 20, stream)                               # same number of chunks: the block comes back
+    q = lib.cnsn_arena_alloc(0, 90 << 20, stream)                               # within an eighth of a free block: it comes back
     assert q == p and arena.stats(DEV)["hits"] == s1["hits"] + 1
+    lib.cnsn_arena_free(C.c_void_p(q))
+    small = lib.cnsn_arena_alloc(0, 40 << 20, stream)                           # the 100 MiB block would waste more than 1/8: new
+    assert small and small != p and arena.stats(DEV)["misses"] == s1["misses"] + 1
+    lib.cnsn_arena_free(C.c_void_p(small))
     assert lib.cnsn_arena_alloc(0, 0, stream) is None
     failed = arena.stats(DEV)["failed"]
     assert lib.cnsn_arena_alloc(0, 400 << 30, stream) is None                   # more than the part has: NULL, the caller falls back
-    assert arena.stats(DEV)["failed"] == failed + 1
+    st = arena.stats(DEV)
+    assert st["failed"] == failed + 1 and st["broken"] == 0                     # ... out of memory is not "does not work here"
     again = lib.cnsn_arena_alloc(0, 10 << 20, stream)                           # ... and the arena goes on serving
     assert again and lib.cnsn_arena_free(C.c_void_p(again)) == 0
-    lib.cnsn_arena_free(C.c_void_p(q))
     freed = arena.trim(DEV)
-    assert freed >= 2 * (56 << 20) and arena.stats(DEV)["mapped_bytes"] == arena.stats(DEV)["in_use_bytes"]
+    assert freed >= (150 << 20) and arena.stats(DEV)["mapped_bytes"] == arena.stats(DEV)["in_use_bytes"]
     assert lib.cnsn_arena_owns(C.c_void_p(p)) == 0
     r = lib.cnsn_arena_alloc(0, 100 << 20, stream)                              # a NEW address range: an unmapped one is never
     assert r and r != p                                                         # mapped again (stale translations, see below)
     lib.cnsn_arena_free(C.c_void_p(r))
+
+
+def test_c_abi_cache_is_capped_and_evicts_the_least_recently_used():
+    """review of round 5: the cache had no cap, no eviction and exact-size lists only.  cnsn_arena_set_limit (default: half of
+    the device memory, CNSN_ARENA_MAX_MB): free blocks go, least recently freed first, when a new block would exceed the cap;
+    with everything in use the request is refused and the caller allocates as it always did."""
+    lib = cnsn_amd.lib()
+    arena.trim()
+    stream = C.c_void_p(torch.cuda.current_stream(DEV).cuda_stream)
+    base = arena.stats(DEV)["mapped_bytes"]
+    arena.set_limit_mb((base >> 20) + 300)
+    try:
+        a = lib.cnsn_arena_alloc(0, 100 << 20, stream)
+        b = lib.cnsn_arena_alloc(0, 60 << 20, stream)
+        lib.cnsn_arena_free(C.c_void_p(a))                                      # a is the older free block
+        lib.cnsn_arena_free(C.c_void_p(b))
+        s0 = arena.stats(DEV)
+        c = lib.cnsn_arena_alloc(0, 200 << 20, stream)                          # 160 + 200 > 300: a goes, b may stay
+        s1 = arena.stats(DEV)
+        assert c and s1["evicted"] == s0["evicted"] + 1 and lib.cnsn_arena_owns(C.c_void_p(a)) == 0
+        assert lib.cnsn_arena_owns(C.c_void_p(b)) == 1 and s1["mapped_bytes"] - base == 260 << 20
+        d = lib.cnsn_arena_alloc(0, 90 << 20, stream)                           # 260 + 90 > 300: b goes too
+        assert d and arena.stats(DEV)["evicted"] == s0["evicted"] + 2
+        failed = arena.stats(DEV)["failed"]
+        assert lib.cnsn_arena_alloc(0, 64 << 20, stream) is None                # everything in use, the cap holds
+        assert arena.stats(DEV)["failed"] == failed + 1 and arena.stats(DEV)["broken"] == 0
+        lib.cnsn_arena_free(C.c_void_p(c))
+        arena.set_limit_mb((base >> 20) + 100)                                  # a lower cap releases free blocks at once
+        assert lib.cnsn_arena_owns(C.c_void_p(c)) == 0
+        lib.cnsn_arena_free(C.c_void_p(d))
+    finally:
+        arena.set_limit_mb(0)
+        arena.trim()
 
 
 def test_trimmed_address_ranges_are_never_mapped_again():
@@ -116,75 +157,142 @@ def test_a_new_large_block_is_the_fastest_of_its_candidates():
     s0 = arena.stats(DEV)
     a = arena.empty_like(small)
     s1 = arena.stats(DEV)
-    assert s1["probed"] == s0["probed"] and s1["blocks"] == s0["blocks"] + 1 and arena.block_gbps(a) == 0.0
-    big = torch.empty(128, 256, 56, 56, device=DEV)                            # 392 MiB: 7 chunks of 56 MiB
+    assert s1["probed"] == s0["probed"] and s1["blocks"] == s0["blocks"] + 1 and arena.block_gbps(a) == 0.0 and _owned(a)
+    big = torch.empty(128, 256, 56, 56, device=DEV)                            # 392 MiB
     b = arena.empty_like(big)
     s2 = arena.stats(DEV)
     assert s2["probed"] == s1["probed"] + 4 and s2["blocks"] == s1["blocks"] + 1 and s2["misses"] == s1["misses"] + 1
     assert s2["mapped_bytes"] - s1["mapped_bytes"] == 392 << 20                # the three losers are gone
     assert arena.block_gbps(b) > 100.0
+    ptr = b.data_ptr()
     del b
     gc.collect()
-    c = arena.empty_like(big)                                                  # steady state: a list pop, nothing timed
-    assert arena.stats(DEV)["probed"] == s2["probed"] and arena.stats(DEV)["hits"] == s2["hits"] + 1
+    c = arena.empty_like(big)                                                  # steady state: torch's cache, nothing created or timed
+    s3 = arena.stats(DEV)
+    assert c.data_ptr() == ptr and s3["probed"] == s2["probed"] and s3["misses"] == s2["misses"]
     arena.set_tries(1)
     d = arena.empty_like(big)
     assert arena.stats(DEV)["probed"] == s2["probed"] and arena.block_gbps(d) == 0.0
     del a, c, d
     gc.collect()
-    arena.trim()
+    assert arena.trim() >= 2 * (392 << 20)
     arena.set_tries(0)
 
 
 def test_prospect_keeps_the_fastest_blocks_on_the_free_list():
+    """(the C ABI's own cache: cnsn_arena_prospect feeds cnsn_arena_alloc)"""
+    lib = cnsn_amd.lib()
     arena.trim()
     x = torch.randn(64, 64, 56, 56, device=DEV)                                # 51 MB
+    nbytes = x.numel() * 4
+    stream = C.c_void_p(torch.cuda.current_stream(DEV).cuda_stream)
     s0 = arena.stats(DEV)
     rep = arena.prospect(x, keep=2, candidates=6)
     s1 = arena.stats(DEV)
     assert rep["candidates"] == 6 and rep["kept"] == 2 and len(rep["GBps_fill"]) == 6
     assert rep["GBps_fill"] == sorted(rep["GBps_fill"], reverse=True) and rep["GBps_fill"][-1] > 100.0
     assert s1["blocks"] == s0["blocks"] + 2 and s1["blocks_in_use"] == s0["blocks_in_use"]      # the other four went back
-    a, b = arena.empty_like(x), arena.empty_like(x)                            # the kept blocks, fastest first
+
+    def gbps(p):
+        v = C.c_float(0.0)
+        assert lib.cnsn_arena_block_gbps(C.c_void_p(p), C.byref(v)) == 0
+        return float(v.value)
+
+    a, b = lib.cnsn_arena_alloc(0, nbytes, stream), lib.cnsn_arena_alloc(0, nbytes, stream)    # the kept blocks, fastest first
     assert arena.stats(DEV)["misses"] == s1["misses"]
-    ga, gb = arena.block_gbps(a), arena.block_gbps(b)
+    ga, gb = gbps(a), gbps(b)
     assert ga >= gb > 0 and round(ga, 1) == rep["GBps_fill"][0] and round(gb, 1) == rep["GBps_fill"][1]
-    arena.set_tries(1)
-    c = arena.empty_like(x)                                                    # a third one: created with one try, never measured
-    assert arena.block_gbps(c) == 0.0
-    del a
-    gc.collect()
-    assert arena.block_gbps(arena.empty_like(x)) == ga                         # a measured free block goes first
+    c = lib.cnsn_arena_alloc(0, nbytes, stream)                                # a third one: below the timed size, never measured
+    assert gbps(c) == 0.0
+    lib.cnsn_arena_free(C.c_void_p(a))
+    assert lib.cnsn_arena_alloc(0, nbytes, stream) == a                        # a measured free block goes first
+    for p in (a, b, c):
+        lib.cnsn_arena_free(C.c_void_p(p))
 
 
-def test_outputs_above_the_threshold_come_from_the_arena_and_go_back_to_it():
+def test_outputs_above_the_threshold_come_from_the_arena_and_torch_sees_them():
+    """review of round 5, "outputs that torch's allocator knows about" (models/cnsn.py:29,150 return ordinary tensors): the
+    arena's blocks are segments of a torch MemPool — counted, cached, split and released by the caching allocator"""
     arena.enable(min_mb=8)
     x = torch.randn(32, 32, 56, 56, device=DEV, requires_grad=True)            # 12.8 MB
     mod = cnsn_amd.CNSN(cnsn_amd.CrossNorm("neither", 1), fill_sn(cnsn_amd.SelfNorm(32), 3, torch.float32)).to(DEV).train()
     mod.crossnorm.active = True
+    nbytes = x.numel() * 4
+    m0 = torch.cuda.memory_allocated(DEV)
     y = mod(x)
     assert _owned(y) and y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype and y.device == x.device
+    assert torch.cuda.memory_allocated(DEV) - m0 >= nbytes                     # torch.cuda.memory_allocated counts the output
     gx, = torch.autograd.grad(y, [x], torch.randn_like(y))
     assert _owned(gx)
+    segs = torch.cuda.memory_snapshot(arena.pool_id(DEV))
+    assert segs and all(cnsn_amd.lib().cnsn_arena_owns(C.c_void_p(s["address"])) == 1 for s in segs)
     ptr = y.data_ptr()
-    in_use = arena.stats(DEV)["blocks_in_use"]
     z = (y * 2).sum()                          # torch ops read arena tensors like any other
     assert torch.isfinite(z)
     v = y.view(32, -1)[3:5]                     # views keep the block alive
     del y
-    assert arena.stats(DEV)["blocks_in_use"] == in_use
-    del v, gx
+    m1 = torch.cuda.memory_allocated(DEV)
+    del v
     gc.collect()
-    assert arena.stats(DEV)["blocks_in_use"] == in_use - 2
+    assert m1 - torch.cuda.memory_allocated(DEV) >= nbytes
     with torch.no_grad():
         y2 = mod(x)                             # the freed block serves the next call of the same size
-    assert y2.data_ptr() in (ptr, ) or _owned(y2)
+    assert y2.data_ptr() == ptr
+    y2.record_stream(torch.cuda.Stream(DEV))    # ... and record_stream means what it means for any tensor
     small = torch.randn(2, 32, 56, 56, device=DEV)
     with torch.no_grad():
-        assert not _owned(mod(small))           # below the threshold: torch's allocator, as before
+        assert not _owned(mod(small))           # below the threshold: torch's default pool, as before
     arena.disable()
     with torch.no_grad():
         assert not _owned(mod(x))
+
+
+def test_a_smaller_batch_reuses_the_blocks_of_the_full_one():
+    """review of round 5: exact-size free lists made every distinct batch size (the last, partial batch of an epoch) pin a
+    block set of its own.  The caching allocator splits the pool's free blocks instead."""
+    arena.enable(min_mb=1)
+    arena.trim()
+    sn = fill_sn(cnsn_amd.SelfNorm(64), 4, torch.float32).to(DEV).eval()
+    with torch.no_grad():
+        for n in (64, 64):
+            y = sn(torch.randn(n, 64, 56, 56, device=DEV))
+            assert _owned(y)
+            del y
+        mapped = arena.stats(DEV)["mapped_bytes"]
+        for n in (48, 33, 64, 17, 50):
+            y = sn(torch.randn(n, 64, 56, 56, device=DEV))
+            assert _owned(y)
+            del y
+        assert arena.stats(DEV)["mapped_bytes"] == mapped
+
+
+def test_free_arena_blocks_do_not_cause_an_out_of_memory_error():
+    """review of round 5: blocks the arena held were invisible to torch's free-cache-and-retry, so a model near the HBM limit
+    that fits with the reference's plain allocation could fail with the arena on.  Now: an allocation that does not fit next to
+    the pool's FREE blocks gets them (use_on_oom / the allocator's out-of-memory path)."""
+    arena.enable(min_mb=1)
+    arena.trim()
+    gc.collect()
+    torch.cuda.empty_cache()
+    like = torch.empty(1 << 30, dtype=torch.uint8, device=DEV)
+    a = arena.empty_like(like)                                                  # 1 GiB block of the arena, then free in its pool
+    assert _owned(a)
+    del a, like
+    gc.collect()
+    torch.cuda.empty_cache()
+    free_b, _ = torch.cuda.mem_get_info(DEV)
+    filler = torch.empty(free_b - (512 << 20), dtype=torch.uint8, device=DEV)   # the device is full but for 512 MiB
+    try:
+        t = torch.empty(900 << 20, dtype=torch.uint8, device=DEV)               # fits only with the arena's idle GiB
+        t.fill_(3)
+        torch.cuda.synchronize()
+        assert int(t[-1]) == 3
+        del t
+    finally:
+        del filler
+        gc.collect()
+        torch.cuda.empty_cache()
+        arena.trim()
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
@@ -243,31 +351,39 @@ def test_fused_block_and_building_blocks_use_it_too():
     assert _owned(out)
 
 
-def test_a_block_last_used_on_another_stream_is_ordered_behind_it():
-    """a block freed after work was queued on stream A and handed out on stream B: B's launch must not overtake A's reads"""
+def test_a_block_used_on_another_stream_is_protected_by_record_stream():
+    """review of round 5: `y.record_stream(s)` was a no-op on the arena's from_blob tensors (the caching allocator ignores
+    pointers it did not allocate), so a block could be re-used while another stream still read it.  As pool blocks they follow
+    the allocator's rules: a block freed while stream B's recorded work is pending is not handed out again before that work is
+    done, and a request on another stream never gets a block of stream A."""
     arena.enable(min_mb=1)
     x = torch.randn(64, 64, 56, 56, device=DEV)
     sn = fill_sn(cnsn_amd.SelfNorm(64), 4, torch.float32).to(DEV).eval()
-    a, b = torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)
+    b = torch.cuda.Stream(DEV)
     torch.cuda.synchronize()
     with torch.no_grad():
         want = sn(x).clone()
         torch.cuda.synchronize()
         for _ in range(10):
-            with torch.cuda.stream(a):
-                y = sn(x)                               # block handed out on A
-                acc = y.clone()
-                for _ in range(20):                     # a queue of reads of y on A
-                    acc = torch.maximum(acc, y)
-                ptr = y.data_ptr()
-                del y                                   # freed while A still has work queued that reads it
+            y = sn(x)                                   # block handed out on the current stream
+            assert _owned(y)
+            ptr = y.data_ptr()
+            b.wait_stream(torch.cuda.current_stream(DEV))
             with torch.cuda.stream(b):
-                t = _ffi.glue().arena_empty_like(x)     # the same block, now on B ...
-                assert t.data_ptr() == ptr
-                t.fill_(float("nan"))                   # ... overwritten at once
+                acc = y.clone()
+                for _ in range(20):                     # a queue of reads of y on B
+                    acc = torch.maximum(acc, y)
+            y.record_stream(b)
+            del y                                       # freed while B still has work queued that reads it
+            t = arena.empty_like(x)                     # the next request on the first stream ...
+            t.fill_(float("nan"))                       # ... overwrites its block at once
+            assert _owned(t) and t.data_ptr() != ptr    # (not y's block: B's reads are still pending)
+            with torch.cuda.stream(b):
+                u = arena.empty_like(x)                 # a request on B never gets a block that belongs to another stream
+                assert u.data_ptr() not in (ptr, t.data_ptr())
             torch.cuda.synchronize()
             assert torch.equal(acc, want)
-            del t
+            del t, u
 
 
 def test_graph_capture_stays_on_torchs_allocator():

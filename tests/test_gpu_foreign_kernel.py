@@ -118,6 +118,80 @@ def test_grid_headroom_next_to_32_held_cus(headroom_env):
 
 
 @pytest.mark.skipif(not os.path.exists(LIB), reason="tools/liboccupy.so not built")
+def test_process_group_defaults_keep_the_headline_step_at_its_quiet_time(monkeypatch):
+    """review of round 5, item 3: the first real 8-rank run must not be a time-out log.  What `_ffi.under_process_group_defaults`
+    sets WITHOUT being asked (2 s waits, grid head-room for RCCL's channels) is what a rank runs with: the headline step
+    (256,256,56,56) fp32 CrossNorm+SelfNorm next to a foreign kernel that holds 32 CUs for longer than the step — zero
+    time-outs, the same bits, and no more than 1.1 x the quiet time (a full-size grid measured 1.5-1.7 x,
+    profiles/r05_exchange_hardening.md)."""
+    import torch.distributed as dist
+    from cnsn_amd import _ffi
+    monkeypatch.delenv("CNSN_HEADROOM_CUS", raising=False)
+    monkeypatch.delenv("CNSN_WAIT_MS", raising=False)
+    cnsn_amd.reload_env()
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 8)
+    lib = cnsn_amd.lib()
+    try:
+        assert _ffi.under_process_group_defaults() == {"wait_ms": 2000, "headroom_cus": 32}
+        occ = C.CDLL(LIB)
+        occ.occupy_launch.restype = C.c_int
+        occ.occupy_launch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+        shape = (256, 256, 56, 56)
+        g = torch.Generator(device=DEV).manual_seed(11)
+        x = (torch.randn(shape, device=DEV, generator=g) + 0.3).requires_grad_()
+        gy = torch.randn(shape, device=DEV, generator=g)
+        cn = cnsn_amd.CrossNorm("neither", 1)
+        mod = cnsn_amd.CNSN(cn, fill_sn(cnsn_amd.SelfNorm(shape[1]), 3, torch.float32)).to(DEV).train()
+        state = {k: v.clone() for k, v in mod.state_dict().items()}
+        draws = cnsn_amd.draw_cn(shape, "neither", 1)
+
+        def run():
+            mod.load_state_dict(state)
+            cn.active = True
+            cn.next_draws = draws
+            y = mod(x)
+            gx, = torch.autograd.grad(y, [x], gy)
+            return y.detach(), gx
+
+        want = [t.clone() for t in run()]
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        before = lib.cnsn_resident_timeouts()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        e[0].record()
+        for _ in range(10):
+            run()
+        e[1].record()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=DEV)
+        assert occ.occupy_launch(32, 160 * 1024, 70, C.c_void_p(side.cuda_stream)) == 0
+        time.sleep(0.002)
+        e[2].record()
+        got = [run() for _ in range(10)]
+        e[3].record()
+        torch.cuda.current_stream().synchronize()
+        held = not side.query()
+        side.synchronize()
+        quiet_ms, busy_ms = e[0].elapsed_time(e[1]) / 10, e[2].elapsed_time(e[3]) / 10
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump({"headroom_cus": 32, "cus_held": 32, "quiet_ms": round(quiet_ms, 4), "busy_ms": round(busy_ms, 4),
+                   "foreign_kernel_outlived_ours": bool(held)},
+                  open(os.path.join(ROOT, "gpurun_out", "foreign_kernel_pg_defaults.json"), "w"), indent=1)
+        assert held, "the foreign kernel ended before the steps did: nothing was tested"
+        assert lib.cnsn_resident_timeouts() == before
+        for out in got:
+            for a, b in zip(out, want):
+                assert torch.equal(a, b)
+        assert busy_ms <= 1.1 * quiet_ms, (quiet_ms, busy_ms)
+    finally:
+        lib.cnsn_set_headroom_cus(0)
+        lib.cnsn_set_wait_ms(0)
+        _ffi.forget_plans()
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="tools/liboccupy.so not built")
 @pytest.mark.parametrize("cus", [16, 64, 128])
 def test_cluster_kernels_next_to_a_foreign_persistent_kernel(cus):
     occ = C.CDLL(LIB)
