@@ -214,12 +214,20 @@ class SelfNorm(nn.Module):
         `forward` then composes the op from its building blocks (`_forward_composed`)."""
         mods = self._modules                        # (plain dict reads: this runs on every forward)
         g_bn = mods["g_bn"]
-        if type(g_bn) is not nn.BatchNorm1d or g_bn._parameters["weight"] is None or g_bn._parameters["bias"] is None:
+
+        def affine(bn):
+            # a replica made by nn.DataParallel (cifar.py:395) keeps its parameters as plain attributes in __dict__ and an EMPTY
+            # `_parameters` (torch/nn/parallel/replicate.py): look in both places (tests/test_gpu_data_parallel_one_device.py)
+            par, own = bn._parameters, bn.__dict__
+            return (par.get("weight") if "weight" in par else own.get("weight")) is not None and \
+                   (par.get("bias") if "bias" in par else own.get("bias")) is not None
+
+        if type(g_bn) is not nn.BatchNorm1d or not affine(g_bn):
             return False
         if self.f_fc is None:
             return True
         f_bn = mods["f_bn"]
-        if type(f_bn) is not nn.BatchNorm1d or f_bn._parameters["weight"] is None or f_bn._parameters["bias"] is None:
+        if type(f_bn) is not nn.BatchNorm1d or not affine(f_bn):
             return False
         return self._bn_peek(g_bn) == self._bn_peek(f_bn)
 

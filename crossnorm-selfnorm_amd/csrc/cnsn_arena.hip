@@ -448,12 +448,14 @@ void* cnsn_arena_alloc(int device, size_t bytes, void* stream_) {
         std::vector<Block*> drop;
         const uint64_t cap = resolve_limit(d);
         if (d.mapped + need > cap) {  // the cap: least recently used free blocks make room
-            evict_lru(a, d, need, cap, &drop);
-            settle_and_release(drop);
-            if (d.mapped + need > cap) {  // (everything left is in use: the caller allocates as it always did)
+            uint64_t idle = 0;
+            for (auto& kv : d.free_by_size) idle += kv.first;
+            if (d.mapped - idle + need > cap) {  // (not even with every free block gone: the caller allocates as it always did)
                 ++d.failed;
                 return nullptr;
             }
+            evict_lru(a, d, need, cap, &drop);
+            settle_and_release(drop);
         }
         hipError_t err = hipSuccess;
         b = new_block(a, d, device, need, stream, &err);

@@ -91,16 +91,16 @@ namespace hca = c10::hip::HIPCachingAllocator;
 struct ArenaPools {
     std::mutex mu;
     std::shared_ptr<hca::HIPAllocator> allocator;
-    std::unordered_map<int, at::cuda::MemPool*> by_device;  // (leaked on purpose: tensors outlive static destructors)
+    std::unordered_map<int, std::shared_ptr<at::cuda::MemPool>> by_device;
     bool unusable = false;  // this torch build refused the pool once: torch's default pool from then on
 };
 ArenaPools& arena_pools() {
-    static ArenaPools* p = new ArenaPools;
+    static ArenaPools* p = new ArenaPools;  // (leaked on purpose: tensors outlive static destructors)
     return *p;
 }
 
 // the pool of `device` (created on first use with that device current), or nullptr
-at::cuda::MemPool* arena_pool(int device) {
+std::shared_ptr<at::cuda::MemPool> arena_pool(int device) {
     ArenaPools& ps = arena_pools();
     std::lock_guard<std::mutex> lock(ps.mu);
     if (ps.unusable) return nullptr;
@@ -112,7 +112,7 @@ at::cuda::MemPool* arena_pool(int device) {
                 [](size_t bytes, int dev, hipStream_t stream) { return cnsn_arena_map(bytes, dev, (void*)stream); },
                 [](void* ptr, size_t bytes, int dev, hipStream_t stream) { cnsn_arena_unmap(ptr, bytes, dev, (void*)stream); });
         c10::DeviceGuard guard(c10::Device(c10::DeviceType::CUDA, (c10::DeviceIndex)device));
-        auto* pool = new at::cuda::MemPool(ps.allocator.get(), /*is_user_created=*/true, /*use_on_oom=*/true);
+        std::shared_ptr<at::cuda::MemPool> pool(new at::cuda::MemPool(ps.allocator.get(), /*is_user_created=*/true, /*use_on_oom=*/true));
         ps.by_device.emplace(device, pool);
         return pool;
     } catch (const c10::Error&) {
@@ -125,13 +125,15 @@ at::cuda::MemPool* arena_pool(int device) {
 struct ToArenaPool {
     c10::DeviceIndex dev;
     c10::MempoolId_t id;
-    ToArenaPool(int device, at::cuda::MemPool* pool) : dev((c10::DeviceIndex)device), id(pool->id()) {
+    std::shared_ptr<at::cuda::MemPool> pool;  // (a trim may retire the pool meanwhile: the last holder destroys it)
+    ToArenaPool(int device, std::shared_ptr<at::cuda::MemPool> p) : dev((c10::DeviceIndex)device), id(p->id()), pool(std::move(p)) {
         const auto tid = std::this_thread::get_id();
         hca::beginAllocateToPool(dev, id, [tid](hipStream_t) { return std::this_thread::get_id() == tid; });
     }
     ~ToArenaPool() {
         hca::endAllocateToPool(dev, id);
         hca::releasePool(dev, id);
+        pool.reset();  // (after the pool's use count is back to what ~MemPool expects)
     }
 };
 
@@ -142,24 +144,34 @@ Tensor arena_empty(at::IntArrayRef sizes, at::IntArrayRef strides, const at::Ten
         (void)hipGetLastError();
         return Tensor();
     }
-    at::cuda::MemPool* pool = arena_pool((int)dev.index());
+    std::shared_ptr<at::cuda::MemPool> pool = arena_pool((int)dev.index());
     if (!pool) return Tensor();
-    ToArenaPool scope((int)dev.index(), pool);
+    ToArenaPool scope((int)dev.index(), std::move(pool));
     // (out of memory: the caching allocator has by now released its own caches AND this pool's; the error is the one the
     // reference's plain allocation would raise)
     return at::empty_strided(sizes, strides, opt.device(dev));
 }
 
-// bytes the pool of `device` gives back to the driver (free cached blocks; `torch.cuda.empty_cache()` leaves user pools alone)
+// Give the free cached blocks of the arena's pool on `device` (< 0: every device) back to the driver.  The caching allocator
+// releases the cached blocks of a user pool only once nobody holds the pool (`emptyCache(id)` walks the FREEABLE pools), so a
+// trim RETIRES the pool: ~MemPool drops the last reference and empties its cache, tensors still alive keep their blocks (which
+// go back to the retired pool and are released by the next `torch.cuda.empty_cache()` or out-of-memory retry), and the next
+// output gets a fresh pool.
 void arena_pool_trim(int device) {
     ArenaPools& ps = arena_pools();
-    std::vector<c10::MempoolId_t> ids;
+    std::vector<std::shared_ptr<at::cuda::MemPool>> retired;
     {
         std::lock_guard<std::mutex> lock(ps.mu);
-        for (auto& kv : ps.by_device)
-            if (device < 0 || kv.first == device) ids.push_back(kv.second->id());
+        for (auto it = ps.by_device.begin(); it != ps.by_device.end();) {
+            if (device < 0 || it->first == device) {
+                retired.push_back(std::move(it->second));
+                it = ps.by_device.erase(it);
+            } else {
+                ++it;
+            }
+        }
     }
-    for (auto id : ids) hca::emptyCache(id);
+    retired.clear();  // (~MemPool here, or in the thread that is allocating from it right now when its scope ends)
 }
 
 // `x` is dense (contiguous in NCHW or channels-last order, aligned): a fresh tensor of its shape, type AND memory order for an
@@ -748,7 +760,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("arena_trim", [](int64_t device) { arena_pool_trim((int)device); },
           "release the free cached blocks of the arena's torch pool (device < 0: every device)");
     m.def("arena_pool_id", [](int64_t device) {
-        at::cuda::MemPool* p = arena_pool((int)device);
+        std::shared_ptr<at::cuda::MemPool> p = arena_pool((int)device);
         return p ? std::make_pair((int64_t)p->id().first, (int64_t)p->id().second) : std::make_pair((int64_t)0, (int64_t)0);
     }, "id of the torch MemPool behind the arena on `device` ((0, 0): none) — for torch.cuda.memory_snapshot(id)");
     m.def("out_like", &out_like, "the op's output allocation for a dense x: arena from the threshold on, else torch");

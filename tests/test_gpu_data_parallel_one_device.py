@@ -56,18 +56,22 @@ def test_two_replicas_on_one_device_equal_one_thread(crop, hw, arena_mb):
         np.random.seed(3)
         torch.manual_seed(3)
         draws = cnsn_amd.draw_cn((half, c, hw, hw), crop, 1)
-        state = {k: v.clone() for k, v in net.state_dict().items()}
+        state = {k: v.clone() for k, v in net.named_buffers()}
 
         def arm():
-            net.load_state_dict(state)
+            with torch.no_grad():
+                for k, v in net.named_buffers():        # same running statistics / counters in front of every forward
+                    v.copy_(state[k])
             net.site1.crossnorm.active = True
             net.site1.crossnorm.next_draws = draws      # (replicas copy the module's __dict__: both halves use these draws)
-            net.zero_grad(set_to_none=True)
 
         # one thread: the two halves one after the other
         outs = []
+        net.zero_grad(set_to_none=True)
+        arm()
         for part in (slice(0, half), slice(half, n)):
-            arm()
+            net.site1.crossnorm.active = True            # (CrossNorm.forward always disarms itself, models/cnsn.py:108)
+            net.site1.crossnorm.next_draws = draws
             outs.append(net(x[part]))
         loss = nn.functional.cross_entropy(torch.cat(outs), target)
         loss.backward()
@@ -80,6 +84,7 @@ def test_two_replicas_on_one_device_equal_one_thread(crop, hw, arena_mb):
         dp = nn.DataParallel(net, device_ids=[0, 0])
         for _ in range(3):                               # (repeat: thread interleavings differ from run to run)
             arm()
+            net.zero_grad(set_to_none=True)
             logits = dp(x)
             loss = nn.functional.cross_entropy(logits, target)
             loss.backward()

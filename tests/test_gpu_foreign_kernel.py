@@ -169,15 +169,19 @@ def test_process_group_defaults_keep_the_headline_step_at_its_quiet_time(monkeyp
         assert occ.occupy_launch(32, 160 * 1024, 70, C.c_void_p(side.cuda_stream)) == 0
         time.sleep(0.002)
         e[2].record()
-        got = [run() for _ in range(10)]
+        for _ in range(10):
+            run()                                        # (outputs dropped at once, like a training loop's: no new blocks)
         e[3].record()
         torch.cuda.current_stream().synchronize()
         held = not side.query()
+        got = [run() for _ in range(2)]                  # ... and two more next to the holder whose bits are compared
+        torch.cuda.current_stream().synchronize()
+        held_bits = not side.query()
         side.synchronize()
         quiet_ms, busy_ms = e[0].elapsed_time(e[1]) / 10, e[2].elapsed_time(e[3]) / 10
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         json.dump({"headroom_cus": 32, "cus_held": 32, "quiet_ms": round(quiet_ms, 4), "busy_ms": round(busy_ms, 4),
-                   "foreign_kernel_outlived_ours": bool(held)},
+                   "foreign_kernel_outlived_ours": bool(held), "foreign_kernel_outlived_the_compared_steps": bool(held_bits)},
                   open(os.path.join(ROOT, "gpurun_out", "foreign_kernel_pg_defaults.json"), "w"), indent=1)
         assert held, "the foreign kernel ended before the steps did: nothing was tested"
         assert lib.cnsn_resident_timeouts() == before
