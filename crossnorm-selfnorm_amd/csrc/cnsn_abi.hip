@@ -87,6 +87,8 @@ size_t cnsn_context_bytes(const cnsn_problem_t* prob) {
     Plan pl;
     if (make_plan(prob, pl) != CNSN_OK) return 0;
     const cnsn_problem_t& p = pl.pr;
+    if (p.layout == CNSN_LAYOUT_NHWC)  // the single-launch channels-last kernels keep their barrier counter in the control block
+        return (nhwc_slim_record(pl) && nhwc_supported(pl, false) && p.N <= kBlock) ? (size_t)kCtlBytes + 2 * kPongRegion : 0;
     bool any = false;
     for (int bw = 0; bw < 2 && !any; ++bw)
         any = resident_plan(p, pl.boxed, false, bw != 0).ok || resident_fused_plan(p, pl.boxed, false, CNSN_ADD_PRE, bw != 0).ok ||
@@ -146,7 +148,7 @@ size_t cnsn_workspace_bytes(const cnsn_problem_t* prob) {
     Plan pl;
     if (make_plan(prob, pl) != CNSN_OK) return 0;
     if (pl.pr.layout == CNSN_LAYOUT_NHWC)  // (+ the pixel chunks' partial sums and the plane-order rows: cnsn_nhwc.hip)
-        return nhwc_supported(pl, false) ? ((workspace_bytes_of(pl) + 255) & ~(size_t)255) + nhwc_extra_bytes(pl) : 0;
+        return nhwc_workspace_bytes(pl);
     return workspace_bytes_of(pl);
 }
 

@@ -20,6 +20,7 @@ const char* const kNames[K_COUNT] = {
     "CNSN_ARENA_TRIES",
     "CNSN_ARENA_SPREAD_GB",
     "CNSN_MID_BLOCK",
+    "CNSN_NHWC_FUSED",
     "CNSN_ARENA_MAX_MB",
 };
 

@@ -77,7 +77,8 @@ int cnsn_which_path(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int 
     const cnsn_problem_t& p = pl.pr;
     const bool chan = p.cn_active && has_chan_perm;
     const bool bwd = backward != 0;
-    if (p.layout == CNSN_LAYOUT_NHWC) return (chan || !nhwc_supported(pl, false)) ? CNSN_E_UNSUPPORTED : CNSN_PATH_STREAMING;
+    if (p.layout == CNSN_LAYOUT_NHWC)
+        return (chan || !nhwc_supported(pl, false)) ? CNSN_E_UNSUPPORTED : (nhwc_fused_ok(pl) ? CNSN_PATH_RESIDENT : CNSN_PATH_STREAMING);
     // the backward of an epilogue without ReLU and without PRE add is the plain backward
     const bool fused = bwd ? (e.relu || e.add == ADD_PRE) : (e.relu || e.add != ADD_NONE);
     if (resident_sn_prefers(p, pl.boxed, fused ? e.add : ADD_NONE, fused ? e.relu : 0, bwd)) return CNSN_PATH_RESIDENT;

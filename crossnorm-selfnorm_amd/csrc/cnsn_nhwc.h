@@ -14,4 +14,20 @@ int nhwc_backward(Plan& pl, int add, int relu, const void* gy, const void* x, co
                   GateDev f, const float* saved, void* dx, void* d_addend, GateGradDev dg, GateGradDev df, void* workspace,
                   size_t workspace_bytes, hipStream_t stream);
 
+// whole workspace a channels-last call may need (either strategy)
+size_t nhwc_workspace_bytes(const Plan& pl);
+
+// ---- single-launch kernels (cnsn_nhwc_fused.hip; SelfNorm alone, one gate, N <= 256) and the slim `saved` record they share with
+// the two-pass kernels (cnsn_nhwc_fused_kernels.h)
+bool nhwc_slim_record(const Plan& pl);  // this call's `saved` is the slim record (channels-last, no CrossNorm, one gate)
+bool nhwc_fused_ok(const Plan& pl);     // the single-launch kernels take the call (strategy, switches, health, shape)
+size_t nhwc_fused_extra_bytes(const Plan& pl);
+int nhwc_fused_forward(Plan& pl, int add, int relu, const void* x, const void* addend, GateDev g, void* y, float* saved,
+                       void* workspace, size_t workspace_bytes, hipStream_t stream);
+int nhwc_fused_backward(Plan& pl, int add, int relu, const void* gy, const void* x, const void* addend, GateDev g,
+                        const float* saved, void* dx, void* d_addend, GateGradDev dg, void* workspace, size_t workspace_bytes,
+                        hipStream_t stream);
+void nhwc_slim_from_saved(const Plan& pl, const double* saved_d, float* slim, hipStream_t stream);
+void nhwc_saved_from_slim(const Plan& pl, const float* slim, int relu, double* saved_d, float* rows, hipStream_t stream);
+
 }  // namespace cnsn

@@ -74,7 +74,16 @@ bool nhwc_supported(const Plan& pl, bool has_chan_perm) {
 
 size_t nhwc_extra_bytes(const Plan& pl) {
     const NhwcGeom g = make_nhwc_geom(pl);
-    return align256((size_t)g.S * 2 * g.P * 4) + align256(4 * g.P * 4) + 256;  // part | kshift (forward) / rows (backward)
+    // part | kshift (forward) / rows (backward) | the common `saved` record a SelfNorm-only backward expands the slim one into
+    return align256((size_t)g.S * 2 * g.P * 4) + align256(4 * g.P * 4) + (nhwc_slim_record(pl) ? align256(saved_doubles_of(pl) * 8) : 0) +
+           256;
+}
+
+size_t nhwc_workspace_bytes(const Plan& pl) {
+    if (!nhwc_supported(pl, false)) return 0;
+    const size_t two_pass = align256(workspace_bytes_of(pl)) + nhwc_extra_bytes(pl);
+    const size_t fused = nhwc_slim_record(pl) ? nhwc_fused_extra_bytes(pl) : 0;
+    return two_pass > fused ? two_pass : fused;
 }
 
 int nhwc_forward(Plan& pl, int add, int relu, const void* x, const void* addend, const int64_t* perm, GateDev g, GateDev f, void* y,
@@ -82,13 +91,18 @@ int nhwc_forward(Plan& pl, int add, int relu, const void* x, const void* addend,
     const cnsn_problem_t& p = pl.pr;
     if (!nhwc_supported(pl, false)) return CNSN_E_UNSUPPORTED;
     if (p.cn_active && !perm) return CNSN_E_UNSUPPORTED;  // (the mid kernels read the device array)
+    if (nhwc_fused_ok(pl)) {  // SelfNorm (+ epilogue) in ONE launch: cnsn_nhwc_fused_kernels.h
+        const int st = nhwc_fused_forward(pl, add, relu, x, addend, g, y, saved, workspace, workspace_bytes, stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
+    }
     const size_t base = align256(workspace_bytes_of(pl));
     if (workspace_bytes < base + nhwc_extra_bytes(pl)) return CNSN_E_WORKSPACE;
     const NhwcGeom ng = make_nhwc_geom(pl);
-    pl.mid.save_coefs = (relu && saved) ? 1 : 0;
+    const bool slim = nhwc_slim_record(pl);  // `saved` holds the slim record: the mid kernel's own goes to the workspace
+    pl.mid.save_coefs = (relu && saved && !slim) ? 1 : 0;
     const size_t P = pl.P;
     double* mom = (double*)workspace;
-    double* saved_d = saved ? (double*)saved : mom + 6 * P;
+    double* saved_d = (saved && !slim) ? (double*)saved : mom + 6 * P;
     float* coef = (float*)(mom + 6 * P + saved_doubles_of(pl));
     float* part = (float*)((char*)workspace + base);
     float* kshift = (float*)((char*)part + align256((size_t)ng.S * 2 * P * 4));
@@ -107,6 +121,7 @@ int nhwc_forward(Plan& pl, int add, int relu, const void* x, const void* addend,
     // all compute units, the same loads inside mid_fwd_kernel's 128-256 workgroups cost it 5-13 us: profiles/r05_mid_blocks.md)
     nhwc_finish_stats_kernel<<<pblocks, kBlock, 0, stream>>>(part, kshift, ng.S, P, ng.M, mom);
     launch_mid_fwd(pl, mom, perm, nullptr, g, f, coef, saved_d, stream);
+    if (slim && saved) nhwc_slim_from_saved(pl, saved_d, saved, stream);
     ApplyCoef cf{coef + FC_A_IN * P, coef + FC_XR * P, coef + FC_B_IN * P, coef + FC_A_OUT * P, coef + FC_B_OUT * P};
     dispatch_nhwc(p.dtype, [&](auto tt, auto vt) {
         using T = typename decltype(tt)::type;
@@ -126,6 +141,10 @@ int nhwc_backward(Plan& pl, int add, int relu, const void* gy, const void* x, co
     if (!nhwc_supported(pl, false)) return CNSN_E_UNSUPPORTED;
     if (p.cn_active && !perm) return CNSN_E_UNSUPPORTED;
     if (add == ADD_POST && relu && !d_addend) return CNSN_E_NULL;
+    if (nhwc_fused_ok(pl)) {
+        const int st = nhwc_fused_backward(pl, add, relu, gy, x, addend, g, saved, dx, d_addend, dg, workspace, workspace_bytes, stream);
+        if (st != CNSN_E_UNSUPPORTED) return st;
+    }
     const size_t base = align256(workspace_bytes_of(pl));
     if (workspace_bytes < base + nhwc_extra_bytes(pl)) return CNSN_E_WORKSPACE;
     const NhwcGeom ng = make_nhwc_geom(pl);
@@ -133,14 +152,19 @@ int nhwc_backward(Plan& pl, int add, int relu, const void* gy, const void* x, co
     double* tmp = (double*)workspace;
     float* sums = (float*)(tmp + BT_ROWS * P);
     float* coef = sums + 4 * P;
-    const double* saved_d = (const double*)saved;
+    const bool slim = nhwc_slim_record(pl);
     float* part = (float*)((char*)workspace + base);
     float* rows = (float*)((char*)part + align256((size_t)ng.S * 2 * P * 4));
+    double* expanded = (double*)((char*)rows + align256(4 * P * 4));  // (slim only)
+    const double* saved_d = slim ? expanded : (const double*)saved;
     const int blocks = ng.N * ng.S * ng.ncb;
     const int pblocks = (int)((P + kBlock - 1) / kBlock);
     // the backward of an epilogue without ReLU and without PRE add is the plain backward
     const int eff_add = (relu || add == ADD_PRE) ? add : ADD_NONE;
-    nhwc_saved_rows_kernel<<<pblocks, kBlock, 0, stream>>>(saved_d, p.N, p.C, relu, rows);
+    if (slim)
+        nhwc_saved_from_slim(pl, saved, relu, expanded, rows, stream);
+    else
+        nhwc_saved_rows_kernel<<<pblocks, kBlock, 0, stream>>>(saved_d, p.N, p.C, relu, rows);
     dispatch_nhwc(p.dtype, [&](auto tt, auto vt) {
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value;

@@ -38,8 +38,9 @@ template <int VEC>
 struct NhwcThread {
     int n, s, vc, r, p0, p1;
     bool active;
-    __device__ __forceinline__ explicit NhwcThread(const NhwcGeom& g) {
-        int b = blockIdx.x;
+    __device__ __forceinline__ explicit NhwcThread(const NhwcGeom& g) : NhwcThread(g, (int)blockIdx.x) {}
+    // tile number b = (n * S + s) * ncb + cb (the two-pass kernels launch one workgroup per tile; the single-launch kernels loop)
+    __device__ __forceinline__ NhwcThread(const NhwcGeom& g, int b) {
         const int cb = b % g.ncb;
         b /= g.ncb;
         s = b % g.S;

@@ -90,12 +90,56 @@ struct PongState {
     int next = 0;
 };
 std::unordered_map<void*, PongState> g_pong;  // (under g_ctx_mu)
+
+// A launch that gave up leaves its context with the control word flipped (every later wait would drain at once), the granule
+// regions half cleared and the barrier counter of the single-launch channels-last kernels short of arrivals.  Nobody uses the
+// cluster kernels until somebody re-arms them (cnsn_resident_rearm); the first launch after that finds the count of time-outs
+// changed and puts the control block back in order — on the stream, in launch order (all cluster launches are chained).
+struct CtxHealth {
+    int timeouts = 0;                  // resident_timeouts() when the context was last known to be in order
+    unsigned long long arrivals = 0;   // barrier arrivals the launches so far have left in the context's counter
+};
+std::unordered_map<void*, CtxHealth> g_health;  // (under g_ctx_mu)
+
+CtxHealth& heal_context_locked(void* context, hipStream_t stream) {
+    CtxHealth& h = g_health[context];
+    const int now = resident_timeouts();
+    if (h.timeouts != now) {
+        if (hipMemsetAsync(context, 0, kCtlBytes, stream) != hipSuccess) (void)hipGetLastError();
+        g_pong.erase(context);
+        h.arrivals = 0;
+        h.timeouts = now;
+    }
+    return h;
+}
 }  // namespace
 
 void resident_context_forget(void* context) {
     std::lock_guard<std::mutex> lock(g_ctx_mu);
     g_ctx_epoch[context] = 0;
     g_pong.erase(context);
+    g_health[context] = CtxHealth{resident_timeouts(), 0ull};
+}
+
+BarArea resident_bar_area(const cnsn_problem_t& p, void* workspace_ctl, hipStream_t stream, unsigned long long arrivals) {
+    BarArea ba{(unsigned*)workspace_ctl, (unsigned long long*)((char*)workspace_ctl + kBarOffset), 0ull, true};
+    if (!p.context || p.context_bytes < (uint64_t)kCtlBytes) return ba;
+    if (const char* e = knob(K_CONTEXT))
+        if (e[0] == '0') return ba;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return ba;  // a replay would repeat `base`: count from zero in the workspace instead
+    }
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    if (g_ctx_epoch.find(p.context) == g_ctx_epoch.end()) return ba;  // never initialised through cnsn_context_init
+    CtxHealth& h = heal_context_locked(p.context, stream);
+    ba.ctl = (unsigned*)p.context;
+    ba.count = (unsigned long long*)((char*)p.context + kBarOffset);
+    ba.base = h.arrivals;
+    ba.need_fill = false;
+    h.arrivals += arrivals;
+    return ba;
 }
 
 bool resident_pong_acquire(const cnsn_problem_t& p, size_t fill_bytes, hipStream_t stream, PongArea* out) {
@@ -112,6 +156,7 @@ bool resident_pong_acquire(const cnsn_problem_t& p, size_t fill_bytes, hipStream
     }
     std::lock_guard<std::mutex> lock(g_ctx_mu);
     if (g_ctx_epoch.find(p.context) == g_ctx_epoch.end()) return false;  // never initialised through cnsn_context_init
+    (void)heal_context_locked(p.context, stream);
     PongState& st = g_pong[p.context];
     if (st.bytes != (size_t)p.context_bytes) st = PongState{(size_t)p.context_bytes, {0, 0}, 0};
     const int r = st.next;
@@ -158,6 +203,7 @@ ExchangeArea resident_exchange_area(const cnsn_problem_t& p, size_t tagged_bytes
         std::lock_guard<std::mutex> lock(g_ctx_mu);
         auto it = g_ctx_epoch.find(p.context);
         if (it == g_ctx_epoch.end()) return ea;  // never initialised through cnsn_context_init: not trusted
+        (void)heal_context_locked(p.context, stream);
         if (const char* e = knob(K_EPOCH_START))  // (tests: start close to the wrap-around)
             if (it->second == 0) it->second = (unsigned)strtoul(e, nullptr, 0);
         epoch = ++it->second;

@@ -1728,6 +1728,21 @@ struct PongArea {
 bool resident_pong_acquire(const cnsn_problem_t& p, size_t fill_bytes, hipStream_t stream, PongArea* out);
 void resident_pong_commit(const cnsn_problem_t& p, size_t fill_bytes);  // the launch was issued: the other region will be clean
 
+// The grid barrier of the single-launch channels-last kernels (cnsn_nhwc_fused_kernels.h): a 64-bit arrival counter in the
+// SECOND half of the control block's second line (bytes 192..199; the first line holds the time-out word every waiting wave
+// polls, bytes 128..135 the ticket counter of SNX_DYNAMIC builds).  In a persistent context the counter only grows — the host
+// counts the arrivals every launch leaves (`arrivals` = barriers x workgroups of this one) and hands out `base`; without a
+// usable context (none, CNSN_CONTEXT=0, stream capture) the caller zeroes kCtlBytes at `workspace_ctl` in front of the launch
+// (`need_fill`).  Control word idle value: 0 either way.  Call inside the ResidentChain.
+constexpr int kBarOffset = 192;
+struct BarArea {
+    unsigned* ctl;
+    unsigned long long* count;
+    unsigned long long base;
+    bool need_fill;
+};
+BarArea resident_bar_area(const cnsn_problem_t& p, void* workspace_ctl, hipStream_t stream, unsigned long long arrivals);
+
 struct ResidentChain {
     explicit ResidentChain(hipStream_t stream);
     ~ResidentChain();
