@@ -14,7 +14,7 @@ STRATEGY_AUTO, STRATEGY_TWO_PASS, STRATEGY_RESIDENT, STRATEGY_LOCAL, STRATEGY_MO
 ADD_NONE, ADD_PRE, ADD_POST = 0, 1, 2
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 PATHS = {0: "streaming", 1: "packed", 2: "resident", 3: "local", 4: "mono"}
-ABI_VERSION = 7
+ABI_VERSION = 8
 PERM_INLINE_MAX = 1024       # CNSN_PERM_INLINE_MAX
 E_UNSUPPORTED = -9
 
@@ -63,7 +63,7 @@ class ArenaStats(C.Structure):
 class Epilogue(C.Structure):
     """cnsn_epilogue_t"""
     _fields_ = [("struct_bytes", C.c_int32), ("add_mode", C.c_int32), ("relu", C.c_int32),
-                ("reserved", C.c_int32), ("addend", C.c_void_p)]
+                ("reserved", C.c_int32), ("addend", C.c_void_p), ("sum_out", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/cnsn_hip.h declares
@@ -111,6 +111,7 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GateGrad),
                                       C.POINTER(GateGrad), C.c_void_p, C.c_size_t, C.c_void_p]),
     "cnsn_which_path": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.c_int, C.c_int]),
+    "cnsn_keeps_sum": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue)]),
     "cnsn_sn_cluster_plan": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.c_int]),
     "cnsn_bnrelu_plan": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.c_int]),
     "cnsn_forward_bnrelu": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.POINTER(BnTail), C.c_void_p,

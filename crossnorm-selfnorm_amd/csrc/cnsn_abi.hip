@@ -88,7 +88,7 @@ size_t cnsn_context_bytes(const cnsn_problem_t* prob) {
     if (make_plan(prob, pl) != CNSN_OK) return 0;
     const cnsn_problem_t& p = pl.pr;
     if (p.layout == CNSN_LAYOUT_NHWC)  // the single-launch channels-last kernels keep their barrier counter in the control block
-        return (nhwc_slim_record(pl) && nhwc_supported(pl, false) && p.N <= kBlock) ? (size_t)kCtlBytes + 2 * kPongRegion : 0;
+        return (nhwc_slim_record(pl) && nhwc_supported(pl, false) && p.N <= kBlock) ? (size_t)kCtlBytes + kBarBlock + 2 * kPongRegion : 0;
     bool any = false;
     for (int bw = 0; bw < 2 && !any; ++bw)
         any = resident_plan(p, pl.boxed, false, bw != 0).ok || resident_fused_plan(p, pl.boxed, false, CNSN_ADD_PRE, bw != 0).ok ||
@@ -98,8 +98,8 @@ size_t cnsn_context_bytes(const cnsn_problem_t* prob) {
     // (+ 256: the scalar-path gather reads whole 256-byte groups)
     if (!any) return 0;
     const size_t general = kCtlBytes + (size_t)p.N * p.C * 6 * 8 + 256, sn = resident_sn_exchange_bytes(p);
-    // + the two untagged granule regions at the end (resident_pong_acquire)
-    return (general > sn ? general : sn) + 2 * kPongRegion;
+    // + the barrier block (resident_bar_area) and the two untagged granule regions at the end (resident_pong_acquire)
+    return (general > sn ? general : sn) + kBarBlock + 2 * kPongRegion;
 }
 
 int cnsn_context_init(void* context, size_t bytes, void* stream) {

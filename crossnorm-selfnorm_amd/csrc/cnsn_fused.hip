@@ -22,10 +22,11 @@ struct EpiPlan {
     int add;  // AddMode
     int relu;
     const void* addend;
+    void* sum_out;  // (ABI 8) where x + addend is kept (PRE, channels-last strategies only)
 };
 
 int parse_epilogue(const cnsn_epilogue_t* epi, EpiPlan& e) {
-    e = EpiPlan{ADD_NONE, 0, nullptr};
+    e = EpiPlan{ADD_NONE, 0, nullptr, nullptr};
     if (!epi) return CNSN_OK;
     if (epi->struct_bytes != (int32_t)sizeof(cnsn_epilogue_t)) return CNSN_E_STRUCT;
     if (epi->add_mode != CNSN_ADD_NONE && epi->add_mode != CNSN_ADD_PRE && epi->add_mode != CNSN_ADD_POST)
@@ -37,12 +38,17 @@ int parse_epilogue(const cnsn_epilogue_t* epi, EpiPlan& e) {
         if (!e.addend) return CNSN_E_NULL;
         if (((uintptr_t)e.addend & 15u) != 0) return CNSN_E_ALIGN;
     }
+    e.sum_out = epi->sum_out;
+    if (e.sum_out) {
+        if (e.add != ADD_PRE) return CNSN_E_UNSUPPORTED;
+        if (((uintptr_t)e.sum_out & 15u) != 0) return CNSN_E_ALIGN;
+    }
     return CNSN_OK;
 }
 
 // the same without looking at the addend pointer (cnsn_which_path)
 int parse_epilogue_shape(const cnsn_epilogue_t* epi, EpiPlan& e) {
-    e = EpiPlan{ADD_NONE, 0, nullptr};
+    e = EpiPlan{ADD_NONE, 0, nullptr, nullptr};
     if (!epi) return CNSN_OK;
     if (epi->struct_bytes != (int32_t)sizeof(cnsn_epilogue_t)) return CNSN_E_STRUCT;
     if (epi->add_mode != CNSN_ADD_NONE && epi->add_mode != CNSN_ADD_PRE && epi->add_mode != CNSN_ADD_POST)
@@ -114,6 +120,14 @@ int cnsn_sn_cluster_plan(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi,
     return resident_sn_plan(pl.pr, pl.boxed, fused ? e.add : ADD_NONE, fused ? e.relu : 0, bwd).ok ? 1 : 0;
 }
 
+int cnsn_keeps_sum(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi) {
+    EpiPlan e;
+    if (!prob || parse_epilogue_shape(epi, e) != CNSN_OK || e.add != ADD_PRE || prob->layout != CNSN_LAYOUT_NHWC) return 0;
+    Plan pl;
+    if (make_plan(prob, pl) != CNSN_OK) return 0;
+    return nhwc_supported(pl, false) ? 1 : 0;
+}
+
 int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const void* x, const int64_t* perm,
                        const int64_t* chan_perm, const cnsn_gate_t* g, const cnsn_gate_t* f, void* y, float* saved,
                        void* workspace, size_t workspace_bytes, void* stream_) {
@@ -130,8 +144,9 @@ int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, c
         if (pl.pr.sn_active && !gate_ok(g)) return CNSN_E_NULL;
         if (pl.pr.sn_active && pl.pr.sn_two && !gate_ok(f)) return CNSN_E_NULL;
         return nhwc_forward(pl, e.add, e.relu, x, e.addend, perm, gate_dev(g), gate_dev(f), y, saved, workspace, workspace_bytes,
-                            (hipStream_t)stream_);
+                            (hipStream_t)stream_, e.sum_out);
     }
+    if (e.sum_out) return CNSN_E_UNSUPPORTED;  // (cnsn_keeps_sum() == 0: single-touch strategies read x and the addend once anyway)
     if (e.add == ADD_NONE && !e.relu)
         return cnsn_forward(prob, x, perm, chan_perm, g, f, y, saved, workspace, workspace_bytes, stream_);
     Plan pl;

@@ -58,7 +58,7 @@ int parse(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, Plan& pl, Tail
     if (pl.pr.layout != CNSN_LAYOUT_NCHW) return CNSN_OK;  // (not offered for channels-last tensors: tp.ok stays false)
     if (epi) {
         if (epi->struct_bytes != (int32_t)sizeof(cnsn_epilogue_t)) return CNSN_E_STRUCT;
-        if (epi->relu || !(epi->add_mode == CNSN_ADD_NONE || epi->add_mode == CNSN_ADD_PRE)) return CNSN_OK;  // (not offered)
+        if (epi->relu || epi->sum_out || !(epi->add_mode == CNSN_ADD_NONE || epi->add_mode == CNSN_ADD_PRE)) return CNSN_OK;  // (not offered)
         tp.add = epi->add_mode;
         tp.addend = epi->addend;
         if (tp.add == ADD_PRE && need_addend) {

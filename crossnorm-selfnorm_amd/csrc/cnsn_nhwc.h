@@ -8,8 +8,9 @@ namespace cnsn {
 bool nhwc_supported(const Plan& pl, bool has_chan_perm);
 // bytes the channels-last path needs behind the two-pass workspace (partial sums of the pixel chunks, plane-order rows)
 size_t nhwc_extra_bytes(const Plan& pl);
+// sum_out (ADD_PRE only, may be null, may alias x): where X = x + addend is kept (cnsn_epilogue_t.sum_out, ABI 8)
 int nhwc_forward(Plan& pl, int add, int relu, const void* x, const void* addend, const int64_t* perm, GateDev g, GateDev f, void* y,
-                 float* saved, void* workspace, size_t workspace_bytes, hipStream_t stream);
+                 float* saved, void* workspace, size_t workspace_bytes, hipStream_t stream, void* sum_out = nullptr);
 int nhwc_backward(Plan& pl, int add, int relu, const void* gy, const void* x, const void* addend, const int64_t* perm, GateDev g,
                   GateDev f, const float* saved, void* dx, void* d_addend, GateGradDev dg, GateGradDev df, void* workspace,
                   size_t workspace_bytes, hipStream_t stream);
@@ -23,7 +24,7 @@ bool nhwc_slim_record(const Plan& pl);  // this call's `saved` is the slim recor
 bool nhwc_fused_ok(const Plan& pl);     // the single-launch kernels take the call (strategy, switches, health, shape)
 size_t nhwc_fused_extra_bytes(const Plan& pl);
 int nhwc_fused_forward(Plan& pl, int add, int relu, const void* x, const void* addend, GateDev g, void* y, float* saved,
-                       void* workspace, size_t workspace_bytes, hipStream_t stream);
+                       void* workspace, size_t workspace_bytes, hipStream_t stream, void* sum_out = nullptr);
 int nhwc_fused_backward(Plan& pl, int add, int relu, const void* gy, const void* x, const void* addend, GateDev g,
                         const float* saved, void* dx, void* d_addend, GateGradDev dg, void* workspace, size_t workspace_bytes,
                         hipStream_t stream);

@@ -87,12 +87,12 @@ size_t nhwc_workspace_bytes(const Plan& pl) {
 }
 
 int nhwc_forward(Plan& pl, int add, int relu, const void* x, const void* addend, const int64_t* perm, GateDev g, GateDev f, void* y,
-                 float* saved, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                 float* saved, void* workspace, size_t workspace_bytes, hipStream_t stream, void* sum_out) {
     const cnsn_problem_t& p = pl.pr;
     if (!nhwc_supported(pl, false)) return CNSN_E_UNSUPPORTED;
     if (p.cn_active && !perm) return CNSN_E_UNSUPPORTED;  // (the mid kernels read the device array)
     if (nhwc_fused_ok(pl)) {  // SelfNorm (+ epilogue) in ONE launch: cnsn_nhwc_fused_kernels.h
-        const int st = nhwc_fused_forward(pl, add, relu, x, addend, g, y, saved, workspace, workspace_bytes, stream);
+        const int st = nhwc_fused_forward(pl, add, relu, x, addend, g, y, saved, workspace, workspace_bytes, stream, sum_out);
         if (st != CNSN_E_UNSUPPORTED) return st;
     }
     const size_t base = align256(workspace_bytes_of(pl));
@@ -112,10 +112,11 @@ int nhwc_forward(Plan& pl, int add, int relu, const void* x, const void* addend,
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value;
         const size_t lds = (size_t)2 * ng.rows * ng.tcb * VEC * 4;
-        if (add == ADD_PRE)
-            nhwc_stats_kernel<T, VEC, ADD_PRE><<<blocks, kBlock, lds, stream>>>((const T*)x, (const T*)addend, ng, part, kshift);
+        if (add == ADD_PRE)  // (keeps X = x + addend in sum_out when the caller asked for it: the apply pass then reads ONE tensor)
+            nhwc_stats_kernel<T, VEC, ADD_PRE><<<blocks, kBlock, lds, stream>>>((const T*)x, (const T*)addend, ng, part, kshift,
+                                                                                 (T*)sum_out);
         else
-            nhwc_stats_kernel<T, VEC, ADD_NONE><<<blocks, kBlock, lds, stream>>>((const T*)x, nullptr, ng, part, kshift);
+            nhwc_stats_kernel<T, VEC, ADD_NONE><<<blocks, kBlock, lds, stream>>>((const T*)x, nullptr, ng, part, kshift, nullptr);
     });
     // (merging the pixel chunks inside the mid kernel instead of by this launch was measured: the finishing kernel takes 5-7 us on
     // all compute units, the same loads inside mid_fwd_kernel's 128-256 workgroups cost it 5-13 us: profiles/r05_mid_blocks.md)
@@ -126,6 +127,10 @@ int nhwc_forward(Plan& pl, int add, int relu, const void* x, const void* addend,
     dispatch_nhwc(p.dtype, [&](auto tt, auto vt) {
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value;
+        if (add == ADD_PRE && sum_out) {
+            nhwc_apply_fwd_kernel<T, VEC, ADD_NONE><<<blocks, kBlock, 0, stream>>>((const T*)sum_out, nullptr, (T*)y, ng, cf, relu);
+            return;
+        }
         with_add3(add, [&](auto at) {
             constexpr int ADD = decltype(at)::value;
             nhwc_apply_fwd_kernel<T, VEC, ADD><<<blocks, kBlock, 0, stream>>>((const T*)x, (const T*)addend, (T*)y, ng, cf, relu);

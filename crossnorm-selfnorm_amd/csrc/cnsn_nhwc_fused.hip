@@ -67,20 +67,22 @@ NhwcFusedArgs make_args(const Plan& pl, const NhwcGeom& ng, int relu, int gc) {
     return a;
 }
 
-// issue `kern` with a co-resident grid; barriers x grid arrivals are booked on the context before the launch
+// issue `kern` with a co-resident grid (a multiple of 8: the barrier's groups are equal); the barriers are booked on the
+// context before the launch
 template <typename Kern, typename... Args>
-int launch_fused(const Plan& pl, Kern kern, size_t lds, NhwcFusedArgs& a, void* ws_ctl, hipStream_t stream, Args... args) {
-    int grid = reshost::grid_for(kern, lds, 1, a.ntiles);
-    if (grid < 1) return CNSN_E_UNSUPPORTED;
+int launch_fused(const Plan& pl, Kern kern, size_t lds, NhwcFusedArgs& a, void* ws_bar, hipStream_t stream, Args... args) {
+    const int grid = reshost::grid_for(kern, lds, 8, a.ntiles & ~7);
+    if (grid < 8) return CNSN_E_UNSUPPORTED;
     ResidentChain chain(stream);  // persistent grids of different streams never overlap
-    const BarArea ba = resident_bar_area(pl.pr, ws_ctl, stream, 2ull * (unsigned long long)grid);
+    const BarArea ba = resident_bar_area(pl.pr, ws_bar, stream, grid, 2);
     if (ba.need_fill) {
-        const hipError_t e = hipMemsetAsync(ws_ctl, 0, kCtlBytes, stream);
+        const hipError_t e = hipMemsetAsync(ws_bar, 0, kBarBlock, stream);
         if (e != hipSuccess) return (int)e;
     }
     a.bar.ctl = ba.ctl;
-    a.bar.count = ba.count;
-    a.bar.base = ba.base;
+    a.bar.block = ba.block;
+    a.bar.group_base = ba.group_base;
+    a.bar.bar_base = ba.bar_base;
     kern<<<grid, kBlock, lds, stream>>>(a, args...);
     return launch_status();
 }
@@ -94,12 +96,15 @@ NhwcGeom nhwc_fused_geom(const Plan& pl) {
     g.C = p.C;
     g.M = p.H * p.W;
     g.tc = p.C / vec_of(p.dtype);
+    // tiles: two per workgroup of the persistent grid (CNSN_NHWC_WG_PER_CU x the compute units).  First narrower column blocks
+    // — down to 64 vector columns: a wave still reads 1 KB of one pixel's row at a time, and nothing is paid for the split —
+    // then pixel chunks, each of which costs a row of partial sums per plane (8 floats a chunk and plane against a 7x7 plane's
+    // 49 elements): at least 8 pixels per thread and chunk where the plane allows it.
+    const long target = 2l * CNSN_NHWC_WG_PER_CU * reshost::cu_count();
     g.tcb = g.tc < kBlock ? g.tc : kBlock;
+    while (g.tcb > 64 && g.tcb % 2 == 0 && (long)g.N * ((g.tc + g.tcb - 1) / g.tcb) < target) g.tcb /= 2;
     g.rows = kBlock / g.tcb;
     g.ncb = (g.tc + g.tcb - 1) / g.tcb;
-    // tiles: one to two per workgroup of the persistent grid (CNSN_NHWC_WG_PER_CU x the compute units), at least 8 pixels per
-    // thread and chunk where the plane allows it
-    const long target = 2l * CNSN_NHWC_WG_PER_CU * reshost::cu_count();
     const long per_chunk = (long)g.N * g.ncb;
     int S = (int)((target + per_chunk - 1) / per_chunk);
     const int s_max = g.M / (8 * g.rows) > 0 ? g.M / (8 * g.rows) : 1;
@@ -130,11 +135,11 @@ bool nhwc_fused_ok(const Plan& pl) {
 
 size_t nhwc_fused_extra_bytes(const Plan& pl) {
     const NhwcGeom g = nhwc_fused_geom(pl);
-    return align256((size_t)g.S * 2 * g.P * 4) + align256(4 * g.P * 4) + kCtlBytes + 256;  // part | kshift, gate / cX, c0 | control block
+    return align256((size_t)g.S * 2 * g.P * 4) + align256(4 * g.P * 4) + kBarBlock + 256;  // part | kshift, gate / cX, c0 | barrier block
 }
 
 int nhwc_fused_forward(Plan& pl, int add, int relu, const void* x, const void* addend, GateDev gg, void* y, float* saved,
-                       void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                       void* workspace, size_t workspace_bytes, hipStream_t stream, void* sum_out) {
     const cnsn_problem_t& p = pl.pr;
     if (!nhwc_fused_ok(pl)) return CNSN_E_UNSUPPORTED;
     if (add != ADD_NONE && !addend) return CNSN_E_NULL;
@@ -145,23 +150,29 @@ int nhwc_fused_forward(Plan& pl, int add, int relu, const void* x, const void* a
     a.part = (float*)workspace;
     a.kshift = (float*)((char*)workspace + align256((size_t)ng.S * 2 * P * 4));
     a.slim = saved;
+    a.sum_out = add == ADD_PRE ? sum_out : nullptr;
     a.gout = saved ? saved + (size_t)SL_G * P : a.kshift + P;
     // the first read with the default cache policy when the second one can find it on chip (what phase A reads within reach of
     // the 256 MiB Infinity Cache); non-temporal like every other single-use access beyond that
     a.keep = (size_t)(add == ADD_PRE ? 2 : 1) * P * ng.M * elem_bytes(p.dtype) <= ((size_t)320 << 20) ? 1 : 0;
-    void* ws_ctl = (char*)a.kshift + align256(4 * P * 4);
+    void* ws_bar = (char*)a.kshift + align256(4 * P * 4);
     int status = CNSN_E_UNSUPPORTED;
     dispatch_t(p.dtype, [&](auto tt, auto vt) {
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value;
         const size_t lds = (size_t)2 * ng.rows * ng.tcb * VEC * 4;
+        if (a.sum_out) {  // (the second read is of what phase A wrote: the first one need not stay in the caches)
+            status = launch_fused(pl, nhwc_fused_fwd_kernel<T, VEC, ADD_PRE, false, true>, lds, a, ws_bar, stream, (const T*)x,
+                                  (const T*)addend, (T*)y, gg);
+            return;
+        }
         with_add(add, [&](auto at) {
             constexpr int ADD = decltype(at)::value;
             if (a.keep)
-                status = launch_fused(pl, nhwc_fused_fwd_kernel<T, VEC, ADD, true>, lds, a, ws_ctl, stream, (const T*)x, (const T*)addend,
+                status = launch_fused(pl, nhwc_fused_fwd_kernel<T, VEC, ADD, true>, lds, a, ws_bar, stream, (const T*)x, (const T*)addend,
                                       (T*)y, gg);
             else
-                status = launch_fused(pl, nhwc_fused_fwd_kernel<T, VEC, ADD, false>, lds, a, ws_ctl, stream, (const T*)x,
+                status = launch_fused(pl, nhwc_fused_fwd_kernel<T, VEC, ADD, false>, lds, a, ws_bar, stream, (const T*)x,
                                       (const T*)addend, (T*)y, gg);
         });
     });
@@ -190,7 +201,7 @@ int nhwc_fused_backward(Plan& pl, int add, int relu, const void* gy, const void*
     a.part = (float*)workspace;
     a.coefb = (float*)((char*)workspace + align256((size_t)ng.S * 2 * P * 4));
     a.slim = const_cast<float*>(saved);
-    void* ws_ctl = (char*)a.coefb + align256(4 * P * 4);
+    void* ws_bar = (char*)a.coefb + align256(4 * P * 4);
     int status = CNSN_E_UNSUPPORTED;
     dispatch_t(p.dtype, [&](auto tt, auto vt) {
         using T = typename decltype(tt)::type;
@@ -199,10 +210,10 @@ int nhwc_fused_backward(Plan& pl, int add, int relu, const void* gy, const void*
         with_add(eff_add, [&](auto at) {
             constexpr int ADD = decltype(at)::value;
             if (a.keep)
-                status = launch_fused(pl, nhwc_fused_bwd_kernel<T, VEC, ADD, true>, lds, a, ws_ctl, stream, (const T*)gy, (const T*)x,
+                status = launch_fused(pl, nhwc_fused_bwd_kernel<T, VEC, ADD, true>, lds, a, ws_bar, stream, (const T*)gy, (const T*)x,
                                       (const T*)addend, (T*)dx, (T*)d_addend, gg, dg);
             else
-                status = launch_fused(pl, nhwc_fused_bwd_kernel<T, VEC, ADD, false>, lds, a, ws_ctl, stream, (const T*)gy, (const T*)x,
+                status = launch_fused(pl, nhwc_fused_bwd_kernel<T, VEC, ADD, false>, lds, a, ws_bar, stream, (const T*)gy, (const T*)x,
                                       (const T*)addend, (T*)dx, (T*)d_addend, gg, dg);
         });
     });

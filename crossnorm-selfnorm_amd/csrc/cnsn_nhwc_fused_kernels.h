@@ -21,11 +21,15 @@
 // channels of a pixel, so a plane's statistics are COLUMN sums — no cross-lane reduction at all, where the NCHW kernels need a
 // wave reduction per plane.
 //
-// The barrier: a 64-bit arrival counter that only ever grows (in the persistent context; the host knows how many arrivals
-// earlier launches left and passes that as `base`, so nothing is cleared between launches), one relaxed agent-scope add per
-// workgroup, polled by one lane per workgroup with the library's bounded wait and give-up protocol (the
-// control word flips, the pinned host word counts, every workgroup marks what it still owed with NaNs).  Every wave fences
-// (release) before it arrives and (acquire) after it leaves: the L2s of the eight XCDs are not coherent with each other.
+// The barrier (resident_bar_area, cnsn_resident_kernels.h): counters that only ever grow (in the persistent context; the host
+// knows what earlier launches left and passes the bases, so nothing is cleared between launches), sharded so that no word
+// sees more than an eighth of the grid: a workgroup arrives at the counter of its group (blockIdx % 8), the last arriver of a
+// group at the top counter, the last arriver there writes the eight generation words, everybody polls its group's — one lane
+// per workgroup, with the library's bounded wait and give-up protocol (the control word flips, the
+// pinned host word counts, every workgroup marks what it still owed with NaNs).  No fences: everything that crosses a
+// barrier is stored write-through and loaded past the L1 (`sc1`: st_coh2 / ld_coh2 of cnsn_nhwc_kernels.h), every wave waits
+// for its stores' acknowledgements before its workgroup arrives.  (The first version fenced — release + acquire, agent scope,
+// in every wave — and spent ~200 us per barrier at 1 024 workgroups: 0.41 ms for a 7x7 site whose tensor passes take 0.06.)
 //
 // `saved`, the SLIM record (declared second contract, tests/test_gpu_saved_contract.py): a channels-last call WITHOUT CrossNorm
 // and with ONE gate keeps five floats per plane in plane order (p = n*C + c) — mean as a (hi, lo) float pair, std, gate g,
@@ -57,13 +61,14 @@ __host__ __device__ inline const double* slim_rstd(const float* slim, size_t P) 
 }
 
 struct GridBar {
-    unsigned long long* count;  // arrivals: monotone in a context, zeroed in front of the launch otherwise
-    unsigned long long base;    // arrivals before this launch
-    unsigned* ctl;              // word 0: the time-out flag every cluster kernel of the library shares
+    char* block;                   // the barrier block: group counters, top counter, generation words (kBarLine apart)
+    unsigned long long group_base; // arrivals in every group counter before this launch
+    unsigned long long bar_base;   // barriers before this launch
+    unsigned* ctl;                 // word 0: the time-out flag every cluster kernel of the library shares
     unsigned ctl_idle;
     unsigned* host_flag;
     long long wait_ticks;
-    int fault;                  // tests (CNSN_FAULT_INJECT=1): the last workgroup never arrives at the first barrier
+    int fault;                     // tests (CNSN_FAULT_INJECT=1): the last workgroup never arrives at the first barrier
 };
 
 struct NhwcFusedArgs {
@@ -78,22 +83,37 @@ struct NhwcFusedArgs {
     float* gout;    // [P] forward: the gate as the apply phase reads it (the SL_G row of `slim` when there is one)
     float* coefb;   // [2][P] backward: cX, c0
     float* slim;    // forward: written (may be null); backward: read
+    void* sum_out;  // forward, ADD_PRE, SUM kernels: where X = x + addend is kept (phase A writes it, phase C reads it)
     GridBar bar;
 };
 
-// k-th barrier of the launch (k = 1, 2).  false: the launch gave up (this workgroup's wait ran out, or somebody else's did).
+// k-th barrier of the launch (k = 1, 2); gridDim.x is a multiple of 8.  false: the launch gave up (this workgroup's wait ran
+// out, or somebody else's did).
 __device__ __forceinline__ bool grid_barrier(const GridBar& b, unsigned k, int* flag) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (every wave: its own stores are out of this XCD's L2 before anybody is told)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every wave: its write-through stores have been acknowledged)
     __syncthreads();
     if (threadIdx.x == 0) {
         int ok = 1;
-        if (!(b.fault && k == 1 && blockIdx.x + 1 == gridDim.x))
-            __hip_atomic_fetch_add((gu64*)b.count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long target = b.base + (unsigned long long)k * gridDim.x;
+        const unsigned grp = blockIdx.x & 7u;
+        const unsigned long long want = b.bar_base + k;
+        gu64* gen = (gu64*)(b.block + (kBarGen + grp) * kBarLine);
+        if (!(b.fault && k == 1 && blockIdx.x + 1 == gridDim.x)) {
+            const unsigned long long mine =
+                __hip_atomic_fetch_add((gu64*)(b.block + grp * kBarLine), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+            if (mine == b.group_base + (unsigned long long)k * (gridDim.x >> 3)) {  // last of the group
+                const unsigned long long top =
+                    __hip_atomic_fetch_add((gu64*)(b.block + kBarTop * kBarLine), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+                if (top == 8ull * want) {  // last of the grid
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        __hip_atomic_store((gu64*)(b.block + (kBarGen + q) * kBarLine), want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
         long long t_start = 0;
         for (unsigned spins = 0;; ++spins) {
-            if (__hip_atomic_load((gu64*)b.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
-            __builtin_amdgcn_s_sleep(8);
+            if (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+            __builtin_amdgcn_s_sleep(10);
             if ((spins & 15u) == 15u) {
                 const long long now = (long long)wall_clock64();
                 if (t_start == 0) t_start = now;
@@ -113,8 +133,7 @@ __device__ __forceinline__ bool grid_barrier(const GridBar& b, unsigned k, int* 
         }
         *flag = ok;
     }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (every wave: nothing it reads from now on is an older copy)
+    __syncthreads();  // (what follows loads the other workgroups' results past the L1: ld_coh2)
     return *flag != 0;
 }
 
@@ -138,6 +157,7 @@ __device__ __forceinline__ Vec<T, VEC> nhwc_ld(const T* p) {
         return load_vec<T, VEC>(p);
 }
 
+// GC adjacent per-plane floats of another workgroup's making (coherent) / of the previous launch's (plain)
 template <int GC>
 __device__ __forceinline__ void load_group(const float* __restrict__ p, double (&o)[GC]) {
 #pragma unroll
@@ -147,11 +167,21 @@ __device__ __forceinline__ void load_group(const float* __restrict__ p, double (
     }
 }
 template <int GC>
-__device__ __forceinline__ void add_group(const float* __restrict__ p, double (&o)[GC]) {
+__device__ __forceinline__ void load_group_coh(const float* __restrict__ p, double (&o)[GC]) {
 #pragma unroll
-    for (int q = 0; q < GC / 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
-        o[4 * q] += (double)v.x, o[4 * q + 1] += (double)v.y, o[4 * q + 2] += (double)v.z, o[4 * q + 3] += (double)v.w;
+    for (int q = 0; q < GC / 2; ++q) {
+        float a, b;
+        ld_coh2(p + 2 * q, a, b);
+        o[2 * q] = a, o[2 * q + 1] = b;
+    }
+}
+template <int GC>
+__device__ __forceinline__ void add_group_coh(const float* __restrict__ p, double (&o)[GC]) {
+#pragma unroll
+    for (int q = 0; q < GC / 2; ++q) {
+        float a, b;
+        ld_coh2(p + 2 * q, a, b);
+        o[2 * q] += (double)a, o[2 * q + 1] += (double)b;
     }
 }
 template <int GC>
@@ -159,14 +189,23 @@ __device__ __forceinline__ void store_group(float* __restrict__ p, const float (
 #pragma unroll
     for (int q = 0; q < GC / 4; ++q) *reinterpret_cast<float4*>(p + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
 }
+template <int GC>
+__device__ __forceinline__ void store_group_coh(float* __restrict__ p, const float (&o)[GC]) {
+#pragma unroll
+    for (int q = 0; q < GC / 2; ++q) st_coh2(p + 2 * q, o[2 * q], o[2 * q + 1]);
+}
 
 // ================================================================================================
 // forward
 // ================================================================================================
-template <typename T, int VEC, int ADD, bool KEEP>
+// SUM (ADD_PRE only): phase A also writes X = x + addend to a.sum_out (default cache policy), phase C reads that ONE tensor;
+// the backward is then the ADD_NONE backward on X (cnsn_epilogue_t.sum_out, ABI 8)
+template <typename T, int VEC, int ADD, bool KEEP, bool SUM = false>
 __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_fwd_kernel(NhwcFusedArgs a, const T* __restrict__ x,
                                                                                       const T* __restrict__ addend, T* __restrict__ y,
                                                                                       GateDev gg) {
+    static_assert(!SUM || ADD == ADD_PRE, "the kept sum is the PRE add's");
+    T* const xsum = SUM ? (T*)a.sum_out : nullptr;  // (written in phase A, read in phase C: no __restrict__)
     extern __shared__ float lds[];
     __shared__ double red[4 * CNSN_NHWC_GC];
     __shared__ int bar_flag;
@@ -187,14 +226,17 @@ __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_fwd_ke
 #pragma unroll
             for (int j = 0; j < VEC; ++j) K[j] = ADD == ADD_PRE ? sum_t<T>(to_float(v0.v[j]), to_float(b0.v[j])) : to_float(v0.v[j]);
             constexpr int U = ADD == ADD_PRE ? 2 : 4;
-            auto eat = [&](const Vec<T, VEC>& va, const Vec<T, VEC>& vb) {
+            auto eat = [&](const Vec<T, VEC>& va, const Vec<T, VEC>& vb, size_t e) {
+                Vec<T, VEC> keep;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     const float X = ADD == ADD_PRE ? sum_t<T>(to_float(va.v[j]), to_float(vb.v[j])) : to_float(va.v[j]);
+                    keep.v[j] = from_float<T>(X);  // (exact: sum_t rounds to T)
                     const float d = X - K[j];
                     acc[0][j] += d;
                     acc[1][j] = fmaf(d, d, acc[1][j]);
                 }
+                if constexpr (SUM) store_vec<T, VEC>(xsum + e, keep);
             };
             int p = t.p0 + t.r;
             for (; p + (U - 1) * g.rows < t.p1; p += U * g.rows) {
@@ -206,18 +248,18 @@ __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_fwd_ke
                     if constexpr (ADD == ADD_PRE) vb[u] = nhwc_ld<T, VEC, !KEEP>(addend + e);
                 }
 #pragma unroll
-                for (int u = 0; u < U; ++u) eat(va[u], ADD == ADD_PRE ? vb[u] : va[u]);
+                for (int u = 0; u < U; ++u) eat(va[u], ADD == ADD_PRE ? vb[u] : va[u], t.elem(g, p + u * g.rows));
             }
             for (; p < t.p1; p += g.rows) {
                 const size_t e = t.elem(g, p);
                 const Vec<T, VEC> va = nhwc_ld<T, VEC, !KEEP>(x + e);
                 Vec<T, VEC> vb = va;
                 if constexpr (ADD == ADD_PRE) vb = nhwc_ld<T, VEC, !KEEP>(addend + e);
-                eat(va, vb);
+                eat(va, vb, e);
             }
-            if (t.s == 0 && t.r == 0) store_planes<VEC>(a.kshift + t.plane0(g), K);
+            if (t.s == 0 && t.r == 0) store_planes_coh<VEC>(a.kshift + t.plane0(g), K);
         }
-        nhwc_rows_sum<VEC, 2>(g, t, acc, lds, a.part);
+        nhwc_rows_sum<VEC, 2, true>(g, t, acc, lds, a.part);
         __syncthreads();  // (lds is the next tile's)
     }
     if (!grid_barrier(a.bar, 1, &bar_flag)) {
@@ -234,10 +276,10 @@ __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_fwd_ke
 #pragma unroll
         for (int j = 0; j < GC; ++j) s1[j] = s2[j] = 0.0;
         for (int s = 0; s < g.S; ++s) {
-            add_group<GC>(a.part + ((size_t)s * 2 + 0) * g.P + p0, s1);
-            add_group<GC>(a.part + ((size_t)s * 2 + 1) * g.P + p0, s2);
+            add_group_coh<GC>(a.part + ((size_t)s * 2 + 0) * g.P + p0, s1);
+            add_group_coh<GC>(a.part + ((size_t)s * 2 + 1) * g.P + p0, s2);
         }
-        load_group<GC>(a.kshift + p0, mean);
+        load_group_coh<GC>(a.kshift + p0, mean);
         const double M = (double)g.M;
 #pragma unroll
         for (int j = 0; j < GC; ++j) {
@@ -296,12 +338,12 @@ __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_fwd_ke
                 o_lo[j] = (float)(mean[j] - (double)o_hi[j]);
                 o_sig[j] = (float)sig[j];
             }
-            store_group<GC>(a.gout + p0, o_g);
+            store_group_coh<GC>(a.gout + p0, o_g);  // (phase C reads it)
             if (a.slim) {
                 store_group<GC>(a.slim + (size_t)SL_MU_HI * g.P + p0, o_hi);
                 store_group<GC>(a.slim + (size_t)SL_MU_LO * g.P + p0, o_lo);
                 store_group<GC>(a.slim + (size_t)SL_SIG * g.P + p0, o_sig);
-                if (a.gout != a.slim + (size_t)SL_G * g.P) store_group<GC>(a.slim + (size_t)SL_G * g.P + p0, o_g);
+                if (a.gout != a.slim + (size_t)SL_G * g.P) store_group<GC>(a.slim + (size_t)SL_G * g.P + p0, o_g);  // (never: see the host)
                 store_group<GC>(a.slim + (size_t)SL_ZH * g.P + p0, o_zh);
             }
         }
@@ -319,14 +361,16 @@ __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_fwd_ke
         const NhwcThread<VEC> t(g, tile);
         if (!t.active) continue;
         float gate[VEC];
-        load_planes<VEC>(a.gout + t.plane0(g), gate);
-        constexpr int U = ADD == ADD_NONE ? 4 : 2;
+        load_planes_coh<VEC>(a.gout + t.plane0(g), gate);
+        constexpr bool TWO = ADD != ADD_NONE && !SUM;  // a second tensor to read
+        constexpr int U = TWO ? 2 : 4;
+        const T* const xin = SUM ? (const T*)xsum : x;
         auto emit = [&](const Vec<T, VEC>& va, const Vec<T, VEC>& vb, size_t e) {
             Vec<T, VEC> o;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 float f = to_float(va.v[j]);
-                if constexpr (ADD == ADD_PRE) f = sum_t<T>(f, to_float(vb.v[j]));
+                if constexpr (ADD == ADD_PRE && !SUM) f = sum_t<T>(f, to_float(vb.v[j]));
                 float v = gate[j] * f;  // one rounding, like the reference's x * g (:150)
                 if constexpr (ADD == ADD_POST) v += to_float(vb.v[j]);
                 o.v[j] = from_float<T>(a.relu ? fmaxf(v, 0.f) : v);
@@ -341,17 +385,17 @@ __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_fwd_ke
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const size_t e = t.elem(g, t.p0 + t.r + (q - u) * g.rows);
-                va[u] = load_vec_nt<T, VEC>(x + e);
-                if constexpr (ADD != ADD_NONE) vb[u] = load_vec_nt<T, VEC>(addend + e);
+                va[u] = load_vec_nt<T, VEC>(xin + e);
+                if constexpr (TWO) vb[u] = load_vec_nt<T, VEC>(addend + e);
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) emit(va[u], ADD != ADD_NONE ? vb[u] : va[u], t.elem(g, t.p0 + t.r + (q - u) * g.rows));
+            for (int u = 0; u < U; ++u) emit(va[u], TWO ? vb[u] : va[u], t.elem(g, t.p0 + t.r + (q - u) * g.rows));
         }
         for (; q >= 0; --q) {
             const size_t e = t.elem(g, t.p0 + t.r + q * g.rows);
-            const Vec<T, VEC> va = load_vec_nt<T, VEC>(x + e);
+            const Vec<T, VEC> va = load_vec_nt<T, VEC>(xin + e);
             Vec<T, VEC> vb = va;
-            if constexpr (ADD != ADD_NONE) vb = load_vec_nt<T, VEC>(addend + e);
+            if constexpr (TWO) vb = load_vec_nt<T, VEC>(addend + e);
             emit(va, vb, e);
         }
     }
@@ -416,7 +460,7 @@ __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_bwd_ke
                 eat(vg, vx, vb);
             }
         }
-        nhwc_rows_sum<VEC, 2>(g, t, acc, lds, a.part);
+        nhwc_rows_sum<VEC, 2, true>(g, t, acc, lds, a.part);
         __syncthreads();
     }
     if (!grid_barrier(a.bar, 1, &bar_flag)) {
@@ -433,8 +477,8 @@ __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_bwd_ke
 #pragma unroll
         for (int j = 0; j < GC; ++j) S1[j] = S2[j] = 0.0;
         for (int s = 0; s < g.S; ++s) {
-            add_group<GC>(a.part + ((size_t)s * 2 + 0) * g.P + p0, S1);
-            add_group<GC>(a.part + ((size_t)s * 2 + 1) * g.P + p0, S2);
+            add_group_coh<GC>(a.part + ((size_t)s * 2 + 0) * g.P + p0, S1);
+            add_group_coh<GC>(a.part + ((size_t)s * 2 + 1) * g.P + p0, S2);
         }
         load_group<GC>(a.slim + (size_t)SL_MU_HI * g.P + p0, mu);
         load_group<GC>(a.slim + (size_t)SL_MU_LO * g.P + p0, lo);
@@ -487,8 +531,8 @@ __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_bwd_ke
             dg.dw[2 * (c0 + threadIdx.x) + 1] = (float)w1;
         }
         if (live) {
-            store_group<GC>(a.coefb + p0, o_cx);
-            store_group<GC>(a.coefb + g.P + p0, o_c0);
+            store_group_coh<GC>(a.coefb + p0, o_cx);  // (phase C' reads them)
+            store_group_coh<GC>(a.coefb + g.P + p0, o_c0);
         }
         __syncthreads();
     }
@@ -506,9 +550,9 @@ __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_bwd_ke
         const size_t pl = t.plane0(g);
         float cG[VEC], cX[VEC], xr[VEC], c0[VEC];
         load_planes<VEC>(row_g + pl, cG);
-        load_planes<VEC>(a.coefb + pl, cX);
+        load_planes_coh<VEC>(a.coefb + pl, cX);
         load_planes<VEC>(row_mu + pl, xr);
-        load_planes<VEC>(a.coefb + g.P + pl, c0);
+        load_planes_coh<VEC>(a.coefb + g.P + pl, c0);
         auto emit = [&](const Vec<T, VEC>& vg, const Vec<T, VEC>& vx, const Vec<T, VEC>& vb, size_t e) {
             Vec<T, VEC> o, om;
 #pragma unroll

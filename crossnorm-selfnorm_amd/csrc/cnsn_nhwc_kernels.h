@@ -74,8 +74,36 @@ __device__ __forceinline__ void store_planes(float* __restrict__ p, const float 
     for (int q = 0; q < VEC / 4; ++q) *reinterpret_cast<float4*>(p + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
 }
 
+// The same, AGENT-COHERENT: what one workgroup writes and another reads INSIDE a launch (the single-launch kernels of
+// cnsn_nhwc_fused_kernels.h, across their grid barriers).  The L2s of the eight XCDs are not coherent with each other and a
+// compute unit's L1 is never refreshed by another one's stores: relaxed agent-scope atomics compile to `sc1` accesses — stores
+// written through to memory, loads served past the L1 — 8 bytes at a time (the widest the builtin takes); a full release /
+// acquire fence pair in every wave instead cost these launches ~200 us per barrier.
+typedef __attribute__((address_space(1))) unsigned long long nhwc_gu64;
+__device__ __forceinline__ void st_coh2(float* p, float a, float b) {
+    __hip_atomic_store((nhwc_gu64*)p, ((unsigned long long)__float_as_uint(b) << 32) | (unsigned long long)__float_as_uint(a),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ld_coh2(const float* p, float& a, float& b) {
+    const unsigned long long v = __hip_atomic_load((nhwc_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = __uint_as_float((unsigned)v);
+    b = __uint_as_float((unsigned)(v >> 32));
+}
+template <int VEC>
+__device__ __forceinline__ void load_planes_coh(const float* __restrict__ p, float (&o)[VEC]) {
+    static_assert(VEC % 2 == 0, "whole pairs");
+#pragma unroll
+    for (int q = 0; q < VEC / 2; ++q) ld_coh2(p + 2 * q, o[2 * q], o[2 * q + 1]);
+}
+template <int VEC>
+__device__ __forceinline__ void store_planes_coh(float* __restrict__ p, const float (&o)[VEC]) {
+#pragma unroll
+    for (int q = 0; q < VEC / 2; ++q) st_coh2(p + 2 * q, o[2 * q], o[2 * q + 1]);
+}
+
 // rows of a block -> one value per (column, channel-in-vector, accumulator), fixed order; lds: [NACC][rows][tcb*VEC] floats
-template <int VEC, int NACC>
+// (COH: the partial sums are read by other workgroups of the same launch)
+template <int VEC, int NACC, bool COH = false>
 __device__ __forceinline__ void nhwc_rows_sum(const NhwcGeom& g, const NhwcThread<VEC>& t, float (&acc)[NACC][VEC], float* lds,
                                               float* __restrict__ part) {
     const int col = (int)threadIdx.x % g.tcb, width = g.tcb * VEC;
@@ -96,7 +124,10 @@ __device__ __forceinline__ void nhwc_rows_sum(const NhwcGeom& g, const NhwcThrea
                 v[j] = 0.f;
                 for (int q = 0; q < g.rows; ++q) v[j] += lds[((size_t)k * g.rows + q) * width + col * VEC + j];
             }
-            store_planes<VEC>(part + ((size_t)t.s * NACC + k) * g.P + p, v);
+            if constexpr (COH)
+                store_planes_coh<VEC>(part + ((size_t)t.s * NACC + k) * g.P + p, v);
+            else
+                store_planes<VEC>(part + ((size_t)t.s * NACC + k) * g.P + p, v);
         }
     }
 }
@@ -106,7 +137,8 @@ __device__ __forceinline__ void nhwc_rows_sum(const NhwcGeom& g, const NhwcThrea
 // ------------------------------------------------------------------------------------------------
 template <typename T, int VEC, int ADD>
 __global__ __launch_bounds__(kBlock) void nhwc_stats_kernel(const T* __restrict__ x, const T* __restrict__ addend, NhwcGeom g,
-                                                            float* __restrict__ part, float* __restrict__ kshift) {
+                                                            float* __restrict__ part, float* __restrict__ kshift,
+                                                            T* __restrict__ sum_out) {
     extern __shared__ float lds[];
     const NhwcThread<VEC> t(g);
     float K[VEC], acc[2][VEC];
@@ -130,26 +162,37 @@ __global__ __launch_bounds__(kBlock) void nhwc_stats_kernel(const T* __restrict_
                 if constexpr (ADD == ADD_PRE) vb[u] = load_vec_nt<T, VEC>(addend + e);
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int u = 0; u < U; ++u) {
+                Vec<T, VEC> keep;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     const float X = ADD == ADD_PRE ? sum_t<T>(to_float(va[u].v[j]), to_float(vb[u].v[j])) : to_float(va[u].v[j]);
+                    keep.v[j] = from_float<T>(X);  // (exact: sum_t rounds to T)
                     const float d = X - K[j];
                     acc[0][j] += d;
                     acc[1][j] = fmaf(d, d, acc[1][j]);
                 }
+                if constexpr (ADD == ADD_PRE) {
+                    if (sum_out) store_vec<T, VEC>(sum_out + t.elem(g, p + u * g.rows), keep);  // (default policy: the apply pass reads it next)
+                }
+            }
         }
         for (; p < t.p1; p += g.rows) {
             const size_t e = t.elem(g, p);
             const Vec<T, VEC> va = load_vec_nt<T, VEC>(x + e);
             Vec<T, VEC> vb = va;
             if constexpr (ADD == ADD_PRE) vb = load_vec_nt<T, VEC>(addend + e);
+            Vec<T, VEC> keep;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const float X = ADD == ADD_PRE ? sum_t<T>(to_float(va.v[j]), to_float(vb.v[j])) : to_float(va.v[j]);
+                keep.v[j] = from_float<T>(X);
                 const float d = X - K[j];
                 acc[0][j] += d;
                 acc[1][j] = fmaf(d, d, acc[1][j]);
+            }
+            if constexpr (ADD == ADD_PRE) {
+                if (sum_out) store_vec<T, VEC>(sum_out + e, keep);
             }
         }
         if (t.s == 0 && t.r == 0) {
@@ -161,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void nhwc_stats_kernel(const T* __restrict_
 }
 
 // the pixel chunks of a plane, in order: moments (double) for the mid kernel
-__global__ __launch_bounds__(kBlock) void nhwc_finish_stats_kernel(const float* __restrict__ part, const float* __restrict__ kshift,
+static __global__ __launch_bounds__(kBlock) void nhwc_finish_stats_kernel(const float* __restrict__ part, const float* __restrict__ kshift,
                                                                    int S, size_t P, int M, double* __restrict__ mom) {
     const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= P) return;
@@ -176,7 +219,7 @@ __global__ __launch_bounds__(kBlock) void nhwc_finish_stats_kernel(const float* 
 }
 
 // ... and the two backward sums (float rows as bwd_reduce_kernel writes them)
-__global__ __launch_bounds__(kBlock) void nhwc_finish_sums_kernel(const float* __restrict__ part, int S, size_t P,
+static __global__ __launch_bounds__(kBlock) void nhwc_finish_sums_kernel(const float* __restrict__ part, int S, size_t P,
                                                                   float* __restrict__ sums) {
     const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= P) return;
@@ -241,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void nhwc_apply_fwd_kernel(const T* __restr
 // channel and row by row over the batch (cnsn_layout.h), which a thread that owns VEC adjacent CHANNELS would read 8 bytes at a
 // time from 64-byte sectors in every pixel chunk; once here instead.  rows: [0] float(mu_c), [1..3] a_in, xr, b_in (ReLU only)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void nhwc_saved_rows_kernel(const double* __restrict__ saved, int N, int C, int relu,
+static __global__ __launch_bounds__(kBlock) void nhwc_saved_rows_kernel(const double* __restrict__ saved, int N, int C, int relu,
                                                                  float* __restrict__ rows) {
     const size_t P = (size_t)N * C, p = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= P) return;

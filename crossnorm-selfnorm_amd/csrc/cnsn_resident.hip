@@ -96,8 +96,10 @@ std::unordered_map<void*, PongState> g_pong;  // (under g_ctx_mu)
 // cluster kernels until somebody re-arms them (cnsn_resident_rearm); the first launch after that finds the count of time-outs
 // changed and puts the control block back in order — on the stream, in launch order (all cluster launches are chained).
 struct CtxHealth {
-    int timeouts = 0;                  // resident_timeouts() when the context was last known to be in order
-    unsigned long long arrivals = 0;   // barrier arrivals the launches so far have left in the context's counter
+    int timeouts = 0;                    // resident_timeouts() when the context was last known to be in order
+    size_t bytes = 0;                    // size the barrier block's position was derived from
+    unsigned long long group_base = 0;   // arrivals the launches so far have left in every group counter of the barrier block
+    unsigned long long bar_base = 0;     // barriers so far
 };
 std::unordered_map<void*, CtxHealth> g_health;  // (under g_ctx_mu)
 
@@ -107,7 +109,7 @@ CtxHealth& heal_context_locked(void* context, hipStream_t stream) {
     if (h.timeouts != now) {
         if (hipMemsetAsync(context, 0, kCtlBytes, stream) != hipSuccess) (void)hipGetLastError();
         g_pong.erase(context);
-        h.arrivals = 0;
+        h.bytes = 0;  // (the barrier block is cleared by the next launch that uses it: resident_bar_area)
         h.timeouts = now;
     }
     return h;
@@ -118,27 +120,38 @@ void resident_context_forget(void* context) {
     std::lock_guard<std::mutex> lock(g_ctx_mu);
     g_ctx_epoch[context] = 0;
     g_pong.erase(context);
-    g_health[context] = CtxHealth{resident_timeouts(), 0ull};
+    g_health[context] = CtxHealth{resident_timeouts(), 0, 0ull, 0ull};
 }
 
-BarArea resident_bar_area(const cnsn_problem_t& p, void* workspace_ctl, hipStream_t stream, unsigned long long arrivals) {
-    BarArea ba{(unsigned*)workspace_ctl, (unsigned long long*)((char*)workspace_ctl + kBarOffset), 0ull, true};
-    if (!p.context || p.context_bytes < (uint64_t)kCtlBytes) return ba;
+BarArea resident_bar_area(const cnsn_problem_t& p, void* workspace_bar, hipStream_t stream, int grid, int barriers) {
+    BarArea ba{(unsigned*)((char*)workspace_bar + kBarCtl * kBarLine), (char*)workspace_bar, 0ull, 0ull, true};
+    if (!p.context || p.context_bytes < (uint64_t)kCtlBytes + kBarBlock + 2 * kPongRegion) return ba;
     if (const char* e = knob(K_CONTEXT))
         if (e[0] == '0') return ba;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
-        return ba;  // a replay would repeat `base`: count from zero in the workspace instead
+        return ba;  // a replay would repeat the bases: count from zero in the workspace instead
     }
     std::lock_guard<std::mutex> lock(g_ctx_mu);
     if (g_ctx_epoch.find(p.context) == g_ctx_epoch.end()) return ba;  // never initialised through cnsn_context_init
     CtxHealth& h = heal_context_locked(p.context, stream);
+    char* block = (char*)p.context + (size_t)p.context_bytes - 2 * kPongRegion - kBarBlock;
+    if (h.bytes != (size_t)p.context_bytes) {  // first use, healed after a time-out, or the caller passes another extent
+        if (hipMemsetAsync(block, 0, kBarBlock, stream) != hipSuccess) {
+            (void)hipGetLastError();
+            return ba;
+        }
+        h.bytes = (size_t)p.context_bytes;
+        h.group_base = h.bar_base = 0;
+    }
     ba.ctl = (unsigned*)p.context;
-    ba.count = (unsigned long long*)((char*)p.context + kBarOffset);
-    ba.base = h.arrivals;
+    ba.block = block;
+    ba.group_base = h.group_base;
+    ba.bar_base = h.bar_base;
     ba.need_fill = false;
-    h.arrivals += arrivals;
+    h.group_base += (unsigned long long)barriers * (unsigned long long)(grid / 8);
+    h.bar_base += (unsigned long long)barriers;
     return ba;
 }
 
@@ -182,7 +195,7 @@ void resident_pong_commit(const cnsn_problem_t& p, size_t fill_bytes) {
 ExchangeArea resident_exchange_area(const cnsn_problem_t& p, size_t tagged_bytes, void* workspace, hipStream_t stream,
                                     bool prefer_context) {
     ExchangeArea ea{workspace, 0u};
-    if (!p.context || p.context_bytes < tagged_bytes + 2 * kPongRegion) return ea;  // (the last two regions are not for tagged granules)
+    if (!p.context || p.context_bytes < tagged_bytes + kBarBlock + 2 * kPongRegion) return ea;  // (the barrier block and the two regions at the end are not for tagged granules)
     if (const char* e = knob(K_CONTEXT)) {
         if (e[0] == '0') return ea;
     } else if (!prefer_context && ((size_t)p.N * p.C * p.H * p.W * elem_bytes(p.dtype) >= ((size_t)64 << 20) ||
@@ -215,6 +228,7 @@ ExchangeArea resident_exchange_area(const cnsn_problem_t& p, size_t tagged_bytes
             }
             epoch = it->second = 1;
             g_pong.erase(p.context);  // (the clear zeroed the granule regions too: not 'empty' any more)
+            g_health[p.context].bytes = 0;  // (... and the barrier block: its bases start again)
         }
     }
     ea.base = p.context;

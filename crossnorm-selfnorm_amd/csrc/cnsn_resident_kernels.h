@@ -1728,20 +1728,31 @@ struct PongArea {
 bool resident_pong_acquire(const cnsn_problem_t& p, size_t fill_bytes, hipStream_t stream, PongArea* out);
 void resident_pong_commit(const cnsn_problem_t& p, size_t fill_bytes);  // the launch was issued: the other region will be clean
 
-// The grid barrier of the single-launch channels-last kernels (cnsn_nhwc_fused_kernels.h): a 64-bit arrival counter in the
-// SECOND half of the control block's second line (bytes 192..199; the first line holds the time-out word every waiting wave
-// polls, bytes 128..135 the ticket counter of SNX_DYNAMIC builds).  In a persistent context the counter only grows — the host
-// counts the arrivals every launch leaves (`arrivals` = barriers x workgroups of this one) and hands out `base`; without a
-// usable context (none, CNSN_CONTEXT=0, stream capture) the caller zeroes kCtlBytes at `workspace_ctl` in front of the launch
-// (`need_fill`).  Control word idle value: 0 either way.  Call inside the ResidentChain.
-constexpr int kBarOffset = 192;
+// The grid barrier of the single-launch channels-last kernels (cnsn_nhwc_fused_kernels.h): a BARRIER BLOCK of kBarBlock bytes,
+// 17 counters in cache lines of their own — eight group counters (a workgroup arrives at counter blockIdx % 8: the XCD it runs
+// on as far as anybody has observed, which matters for speed only), one top counter the last arriver of each group bumps, eight
+// generation words the last arriver at the top writes and the members of a group poll.  One word with 1 024 arrivers and
+// 1 024 pollers serialises at ~12 ns per access; sharded like this a barrier of 1 024 workgroups costs ~10 us
+// (MI355X_MICROARCH.md, rows barrier-counter / barrier-xcd).  Every counter only GROWS: in a persistent context the host
+// keeps, per context, what the launches so far have left (`group_base` arrivals per group counter, `bar_base` barriers) and
+// nothing is cleared between launches; the block lies in front of the two granule regions at the end of the context
+// (cnsn_context_bytes counts it, resident_exchange_area keeps tagged granules out of it).  Without a usable context (none,
+// CNSN_CONTEXT=0, stream capture, too small) the block is `workspace_bar` and the caller zeroes it in front of the launch
+// (`need_fill`).  The grid must be a multiple of 8 (equal groups).  Control word (`ctl`, the time-out flag every waiting
+// workgroup of the library watches) idle value: 0 either way.  Call inside the ResidentChain.
+constexpr size_t kBarBlock = 4096;
+constexpr int kBarLine = 128;   // bytes between two counters
+constexpr int kBarTop = 8;      // line of the top counter; lines 0..7 group counters, 9..16 generation words, 17: control word
+constexpr int kBarGen = 9;
+constexpr int kBarCtl = 17;     // (workspace form only: a context's control word is its word 0)
 struct BarArea {
     unsigned* ctl;
-    unsigned long long* count;
-    unsigned long long base;
+    char* block;
+    unsigned long long group_base;  // arrivals every group counter holds before this launch
+    unsigned long long bar_base;    // barriers before this launch (top counter = 8 x, generation words = 1 x)
     bool need_fill;
 };
-BarArea resident_bar_area(const cnsn_problem_t& p, void* workspace_ctl, hipStream_t stream, unsigned long long arrivals);
+BarArea resident_bar_area(const cnsn_problem_t& p, void* workspace_bar, hipStream_t stream, int grid, int barriers);
 
 struct ResidentChain {
     explicit ResidentChain(hipStream_t stream);

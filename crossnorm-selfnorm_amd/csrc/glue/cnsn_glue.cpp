@@ -365,6 +365,15 @@ struct GateTensors {  // float32 contiguous views/copies + where running stats m
     }
 };
 
+// CNSN_KEEP_SUM=0: never keep x + addend for the backward (A/B knob)
+bool keep_sum_enabled() {
+    static const bool on = [] {
+        const char* e = std::getenv("CNSN_KEEP_SUM");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
    public:
     // cfg: [cn_active, cb0..3, sb0..3, sn_active, sn_two, sn_training, strategy, need_backward, add_mode, relu]
@@ -397,7 +406,7 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
         }
         cnsn_problem_t prob = make_problem(x, c);
         prob.layout = nhwc ? CNSN_LAYOUT_NHWC : CNSN_LAYOUT_NCHW;
-        const cnsn_epilogue_t epi = make_epilogue(c, addend);
+        cnsn_epilogue_t epi = make_epilogue(c, addend);
         const bool has_epi = c.add_mode != CNSN_ADD_NONE || c.relu;
         const at::Device dev = x.device();
         attach_context(prob, dev, c10::hip::getCurrentHIPStream(dev.index()).stream());
@@ -424,6 +433,14 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
 
         Tensor y = out_like(x);
         const bool need_bwd = cfg[13] != 0;  // decided by the caller (grad mode on and something requires grad)
+        // A PRE add in front of a channels-last call (two tensor passes each way): the forward KEEPS X = x + addend and the
+        // backward reads that one tensor instead of two, twice (cnsn_epilogue_t.sum_out, ABI 8).  X is what the reference's
+        // in-place `out += identity` leaves (resnet_cnsn.py:117) and what its autograd saves; x and the addend are not saved.
+        Tensor xsum;
+        if (need_bwd && nhwc && c.add_mode == CNSN_ADD_PRE && keep_sum_enabled() && cnsn_keeps_sum(&prob, &epi) == 1) {
+            xsum = out_like(x);
+            epi.sum_out = xsum.data_ptr();
+        }
         const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
         const size_t ws_bytes = cnsn_workspace_bytes(&prob);
         Tensor saved;
@@ -450,6 +467,8 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
             if (two) gf.write_back();
         }
         if (need_bwd) {
+            ctx->saved_data["kept_sum"] = xsum.defined();
+            if (xsum.defined()) cfg[14] = CNSN_ADD_NONE;  // the backward is the backward of the op WITHOUT the add, on X
             ctx->saved_data["cfg"] = cfg;
             ctx->saved_data["fcfg"] = fcfg;
             ctx->saved_data["pd"] = std::vector<int64_t>{
@@ -458,11 +477,11 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
                 two ? (int64_t)f_gamma->scalar_type() : -1, two ? (int64_t)f_beta->scalar_type() : -1};
             Tensor none;
             ctx->saved_data["perm_host"] = perm_host.defined() ? c10::IValue(perm_host) : c10::IValue();
-            ctx->save_for_backward({x, saved, perm.defined() ? perm : none, chan.defined() ? chan : none,
+            ctx->save_for_backward({xsum.defined() ? xsum : x, saved, perm.defined() ? perm : none, chan.defined() ? chan : none,
                                     c.sn_active ? gg.w : none, c.sn_active ? gg.gamma : none, c.sn_active ? gg.beta : none,
                                     c.sn_active ? gg.rm : none, c.sn_active ? gg.rv : none, two ? gf.w : none,
                                     two ? gf.gamma : none, two ? gf.beta : none, two ? gf.rm : none, two ? gf.rv : none,
-                                    addend.defined() ? addend : none});
+                                    (addend.defined() && !xsum.defined()) ? addend : none});
         }
         return y;
     }
@@ -539,7 +558,7 @@ class FusedCNSN : public torch::autograd::Function<FusedCNSN> {
             prob.perm_host = nullptr;
             st = launch();
         }
-        if (c.add_mode == CNSN_ADD_PRE) d_add = dx;
+        if (c.add_mode == CNSN_ADD_PRE || ctx->saved_data["kept_sum"].toBool()) d_add = dx;
         check_status(st, "cnsn_backward");
 
         auto cast = [](const Tensor& t, int64_t code) {

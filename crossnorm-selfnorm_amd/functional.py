@@ -4,6 +4,8 @@ with torch ops on the activation tensor.  HIP device tensors only — other inpu
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
+import os
 import threading
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
@@ -262,13 +264,18 @@ class FusedConfig:
 _ADD_MODES = {"none": _ffi.ADD_NONE, "pre": _ffi.ADD_PRE, "post": _ffi.ADD_POST}
 
 
-def _epilogue(cfg: FusedConfig, addend):
+def _epilogue(cfg: FusedConfig, addend, sum_out=None):
     e = _ffi.Epilogue()
     e.struct_bytes = C.sizeof(_ffi.Epilogue)
     e.add_mode = _ADD_MODES[cfg.add_mode]
     e.relu = int(cfg.relu)
     e.addend = addend.data_ptr() if addend is not None else None
+    e.sum_out = sum_out.data_ptr() if sum_out is not None else None
     return e
+
+
+# CNSN_KEEP_SUM=0: never keep x + addend for the backward (A/B knob; cnsn_epilogue_t.sum_out, ABI 8)
+_KEEP_SUM = os.environ.get("CNSN_KEEP_SUM", "1") != "0"
 
 
 def which_path(x: torch.Tensor, cfg: FusedConfig, backward: bool = False, chan_perm: bool = False) -> str:
@@ -407,6 +414,13 @@ class FusedCNSN(torch.autograd.Function):
         saved = torch.empty(saved_floats, dtype=torch.float32, device=dev) if need_bwd else None
         ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=dev)
         epi = _epilogue(cfg, addend) if cfg.has_epilogue else None
+        # A PRE add in front of a channels-last call (two tensor passes each way): the forward KEEPS X = x + addend and the
+        # backward reads that one tensor instead of two, twice (cnsn_epilogue_t.sum_out).  X is what the reference's in-place
+        # `out += identity` leaves (resnet_cnsn.py:117) and what its autograd saves; x and the addend are not saved here.
+        xsum = None
+        if need_bwd and nhwc and cfg.add_mode == "pre" and _KEEP_SUM and lib.cnsn_keeps_sum(C.byref(prob), C.byref(epi)) == 1:
+            xsum = _out_like(x)
+            epi.sum_out = xsum.data_ptr()
 
         def launch():
             return lib.cnsn_forward_fused(C.byref(prob), C.byref(epi) if epi else None, _ptr(x),
@@ -431,8 +445,14 @@ class FusedCNSN(torch.autograd.Function):
             ctx.param_dtypes = tuple(t.dtype if t is not None else None
                                      for t in (g_w, g_gamma, g_beta, f_w, f_gamma, f_beta))
             ctx.perm_host = perm_host                  # (a CPU tensor: kept alive for the backward's launch argument)
-            ctx.save_for_backward(x, saved, perm if cfg.cn_active else None,
-                                  chan_perm if cfg.cn_active else None, addend)
+            ctx.kept_sum = xsum is not None
+            if xsum is not None:                       # the backward is the backward of the op WITHOUT the add, on X
+                ctx.cfg = dataclasses.replace(cfg, add_mode="none")
+                ctx.save_for_backward(xsum, saved, perm if cfg.cn_active else None,
+                                      chan_perm if cfg.cn_active else None, None)
+            else:
+                ctx.save_for_backward(x, saved, perm if cfg.cn_active else None,
+                                      chan_perm if cfg.cn_active else None, addend)
         return y
 
     @staticmethod
@@ -485,7 +505,7 @@ class FusedCNSN(torch.autograd.Function):
             prob.perm_host = None
             st = launch(_h2d.to_device(perm_host, dev))
         _ffi.check(st, "cnsn_backward")
-        if cfg.add_mode == "pre":       # d(x + addend) reaches both terms unchanged
+        if cfg.add_mode == "pre" or ctx.kept_sum:       # d(x + addend) reaches both terms unchanged
             d_add = dx
         pd = ctx.param_dtypes
         out_g = [None] * 3 if gg is None else [t if t.dtype == pd[i] else t.to(pd[i]) for i, t in enumerate(gg)]

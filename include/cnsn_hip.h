@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CNSN_ABI_VERSION 7
+#define CNSN_ABI_VERSION 8
 
 /* Largest batch whose permutation can travel as a launch argument (cnsn_problem_t.perm_host). */
 #define CNSN_PERM_INLINE_MAX 1024
@@ -188,7 +188,21 @@ typedef struct cnsn_epilogue {
     int32_t relu;         /* 1: y = max(y, 0) last (nn.ReLU, resnet_cnsn.py:122)              */
     int32_t reserved;
     const void* addend;   /* same shape / dtype / layout as x; NULL iff add_mode == NONE       */
+    void* sum_out;        /* (ABI 8) add_mode PRE only, may be NULL: where X = x + addend is KEPT (x's shape / dtype /
+                           * layout; rounded to the dtype like the reference's in-place `out += identity`,
+                           * resnet_cnsn.py:117; it must NOT alias x or addend: every pixel chunk of a plane reads the
+                           * plane's first pixel as its shift).  A forward that
+                           * wrote it is followed by cnsn_backward_fused with add_mode NONE (same relu), x = sum_out and
+                           * the forward's `saved`: the backward then reads ONE tensor instead of two, twice — the
+                           * channels-last strategies (two tensor passes each way) move 10 tensor passes per step
+                           * instead of 12, and the forward's second pass finds X in the caches it was just written
+                           * through.  Only calls for which cnsn_keeps_sum() answers 1 take it; others return
+                           * CNSN_E_UNSUPPORTED when it is set (single-touch strategies gain nothing from it). */
 } cnsn_epilogue_t;
+
+/* 1: cnsn_forward_fused(prob, epi, ...) writes epi->sum_out when it is set (channels-last layout, add_mode PRE, a call the
+ * channels-last kernels take); 0 otherwise.  (ABI 8) */
+int cnsn_keeps_sum(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi);
 
 /* As cnsn_forward with the epilogue `epi` (NULL = none).  `saved` from this call must go to
  * cnsn_backward_fused with the same `epi`. */

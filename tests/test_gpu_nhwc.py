@@ -87,7 +87,8 @@ def test_channels_last_equals_the_nchw_path_and_reports_its_kernels(ctypes_path)
         assert float((u - v).abs().max()) <= 1e-4 * max(1.0, float(u.abs().max()))
     assert float((a[4] - b[4]).abs().max()) <= 1e-6 and a[5] == b[5] == 1
     cfg = cnsn_amd.FusedConfig(sn_active=True, add_mode="pre", relu=True)
-    assert cnsn_amd.which_path(x.contiguous(memory_format=CL), cfg) == "streaming"
+    # (SelfNorm alone on a channels-last tensor: the single-launch kernels, reported as "resident"; CNSN_NHWC_FUSED=0: two-pass)
+    assert cnsn_amd.which_path(x.contiguous(memory_format=CL), cfg) in ("resident", "streaming")
     assert cnsn_amd.which_path(x, cfg) != "streaming"
 
 
@@ -176,3 +177,77 @@ def test_resnet50_in_channels_last_matches_the_nchw_model():
         b(x.contiguous(memory_format=CL))
     h.remove()
     assert seen == [] or all(u and v for u, v in seen)      # (the fused block path calls forward_block, not forward: nothing to see then)
+
+
+@pytest.mark.parametrize("fused", ["1", "0"], ids=["single-launch", "two-pass"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("kind", ["sn", "cnsn"])
+@pytest.mark.parametrize("relu", [True, False])
+def test_kept_sum_gives_the_same_bits(fused, dtype, kind, relu, monkeypatch):
+    """cnsn_epilogue_t.sum_out (ABI 8): a PRE add in front of a channels-last call keeps X = x + addend for the backward, which is
+    then the backward of the op WITHOUT the add on X.  Same arithmetic -> the SAME BITS as the call that saves x and the addend
+    (y, dx, d_addend, parameter gradients, running statistics), under both channels-last strategies; and cnsn_keeps_sum() /
+    CNSN_E_UNSUPPORTED say which calls take it."""
+    import os
+    shape = (12, 64, 14, 14)
+    torch.manual_seed(11)
+    np.random.seed(11)
+    x = (torch.randn(shape, device=DEV) * 1.3 + 0.2).to(dtype)
+    add = (torch.randn(shape, device=DEV) * 0.7).to(dtype)
+    gy = torch.randn(shape, device=DEV).to(dtype)
+    perm = torch.randperm(shape[0])
+    monkeypatch.setenv("CNSN_NHWC_FUSED", fused)
+    cnsn_amd.lib().cnsn_reload_env()
+    try:
+        outs = []
+        for keep in (True, False):
+            monkeypatch.setattr(F_, "_KEEP_SUM", keep)
+            sn = fill_sn(cnsn_amd.SelfNorm(shape[1]), 4, torch.float32).to(DEV).train()
+            xg = x.clone(memory_format=CL).requires_grad_()
+            ag = add.clone(memory_format=CL).requires_grad_()
+            kw, g, f = sn._fused_args()
+            cfg = cnsn_amd.FusedConfig(add_mode="pre", relu=relu, cn_active=(kind == "cnsn"), **kw)
+            y = F_.FusedCNSN.apply(xg, cfg, perm if kind == "cnsn" else None, None, g.fc_weight, g.bn_weight, g.bn_bias,
+                                   g.running_mean, g.running_var, *(None,) * 5, ag, g.num_batches_tracked, None)
+            saved_x = y.grad_fn.saved_tensors[0]
+            y.backward(gy.contiguous(memory_format=CL))
+            torch.cuda.synchronize()
+            if keep:   # what was saved IS the rounded sum, and neither input
+                assert saved_x.data_ptr() not in (xg.data_ptr(), ag.data_ptr())
+                assert torch.equal(saved_x, (xg.detach() + ag.detach()))
+            else:
+                assert saved_x.data_ptr() == xg.data_ptr()
+            outs.append((y.detach().clone(), xg.grad.clone(), ag.grad.clone(), [p.grad.clone() for p in sn.parameters()],
+                         sn.g_bn.running_mean.clone(), sn.g_bn.running_var.clone()))
+        a, b = outs
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        assert all(torch.equal(u, v) for u, v in zip(a[3], b[3])) and torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
+    finally:
+        monkeypatch.delenv("CNSN_NHWC_FUSED")
+        cnsn_amd.lib().cnsn_reload_env()
+
+
+def test_keeps_sum_query_and_refusals():
+    x = torch.randn(4, 16, 8, 8, device=DEV)
+    cfg = cnsn_amd.FusedConfig(sn_active=True, add_mode="pre", relu=True)
+    lib = cnsn_amd.lib()
+
+    def keeps(t, c, nhwc):
+        prob = F_._problem(t, c)
+        prob.layout = _ffi.LAYOUT_NHWC if nhwc else _ffi.LAYOUT_NCHW
+        return lib.cnsn_keeps_sum(C.byref(prob), C.byref(F_._epilogue(c, None)))
+    assert keeps(x, cfg, True) == 1
+    assert keeps(x, cfg, False) == 0                                                        # NCHW strategies read both tensors once
+    assert keeps(x, cnsn_amd.FusedConfig(sn_active=True, add_mode="post", relu=True), True) == 0
+    assert keeps(torch.randn(4, 6, 8, 8, device=DEV), cfg, True) == 0                       # no whole 16-byte vector of channels
+    # an NCHW call with sum_out set is refused, not silently computed without it
+    prob = F_._problem(x, cfg)
+    add, y, keep = torch.randn_like(x), torch.empty_like(x), torch.empty_like(x)
+    epi = F_._epilogue(cfg, add, keep)
+    sn = fill_sn(cnsn_amd.SelfNorm(16), 1, torch.float32).to(DEV).train()
+    g = F_._GateBuffers(sn.g_fc.weight, sn.g_bn.weight, sn.g_bn.bias, sn.g_bn.running_mean, sn.g_bn.running_var)
+    ws_bytes = lib.cnsn_workspace_bytes(C.byref(prob))
+    ws = torch.empty(ws_bytes // 4 + 4, device=DEV)
+    st = lib.cnsn_forward_fused(C.byref(prob), C.byref(epi), x.data_ptr(), None, None, C.byref(g.c), None, y.data_ptr(), None,
+                                ws.data_ptr(), ws_bytes, None)
+    assert st == _ffi.E_UNSUPPORTED

@@ -16,7 +16,7 @@ print(f"| site | NCHW fwd / bwd ms | channels-last fwd / bwd ms | bytes x (MB) |
 print("|---|---|---|---|")
 for shape in ((256, 256, 56, 56), (256, 512, 28, 28), (256, 1024, 14, 14), (256, 2048, 7, 7)):
     row = []
-    for fmt in (torch.contiguous_format, torch.channels_last):
+    for fmt in ((torch.channels_last,) if "cl" in sys.argv[2:] else (torch.contiguous_format, torch.channels_last)):
         x = torch.randn(shape, device=dev).to(dt).contiguous(memory_format=fmt).requires_grad_()
         b = torch.randn(shape, device=dev).to(dt).contiguous(memory_format=fmt).requires_grad_()
         gy = torch.randn(shape, device=dev).to(dt).contiguous(memory_format=fmt)
@@ -36,4 +36,6 @@ for shape in ((256, 256, 56, 56), (256, 512, 28, 28), (256, 1024, 14, 14), (256,
                 tb += ev[1].elapsed_time(ev[2]) / 10
         row.append(f"{tf:.3f} / {tb:.3f}")
         del x, b, gy, y
+    if len(row) < 2:
+        row.insert(0, "-")
     print(f"| {shape} | {row[0]} | {row[1]} | {shape[0] * shape[1] * shape[2] * shape[3] * (2 if dt == torch.bfloat16 else 4) / 1e6:.0f} |")
