@@ -47,7 +47,9 @@ def calc_ins_mean_std(x, eps=1e-5):
     float64 (the reference takes any floating dtype, :12-16): the parameter-free ops — this one, `instance_norm_mix`,
     `cn_op_2ins_space_chan` / `CrossNorm` — accept it, compute on a float32 copy with the float32 kernels (whose plane
     statistics and scalar algebra are fp32 / fp64 as for any input) and return float64: float32 ACCURACY in a float64
-    container, differentiable through the two casts.  SelfNorm's gate with float64 parameters is still refused."""
+    container, differentiable through the two casts.  So do `SelfNorm` and `CNSN` (round 6; models/cnsn.py:130-150 takes any
+    floating dtype): float64 activations go through the float32 kernels, the gate's parameters — float32 or, after
+    `module.double()`, float64 — are read as float32 and get gradients in their own dtype."""
     assert x.dim() == 4
     if _is_f64(x):
         mean, std = _F.PlaneStats.apply(x.float(), float(eps), None, True)
@@ -276,6 +278,8 @@ class SelfNorm(nn.Module):
         return kw, None, None
 
     def forward(self, x):
+        if _is_f64(x):     # (float32 accuracy in a float64 container: see calc_ins_mean_std)
+            return self.forward(x.float()).double()
         if not self._fusable():
             return self._forward_composed(x)
         kw, g, f = self._fused_args()
@@ -292,6 +296,8 @@ class CNSN(nn.Module):
         self.selfnorm = selfnorm
 
     def forward(self, x):
+        if _is_f64(x):
+            return self.forward(x.float()).double()
         cn, sn = self.crossnorm, self.selfnorm
         fuse = (cn is not None and sn is not None and type(cn) is CrossNorm and type(sn) is SelfNorm and sn._fusable()
                 and cn.active and cn.training)
@@ -317,6 +323,8 @@ class CNSN(nn.Module):
         RNG draws, `active` reset and BatchNorm1d book-keeping are those of `forward`."""
         assert add_mode in ("none", "pre", "post")
         assert (addend is None) == (add_mode == "none")
+        if _is_f64(x):
+            return self.forward_block(x.float(), None if addend is None else addend.float(), add_mode, relu).double()
         cn, sn = self.crossnorm, self.selfnorm
         ours = (cn is None or type(cn) is CrossNorm) and (sn is None or (type(sn) is SelfNorm and sn._fusable()))
         cn_on = cn is not None and cn.active and cn.training

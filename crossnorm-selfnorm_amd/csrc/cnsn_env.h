@@ -35,7 +35,7 @@ enum Knob {
     K_ARENA_TRIES,    // CNSN_ARENA_TRIES   candidates the output arena times per new block of 384 MiB or more (default 8; 1: none)
     K_ARENA_SPREAD_GB,// CNSN_ARENA_SPREAD_GB  GB of physical memory held between an arena block's candidates (A/B knob, default 0)
     K_MID_BLOCK,      // CNSN_MID_BLOCK     256: the mid kernels never take 1024-thread workgroups (A/B knob)
-    K_NHWC_FUSED,     // CNSN_NHWC_FUSED    single-launch channels-last kernels: 0 never, 1 AUTO (default), 2 wherever they apply
+    K_NHWC_FUSED,     // CNSN_NHWC_FUSED    single-launch channels-last kernels: 0 never, 1 AUTO (default), 2 wherever they apply, n > 2: AUTO up to n MiB
     K_ARENA_MAX_MB,   // CNSN_ARENA_MAX_MB  cap in MiB on what cnsn_arena_alloc's cache holds per device (default: half of the device memory)
     K_COUNT
 };

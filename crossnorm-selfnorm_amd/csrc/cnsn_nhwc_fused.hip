@@ -11,11 +11,12 @@ namespace {
 int vec_of(int dtype) { return 16 / elem_bytes(dtype); }
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// 0 never, 1 the AUTO rule (default), 2 wherever the kernels apply (CNSN_NHWC_FUSED)
+// 0 never, 1 the AUTO rule (default), 2 wherever the kernels apply, n > 2: AUTO for tensors of at most n MiB (CNSN_NHWC_FUSED)
 int fused_mode() {
     const char* e = knob(K_NHWC_FUSED);
     if (!e) return 1;
-    return e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);
+    const int v = atoi(e);
+    return v < 0 ? 0 : v;
 }
 
 template <typename F>
@@ -130,6 +131,7 @@ bool nhwc_fused_ok(const Plan& pl) {
     if (mode == 0) return false;
     if (p.N > kBlock || p.C % CNSN_NHWC_GC != 0 || p.H * p.W < 2) return false;  // (phase B: a thread per instance)
     if (p.strategy == CNSN_STRATEGY_AUTO && !resident_auto_enabled()) return false;
+    if (mode > 2 && p.strategy == CNSN_STRATEGY_AUTO && pl.P * (size_t)(p.H * p.W) * elem_bytes(p.dtype) > ((size_t)mode << 20)) return false;
     return true;
 }
 

@@ -27,7 +27,7 @@
 // group at the top counter, the last arriver there writes the eight generation words, everybody polls its group's — one lane
 // per workgroup, with the library's bounded wait and give-up protocol (the control word flips, the
 // pinned host word counts, every workgroup marks what it still owed with NaNs).  No fences: everything that crosses a
-// barrier is stored write-through and loaded past the L1 (`sc1`: st_coh2 / ld_coh2 of cnsn_nhwc_kernels.h), every wave waits
+// barrier is stored write-through and loaded past the L1 (`sc1`: CohBuf of cnsn_nhwc_kernels.h), every wave waits
 // for its stores' acknowledgements before its workgroup arrives.  (The first version fenced — release + acquire, agent scope,
 // in every wave — and spent ~200 us per barrier at 1 024 workgroups: 0.41 ms for a 7x7 site whose tensor passes take 0.06.)
 //
@@ -133,7 +133,7 @@ __device__ __forceinline__ bool grid_barrier(const GridBar& b, unsigned k, int* 
         }
         *flag = ok;
     }
-    __syncthreads();  // (what follows loads the other workgroups' results past the L1: ld_coh2)
+    __syncthreads();  // (what follows loads the other workgroups' results past the L1: CohBuf)
     return *flag != 0;
 }
 
@@ -157,6 +157,16 @@ __device__ __forceinline__ Vec<T, VEC> nhwc_ld(const T* p) {
         return load_vec<T, VEC>(p);
 }
 
+// Which channel group the workgroup in slot `slot` of phase B takes.  A thread reads GC adjacent floats (16-32 bytes) of a row
+// that is C floats long: the 64-byte sector it touches belongs to 2-4 ADJACENT groups.  Workgroups are placed on the XCD
+// blockIdx % 8 (observed, not promised), so adjacent groups go to slots 8 apart: the sector is fetched into ONE L2 once
+// instead of into several (PMC at 7x7: the backward read 1.6 x the tensor passes' bytes with the identity mapping).
+__device__ __forceinline__ int phase_b_group(int slot, int ngroups) {
+    if ((ngroups & 7) != 0) return slot;
+    const int per = ngroups >> 3;
+    return (slot & 7) * per + (slot >> 3);
+}
+
 // GC adjacent per-plane floats of another workgroup's making (coherent) / of the previous launch's (plain)
 template <int GC>
 __device__ __forceinline__ void load_group(const float* __restrict__ p, double (&o)[GC]) {
@@ -167,34 +177,24 @@ __device__ __forceinline__ void load_group(const float* __restrict__ p, double (
     }
 }
 template <int GC>
-__device__ __forceinline__ void load_group_coh(const float* __restrict__ p, double (&o)[GC]) {
+__device__ __forceinline__ void load_group_coh(const CohBuf& b, size_t idx, double (&o)[GC]) {
+    float f[GC];
+    b.load<GC>(idx, f);
 #pragma unroll
-    for (int q = 0; q < GC / 2; ++q) {
-        float a, b;
-        ld_coh2(p + 2 * q, a, b);
-        o[2 * q] = a, o[2 * q + 1] = b;
-    }
+    for (int j = 0; j < GC; ++j) o[j] = (double)f[j];
 }
 template <int GC>
-__device__ __forceinline__ void add_group_coh(const float* __restrict__ p, double (&o)[GC]) {
+__device__ __forceinline__ void add_group_coh(const CohBuf& b, size_t idx, double (&o)[GC]) {
+    float f[GC];
+    b.load<GC>(idx, f);
 #pragma unroll
-    for (int q = 0; q < GC / 2; ++q) {
-        float a, b;
-        ld_coh2(p + 2 * q, a, b);
-        o[2 * q] += (double)a, o[2 * q + 1] += (double)b;
-    }
+    for (int j = 0; j < GC; ++j) o[j] += (double)f[j];
 }
 template <int GC>
 __device__ __forceinline__ void store_group(float* __restrict__ p, const float (&o)[GC]) {
 #pragma unroll
     for (int q = 0; q < GC / 4; ++q) *reinterpret_cast<float4*>(p + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
 }
-template <int GC>
-__device__ __forceinline__ void store_group_coh(float* __restrict__ p, const float (&o)[GC]) {
-#pragma unroll
-    for (int q = 0; q < GC / 2; ++q) st_coh2(p + 2 * q, o[2 * q], o[2 * q + 1]);
-}
-
 // ================================================================================================
 // forward
 // ================================================================================================
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_fwd_ke
                 if constexpr (ADD == ADD_PRE) vb = nhwc_ld<T, VEC, !KEEP>(addend + e);
                 eat(va, vb, e);
             }
-            if (t.s == 0 && t.r == 0) store_planes_coh<VEC>(a.kshift + t.plane0(g), K);
+            if (t.s == 0 && t.r == 0) CohBuf(a.kshift).store<VEC>(t.plane0(g), K);
         }
         nhwc_rows_sum<VEC, 2, true>(g, t, acc, lds, a.part);
         __syncthreads();  // (lds is the next tile's)
@@ -268,18 +268,20 @@ __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_fwd_ke
     }
 
     // ---- B: per-plane algebra, GC adjacent channels per workgroup, thread n = instance n (N <= 256)
-    for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
+    for (int slot = blockIdx.x; slot < a.ngroups; slot += gridDim.x) {
+        const int grp = phase_b_group(slot, a.ngroups);
         const int c0 = grp * GC, n = threadIdx.x;
         const bool live = n < g.N;
         const size_t p0 = (size_t)(live ? n : 0) * g.C + c0;
         double s1[GC], s2[GC], mean[GC], sig[GC], z[GC];
 #pragma unroll
         for (int j = 0; j < GC; ++j) s1[j] = s2[j] = 0.0;
+        const CohBuf pb(a.part);
         for (int s = 0; s < g.S; ++s) {
-            add_group_coh<GC>(a.part + ((size_t)s * 2 + 0) * g.P + p0, s1);
-            add_group_coh<GC>(a.part + ((size_t)s * 2 + 1) * g.P + p0, s2);
+            add_group_coh<GC>(pb, ((size_t)s * 2 + 0) * g.P + p0, s1);
+            add_group_coh<GC>(pb, ((size_t)s * 2 + 1) * g.P + p0, s2);
         }
-        load_group_coh<GC>(a.kshift + p0, mean);
+        load_group_coh<GC>(CohBuf(a.kshift), p0, mean);
         const double M = (double)g.M;
 #pragma unroll
         for (int j = 0; j < GC; ++j) {
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_fwd_ke
                 o_lo[j] = (float)(mean[j] - (double)o_hi[j]);
                 o_sig[j] = (float)sig[j];
             }
-            store_group_coh<GC>(a.gout + p0, o_g);  // (phase C reads it)
+            CohBuf(a.gout).store<GC>(p0, o_g);  // (phase C reads it)
             if (a.slim) {
                 store_group<GC>(a.slim + (size_t)SL_MU_HI * g.P + p0, o_hi);
                 store_group<GC>(a.slim + (size_t)SL_MU_LO * g.P + p0, o_lo);
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_fwd_ke
         const NhwcThread<VEC> t(g, tile);
         if (!t.active) continue;
         float gate[VEC];
-        load_planes_coh<VEC>(a.gout + t.plane0(g), gate);
+        CohBuf(a.gout).load<VEC>(t.plane0(g), gate);
         constexpr bool TWO = ADD != ADD_NONE && !SUM;  // a second tensor to read
         constexpr int U = TWO ? 2 : 4;
         const T* const xin = SUM ? (const T*)xsum : x;
@@ -469,16 +471,18 @@ __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_bwd_ke
     }
 
     // ---- B': gate / BatchNorm1d backward per channel (closed form: oracle/closed_form.py, csrc/cnsn_algebra.h with a = a1 = 1)
-    for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
+    for (int slot = blockIdx.x; slot < a.ngroups; slot += gridDim.x) {
+        const int grp = phase_b_group(slot, a.ngroups);
         const int c0 = grp * GC, n = threadIdx.x;
         const bool live = n < g.N;
         const size_t p0 = (size_t)(live ? n : 0) * g.C + c0;
         double S1[GC], S2[GC], mu[GC], lo[GC], gate[GC], zh[GC], sig[GC];
 #pragma unroll
         for (int j = 0; j < GC; ++j) S1[j] = S2[j] = 0.0;
+        const CohBuf pb(a.part);
         for (int s = 0; s < g.S; ++s) {
-            add_group_coh<GC>(a.part + ((size_t)s * 2 + 0) * g.P + p0, S1);
-            add_group_coh<GC>(a.part + ((size_t)s * 2 + 1) * g.P + p0, S2);
+            add_group_coh<GC>(pb, ((size_t)s * 2 + 0) * g.P + p0, S1);
+            add_group_coh<GC>(pb, ((size_t)s * 2 + 1) * g.P + p0, S2);
         }
         load_group<GC>(a.slim + (size_t)SL_MU_HI * g.P + p0, mu);
         load_group<GC>(a.slim + (size_t)SL_MU_LO * g.P + p0, lo);
@@ -531,8 +535,9 @@ __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_bwd_ke
             dg.dw[2 * (c0 + threadIdx.x) + 1] = (float)w1;
         }
         if (live) {
-            store_group_coh<GC>(a.coefb + p0, o_cx);  // (phase C' reads them)
-            store_group_coh<GC>(a.coefb + g.P + p0, o_c0);
+            const CohBuf cb(a.coefb);  // (phase C' reads them)
+            cb.store<GC>(p0, o_cx);
+            cb.store<GC>(g.P + p0, o_c0);
         }
         __syncthreads();
     }
@@ -550,9 +555,10 @@ __global__ __launch_bounds__(kBlock, CNSN_NHWC_WG_PER_CU) void nhwc_fused_bwd_ke
         const size_t pl = t.plane0(g);
         float cG[VEC], cX[VEC], xr[VEC], c0[VEC];
         load_planes<VEC>(row_g + pl, cG);
-        load_planes_coh<VEC>(a.coefb + pl, cX);
+        const CohBuf cb(a.coefb);
+        cb.load<VEC>(pl, cX);
         load_planes<VEC>(row_mu + pl, xr);
-        load_planes_coh<VEC>(a.coefb + g.P + pl, c0);
+        cb.load<VEC>(g.P + pl, c0);
         auto emit = [&](const Vec<T, VEC>& vg, const Vec<T, VEC>& vx, const Vec<T, VEC>& vb, size_t e) {
             Vec<T, VEC> o, om;
 #pragma unroll

@@ -76,30 +76,37 @@ __device__ __forceinline__ void store_planes(float* __restrict__ p, const float 
 
 // The same, AGENT-COHERENT: what one workgroup writes and another reads INSIDE a launch (the single-launch kernels of
 // cnsn_nhwc_fused_kernels.h, across their grid barriers).  The L2s of the eight XCDs are not coherent with each other and a
-// compute unit's L1 is never refreshed by another one's stores: relaxed agent-scope atomics compile to `sc1` accesses — stores
-// written through to memory, loads served past the L1 — 8 bytes at a time (the widest the builtin takes); a full release /
-// acquire fence pair in every wave instead cost these launches ~200 us per barrier.
-typedef __attribute__((address_space(1))) unsigned long long nhwc_gu64;
-__device__ __forceinline__ void st_coh2(float* p, float a, float b) {
-    __hip_atomic_store((nhwc_gu64*)p, ((unsigned long long)__float_as_uint(b) << 32) | (unsigned long long)__float_as_uint(a),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void ld_coh2(const float* p, float& a, float& b) {
-    const unsigned long long v = __hip_atomic_load((nhwc_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    a = __uint_as_float((unsigned)v);
-    b = __uint_as_float((unsigned)(v >> 32));
-}
-template <int VEC>
-__device__ __forceinline__ void load_planes_coh(const float* __restrict__ p, float (&o)[VEC]) {
-    static_assert(VEC % 2 == 0, "whole pairs");
+// compute unit's L1 is never refreshed by another one's stores: these accesses carry `sc1` — stores written through to
+// memory, loads served past the L1 — 16 bytes at a time through a buffer descriptor over the whole side array (aux bit 4 of
+// the raw buffer builtins; a relaxed agent-scope atomic is the same instruction but at most 8 bytes wide, and an 8-byte
+// write-through store is a fabric transaction of its own: PMC write traffic of the 7x7 sites 1.38-1.62 x the tensor's with
+// those).  A full release / acquire fence pair in every wave instead cost these launches ~200 us per barrier.
+struct CohBuf {
+    __amdgpu_buffer_rsrc_t r;
+    // `base`: wave-uniform (a kernel argument), 16-byte aligned; every index below is a multiple of 4 floats, < 2^29
+    __device__ __forceinline__ explicit CohBuf(const float* base)
+        : r(__builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffff0, 0x00020000)) {}
+    __device__ __forceinline__ void st4(size_t idx, float a, float b, float c, float d) const {
+        nt_u4 v;
+        v.x = __float_as_uint(a), v.y = __float_as_uint(b), v.z = __float_as_uint(c), v.w = __float_as_uint(d);
+        __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(idx * 4), 0, 16);
+    }
+    __device__ __forceinline__ void ld4(size_t idx, float& a, float& b, float& c, float& d) const {
+        const nt_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(idx * 4), 0, 16);
+        a = __uint_as_float(v.x), b = __uint_as_float(v.y), c = __uint_as_float(v.z), d = __uint_as_float(v.w);
+    }
+    template <int VEC>
+    __device__ __forceinline__ void load(size_t idx, float (&o)[VEC]) const {
+        static_assert(VEC % 4 == 0, "whole float4s");
 #pragma unroll
-    for (int q = 0; q < VEC / 2; ++q) ld_coh2(p + 2 * q, o[2 * q], o[2 * q + 1]);
-}
-template <int VEC>
-__device__ __forceinline__ void store_planes_coh(float* __restrict__ p, const float (&o)[VEC]) {
+        for (int q = 0; q < VEC / 4; ++q) ld4(idx + 4 * q, o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    }
+    template <int VEC>
+    __device__ __forceinline__ void store(size_t idx, const float (&o)[VEC]) const {
 #pragma unroll
-    for (int q = 0; q < VEC / 2; ++q) st_coh2(p + 2 * q, o[2 * q], o[2 * q + 1]);
-}
+        for (int q = 0; q < VEC / 4; ++q) st4(idx + 4 * q, o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    }
+};
 
 // rows of a block -> one value per (column, channel-in-vector, accumulator), fixed order; lds: [NACC][rows][tcb*VEC] floats
 // (COH: the partial sums are read by other workgroups of the same launch)
@@ -114,6 +121,23 @@ __device__ __forceinline__ void nhwc_rows_sum(const NhwcGeom& g, const NhwcThrea
             for (int j = 0; j < VEC; ++j) lds[((size_t)k * g.rows + t.r) * width + col * VEC + j] = t.active ? acc[k][j] : 0.f;
     }
     __syncthreads();
+    if constexpr (COH) {
+        // every thread adds the rows of FOUR adjacent results and stores them with one 16-byte write-through store: a wave
+        // writes 1 KB of contiguous partial sums (the rows in a fixed order, as below)
+        const CohBuf pb(part);
+        const int total = NACC * width, first = (t.vc - col) * VEC;  // channel of the tile's first column
+        for (int ch = (int)threadIdx.x * 4; ch < total; ch += kBlock * 4) {
+            const int k = ch / width, off = ch - k * width;
+            if (first + off >= g.C) continue;  // (the last column block may be partly outside the tensor; C % 4 == 0)
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < g.rows; ++q) {
+                const float4 w = *reinterpret_cast<const float4*>(lds + ((size_t)k * g.rows + q) * width + off);
+                v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
+            }
+            pb.st4(((size_t)t.s * NACC + k) * g.P + (size_t)t.n * g.C + first + off, v.x, v.y, v.z, v.w);
+        }
+        return;
+    }
     if (t.r == 0 && t.active) {
         const size_t p = t.plane0(g);
 #pragma unroll
@@ -124,10 +148,7 @@ __device__ __forceinline__ void nhwc_rows_sum(const NhwcGeom& g, const NhwcThrea
                 v[j] = 0.f;
                 for (int q = 0; q < g.rows; ++q) v[j] += lds[((size_t)k * g.rows + q) * width + col * VEC + j];
             }
-            if constexpr (COH)
-                store_planes_coh<VEC>(part + ((size_t)t.s * NACC + k) * g.P + p, v);
-            else
-                store_planes<VEC>(part + ((size_t)t.s * NACC + k) * g.P + p, v);
+            store_planes<VEC>(part + ((size_t)t.s * NACC + k) * g.P + p, v);
         }
     }
 }

@@ -19,7 +19,9 @@ namespace cnsn {
 //   * lanes past the end of the plane in its partly filled slot get voffset = tensor bytes (same effect).  Slots are
 //     RIGHT-ALIGNED — slot j holds vectors (j - shift)*64 + lane with shift = NV - slots needed — so that the partly filled
 //     slot is always slot NV-1 and the choice between the two voffset registers is made at compile time;
-//   * everything stays below 2^32 as long as the tensor is smaller than 2 GiB (the plan checks).
+//   * everything stays below 2^32 as long as the tensor is smaller than 1 GiB (the plans check): the largest sum an
+//     instruction can see is dead + dead (a dead plane AND a dead lane) + s*stride + a slot offset = 2*bytes + less than
+//     bytes + a few KB; with bytes < 2^30 that is < 2^32 - no wrap back into the tensor (round-5 advisor: below 2 GiB it could).
 template <typename T, int VEC, int NV>
 struct PlaneIo {
     static constexpr int VB = VEC * (int)sizeof(T), SLOT = 64 * VB;
@@ -50,7 +52,7 @@ struct PlaneIo {
         return exists ? ((unsigned)n0 * (unsigned)C + (unsigned)c) * (unsigned)M * (unsigned)sizeof(T) : dead;
     }
     __device__ __forceinline__ unsigned at(unsigned span_off, unsigned stride, int s, int nlive) const {
-        return (s < nlive ? span_off : dead) + (unsigned)s * stride;  // (dead + s*stride < 2^32: the tensor is below 2 GiB)
+        return (s < nlive ? span_off : dead) + (unsigned)s * stride;  // (dead + s*stride < 2^31: the tensor is below 1 GiB)
     }
     __device__ __forceinline__ bool valid(int j) const { return j >= shift && (j < NV - 1 || lane < tail); }
     __device__ __forceinline__ int voff(int j) const { return j == NV - 1 ? voff_part : voff_full; }

@@ -35,6 +35,15 @@ bool dispatch_pipe(int dtype, int vec, int nv, F&& f) {
     return false;
 }
 
+// Which (element size, slots, crop boxes) classes of the pipelined forward are BUILT: the ones an AUTO rule of
+// resident_pipe_plan can pick (round 6, the variant budget: 15 of the 36 instantiations were reachable with CNSN_PIPE=2
+// only — fp32 un-boxed 8 / 16 slots, fp32 boxed 2 / 7 / 8, 16-bit un-boxed 16, 16-bit boxed 4 / 8 / 13 / 16 — every one of
+// them slower than the plain cluster kernel where it was measured, most of them spilling; those calls run the plain kernel).
+constexpr bool pipe_class_built(int elem, int nv, bool boxed) {
+    if (elem == 4) return boxed ? (nv == 4 || nv == 13 || nv == 16) : (nv == 2 || nv == 4 || nv == 7 || nv == 13);
+    return boxed ? (nv == 2 || nv == 7) : (nv == 2 || nv == 4 || nv == 7 || nv == 8 || nv == 13);
+}
+
 // CNSN_PIPE=0: never; CNSN_PIPE=2: also for grids with fewer than three items per workgroup (tests)
 int pipe_mode() {
     const char* e = knob(K_PIPE);
@@ -53,7 +62,8 @@ ResPlan resident_pipe_plan(const cnsn_problem_t& p, bool boxed, bool has_chan_pe
     if (!boxed && !p.cn_active && !(p.sn_active && p.sn_training)) return none;  // inference: nothing to wait for
     const int vb = rp.vec * elem_bytes(p.dtype);
     if (vb != 16 || rp.nv < 2) return none;
-    if ((size_t)p.N * p.C * p.H * p.W * elem_bytes(p.dtype) >= ((size_t)1 << 31)) return none;  // one descriptor per tensor: see PlaneIo
+    if (!pipe_class_built(elem_bytes(p.dtype), rp.nv, boxed)) return none;  // (not even when forced)
+    if ((size_t)p.N * p.C * p.H * p.W * elem_bytes(p.dtype) >= ((size_t)1 << 30)) return none;  // one descriptor per tensor, 32-bit offsets that must not wrap: see PlaneIo
     const int slots = rp.ppw * rp.nv, nvec = p.H * p.W / rp.vec;
     const int wg_per_cu = pipe_fwd_waves(slots);
     const int grid_max = (wg_per_cu * reshost::cu_count() / rp.K) * rp.K;
@@ -142,10 +152,11 @@ int resident_pipe_forward(const cnsn_problem_t& p, Box cb, Box sb, bool boxed, c
             status = e == hipSuccess ? CNSN_OK : (int)e;
             if (use_pong && e == hipSuccess) resident_pong_commit(p, fill_bytes);
         };
-        if (boxed)
-            launch(resident_fwd_pipe_kernel<T, VEC, NV, PPW, true>);
-        else
-            launch(resident_fwd_pipe_kernel<T, VEC, NV, PPW, false>);
+        if (boxed) {
+            if constexpr (pipe_class_built((int)sizeof(T), NV, true)) launch(resident_fwd_pipe_kernel<T, VEC, NV, PPW, true>);
+        } else {
+            if constexpr (pipe_class_built((int)sizeof(T), NV, false)) launch(resident_fwd_pipe_kernel<T, VEC, NV, PPW, false>);
+        }
     });
     return status;
 }

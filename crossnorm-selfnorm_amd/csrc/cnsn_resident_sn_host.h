@@ -151,7 +151,7 @@ inline SnxPlan plan_impl(const cnsn_problem_t& p, bool boxed, int add, int relu,
     const int M = p.H * p.W, eb = elem_bytes(p.dtype);
     SnxPlan sp = none;
     sp.vec = pick_vec(p.dtype, boxed ? p.W : M);  // (crop boxes: a vector must not straddle two rows)
-    if ((size_t)p.N * p.C * M * eb >= ((size_t)1 << 31)) return none;  // one descriptor per tensor: see PlaneIo
+    if ((size_t)p.N * p.C * M * eb >= ((size_t)1 << 30)) return none;  // one descriptor per tensor, 32-bit offsets that must not wrap: see PlaneIo
     const int vb = sp.vec * eb;
     const int nvec = M / sp.vec;
     // 16-byte vectors; one-slot planes (the 14x14 class) also with 8-byte ones.  Planes of at most 32 vectors stay with

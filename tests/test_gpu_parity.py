@@ -409,8 +409,38 @@ def test_errors():
         cnsn_amd.cn_op_2ins_space_chan(torch.randn(2, 4, 8, 8, device=DEV), crop="bogus")
     with pytest.raises(AssertionError):
         cnsn_amd.calc_ins_mean_std(torch.randn(2, 4, 8, device=DEV))
-    with pytest.raises(TypeError):                     # SelfNorm's gate on float64 input: not offered (float32 parameters)
-        cnsn_amd.SelfNorm(4).to(DEV).train()(torch.randn(2, 4, 8, 8, device=DEV, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("double_params", [False, True], ids=["f32-params", "f64-params"])
+def test_selfnorm_takes_float64_like_the_reference(double_params):
+    """models/cnsn.py:130-150 accepts any floating dtype.  float64 activations (round 6): computed by the float32 kernels,
+    returned as float64 — float32 accuracy (north_star's 1e-5) against the float64 oracle; a module made float64 by
+    `.double()` keeps float64 parameters, running statistics and gradients."""
+    shape = (6, 8, 9, 7)
+    x64 = cond_input(shape, 21)
+    gy64 = torch.randn(shape, generator=torch.Generator().manual_seed(22), dtype=torch.float64)
+    sn_o = fill_sn(orc.SelfNorm(shape[1]), 9, torch.float64).train()
+    xo = x64.clone().requires_grad_()
+    yo = sn_o(xo)
+    yo.backward(gy64)
+    sn = fill_sn(cnsn_amd.SelfNorm(shape[1]), 9, torch.float64 if double_params else torch.float32).to(DEV).train()
+    m = cnsn_amd.CNSN(None, sn)
+    xg = x64.to(DEV).requires_grad_()
+    y = m(xg)
+    assert y.dtype == torch.float64
+    y.backward(gy64.to(DEV))
+    torch.cuda.synchronize()
+    scale = max(1.0, float(yo.abs().max()))
+    assert float((y.detach().cpu() - yo.detach()).abs().max()) <= 1e-5 * scale
+    assert xg.grad.dtype == torch.float64
+    assert float((xg.grad.cpu() - xo.grad).abs().max()) <= 1e-5 * max(1.0, float(xo.grad.abs().max()))
+    for p, q in zip(sn.parameters(), sn_o.parameters()):
+        assert p.grad.dtype == p.dtype
+        assert float((p.grad.cpu().double() - q.grad).abs().max()) <= 1e-4 * max(1.0, float(q.grad.abs().max()))
+    assert float((sn.g_bn.running_var.cpu().double() - sn_o.g_bn.running_var).abs().max()) <= 1e-5
+    # the block form too
+    z = m.forward_block(xg.detach(), xg.detach() * 0.5, add_mode="pre", relu=True)
+    assert z.dtype == torch.float64 and z.shape == xg.shape
 
 
 @pytest.mark.parametrize("crop", ["neither", "both"])

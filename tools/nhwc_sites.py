@@ -14,7 +14,9 @@ dev = torch.device("cuda:0")
 dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
 print(f"| site | NCHW fwd / bwd ms | channels-last fwd / bwd ms | bytes x (MB) |")
 print("|---|---|---|---|")
-for shape in ((256, 256, 56, 56), (256, 512, 28, 28), (256, 1024, 14, 14), (256, 2048, 7, 7)):
+SITES = ((256, 256, 56, 56), (256, 512, 28, 28), (256, 1024, 14, 14), (256, 2048, 7, 7))
+only = [int(a[4:]) for a in sys.argv[2:] if a.startswith("site")]
+for shape in ([SITES[i] for i in only] or SITES):
     row = []
     for fmt in ((torch.channels_last,) if "cl" in sys.argv[2:] else (torch.contiguous_format, torch.channels_last)):
         x = torch.randn(shape, device=dev).to(dt).contiguous(memory_format=fmt).requires_grad_()
