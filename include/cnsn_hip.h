@@ -13,14 +13,15 @@
  *   - The caller owns every buffer the op's entry points take (inputs, outputs, `saved`, `workspace`, `context`); those
  *     entry points enqueue their work on `stream` (a hipStream_t passed as void*; NULL = default stream), never
  *     synchronise the host and never throw.  What the library DOES own, allocate and keep — all of it outside the
- *     numerical path, listed here once (ABI 5-7; SURVEY b2 asked for none of it, DESIGN.md section 1 says why each exists):
+ *     numerical path, listed here once (ABI 5-8; SURVEY b2 asked for none of it, DESIGN.md section 1 says why each exists):
  *       allocates   nothing on the device inside the op's calls.  The OUTPUT ARENA (cnsn_arena_*, below) allocates device
  *                   memory — hipMemCreate / hipMemMap — but only when a caller asks it for a block;
  *       synchronises  the op's calls: never.  The arena: the requesting stream when a NEW block of 384 MiB or more is timed
  *                   (~1 ms per candidate, at creation only), the streams of the blocks it releases (cnsn_arena_trim, the cap);
  *       keeps, per process   which stream the last persistent ("cluster") launch of each device went to (a launch on another
- *                   stream waits for it: one event recorded at that moment); a launch counter and two granule regions per
- *                   exchange context; ONE pinned host word counting cluster launches that gave up (cnsn_resident_timeouts)
+ *                   stream waits for it: one event recorded at that moment); a launch counter, two granule regions and
+ *                   (ABI 8) the bases of the grid-barrier counters per exchange context — the counters themselves live in the
+ *                   caller's context buffer and only grow; ONE pinned host word counting cluster launches that gave up (cnsn_resident_timeouts)
  *                   and the count forgiven by cnsn_resident_rearm; the wait bound (cnsn_set_wait_ms), the grid head-room
  *                   (cnsn_set_headroom_cus) and the strategy switches (cnsn_resident_enable); the CNSN_* environment as of
  *                   load; the arena's blocks, free lists and counters.
@@ -47,8 +48,9 @@ extern "C" {
 /* Largest batch whose permutation can travel as a launch argument (cnsn_problem_t.perm_host). */
 #define CNSN_PERM_INLINE_MAX 1024
 
-/* Element types of the activation tensors.  float64 is NOT offered (the reference's eager path accepts any float tensor,
- * models/cnsn.py:12-16): CNSN_E_DTYPE here, a TypeError naming the three supported types in the Python layer. */
+/* Element types of the activation tensors.  float64 is NOT offered here (the reference's eager path accepts any float tensor,
+ * models/cnsn.py:12-16): CNSN_E_DTYPE.  The Python layer takes float64 tensors through these entry points on a float32 copy
+ * and returns float64 (float32 accuracy in a float64 container: cnsn_amd/cnsn.py). */
 enum cnsn_dtype { CNSN_F32 = 0, CNSN_BF16 = 1, CNSN_F16 = 2 };
 
 enum cnsn_status {
@@ -66,8 +68,12 @@ enum cnsn_status {
 
 /* Memory order of the activation tensors (ABI 6).  The reference takes any layout through `.contiguous()` (models/cnsn.py:14,16:
  * a channels-last tensor is COPIED to NCHW there).  CNSN_LAYOUT_NHWC: element (n, c, h, w) lives at ((n*H + h)*W + w)*C + c — what
- * torch.channels_last tensors and MIOpen's NHWC convolutions use; the op is computed where the tensor lies (two-pass kernels around
- * the same per-plane algebra; `saved`, parameter gradients and running statistics as in NCHW).  Un-boxed calls whose channel count
+ * torch.channels_last tensors and MIOpen's NHWC convolutions use; the op is computed where the tensor lies (two tensor passes each
+ * way around the same per-plane algebra: for SelfNorm alone with one gate — every ResNet-50 site — ONE persistent launch per
+ * direction with two grid barriers, otherwise a launch per pass; parameter gradients and running statistics as in NCHW).  `saved`
+ * of a channels-last call WITHOUT CrossNorm and with one gate is the SLIM record (round 6): five floats per plane in plane
+ * order + C doubles, written and read by both channels-last strategies (any forward feeds any backward of the class,
+ * tests/test_gpu_saved_contract.py); cnsn_saved_floats() still answers the common record's size, an upper bound.  Un-boxed calls whose channel count
  * is a whole number of 16-byte vectors (C % 4 == 0 in fp32, C % 8 == 0 in 16 bits), no channel permutation; everything else
  * returns CNSN_E_UNSUPPORTED and the caller converts to NCHW as the reference does.  cnsn_workspace_bytes() is layout-dependent. */
 enum cnsn_layout { CNSN_LAYOUT_NCHW = 0, CNSN_LAYOUT_NHWC = 1 };
@@ -316,7 +322,11 @@ int cnsn_sn_cluster_plan(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi,
  *                             every buffer before it is passed as cnsn_problem_t.context; the caller orders the
  *                             fill before the first use (same stream, or a synchronisation)
  * Its last 4 MiB are two regions of untagged granules that launches on large tensors use alternately, each launch
- * clearing the other region for the next one (no fill launch; cnsn_context_bytes includes them).
+ * clearing the other region for the next one (no fill launch; cnsn_context_bytes includes them).  In front of them (ABI 8):
+ * a 4 KiB BARRIER BLOCK — the arrival counters of the single-launch channels-last kernels' grid barrier (eight group counters,
+ * a top counter, eight generation words, each in a cache line of its own).  They only grow; the library keeps, per context,
+ * what the launches so far have left in them, so nothing is cleared between launches (a launch that gave up leaves them
+ * short: the next launch that needs the block zeroes it, stream-ordered).
  * One context per device, used by one stream at a time or by streams the library orders itself (its per-device
  * launch chaining).  Not used while `stream` is being captured into a graph (a replay would repeat the launch
  * number): such calls fall back to the workspace.  Nothing in the reference corresponds to this. */
