@@ -7,6 +7,7 @@ SelfNorm sites per forward at batch B, pos='post' (SURVEY.md §3.2): (B,256,56,5
 import torch
 import torch.nn as nn
 
+from . import _sites
 from ._sites import CrossNormSites, make_cnsn, residual_sum
 
 
@@ -33,9 +34,14 @@ class _Bottleneck(nn.Module):
         h = self.cnsn(x) if self.pos == "pre" else x
         h = self.relu(self.bn1(self.conv1(h)))
         h = self.relu(self.bn2(self.conv2(h)))
-        h = self.bn3(self.conv3(h))
+        h = self.conv3(h)
         skip = x if self.downsample is None else self.downsample(x)
-        return residual_sum(getattr(self, "cnsn", None), self.pos, h, skip, relu=True)      # :112-122
+        # :108-122.  pos='post': bn3, the add, the CNSN unit and the ReLU are ONE call when the unit offers it (this library's
+        # `CNSN.forward_bn_block`: one launch per direction on channels-last tensors, the un-fused sequence otherwise)
+        fb = getattr(getattr(self, "cnsn", None), "forward_bn_block", None) if (_sites.FUSE_BLOCK and self.pos == "post") else None
+        if fb is not None and h.is_cuda:
+            return fb(h, self.bn3, skip, relu=True)
+        return residual_sum(getattr(self, "cnsn", None), self.pos, self.bn3(h), skip, relu=True)
 
 
 class ResNet50CNSN(nn.Module, CrossNormSites):

@@ -128,6 +128,61 @@ int cnsn_keeps_sum(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi) {
     return nhwc_supported(pl, false) ? 1 : 0;
 }
 
+// ---- the block's last BatchNorm2d in front of the op (cnsn_nhwc_bnhead_kernels.h) ---------------------------------------------
+namespace {
+int bn_block_parse(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const cnsn_bn_tail_t* bn, Plan& pl, EpiPlan& e, bool shape_only,
+                   bool check_health = true) {
+    int st = shape_only ? parse_epilogue_shape(epi, e) : parse_epilogue(epi, e);
+    if (st) return st;
+    st = make_plan(prob, pl);
+    if (st) return st;
+    if (bn && bn->struct_bytes != (int32_t)sizeof(cnsn_bn_tail_t)) return CNSN_E_STRUCT;
+    if (pl.pr.layout != CNSN_LAYOUT_NHWC || e.add != ADD_PRE || e.sum_out || !nhwc_bnhead_ok(pl, check_health) || (bn && !bn->training))
+        return CNSN_E_UNSUPPORTED;
+    return CNSN_OK;
+}
+}  // namespace
+
+int cnsn_bn_block_plan(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi) {
+    Plan pl;
+    EpiPlan e;
+    const int st = bn_block_parse(prob, epi, nullptr, pl, e, true);
+    return st == CNSN_OK ? 1 : (st == CNSN_E_UNSUPPORTED ? 0 : st);
+}
+
+int cnsn_forward_bn_block(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const cnsn_bn_tail_t* bn, const void* conv_out,
+                          const cnsn_gate_t* g, void* y, float* saved, float* bn_stats, void* workspace, size_t workspace_bytes,
+                          void* stream_) {
+    if (!bn) return CNSN_E_NULL;
+    Plan pl;
+    EpiPlan e;
+    const int st = bn_block_parse(prob, epi, bn, pl, e, false);
+    if (st) return st;
+    if (!conv_out || !y || !workspace || !bn_stats || !bn->weight || !bn->bias || !bn->running_mean || !bn->running_var) return CNSN_E_NULL;
+    if ((((uintptr_t)conv_out | (uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bn_stats) & 15u) != 0) return CNSN_E_ALIGN;
+    if (!gate_ok(g)) return CNSN_E_NULL;
+    return nhwc_bnhead_forward(pl, e.relu, *bn, conv_out, e.addend, gate_dev(g), y, saved, bn_stats, workspace, workspace_bytes,
+                               (hipStream_t)stream_);
+}
+
+int cnsn_backward_bn_block(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const cnsn_bn_tail_t* bn, const void* grad_y,
+                           const void* conv_out, const cnsn_gate_t* g, const float* saved, const float* bn_stats, void* grad_conv_out,
+                           void* grad_identity, const cnsn_gate_grad_t* dg, float* d_bn_weight, float* d_bn_bias, void* workspace,
+                           size_t workspace_bytes, void* stream_) {
+    if (!bn) return CNSN_E_NULL;
+    Plan pl;
+    EpiPlan e;
+    const int st = bn_block_parse(prob, epi, bn, pl, e, false, false);
+    if (st) return st;
+    if (!grad_y || !conv_out || !grad_conv_out || !grad_identity || !saved || !bn_stats || !workspace || !bn->weight) return CNSN_E_NULL;
+    if ((((uintptr_t)grad_y | (uintptr_t)conv_out | (uintptr_t)grad_conv_out | (uintptr_t)grad_identity | (uintptr_t)workspace |
+          (uintptr_t)bn_stats) & 15u) != 0)
+        return CNSN_E_ALIGN;
+    if (!gate_ok(g) || !dg || !dg->d_fc_weight || !dg->d_bn_weight || !dg->d_bn_bias) return CNSN_E_NULL;
+    return nhwc_bnhead_backward(pl, e.relu, *bn, grad_y, conv_out, e.addend, gate_dev(g), saved, bn_stats, grad_conv_out, grad_identity,
+                                gate_grad_dev(dg), d_bn_weight, d_bn_bias, workspace, workspace_bytes, (hipStream_t)stream_);
+}
+
 int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const void* x, const int64_t* perm,
                        const int64_t* chan_perm, const cnsn_gate_t* g, const cnsn_gate_t* f, void* y, float* saved,
                        void* workspace, size_t workspace_bytes, void* stream_) {

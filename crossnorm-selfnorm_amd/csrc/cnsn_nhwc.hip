@@ -82,7 +82,11 @@ size_t nhwc_extra_bytes(const Plan& pl) {
 size_t nhwc_workspace_bytes(const Plan& pl) {
     if (!nhwc_supported(pl, false)) return 0;
     const size_t two_pass = align256(workspace_bytes_of(pl)) + nhwc_extra_bytes(pl);
-    const size_t fused = nhwc_slim_record(pl) ? nhwc_fused_extra_bytes(pl) : 0;
+    size_t fused = nhwc_slim_record(pl) ? nhwc_fused_extra_bytes(pl) : 0;
+    if (nhwc_slim_record(pl) && pl.pr.N <= kBlock && pl.pr.sn_training) {  // (+ the BatchNorm2d-in-front launches: five rows of partial sums)
+        const size_t bn = nhwc_bnhead_extra_bytes(pl);
+        fused = fused > bn ? fused : bn;
+    }
     return two_pass > fused ? two_pass : fused;
 }
 

@@ -1,6 +1,7 @@
 // Channels-last single-launch kernels (cnsn_nhwc_fused_kernels.h): host side.
 #include "cnsn_nhwc.h"
 
+#include "cnsn_nhwc_bnhead_kernels.h"
 #include "cnsn_nhwc_fused_kernels.h"
 #include "cnsn_resident_host.h"
 
@@ -69,10 +70,11 @@ NhwcFusedArgs make_args(const Plan& pl, const NhwcGeom& ng, int relu, int gc) {
 }
 
 // issue `kern` with a co-resident grid (a multiple of 8: the barrier's groups are equal); the barriers are booked on the
-// context before the launch
-template <typename Kern, typename... Args>
-int launch_fused(const Plan& pl, Kern kern, size_t lds, NhwcFusedArgs& a, void* ws_bar, hipStream_t stream, Args... args) {
-    const int grid = reshost::grid_for(kern, lds, 8, a.ntiles & ~7);
+// context before the launch.  `a`: the kernel's first argument (NhwcFusedArgs, or a struct that holds one), `fa` the
+// NhwcFusedArgs inside it
+template <typename A, typename Kern, typename... Args>
+int launch_fused(const Plan& pl, Kern kern, size_t lds, A& a, NhwcFusedArgs& fa, void* ws_bar, hipStream_t stream, Args... args) {
+    const int grid = reshost::grid_for(kern, lds, 8, fa.ntiles & ~7);
     if (grid < 8) return CNSN_E_UNSUPPORTED;
     ResidentChain chain(stream);  // persistent grids of different streams never overlap
     const BarArea ba = resident_bar_area(pl.pr, ws_bar, stream, grid, 2);
@@ -80,10 +82,10 @@ int launch_fused(const Plan& pl, Kern kern, size_t lds, NhwcFusedArgs& a, void* 
         const hipError_t e = hipMemsetAsync(ws_bar, 0, kBarBlock, stream);
         if (e != hipSuccess) return (int)e;
     }
-    a.bar.ctl = ba.ctl;
-    a.bar.block = ba.block;
-    a.bar.group_base = ba.group_base;
-    a.bar.bar_base = ba.bar_base;
+    fa.bar.ctl = ba.ctl;
+    fa.bar.block = ba.block;
+    fa.bar.group_base = ba.group_base;
+    fa.bar.bar_base = ba.bar_base;
     kern<<<grid, kBlock, lds, stream>>>(a, args...);
     return launch_status();
 }
@@ -122,15 +124,15 @@ bool nhwc_slim_record(const Plan& pl) {
     return p.layout == CNSN_LAYOUT_NHWC && !p.cn_active && p.sn_active && !p.sn_two;
 }
 
-bool nhwc_fused_ok(const Plan& pl) {
+bool nhwc_fused_ok(const Plan& pl, bool check_health) {
     const cnsn_problem_t& p = pl.pr;
     if (!nhwc_slim_record(pl) || !nhwc_supported(pl, false)) return false;
     if (p.strategy == CNSN_STRATEGY_TWO_PASS || p.strategy == CNSN_STRATEGY_LOCAL || p.strategy == CNSN_STRATEGY_MONO) return false;
-    if (resident_degraded()) return false;  // a persistent launch gave up and nobody re-armed since: not even when forced
+    if (check_health && resident_degraded()) return false;  // a persistent launch gave up and nobody re-armed since: not even when forced
     const int mode = fused_mode();
     if (mode == 0) return false;
     if (p.N > kBlock || p.C % CNSN_NHWC_GC != 0 || p.H * p.W < 2) return false;  // (phase B: a thread per instance)
-    if (p.strategy == CNSN_STRATEGY_AUTO && !resident_auto_enabled()) return false;
+    if (check_health && p.strategy == CNSN_STRATEGY_AUTO && !resident_auto_enabled()) return false;
     if (mode > 2 && p.strategy == CNSN_STRATEGY_AUTO && pl.P * (size_t)(p.H * p.W) * elem_bytes(p.dtype) > ((size_t)mode << 20)) return false;
     return true;
 }
@@ -164,17 +166,17 @@ int nhwc_fused_forward(Plan& pl, int add, int relu, const void* x, const void* a
         constexpr int VEC = decltype(vt)::value;
         const size_t lds = (size_t)2 * ng.rows * ng.tcb * VEC * 4;
         if (a.sum_out) {  // (the second read is of what phase A wrote: the first one need not stay in the caches)
-            status = launch_fused(pl, nhwc_fused_fwd_kernel<T, VEC, ADD_PRE, false, true>, lds, a, ws_bar, stream, (const T*)x,
+            status = launch_fused(pl, nhwc_fused_fwd_kernel<T, VEC, ADD_PRE, false, true>, lds, a, a, ws_bar, stream, (const T*)x,
                                   (const T*)addend, (T*)y, gg);
             return;
         }
         with_add(add, [&](auto at) {
             constexpr int ADD = decltype(at)::value;
             if (a.keep)
-                status = launch_fused(pl, nhwc_fused_fwd_kernel<T, VEC, ADD, true>, lds, a, ws_bar, stream, (const T*)x, (const T*)addend,
+                status = launch_fused(pl, nhwc_fused_fwd_kernel<T, VEC, ADD, true>, lds, a, a, ws_bar, stream, (const T*)x, (const T*)addend,
                                       (T*)y, gg);
             else
-                status = launch_fused(pl, nhwc_fused_fwd_kernel<T, VEC, ADD, false>, lds, a, ws_bar, stream, (const T*)x,
+                status = launch_fused(pl, nhwc_fused_fwd_kernel<T, VEC, ADD, false>, lds, a, a, ws_bar, stream, (const T*)x,
                                       (const T*)addend, (T*)y, gg);
         });
     });
@@ -212,10 +214,10 @@ int nhwc_fused_backward(Plan& pl, int add, int relu, const void* gy, const void*
         with_add(eff_add, [&](auto at) {
             constexpr int ADD = decltype(at)::value;
             if (a.keep)
-                status = launch_fused(pl, nhwc_fused_bwd_kernel<T, VEC, ADD, true>, lds, a, ws_bar, stream, (const T*)gy, (const T*)x,
+                status = launch_fused(pl, nhwc_fused_bwd_kernel<T, VEC, ADD, true>, lds, a, a, ws_bar, stream, (const T*)gy, (const T*)x,
                                       (const T*)addend, (T*)dx, (T*)d_addend, gg, dg);
             else
-                status = launch_fused(pl, nhwc_fused_bwd_kernel<T, VEC, ADD, false>, lds, a, ws_bar, stream, (const T*)gy, (const T*)x,
+                status = launch_fused(pl, nhwc_fused_bwd_kernel<T, VEC, ADD, false>, lds, a, a, ws_bar, stream, (const T*)gy, (const T*)x,
                                       (const T*)addend, (T*)dx, (T*)d_addend, gg, dg);
         });
     });
@@ -233,6 +235,106 @@ void nhwc_slim_from_saved(const Plan& pl, const double* saved_d, float* slim, hi
 void nhwc_saved_from_slim(const Plan& pl, const float* slim, int relu, double* saved_d, float* rows, hipStream_t stream) {
     const int blocks = (int)((pl.P + kBlock - 1) / kBlock);
     nhwc_saved_from_slim_kernel<<<blocks, kBlock, 0, stream>>>(slim, pl.pr.N, pl.pr.C, relu, saved_d, rows);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// the block's last BatchNorm2d in front of the op (cnsn_nhwc_bnhead_kernels.h): y = act(SelfNorm(BatchNorm2d(conv_out) + identity))
+// ------------------------------------------------------------------------------------------------------------------------
+// check_health false: the BACKWARD of a forward that ran these kernels — there is no other kernel that reads its record, so it
+// runs them whatever has happened to the cluster strategy in between (a bounded wait at worst: DESIGN.md section 6)
+bool nhwc_bnhead_ok(const Plan& pl, bool check_health) {
+    const cnsn_problem_t& p = pl.pr;
+    if (!nhwc_fused_ok(pl, check_health) || !p.sn_training || p.N < 2 || p.C % kBnGc != 0) return false;
+    const NhwcGeom g = nhwc_fused_geom(pl);
+    if ((long)g.N * g.S * g.ncb < 8) return false;                // (a grid of at least one workgroup per barrier group)
+    return (size_t)g.S * kBnFwd * g.P * 4 < ((size_t)1 << 31);  // (32-bit byte offsets into the partial sums: CohBuf)
+}
+
+size_t nhwc_bnhead_extra_bytes(const Plan& pl) {
+    const NhwcGeom g = nhwc_fused_geom(pl);
+    // part | kshift (conv), kshift (identity), gate / cX, c0 | e0, e1 | barrier block
+    return align256((size_t)g.S * kBnFwd * g.P * 4) + align256(4 * g.P * 4) + align256(2 * (size_t)pl.pr.C * 4) + kBarBlock + 256;
+}
+
+namespace {
+NhwcBnArgs make_bn_args(const Plan& pl, const NhwcGeom& ng, int relu, const cnsn_bn_tail_t& bn, float* bn_stats, void* workspace) {
+    const cnsn_problem_t& p = pl.pr;
+    NhwcBnArgs a{};
+    a.f = make_args(pl, ng, relu, kBnGc);
+    a.bn = BnHeadDev{bn.weight, bn.bias, bn.running_mean, bn.running_var, (long long*)bn.num_batches_tracked, bn.eps, bn.momentum};
+    const double R = (double)p.N * (double)ng.M;
+    a.inv_r = 1.0 / R;
+    a.unbias_r = R > 1.0 ? R / (R - 1.0) : 1.0;
+    a.bn_stats = bn_stats;
+    a.f.part = (float*)workspace;
+    float* side = (float*)((char*)workspace + align256((size_t)ng.S * kBnFwd * pl.P * 4));
+    a.f.kshift = side;
+    a.kshift_b = side + pl.P;
+    a.f.gout = side + 2 * pl.P;   // forward without `saved`
+    a.f.coefb = side + 2 * pl.P;  // backward: cX, c0
+    a.chan = (float*)((char*)side + align256(4 * pl.P * 4));
+    return a;
+}
+void* bn_bar_block(const Plan& pl, const NhwcBnArgs& a) { return (char*)a.chan + align256(2 * (size_t)pl.pr.C * 4); }
+}  // namespace
+
+int nhwc_bnhead_forward(Plan& pl, int relu, const cnsn_bn_tail_t& bn, const void* conv_out, const void* identity, GateDev gg, void* y,
+                        float* saved, float* bn_stats, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const cnsn_problem_t& p = pl.pr;
+    if (!nhwc_bnhead_ok(pl) || !bn.training) return CNSN_E_UNSUPPORTED;
+    if (workspace_bytes < nhwc_bnhead_extra_bytes(pl)) return CNSN_E_WORKSPACE;
+    const NhwcGeom ng = nhwc_fused_geom(pl);
+    NhwcBnArgs a = make_bn_args(pl, ng, relu, bn, bn_stats, workspace);
+    a.f.slim = saved;
+    if (saved) a.f.gout = saved + (size_t)SL_G * pl.P;
+    a.f.keep = (size_t)2 * pl.P * ng.M * elem_bytes(p.dtype) <= ((size_t)320 << 20) ? 1 : 0;
+    int status = CNSN_E_UNSUPPORTED;
+    dispatch_t(p.dtype, [&](auto tt, auto vt) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value;
+        const size_t lds = (size_t)3 * ng.rows * ng.tcb * VEC * 4;
+        if (a.f.keep)
+            status = launch_fused(pl, nhwc_bnhead_fwd_kernel<T, VEC, true>, lds, a, a.f, bn_bar_block(pl, a), stream, (const T*)conv_out,
+                                  (const T*)identity, (T*)y, gg);
+        else
+            status = launch_fused(pl, nhwc_bnhead_fwd_kernel<T, VEC, false>, lds, a, a.f, bn_bar_block(pl, a), stream, (const T*)conv_out,
+                                  (const T*)identity, (T*)y, gg);
+    });
+    if (knob(K_DEBUG))
+        fprintf(stderr, "[cnsn] nhwc bn-block fwd: tiles=%d (S=%d rows=%d tcb=%d) groups=%d keep=%d -> status %d\n", a.f.ntiles, ng.S,
+                ng.rows, ng.tcb, a.f.ngroups, a.f.keep, status);
+    return status;
+}
+
+int nhwc_bnhead_backward(Plan& pl, int relu, const cnsn_bn_tail_t& bn, const void* gy, const void* conv_out, const void* identity,
+                         GateDev gg, const float* saved, const float* bn_stats, void* d_conv, void* d_identity, GateGradDev dg,
+                         float* dbn_w, float* dbn_b, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const cnsn_problem_t& p = pl.pr;
+    if (!nhwc_bnhead_ok(pl, false) || !bn.training) return CNSN_E_UNSUPPORTED;
+    if (!saved || !bn_stats || !d_conv || !d_identity || !dbn_w || !dbn_b) return CNSN_E_NULL;
+    if (workspace_bytes < nhwc_bnhead_extra_bytes(pl)) return CNSN_E_WORKSPACE;
+    const NhwcGeom ng = nhwc_fused_geom(pl);
+    NhwcBnArgs a = make_bn_args(pl, ng, relu, bn, const_cast<float*>(bn_stats), workspace);
+    a.f.slim = const_cast<float*>(saved);
+    a.dbn_w = dbn_w;
+    a.dbn_b = dbn_b;
+    a.f.keep = (size_t)3 * pl.P * ng.M * elem_bytes(p.dtype) <= ((size_t)320 << 20) ? 1 : 0;
+    int status = CNSN_E_UNSUPPORTED;
+    dispatch_t(p.dtype, [&](auto tt, auto vt) {
+        using T = typename decltype(tt)::type;
+        constexpr int VEC = decltype(vt)::value;
+        const size_t lds = (size_t)3 * ng.rows * ng.tcb * VEC * 4;
+        if (a.f.keep)
+            status = launch_fused(pl, nhwc_bnhead_bwd_kernel<T, VEC, true>, lds, a, a.f, bn_bar_block(pl, a), stream, (const T*)gy,
+                                  (const T*)conv_out, (const T*)identity, (T*)d_conv, (T*)d_identity, gg, dg);
+        else
+            status = launch_fused(pl, nhwc_bnhead_bwd_kernel<T, VEC, false>, lds, a, a.f, bn_bar_block(pl, a), stream, (const T*)gy,
+                                  (const T*)conv_out, (const T*)identity, (T*)d_conv, (T*)d_identity, gg, dg);
+    });
+    if (knob(K_DEBUG))
+        fprintf(stderr, "[cnsn] nhwc bn-block bwd: tiles=%d (S=%d rows=%d tcb=%d) groups=%d keep=%d -> status %d\n", a.f.ntiles, ng.S,
+                ng.rows, ng.tcb, a.f.ngroups, a.f.keep, status);
+    return status;
 }
 
 }  // namespace cnsn

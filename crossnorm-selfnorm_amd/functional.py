@@ -623,6 +623,123 @@ class FusedCNSNTail(torch.autograd.Function):
                     None, None)
 
 
+# ------------------------------------------------------------------------------------------------
+# the block's last BatchNorm2d in front of the op: y = act(SelfNorm(BatchNorm2d(conv_out) + identity))
+# (cnsn_forward_bn_block / cnsn_backward_bn_block, csrc/cnsn_nhwc_bnhead_kernels.h)
+# ------------------------------------------------------------------------------------------------
+_bn_block_plan_cache = {}
+_ffi._plan_caches.append(_bn_block_plan_cache)
+# CNSN_BN_BLOCK=0: never fold the block's last BatchNorm2d into the op's launch (A/B knob)
+_BN_BLOCK = os.environ.get("CNSN_BN_BLOCK", "1") != "0"
+
+
+def bn_block_plan(x: torch.Tensor, cfg: FusedConfig) -> bool:
+    """True when ONE launch per direction evaluates `act(CNSN(BatchNorm2d(conv_out) + identity))` for this tensor / configuration
+    (cnsn_bn_block_plan: channels-last, SelfNorm alone with one gate in training mode, N <= 256, no stream capture) —
+    remembered per (shape, dtype, configuration, strategy)."""
+    if not _BN_BLOCK or not x.is_cuda or x.dim() != 4 or x.dtype not in _DTYPES or cfg.cn_active or not cfg.sn_training:
+        return False
+    if not x.is_contiguous(memory_format=torch.channels_last) or x.is_contiguous():
+        return False
+    if _ffi.lib().cnsn_resident_degraded():      # (a persistent launch gave up and nobody re-armed since: the un-fused sequence)
+        return False
+    key = (tuple(x.shape), x.dtype, x.device.index, cfg.relu, cfg.sn_two, _strategy)
+    hit = _bn_block_plan_cache.get(key)
+    if hit is None:
+        prob = _problem(x, cfg)
+        prob.layout = _ffi.LAYOUT_NHWC
+        epi = _epilogue(cfg, None)
+        hit = _ffi.lib().cnsn_bn_block_plan(C.byref(prob), C.byref(epi)) == 1
+        _bn_block_plan_cache[key] = hit
+    return hit
+
+
+class FusedBnBlock(torch.autograd.Function):
+    """y = act(SelfNorm(BatchNorm2d(conv_out) + identity)) — the tail of a ResNet bottleneck (resnet_cnsn.py:108-122, pos='post')
+    in one launch per direction.  Saves conv_out and identity (what BatchNorm2d and the add would have saved), never writes
+    BatchNorm2d's output or the sum."""
+
+    @staticmethod
+    def forward(ctx, conv_out, identity, cfg: FusedConfig, g_w, g_gamma, g_beta, g_rm, g_rv, bn_w, bn_b, bn_rm, bn_rv, bn_eps,
+                bn_momentum, g_nbt=None, bn_nbt=None):
+        _require_device(conv_out, "cnsn_forward_bn_block")
+        with torch.cuda.device(conv_out.device):
+            lib = _ffi.lib()
+            _ffi.check_resident_health("cnsn_forward_bn_block")
+            x = _dense_cl(conv_out)
+            _require_device(identity, "cnsn_forward_bn_block(identity)")
+            assert identity.shape == x.shape and identity.dtype == x.dtype, "identity must match conv_out"
+            idt = _dense_cl(identity)
+            prob = _problem(x, cfg)
+            prob.layout = _ffi.LAYOUT_NHWC
+            dev = x.device
+            _context(prob, dev)
+            gate = _GateBuffers(g_w, g_gamma, g_beta, g_rm, g_rv, g_nbt)
+            bw, bb = _f32(bn_w), _f32(bn_b)
+            if bn_nbt is not None and not (bn_nbt.dtype == torch.int64 and bn_nbt.is_cuda and bn_nbt.numel() == 1):
+                bn_nbt.add_(1)
+                bn_nbt = None
+            direct = (bn_rm.dtype == torch.float32 and bn_rm.is_contiguous() and bn_rv.dtype == torch.float32
+                      and bn_rv.is_contiguous())
+            rm = bn_rm.detach() if direct else _f32(bn_rm)
+            rv = bn_rv.detach() if direct else _f32(bn_rv)
+            head = _ffi.BnTail(C.sizeof(_ffi.BnTail), 1, float(bn_eps), float(bn_momentum), bw.data_ptr(), bb.data_ptr(),
+                               rm.data_ptr(), rv.data_ptr(), _ptr(bn_nbt))
+            y = _out_like(x)
+            need_bwd = any(ctx.needs_input_grad)
+            saved_floats, ws_bytes = _sizes(prob)[:2]
+            saved = torch.empty(saved_floats, dtype=torch.float32, device=dev) if need_bwd else None
+            stats = torch.empty(4 * x.shape[1], dtype=torch.float32, device=dev)
+            ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=dev)
+            epi = _epilogue(cfg, idt)
+            st = lib.cnsn_forward_bn_block(C.byref(prob), C.byref(epi), C.byref(head), _ptr(x), C.byref(gate.c), _ptr(y),
+                                           _ptr(saved), _ptr(stats), _ptr(ws), ws_bytes, _stream(x))
+            _ffi.check(st, "cnsn_forward_bn_block")
+            gate.write_back()
+            if not direct:
+                bn_rm.copy_(rm)
+                bn_rv.copy_(rv)
+            if need_bwd:
+                ctx.cfg, ctx.prob, ctx.gate = cfg, prob, gate
+                ctx.head_cfg = (float(bn_eps), float(bn_momentum))
+                ctx.param_dtypes = (g_w.dtype, g_gamma.dtype, g_beta.dtype, bn_w.dtype, bn_b.dtype)
+                ctx.bn_buffers = (bw, bb, rm, rv)
+                ctx.save_for_backward(x, idt, saved, stats)
+            return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, idt, saved, stats = ctx.saved_tensors
+        with torch.cuda.device(x.device):
+            lib = _ffi.lib()
+            cfg, prob, gate = ctx.cfg, ctx.prob, ctx.gate
+            dev = x.device
+            gy = _dense_cl(gy if gy.dtype == x.dtype else gy.to(x.dtype))
+            bw, bb, rm, rv = ctx.bn_buffers
+            eps, mom = ctx.head_cfg
+            head = _ffi.BnTail(C.sizeof(_ffi.BnTail), 1, eps, mom, bw.data_ptr(), bb.data_ptr(), rm.data_ptr(), rv.data_ptr(), None)
+            Cn = x.shape[1]
+            d_conv, d_idt = _out_like(x), _out_like(x)
+            flat = torch.empty(6 * Cn, dtype=torch.float32, device=dev)
+            dw, dgam, dbet = flat[:2 * Cn].view(Cn, 1, 2), flat[2 * Cn:3 * Cn], flat[3 * Cn:4 * Cn]
+            dbw, dbb = flat[4 * Cn:5 * Cn], flat[5 * Cn:]
+            gg = _ffi.GateGrad(_ptr(dw), _ptr(dgam), _ptr(dbet))
+            ws_bytes = _sizes(prob)[1]
+            _context(prob, dev)
+            if torch.cuda.is_current_stream_capturing():
+                prob.context, prob.context_bytes = None, 0
+            ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=dev)
+            epi = _epilogue(cfg, idt)
+            st = lib.cnsn_backward_bn_block(C.byref(prob), C.byref(epi), C.byref(head), _ptr(gy), _ptr(x), C.byref(gate.c),
+                                            _ptr(saved), _ptr(stats), _ptr(d_conv), _ptr(d_idt), C.byref(gg), _ptr(dbw), _ptr(dbb),
+                                            _ptr(ws), ws_bytes, _stream(x))
+            _ffi.check(st, "cnsn_backward_bn_block")
+            pd = ctx.param_dtypes
+            outs = [t if t.dtype == pd[i] else t.to(pd[i]) for i, t in enumerate((dw, dgam, dbet, dbw, dbb))]
+            #       conv   identity cfg  g_w      g_gamma  g_beta  g_rm  g_rv  bn_w     bn_b    bn_rm bn_rv eps   mom   nbt   nbt
+            return (d_conv, d_idt, None, outs[0], outs[1], outs[2], None, None, outs[3], outs[4], None, None, None, None, None, None)
+
+
 def _glue_cfg(cfg: FusedConfig, need_bwd: bool):
     cb = cfg.content_box if cfg.content_box is not None else (-1, -1, -1, -1)
     sb = cfg.style_box if cfg.style_box is not None else (-1, -1, -1, -1)

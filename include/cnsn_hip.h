@@ -311,6 +311,32 @@ int cnsn_which_path(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int 
  * batch moments of BatchNorm1d's input (:121,138) instead of every plane's statistics.  0 otherwise, < 0 argument error. */
 int cnsn_sn_cluster_plan(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, int backward);
 
+/* ---- the block's LAST BatchNorm2d in front of the op (round 6, ABI 8; SURVEY §8 f1 widened by one neighbour) ---------------
+ * A ResNet bottleneck ends `out = self.bn3(out); out += identity; out = self.cnsn(out); out = self.relu(out)`
+ * (models/imagenet/resnet_cnsn.py:108-122, pos='post').  These entry points evaluate
+ *       y = act( CNSN( BatchNorm2d(conv_out) + identity ) )
+ * in ONE persistent launch per direction: BatchNorm2d's batch statistics and the statistics of the sum follow from one set of
+ * per-plane sums of conv_out and identity, neither bn3's output nor the sum is ever written, and the backward re-evaluates
+ * them from the two tensors BatchNorm2d and the add would have saved anyway: 13 tensor passes per block and step instead of
+ * 8 (BatchNorm2d) + 10 (the op).  Values are rounded where the un-fused sequence rounds them (bn3's output, the sum, y); the
+ * statistics are those of the un-rounded sum (rounding noise of zero mean: within north_star's tolerances).
+ *   - channels-last layout, SelfNorm alone (cn_active = 0, one gate), training mode in BOTH normalisations, N <= 256;
+ *     epilogue: add_mode PRE with addend = identity (sum_out NULL), relu 0 / 1.  Anything else — cnsn_bn_block_plan() == 0 —
+ *     returns CNSN_E_UNSUPPORTED: the caller then runs BatchNorm2d itself and cnsn_forward_fused, as the reference does.
+ *   - bn: BatchNorm2d's parameters and buffers (the struct of the fused tail); running statistics and num_batches_tracked are
+ *     updated by the forward as nn.BatchNorm2d does (momentum; running_var takes the unbiased variance).
+ *   - bn_stats: float32 (4, C) — batch mean, rstd and the two coefficients x = alpha*conv_out + beta was evaluated with;
+ *     forward writes, backward reads.  `saved`: cnsn_saved_floats(), as for cnsn_forward_fused; workspace: cnsn_workspace_bytes().
+ *   - backward: grad_conv_out and grad_identity (the gradient of the sum) are both written; d_bn_weight / d_bn_bias: (C). */
+int cnsn_bn_block_plan(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi);
+int cnsn_forward_bn_block(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const cnsn_bn_tail_t* bn, const void* conv_out,
+                          const cnsn_gate_t* g, void* y, float* saved, float* bn_stats, void* workspace, size_t workspace_bytes,
+                          void* stream);
+int cnsn_backward_bn_block(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const cnsn_bn_tail_t* bn, const void* grad_y,
+                           const void* conv_out, const cnsn_gate_t* g, const float* saved, const float* bn_stats,
+                           void* grad_conv_out, void* grad_identity, const cnsn_gate_grad_t* dg, float* d_bn_weight,
+                           float* d_bn_bias, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- persistent exchange context of the cluster-resident strategy --------------------------------
  * The resident kernels hand per-plane scalars from workgroup to workgroup through device memory.  Through the
  * per-call `workspace` (contents unknown) that memory has to be filled with an 'empty' pattern by a launch of its own
