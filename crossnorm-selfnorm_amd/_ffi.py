@@ -115,11 +115,12 @@ SIGNATURES = {
     "cnsn_sn_cluster_plan": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.c_int]),
     "cnsn_bnrelu_plan": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.c_int]),
     "cnsn_bn_block_plan": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue)]),
-    "cnsn_forward_bn_block": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.POINTER(BnTail), C.c_void_p, C.POINTER(Gate),
-                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "cnsn_backward_bn_block": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.POINTER(BnTail), C.c_void_p, C.c_void_p,
-                                         C.POINTER(Gate), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GateGrad),
-                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cnsn_forward_bn_block": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.POINTER(BnTail), C.POINTER(BnTail), C.c_void_p,
+                                        C.POINTER(Gate), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cnsn_backward_bn_block": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.POINTER(BnTail), C.POINTER(BnTail), C.c_void_p,
+                                         C.c_void_p, C.POINTER(Gate), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(GateGrad), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_void_p]),
     "cnsn_forward_bnrelu": (C.c_int, [C.POINTER(Problem), C.POINTER(Epilogue), C.POINTER(BnTail), C.c_void_p,
                                       C.POINTER(Gate), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),

@@ -35,12 +35,17 @@ class _Bottleneck(nn.Module):
         h = self.relu(self.bn1(self.conv1(h)))
         h = self.relu(self.bn2(self.conv2(h)))
         h = self.conv3(h)
-        skip = x if self.downsample is None else self.downsample(x)
-        # :108-122.  pos='post': bn3, the add, the CNSN unit and the ReLU are ONE call when the unit offers it (this library's
-        # `CNSN.forward_bn_block`: one launch per direction on channels-last tensors, the un-fused sequence otherwise)
+        # :99-122.  pos='post': bn3 (and the downsample's BatchNorm2d), the add, the CNSN unit and the ReLU are ONE call when the
+        # unit offers it (this library's `CNSN.forward_bn_block`: one launch per direction on channels-last tensors, the
+        # un-fused sequence otherwise)
         fb = getattr(getattr(self, "cnsn", None), "forward_bn_block", None) if (_sites.FUSE_BLOCK and self.pos == "post") else None
         if fb is not None and h.is_cuda:
-            return fb(h, self.bn3, skip, relu=True)
+            if self.downsample is None:
+                return fb(h, self.bn3, x, relu=True)
+            if len(self.downsample) == 2 and isinstance(self.downsample[1], nn.BatchNorm2d):
+                return fb(h, self.bn3, self.downsample[0](x), relu=True, identity_bn=self.downsample[1])
+            return fb(h, self.bn3, self.downsample(x), relu=True)
+        skip = x if self.downsample is None else self.downsample(x)
         return residual_sum(getattr(self, "cnsn", None), self.pos, self.bn3(h), skip, relu=True)
 
 

@@ -348,17 +348,22 @@ class CNSN(nn.Module):
         cfg = FusedConfig(add_mode=add_mode, relu=bool(relu), **kw)
         return _F.fused_cnsn(x, cfg, perm=perm, chan_perm=chan, g=g, f=f, addend=addend)
 
-    def forward_bn_block(self, conv_out, bn, identity, relu=True):
+    def forward_bn_block(self, conv_out, bn, identity, relu=True, identity_bn=None):
         """`act(self(bn(conv_out) + identity))` — the tail of a ResNet bottleneck:
             out = self.bn3(out); out += identity; out = self.cnsn(out); out = self.relu(out)    (imagenet/resnet_cnsn.py:108-122)
+        `identity_bn`: the skip path ends in a BatchNorm2d of its own (the block's `downsample`, :99-100) and `identity` is the
+        INPUT of that layer — `act(self(bn(conv_out) + identity_bn(identity)))`.
         ONE launch per direction when the fused kernels take the call (`functional.bn_block_plan`: channels-last tensors,
-        SelfNorm alone — the site's CrossNorm idle — with one gate, `bn` a plain affine nn.BatchNorm2d, everything in training
-        mode, N <= 256): 13 tensor passes per block and step instead of BatchNorm2d's 8 + the op's 10; otherwise the same
-        steps as separate calls (`bn`, then `forward_block`).  BatchNorm2d's per-call book-keeping (`num_batches_tracked`,
-        `momentum=None`) is done here exactly as `nn.BatchNorm2d.forward` does it."""
+        SelfNorm alone — the site's CrossNorm idle — with one gate, plain affine nn.BatchNorm2d layers, everything in training
+        mode, N <= 256): 13 tensor passes per block and step instead of BatchNorm2d's 8 (16 with the downsample's) + the op's 10;
+        otherwise the same steps as separate calls (the BatchNorm2d layers, then `forward_block`).  BatchNorm2d's per-call
+        book-keeping (`num_batches_tracked`, `momentum=None`) is done here exactly as `nn.BatchNorm2d.forward` does it."""
         cn, sn = self.crossnorm, self.selfnorm
         armed = cn is not None and cn.active
-        fused = (type(bn) is nn.BatchNorm2d and bn.affine and bn.track_running_stats and bn.training and sn is not None
+
+        def plain(m):
+            return type(m) is nn.BatchNorm2d and m.affine and m.track_running_stats and m.training
+        fused = (plain(bn) and (identity_bn is None or plain(identity_bn)) and sn is not None
                  and type(sn) is SelfNorm and sn.f_fc is None and sn._fusable() and not armed and conv_out.is_cuda
                  and (cn is None or type(cn) is CrossNorm) and identity.shape == conv_out.shape
                  and identity.dtype == conv_out.dtype and not torch.cuda.is_current_stream_capturing())
@@ -366,13 +371,18 @@ class CNSN(nn.Module):
             kw, _, _ = sn._fused_args_peek()
             fused = kw["sn_training"] and _F.bn_block_plan(conv_out, FusedConfig(add_mode="pre", relu=bool(relu), **kw))
         if not fused:
-            return self.forward_block(bn(conv_out), identity, add_mode="pre", relu=relu)
+            skip = identity if identity_bn is None else identity_bn(identity)
+            return self.forward_block(bn(conv_out), skip, add_mode="pre", relu=relu)
         kw, g, _ = sn._fused_args()
         _, bn_eps, bn_mom, bn_counter = SelfNorm._bn_call_state(bn, in_kernel=True)
         cfg = FusedConfig(add_mode="pre", relu=bool(relu), **kw)
+        extra = ()
+        if identity_bn is not None:
+            _, e2, m2, c2 = SelfNorm._bn_call_state(identity_bn, in_kernel=True)
+            extra = (identity_bn.weight, identity_bn.bias, identity_bn.running_mean, identity_bn.running_var, e2, m2, c2)
         return _F.FusedBnBlock.apply(conv_out, identity, cfg, g.fc_weight, g.bn_weight, g.bn_bias, g.running_mean, g.running_var,
                                      bn.weight, bn.bias, bn.running_mean, bn.running_var, bn_eps, bn_mom, g.num_batches_tracked,
-                                     bn_counter)
+                                     bn_counter, *extra)
 
     def forward_block_bn(self, x, addend, add_mode, bn, want_y=True):
         """`y = self(x [+ addend]); z = relu(bn(y))` — the end of one WideResNet block together with the NEXT block's

@@ -150,10 +150,13 @@ int cnsn_bn_block_plan(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi) {
     return st == CNSN_OK ? 1 : (st == CNSN_E_UNSUPPORTED ? 0 : st);
 }
 
-int cnsn_forward_bn_block(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const cnsn_bn_tail_t* bn, const void* conv_out,
-                          const cnsn_gate_t* g, void* y, float* saved, float* bn_stats, void* workspace, size_t workspace_bytes,
-                          void* stream_) {
+int cnsn_forward_bn_block(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const cnsn_bn_tail_t* bn,
+                          const cnsn_bn_tail_t* bn_skip, const void* conv_out, const cnsn_gate_t* g, void* y, float* saved, float* bn_stats,
+                          void* workspace, size_t workspace_bytes, void* stream_) {
     if (!bn) return CNSN_E_NULL;
+    if (bn_skip && (bn_skip->struct_bytes != (int32_t)sizeof(cnsn_bn_tail_t))) return CNSN_E_STRUCT;
+    if (bn_skip && (!bn_skip->weight || !bn_skip->bias || !bn_skip->running_mean || !bn_skip->running_var)) return CNSN_E_NULL;
+    if (bn_skip && !bn_skip->training) return CNSN_E_UNSUPPORTED;
     Plan pl;
     EpiPlan e;
     const int st = bn_block_parse(prob, epi, bn, pl, e, false);
@@ -161,15 +164,18 @@ int cnsn_forward_bn_block(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi
     if (!conv_out || !y || !workspace || !bn_stats || !bn->weight || !bn->bias || !bn->running_mean || !bn->running_var) return CNSN_E_NULL;
     if ((((uintptr_t)conv_out | (uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bn_stats) & 15u) != 0) return CNSN_E_ALIGN;
     if (!gate_ok(g)) return CNSN_E_NULL;
-    return nhwc_bnhead_forward(pl, e.relu, *bn, conv_out, e.addend, gate_dev(g), y, saved, bn_stats, workspace, workspace_bytes,
+    return nhwc_bnhead_forward(pl, e.relu, *bn, bn_skip, conv_out, e.addend, gate_dev(g), y, saved, bn_stats, workspace, workspace_bytes,
                                (hipStream_t)stream_);
 }
 
-int cnsn_backward_bn_block(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const cnsn_bn_tail_t* bn, const void* grad_y,
-                           const void* conv_out, const cnsn_gate_t* g, const float* saved, const float* bn_stats, void* grad_conv_out,
-                           void* grad_identity, const cnsn_gate_grad_t* dg, float* d_bn_weight, float* d_bn_bias, void* workspace,
-                           size_t workspace_bytes, void* stream_) {
+int cnsn_backward_bn_block(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const cnsn_bn_tail_t* bn,
+                           const cnsn_bn_tail_t* bn_skip, const void* grad_y, const void* conv_out, const cnsn_gate_t* g, const float* saved,
+                           const float* bn_stats, void* grad_conv_out, void* grad_identity, const cnsn_gate_grad_t* dg, float* d_bn_weight,
+                           float* d_bn_bias, float* d_bn_skip_weight, float* d_bn_skip_bias, void* workspace, size_t workspace_bytes,
+                           void* stream_) {
     if (!bn) return CNSN_E_NULL;
+    if (bn_skip && (bn_skip->struct_bytes != (int32_t)sizeof(cnsn_bn_tail_t))) return CNSN_E_STRUCT;
+    if (bn_skip && (!bn_skip->weight || !d_bn_skip_weight || !d_bn_skip_bias)) return CNSN_E_NULL;
     Plan pl;
     EpiPlan e;
     const int st = bn_block_parse(prob, epi, bn, pl, e, false, false);
@@ -179,8 +185,9 @@ int cnsn_backward_bn_block(const cnsn_problem_t* prob, const cnsn_epilogue_t* ep
           (uintptr_t)bn_stats) & 15u) != 0)
         return CNSN_E_ALIGN;
     if (!gate_ok(g) || !dg || !dg->d_fc_weight || !dg->d_bn_weight || !dg->d_bn_bias) return CNSN_E_NULL;
-    return nhwc_bnhead_backward(pl, e.relu, *bn, grad_y, conv_out, e.addend, gate_dev(g), saved, bn_stats, grad_conv_out, grad_identity,
-                                gate_grad_dev(dg), d_bn_weight, d_bn_bias, workspace, workspace_bytes, (hipStream_t)stream_);
+    return nhwc_bnhead_backward(pl, e.relu, *bn, bn_skip, grad_y, conv_out, e.addend, gate_dev(g), saved, bn_stats, grad_conv_out,
+                                grad_identity, gate_grad_dev(dg), d_bn_weight, d_bn_bias, d_bn_skip_weight, d_bn_skip_bias, workspace,
+                                workspace_bytes, (hipStream_t)stream_);
 }
 
 int cnsn_forward_fused(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const void* x, const int64_t* perm,

@@ -34,10 +34,12 @@ void nhwc_saved_from_slim(const Plan& pl, const float* slim, int relu, double* s
 // ---- the block's last BatchNorm2d in front of the op (cnsn_nhwc_bnhead_kernels.h; training mode, SelfNorm alone, one gate, N <= 256)
 bool nhwc_bnhead_ok(const Plan& pl, bool check_health = true);
 size_t nhwc_bnhead_extra_bytes(const Plan& pl);
-int nhwc_bnhead_forward(Plan& pl, int relu, const cnsn_bn_tail_t& bn, const void* conv_out, const void* identity, GateDev gg, void* y,
-                        float* saved, float* bn_stats, void* workspace, size_t workspace_bytes, hipStream_t stream);
-int nhwc_bnhead_backward(Plan& pl, int relu, const cnsn_bn_tail_t& bn, const void* gy, const void* conv_out, const void* identity,
-                         GateDev gg, const float* saved, const float* bn_stats, void* d_conv, void* d_identity, GateGradDev dg,
-                         float* dbn_w, float* dbn_b, void* workspace, size_t workspace_bytes, hipStream_t stream);
+// bn2 (may be null): the skip path ends in a BatchNorm2d of its own — `identity` is then ITS input (the downsample convolution's output)
+int nhwc_bnhead_forward(Plan& pl, int relu, const cnsn_bn_tail_t& bn, const cnsn_bn_tail_t* bn2, const void* conv_out, const void* identity,
+                        GateDev gg, void* y, float* saved, float* bn_stats, void* workspace, size_t workspace_bytes, hipStream_t stream);
+int nhwc_bnhead_backward(Plan& pl, int relu, const cnsn_bn_tail_t& bn, const cnsn_bn_tail_t* bn2, const void* gy, const void* conv_out,
+                         const void* identity, GateDev gg, const float* saved, const float* bn_stats, void* d_conv, void* d_identity,
+                         GateGradDev dg, float* dbn_w, float* dbn_b, float* dbn2_w, float* dbn2_b, void* workspace,
+                         size_t workspace_bytes, hipStream_t stream);
 
 }  // namespace cnsn

@@ -24,6 +24,12 @@
 // nothing in fp32), far inside north_star's tolerances (tests/test_gpu_bn_block.py against torch's own composition).  The
 // element-wise values (x, X, y, the ReLU mask, dX) are rounded exactly where the un-fused sequence rounds them.
 // Training mode only (batch statistics in both normalisations): anything else runs the un-fused sequence.
+//
+// TWO: the identity is itself `BatchNorm2d(conv)` — the block's `downsample` (resnet_cnsn.py:99-100: a 1x1 convolution and a
+// BatchNorm2d on the skip path, the first block of every stage).  X = bn3(c1) + bn_d(c2) is affine in BOTH convolution outputs
+// per channel, so the same five plane sums give both BatchNorm2d's batch statistics and the statistics of X; the backward writes
+// the gradients of the two convolution outputs where it wrote those of conv_out and the identity.  Same 13 passes; the
+// downsample's BatchNorm2d costs nothing any more.
 #pragma once
 #include "cnsn_nhwc_fused_kernels.h"
 
@@ -33,13 +39,13 @@
 
 namespace cnsn {
 
-enum BnSlimRow { SLB_E = SL_ROWS, SLB_DM, SLB_ROWS };  // + alpha*M2c + Ccb, mean_c - m per plane (cnsn_nhwc_bnhead_kernels.h)
+enum BnSlimRow { SLB_E = SL_ROWS, SLB_DM, SLB_E2, SLB_DM2, SLB_ROWS };  // + sum (X - mean)(c - mean_c), mean_c - m per plane, for conv_out and (TWO) the skip path's convolution
 __host__ __device__ inline size_t bn_slim_floats(size_t P, int C) { return (size_t)SLB_ROWS * P + 2 * (size_t)C; }
 __host__ __device__ inline double* bn_slim_rstd(float* slim, size_t P) { return reinterpret_cast<double*>(slim + (size_t)SLB_ROWS * P); }
 __host__ __device__ inline const double* bn_slim_rstd(const float* slim, size_t P) {
     return reinterpret_cast<const double*>(slim + (size_t)SLB_ROWS * P);
 }
-enum BnStatRow { BS_MEAN = 0, BS_RSTD, BS_ALPHA, BS_BETA, BS_ROWS };  // float (4, C): what the backward re-evaluates x with
+enum BnStatRow { BS_MEAN = 0, BS_RSTD, BS_ALPHA, BS_BETA, BS_ROWS };  // float (4, C) per BatchNorm2d: what the backward re-evaluates x with; (TWO) the skip path's rows follow: (8, C)
 
 struct BnHeadDev {
     const float* weight;  // (C)
@@ -53,12 +59,15 @@ struct BnHeadDev {
 struct NhwcBnArgs {
     NhwcFusedArgs f;   // geometry, SelfNorm's side arrays (f.part: [S][NTOT][P]), the barrier; f.kshift: the conv output's shift
     BnHeadDev bn;
+    BnHeadDev bn2;           // (TWO) the skip path's BatchNorm2d
     double inv_r, unbias_r;  // 1 / (N*M), N*M / (N*M - 1)
     float* kshift_b;         // [P] shift of the identity's sums
-    float* chan;             // backward: [2][C] e0, e1 (phase B' -> C')
+    float* chan;             // backward: [2][C] e0, e1 (phase B' -> C'); (TWO) [4][C]: + those of the skip path's convolution
     float* bn_stats;         // [BS_ROWS][C]: forward writes, backward reads
     float* dbn_w;            // backward: (C) gradients of BatchNorm2d's weight / bias
     float* dbn_b;
+    float* dbn2_w;           // (TWO) ... of the skip path's
+    float* dbn2_b;
 };
 
 // NK of NTOT accumulators of a tile -> part rows (s*NTOT + k0 + k): the rows of the block added in a fixed order by ALL threads,
@@ -106,14 +115,23 @@ __device__ __forceinline__ float bn_sum(float c, float b, float alpha, float bet
     return sum_t<T>(x, b);
 }
 
+// the skip path's value: the identity as it is, or (TWO) T(alpha2*c2 + beta2), the downsample BatchNorm2d's output
+template <typename T, bool TWO>
+__device__ __forceinline__ float bn_skip(float c2, float alpha2, float beta2) {
+    if constexpr (TWO)
+        return to_float(from_float<T>(fmaf(alpha2, c2, beta2)));
+    else
+        return c2;
+}
+
 constexpr int kBnGc = 4;   // adjacent channels a workgroup takes in phase B / B'
 constexpr int kBnFwd = 5;  // part rows of the forward: sum c', c'^2, b', b'^2, c'*b'
-constexpr int kBnBwd = 3;  // ... of the backward: sum G', G'*(X - mu), G'*(c - m)
+constexpr int kBnBwd = 4;  // ... of the backward: sum G', G'*(X - mu), G'*(c - m) (, TWO: G'*(c2 - m2))
 
 // ================================================================================================
 // forward
 // ================================================================================================
-template <typename T, int VEC, bool KEEP>
+template <typename T, int VEC, bool KEEP, bool TWO>
 __global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_fwd_kernel(NhwcBnArgs a, const T* __restrict__ cv,
                                                                                          const T* __restrict__ idt, T* __restrict__ y,
                                                                                          GateDev gg) {
@@ -216,7 +234,9 @@ __global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_fwd
             t1[j] = live ? M2c[j] + M * d * d : 0.0;
         }
         block_sum_d<GC>(t1, red);
-        double al[GC], be[GC], mf[GC], rs2[GC];
+        double al[GC], be[GC], mf[GC], rs2[GC], al2[GC], be2[GC], mf2[GC];
+#pragma unroll
+        for (int j = 0; j < GC; ++j) al2[j] = 1.0, be2[j] = 0.0, mf2[j] = 0.0;  // (not TWO: the identity as it is)
 #pragma unroll
         for (int j = 0; j < GC; ++j) {
             v2d[j] = t1[j] * a.inv_r;  // biased: what normalises (torch); the unbiased one goes to running_var
@@ -241,12 +261,51 @@ __global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_fwd
             sb.st4((size_t)BS_ALPHA * g.C + c0, (float)al[0], (float)al[1], (float)al[2], (float)al[3]);
             sb.st4((size_t)BS_BETA * g.C + c0, (float)be[0], (float)be[1], (float)be[2], (float)be[3]);
         }
-        // the statistics of X = alpha*c + beta + b of every plane: models/cnsn.py:14,133 on the sum the block forms (:117)
+        if constexpr (TWO) {  // the skip path's BatchNorm2d, the same way from the second set of plane moments
+            double m2b[GC], v2b[GC], rsb[GC];
+#pragma unroll
+            for (int j = 0; j < GC; ++j) t1[j] = live ? mb[j] : 0.0;
+            block_sum_d<GC>(t1, red);
+#pragma unroll
+            for (int j = 0; j < GC; ++j) {
+                m2b[j] = t1[j] * a.f.inv_n;
+                const double d = mb[j] - m2b[j];
+                t1[j] = live ? M2b[j] + M * d * d : 0.0;
+            }
+            block_sum_d<GC>(t1, red);
+#pragma unroll
+            for (int j = 0; j < GC; ++j) {
+                v2b[j] = t1[j] * a.inv_r;
+                v2b[j] = v2b[j] > 0.0 ? v2b[j] : 0.0;
+                rsb[j] = 1.0 / sqrt(v2b[j] + (double)a.bn2.eps);
+                const double alpha = (double)a.bn2.weight[c0 + j] * rsb[j];
+                const float af = (float)alpha, bf = (float)((double)a.bn2.bias[c0 + j] - m2b[j] * alpha);
+                al2[j] = (double)af, be2[j] = (double)bf;
+                mf2[j] = (double)(float)m2b[j];
+            }
+            float* st2 = a.bn_stats + (size_t)BS_ROWS * g.C;
+            if (threadIdx.x < GC) {
+                const int j = threadIdx.x, c = c0 + j;
+                const double mj = pick<GC>(m2b, j), vj = pick<GC>(v2b, j), mom = (double)a.bn2.momentum;
+                a.bn2.run_mean[c] = (float)((1.0 - mom) * (double)a.bn2.run_mean[c] + mom * mj);
+                a.bn2.run_var[c] = (float)((1.0 - mom) * (double)a.bn2.run_var[c] + mom * vj * a.unbias_r);
+                if (c == 0) bump_batches_tracked(a.bn2.nbt);
+                st2[(size_t)BS_MEAN * g.C + c] = (float)pick<GC>(mf2, j);
+                st2[(size_t)BS_RSTD * g.C + c] = (float)pick<GC>(rsb, j);
+            }
+            if (threadIdx.x == 0) {
+                const CohBuf sb(st2);
+                sb.st4((size_t)BS_ALPHA * g.C + c0, (float)al2[0], (float)al2[1], (float)al2[2], (float)al2[3]);
+                sb.st4((size_t)BS_BETA * g.C + c0, (float)be2[0], (float)be2[1], (float)be2[2], (float)be2[3]);
+            }
+        }
+        // the statistics of X = alpha*c + beta + b (TWO: b = alpha2*c2 + beta2) of every plane: models/cnsn.py:14,133 on the sum
+        // the block forms (:117)
         double mean[GC], sig[GC], z[GC], s1[GC], s2[GC];
 #pragma unroll
         for (int j = 0; j < GC; ++j) {
-            mean[j] = al[j] * mc[j] + be[j] + mb[j];
-            const double m2 = al[j] * al[j] * M2c[j] + M2b[j] + 2.0 * al[j] * Ccb[j];
+            mean[j] = al[j] * mc[j] + be[j] + al2[j] * mb[j] + be2[j];
+            const double m2 = al[j] * al[j] * M2c[j] + al2[j] * al2[j] * M2b[j] + 2.0 * al[j] * al2[j] * Ccb[j];
             sig[j] = sqrt((m2 > 0.0 ? m2 : 0.0) / (M - 1.0) + (double)a.f.eps_sn);
             z[j] = (double)gg.w[2 * (c0 + j)] * mean[j] + (double)gg.w[2 * (c0 + j) + 1] * sig[j];
             s1[j] = live ? z[j] : 0.0;
@@ -271,7 +330,7 @@ __global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_fwd
             if (a.f.slim) bn_slim_rstd(a.f.slim, g.P)[c] = pick<GC>(rstd, j);
         }
         if (live) {
-            float o_g[GC], o_zh[GC], o_hi[GC], o_lo[GC], o_sig[GC], o_e[GC], o_dm[GC];
+            float o_g[GC], o_zh[GC], o_hi[GC], o_lo[GC], o_sig[GC], o_e[GC], o_dm[GC], o_e2[GC], o_dm2[GC];
 #pragma unroll
             for (int j = 0; j < GC; ++j) {
                 const double zh = (z[j] - mz[j]) * rstd[j];
@@ -280,8 +339,10 @@ __global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_fwd
                 o_hi[j] = (float)mean[j];
                 o_lo[j] = (float)(mean[j] - (double)o_hi[j]);
                 o_sig[j] = (float)sig[j];
-                o_e[j] = (float)(al[j] * M2c[j] + Ccb[j]);   // sum over the plane of (X - mean)*(c - m): the backward's BatchNorm2d sums
+                o_e[j] = (float)(al[j] * M2c[j] + al2[j] * Ccb[j]);   // sum over the plane of (X - mean)*(c - mean_c): the backward's BatchNorm2d sums
                 o_dm[j] = (float)(mc[j] - mf[j]);
+                o_e2[j] = (float)(al2[j] * M2b[j] + al[j] * Ccb[j]);  // (TWO) ... of (X - mean)*(c2 - mean_c2)
+                o_dm2[j] = (float)(mb[j] - mf2[j]);
             }
             CohBuf(a.f.gout).store<GC>(p0, o_g);  // (phase C reads it)
             if (a.f.slim) {
@@ -291,6 +352,10 @@ __global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_fwd
                 store_group<GC>(a.f.slim + (size_t)SL_ZH * g.P + p0, o_zh);
                 store_group<GC>(a.f.slim + (size_t)SLB_E * g.P + p0, o_e);
                 store_group<GC>(a.f.slim + (size_t)SLB_DM * g.P + p0, o_dm);
+                if constexpr (TWO) {
+                    store_group<GC>(a.f.slim + (size_t)SLB_E2 * g.P + p0, o_e2);
+                    store_group<GC>(a.f.slim + (size_t)SLB_DM2 * g.P + p0, o_dm2);
+                }
             }
         }
         __syncthreads();  // (red is the next group's)
@@ -307,16 +372,21 @@ __global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_fwd
         const int tile = blockIdx.x + i * gridDim.x;
         const NhwcThread<VEC> t(g, tile);
         if (!t.active) continue;
-        float gate[VEC], al[VEC], be[VEC];
+        float gate[VEC], al[VEC], be[VEC], al2[TWO ? VEC : 1], be2[TWO ? VEC : 1];
         CohBuf(a.f.gout).load<VEC>(t.plane0(g), gate);
         const CohBuf sb(a.bn_stats);
         sb.load<VEC>((size_t)BS_ALPHA * g.C + (size_t)t.vc * VEC, al);
         sb.load<VEC>((size_t)BS_BETA * g.C + (size_t)t.vc * VEC, be);
+        if constexpr (TWO) {
+            sb.load<VEC>((size_t)(BS_ROWS + BS_ALPHA) * g.C + (size_t)t.vc * VEC, al2);
+            sb.load<VEC>((size_t)(BS_ROWS + BS_BETA) * g.C + (size_t)t.vc * VEC, be2);
+        }
         auto emit = [&](const Vec<T, VEC>& vc, const Vec<T, VEC>& vb, size_t e) {
             Vec<T, VEC> o;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const float X = bn_sum<T>(to_float(vc.v[j]), to_float(vb.v[j]), al[j], be[j]);
+                const float b = bn_skip<T, TWO>(to_float(vb.v[j]), al2[TWO ? j : 0], be2[TWO ? j : 0]);
+                const float X = bn_sum<T>(to_float(vc.v[j]), b, al[j], be[j]);
                 const float v = gate[j] * X;  // one rounding, like the reference's x * g (:150)
                 o.v[j] = from_float<T>(relu ? fmaxf(v, 0.f) : v);
             }
@@ -346,8 +416,8 @@ __global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_fwd
 // ================================================================================================
 // backward
 // ================================================================================================
-template <typename T, int VEC, bool KEEP>
-__global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_bwd_kernel(NhwcBnArgs a, const T* __restrict__ gy,
+template <typename T, int VEC, bool KEEP, bool TWO>
+__global__ __launch_bounds__(kBlock, TWO ? 2 : CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_bwd_kernel(NhwcBnArgs a, const T* __restrict__ gy,
                                                                                          const T* __restrict__ cv,
                                                                                          const T* __restrict__ idt, T* __restrict__ dconv,
                                                                                          T* __restrict__ didt, GateDev gg, GateGradDev dg) {
@@ -361,14 +431,18 @@ __global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_bwd
     const float* __restrict__ st_m = a.bn_stats + (size_t)BS_MEAN * g.C;
     const float* __restrict__ st_al = a.bn_stats + (size_t)BS_ALPHA * g.C;
     const float* __restrict__ st_be = a.bn_stats + (size_t)BS_BETA * g.C;
+    const float* __restrict__ st2 = a.bn_stats + (size_t)BS_ROWS * g.C;  // (TWO) the skip path's rows
     const int relu = a.f.relu;
 
     // ---- A': per-(n, c) sums of G', G'*(X - float(mean)), G'*(c - float(m)) over a pixel chunk
     for (int tile = blockIdx.x; tile < a.f.ntiles; tile += gridDim.x) {
         const NhwcThread<VEC> t(g, tile);
-        float acc[3][VEC], mu[VEC], gate[VEC], al[VEC], be[VEC], mch[VEC];
+        float acc[3][VEC], acc4[1][VEC], mu[VEC], gate[VEC], al[VEC], be[VEC], mch[VEC], al2[TWO ? VEC : 1], be2[TWO ? VEC : 1],
+            m2ch[TWO ? VEC : 1];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = acc[2][j] = mu[j] = gate[j] = al[j] = be[j] = mch[j] = 0.f;
+        for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = acc[2][j] = acc4[0][j] = mu[j] = gate[j] = al[j] = be[j] = mch[j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < (TWO ? VEC : 1); ++j) al2[j] = be2[j] = m2ch[j] = 0.f;
         if (t.active) {
             const size_t pl = t.plane0(g), ch = (size_t)t.vc * VEC;
             load_planes<VEC>(row_mu + pl, mu);
@@ -376,16 +450,22 @@ __global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_bwd
             load_planes<VEC>(st_al + ch, al);
             load_planes<VEC>(st_be + ch, be);
             load_planes<VEC>(st_m + ch, mch);
+            if constexpr (TWO) {
+                load_planes<VEC>(st2 + (size_t)BS_ALPHA * g.C + ch, al2);
+                load_planes<VEC>(st2 + (size_t)BS_BETA * g.C + ch, be2);
+                load_planes<VEC>(st2 + (size_t)BS_MEAN * g.C + ch, m2ch);
+            }
             auto eat = [&](const Vec<T, VEC>& vg, const Vec<T, VEC>& vc, const Vec<T, VEC>& vb) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    const float c = to_float(vc.v[j]);
-                    const float X = bn_sum<T>(c, to_float(vb.v[j]), al[j], be[j]);
+                    const float c = to_float(vc.v[j]), c2 = to_float(vb.v[j]);
+                    const float X = bn_sum<T>(c, bn_skip<T, TWO>(c2, al2[TWO ? j : 0], be2[TWO ? j : 0]), al[j], be[j]);
                     float G = to_float(vg.v[j]);
                     if (relu) G = relu_open<T>(gate[j] * X) ? G : 0.f;
                     acc[0][j] += G;
                     acc[1][j] = fmaf(G, X - mu[j], acc[1][j]);
                     acc[2][j] = fmaf(G, c - mch[j], acc[2][j]);
+                    if constexpr (TWO) acc4[0][j] = fmaf(G, c2 - m2ch[j], acc4[0][j]);
                 }
             };
             int p = t.p0 + t.r;
@@ -407,6 +487,7 @@ __global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_bwd
             }
         }
         nhwc_rows_sum_part<VEC, 3, kBnBwd>(g, t, acc, 0, lds, a.f.part);
+        if constexpr (TWO) nhwc_rows_sum_part<VEC, 1, kBnBwd>(g, t, acc4, 3, lds, a.f.part);
     }
     if (!grid_barrier(a.f.bar, 1, &bar_flag)) {
         nhwc_mark_owed<T, VEC>(g, a.f.ntiles, dconv);
@@ -419,15 +500,16 @@ __global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_bwd
         const int c0 = grp * GC, n = threadIdx.x;
         const bool live = n < g.N;
         const size_t p0 = (size_t)(live ? n : 0) * g.C + c0;
-        double S1[GC], S2[GC], S3[GC], mu[GC], lo[GC], gate[GC], zh[GC], sig[GC], E[GC], DM[GC];
+        double S1[GC], S2[GC], S3[GC], S4[GC], mu[GC], lo[GC], gate[GC], zh[GC], sig[GC], E[GC], DM[GC], E2[GC], DM2[GC];
 #pragma unroll
-        for (int j = 0; j < GC; ++j) S1[j] = S2[j] = S3[j] = 0.0;
+        for (int j = 0; j < GC; ++j) S1[j] = S2[j] = S3[j] = S4[j] = E2[j] = DM2[j] = 0.0;
         const CohBuf pb(a.f.part);
         for (int s = 0; s < g.S; ++s) {
             const size_t base = (size_t)s * kBnBwd * g.P + p0;
             add_group_coh<GC>(pb, base, S1);
             add_group_coh<GC>(pb, base + g.P, S2);
             add_group_coh<GC>(pb, base + 2 * g.P, S3);
+            if constexpr (TWO) add_group_coh<GC>(pb, base + 3 * g.P, S4);
         }
         load_group<GC>(a.f.slim + (size_t)SL_MU_HI * g.P + p0, mu);
         load_group<GC>(a.f.slim + (size_t)SL_MU_LO * g.P + p0, lo);
@@ -436,6 +518,10 @@ __global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_bwd
         load_group<GC>(a.f.slim + (size_t)SL_SIG * g.P + p0, sig);
         load_group<GC>(a.f.slim + (size_t)SLB_E * g.P + p0, E);
         load_group<GC>(a.f.slim + (size_t)SLB_DM * g.P + p0, DM);
+        if constexpr (TWO) {
+            load_group<GC>(a.f.slim + (size_t)SLB_E2 * g.P + p0, E2);
+            load_group<GC>(a.f.slim + (size_t)SLB_DM2 * g.P + p0, DM2);
+        }
         double dt[GC], acc[2 * GC];
 #pragma unroll
         for (int j = 0; j < GC; ++j) {
@@ -504,6 +590,33 @@ __global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_bwd
             __hip_atomic_store(a.chan + c, e0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // (phase C' reads them)
             __hip_atomic_store(a.chan + g.C + c, e1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if constexpr (TWO) {  // the skip path's BatchNorm2d: the same D1, D2 against ITS convolution output
+            double a2[GC];
+#pragma unroll
+            for (int j = 0; j < GC; ++j) {
+                const double fx = (double)o_cx[j], f0 = (double)o_c0[j];
+                a2[j] = live ? gate[j] * S4[j] + fx * (E2[j] + lo[j] * M * DM2[j]) + f0 * M * DM2[j] : 0.0;
+            }
+            // (D1 is the same sum: kept from the block sum above by the threads that own a channel)
+            double D1k = 0.0;
+            if (threadIdx.x < GC) {
+#pragma unroll
+                for (int q = 0; q < GC; ++q)
+                    if (q == (int)threadIdx.x) D1k = acc[q];
+            }
+            block_sum_d<GC>(a2, red);
+            if (threadIdx.x < GC) {
+                const int c = c0 + threadIdx.x;
+                const double D2b = pick<GC>(a2, (int)threadIdx.x);
+                const float* s2 = a.bn_stats + (size_t)BS_ROWS * g.C;
+                const double rs = (double)s2[(size_t)BS_RSTD * g.C + c], al = (double)s2[(size_t)BS_ALPHA * g.C + c];
+                a.dbn2_b[c] = (float)D1k;
+                a.dbn2_w[c] = (float)(rs * D2b);
+                const float e0 = (float)(-al * D1k * a.inv_r), e1 = (float)(-al * rs * rs * D2b * a.inv_r);
+                __hip_atomic_store(a.chan + 2 * (size_t)g.C + c, e0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.chan + 3 * (size_t)g.C + c, e1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         if (live) {
             const CohBuf cb(a.f.coefb);  // (phase C' reads them)
             cb.store<GC>(p0, o_cx);
@@ -524,6 +637,7 @@ __global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_bwd
         if (!t.active) continue;
         const size_t pl = t.plane0(g), ch = (size_t)t.vc * VEC;
         float cG[VEC], cX[VEC], xr[VEC], c0[VEC], al[VEC], be[VEC], mch[VEC], e0[VEC], e1[VEC];
+        float al2[TWO ? VEC : 1], be2[TWO ? VEC : 1], m2ch[TWO ? VEC : 1], e0b[TWO ? VEC : 1], e1b[TWO ? VEC : 1];
         load_planes<VEC>(row_g + pl, cG);
         load_planes<VEC>(row_mu + pl, xr);
         const CohBuf cb(a.f.coefb), eb(a.chan);
@@ -534,16 +648,26 @@ __global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_bwd
         load_planes<VEC>(st_m + ch, mch);
         eb.load<VEC>(ch, e0);
         eb.load<VEC>((size_t)g.C + ch, e1);
+        if constexpr (TWO) {
+            load_planes<VEC>(st2 + (size_t)BS_ALPHA * g.C + ch, al2);
+            load_planes<VEC>(st2 + (size_t)BS_BETA * g.C + ch, be2);
+            load_planes<VEC>(st2 + (size_t)BS_MEAN * g.C + ch, m2ch);
+            eb.load<VEC>(2 * (size_t)g.C + ch, e0b);
+            eb.load<VEC>(3 * (size_t)g.C + ch, e1b);
+        }
         auto emit = [&](const Vec<T, VEC>& vg, const Vec<T, VEC>& vc, const Vec<T, VEC>& vb, size_t e) {
             Vec<T, VEC> o, od;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const float c = to_float(vc.v[j]);
-                const float X = bn_sum<T>(c, to_float(vb.v[j]), al[j], be[j]);
+                const float c = to_float(vc.v[j]), c2 = to_float(vb.v[j]);
+                const float X = bn_sum<T>(c, bn_skip<T, TWO>(c2, al2[TWO ? j : 0], be2[TWO ? j : 0]), al[j], be[j]);
                 float G = to_float(vg.v[j]);
                 if (relu) G = relu_open<T>(cG[j] * X) ? G : 0.f;
                 const float dX = fmaf(cG[j], G, fmaf(cX[j], X - xr[j], c0[j]));
-                od.v[j] = from_float<T>(dX);
+                if constexpr (TWO)  // the gradient of the skip path's convolution output, through ITS BatchNorm2d
+                    od.v[j] = from_float<T>(fmaf(al2[j], dX, fmaf(e1b[j], c2 - m2ch[j], e0b[j])));
+                else
+                    od.v[j] = from_float<T>(dX);
                 o.v[j] = from_float<T>(fmaf(al[j], dX, fmaf(e1[j], c - mch[j], e0[j])));
             }
             store_vec_nt<T, VEC>(dconv + e, o);

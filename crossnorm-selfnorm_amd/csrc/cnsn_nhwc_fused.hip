@@ -252,16 +252,20 @@ bool nhwc_bnhead_ok(const Plan& pl, bool check_health) {
 
 size_t nhwc_bnhead_extra_bytes(const Plan& pl) {
     const NhwcGeom g = nhwc_fused_geom(pl);
-    // part | kshift (conv), kshift (identity), gate / cX, c0 | e0, e1 | barrier block
-    return align256((size_t)g.S * kBnFwd * g.P * 4) + align256(4 * g.P * 4) + align256(2 * (size_t)pl.pr.C * 4) + kBarBlock + 256;
+    // part | kshift (conv), kshift (identity), gate / cX, c0 | e0, e1 (x 2 with a BatchNorm2d on the skip path) | barrier block
+    return align256((size_t)g.S * kBnFwd * g.P * 4) + align256(4 * g.P * 4) + align256(4 * (size_t)pl.pr.C * 4) + kBarBlock + 256;
 }
 
 namespace {
-NhwcBnArgs make_bn_args(const Plan& pl, const NhwcGeom& ng, int relu, const cnsn_bn_tail_t& bn, float* bn_stats, void* workspace) {
+NhwcBnArgs make_bn_args(const Plan& pl, const NhwcGeom& ng, int relu, const cnsn_bn_tail_t& bn, const cnsn_bn_tail_t* bn2, float* bn_stats,
+                        void* workspace) {
     const cnsn_problem_t& p = pl.pr;
     NhwcBnArgs a{};
     a.f = make_args(pl, ng, relu, kBnGc);
     a.bn = BnHeadDev{bn.weight, bn.bias, bn.running_mean, bn.running_var, (long long*)bn.num_batches_tracked, bn.eps, bn.momentum};
+    if (bn2)
+        a.bn2 = BnHeadDev{bn2->weight, bn2->bias, bn2->running_mean, bn2->running_var, (long long*)bn2->num_batches_tracked, bn2->eps,
+                          bn2->momentum};
     const double R = (double)p.N * (double)ng.M;
     a.inv_r = 1.0 / R;
     a.unbias_r = R > 1.0 ? R / (R - 1.0) : 1.0;
@@ -275,16 +279,16 @@ NhwcBnArgs make_bn_args(const Plan& pl, const NhwcGeom& ng, int relu, const cnsn
     a.chan = (float*)((char*)side + align256(4 * pl.P * 4));
     return a;
 }
-void* bn_bar_block(const Plan& pl, const NhwcBnArgs& a) { return (char*)a.chan + align256(2 * (size_t)pl.pr.C * 4); }
+void* bn_bar_block(const Plan& pl, const NhwcBnArgs& a) { return (char*)a.chan + align256(4 * (size_t)pl.pr.C * 4); }
 }  // namespace
 
-int nhwc_bnhead_forward(Plan& pl, int relu, const cnsn_bn_tail_t& bn, const void* conv_out, const void* identity, GateDev gg, void* y,
-                        float* saved, float* bn_stats, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+int nhwc_bnhead_forward(Plan& pl, int relu, const cnsn_bn_tail_t& bn, const cnsn_bn_tail_t* bn2, const void* conv_out, const void* identity,
+                        GateDev gg, void* y, float* saved, float* bn_stats, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     const cnsn_problem_t& p = pl.pr;
-    if (!nhwc_bnhead_ok(pl) || !bn.training) return CNSN_E_UNSUPPORTED;
+    if (!nhwc_bnhead_ok(pl) || !bn.training || (bn2 && !bn2->training)) return CNSN_E_UNSUPPORTED;
     if (workspace_bytes < nhwc_bnhead_extra_bytes(pl)) return CNSN_E_WORKSPACE;
     const NhwcGeom ng = nhwc_fused_geom(pl);
-    NhwcBnArgs a = make_bn_args(pl, ng, relu, bn, bn_stats, workspace);
+    NhwcBnArgs a = make_bn_args(pl, ng, relu, bn, bn2, bn_stats, workspace);
     a.f.slim = saved;
     if (saved) a.f.gout = saved + (size_t)SL_G * pl.P;
     a.f.keep = (size_t)2 * pl.P * ng.M * elem_bytes(p.dtype) <= ((size_t)320 << 20) ? 1 : 0;
@@ -293,12 +297,13 @@ int nhwc_bnhead_forward(Plan& pl, int relu, const cnsn_bn_tail_t& bn, const void
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value;
         const size_t lds = (size_t)3 * ng.rows * ng.tcb * VEC * 4;
-        if (a.f.keep)
-            status = launch_fused(pl, nhwc_bnhead_fwd_kernel<T, VEC, true>, lds, a, a.f, bn_bar_block(pl, a), stream, (const T*)conv_out,
-                                  (const T*)identity, (T*)y, gg);
+        auto go = [&](auto kern) {
+            status = launch_fused(pl, kern, lds, a, a.f, bn_bar_block(pl, a), stream, (const T*)conv_out, (const T*)identity, (T*)y, gg);
+        };
+        if (bn2)
+            a.f.keep ? go(nhwc_bnhead_fwd_kernel<T, VEC, true, true>) : go(nhwc_bnhead_fwd_kernel<T, VEC, false, true>);
         else
-            status = launch_fused(pl, nhwc_bnhead_fwd_kernel<T, VEC, false>, lds, a, a.f, bn_bar_block(pl, a), stream, (const T*)conv_out,
-                                  (const T*)identity, (T*)y, gg);
+            a.f.keep ? go(nhwc_bnhead_fwd_kernel<T, VEC, true, false>) : go(nhwc_bnhead_fwd_kernel<T, VEC, false, false>);
     });
     if (knob(K_DEBUG))
         fprintf(stderr, "[cnsn] nhwc bn-block fwd: tiles=%d (S=%d rows=%d tcb=%d) groups=%d keep=%d -> status %d\n", a.f.ntiles, ng.S,
@@ -306,30 +311,35 @@ int nhwc_bnhead_forward(Plan& pl, int relu, const cnsn_bn_tail_t& bn, const void
     return status;
 }
 
-int nhwc_bnhead_backward(Plan& pl, int relu, const cnsn_bn_tail_t& bn, const void* gy, const void* conv_out, const void* identity,
-                         GateDev gg, const float* saved, const float* bn_stats, void* d_conv, void* d_identity, GateGradDev dg,
-                         float* dbn_w, float* dbn_b, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+int nhwc_bnhead_backward(Plan& pl, int relu, const cnsn_bn_tail_t& bn, const cnsn_bn_tail_t* bn2, const void* gy, const void* conv_out,
+                         const void* identity, GateDev gg, const float* saved, const float* bn_stats, void* d_conv, void* d_identity,
+                         GateGradDev dg, float* dbn_w, float* dbn_b, float* dbn2_w, float* dbn2_b, void* workspace,
+                         size_t workspace_bytes, hipStream_t stream) {
     const cnsn_problem_t& p = pl.pr;
-    if (!nhwc_bnhead_ok(pl, false) || !bn.training) return CNSN_E_UNSUPPORTED;
-    if (!saved || !bn_stats || !d_conv || !d_identity || !dbn_w || !dbn_b) return CNSN_E_NULL;
+    if (!nhwc_bnhead_ok(pl, false) || !bn.training || (bn2 && !bn2->training)) return CNSN_E_UNSUPPORTED;
+    if (!saved || !bn_stats || !d_conv || !d_identity || !dbn_w || !dbn_b || (bn2 && (!dbn2_w || !dbn2_b))) return CNSN_E_NULL;
     if (workspace_bytes < nhwc_bnhead_extra_bytes(pl)) return CNSN_E_WORKSPACE;
     const NhwcGeom ng = nhwc_fused_geom(pl);
-    NhwcBnArgs a = make_bn_args(pl, ng, relu, bn, const_cast<float*>(bn_stats), workspace);
+    NhwcBnArgs a = make_bn_args(pl, ng, relu, bn, bn2, const_cast<float*>(bn_stats), workspace);
     a.f.slim = const_cast<float*>(saved);
     a.dbn_w = dbn_w;
     a.dbn_b = dbn_b;
+    a.dbn2_w = dbn2_w;
+    a.dbn2_b = dbn2_b;
     a.f.keep = (size_t)3 * pl.P * ng.M * elem_bytes(p.dtype) <= ((size_t)320 << 20) ? 1 : 0;
     int status = CNSN_E_UNSUPPORTED;
     dispatch_t(p.dtype, [&](auto tt, auto vt) {
         using T = typename decltype(tt)::type;
         constexpr int VEC = decltype(vt)::value;
         const size_t lds = (size_t)3 * ng.rows * ng.tcb * VEC * 4;
-        if (a.f.keep)
-            status = launch_fused(pl, nhwc_bnhead_bwd_kernel<T, VEC, true>, lds, a, a.f, bn_bar_block(pl, a), stream, (const T*)gy,
-                                  (const T*)conv_out, (const T*)identity, (T*)d_conv, (T*)d_identity, gg, dg);
+        auto go = [&](auto kern) {
+            status = launch_fused(pl, kern, lds, a, a.f, bn_bar_block(pl, a), stream, (const T*)gy, (const T*)conv_out, (const T*)identity,
+                                  (T*)d_conv, (T*)d_identity, gg, dg);
+        };
+        if (bn2)
+            a.f.keep ? go(nhwc_bnhead_bwd_kernel<T, VEC, true, true>) : go(nhwc_bnhead_bwd_kernel<T, VEC, false, true>);
         else
-            status = launch_fused(pl, nhwc_bnhead_bwd_kernel<T, VEC, false>, lds, a, a.f, bn_bar_block(pl, a), stream, (const T*)gy,
-                                  (const T*)conv_out, (const T*)identity, (T*)d_conv, (T*)d_identity, gg, dg);
+            a.f.keep ? go(nhwc_bnhead_bwd_kernel<T, VEC, true, false>) : go(nhwc_bnhead_bwd_kernel<T, VEC, false, false>);
     });
     if (knob(K_DEBUG))
         fprintf(stderr, "[cnsn] nhwc bn-block bwd: tiles=%d (S=%d rows=%d tcb=%d) groups=%d keep=%d -> status %d\n", a.f.ntiles, ng.S,

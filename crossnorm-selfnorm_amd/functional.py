@@ -654,14 +654,41 @@ def bn_block_plan(x: torch.Tensor, cfg: FusedConfig) -> bool:
     return hit
 
 
+class _Bn2dBuffers:
+    """float32 contiguous views / copies of an nn.BatchNorm2d's tensors + the cnsn_bn_tail_t that points at them (training mode)"""
+
+    def __init__(self, w, b, rm, rv, eps, momentum, nbt):
+        self.src_rm, self.src_rv = rm, rv
+        self.w, self.b = _f32(w), _f32(b)
+        if nbt is not None and not (nbt.dtype == torch.int64 and nbt.is_cuda and nbt.numel() == 1):
+            nbt.add_(1)          # (a counter the kernel cannot reach: counted here, as nn.BatchNorm2d.forward does)
+            nbt = None
+        self.direct = rm.dtype == torch.float32 and rm.is_contiguous() and rv.dtype == torch.float32 and rv.is_contiguous()
+        self.rm = rm.detach() if self.direct else _f32(rm)
+        self.rv = rv.detach() if self.direct else _f32(rv)
+        self.eps, self.momentum = float(eps), float(momentum)
+        self.c = self.struct(nbt)
+
+    def struct(self, nbt=None):
+        return _ffi.BnTail(C.sizeof(_ffi.BnTail), 1, self.eps, self.momentum, self.w.data_ptr(), self.b.data_ptr(), self.rm.data_ptr(),
+                           self.rv.data_ptr(), _ptr(nbt))
+
+    def write_back(self):
+        if not self.direct:
+            self.src_rm.copy_(self.rm)
+            self.src_rv.copy_(self.rv)
+
+
 class FusedBnBlock(torch.autograd.Function):
     """y = act(SelfNorm(BatchNorm2d(conv_out) + identity)) — the tail of a ResNet bottleneck (resnet_cnsn.py:108-122, pos='post')
-    in one launch per direction.  Saves conv_out and identity (what BatchNorm2d and the add would have saved), never writes
-    BatchNorm2d's output or the sum."""
+    in one launch per direction; with `bn2_*` the identity is itself `BatchNorm2d(skip convolution)` (the block's downsample,
+    :99-100) and `identity` is that convolution's output.  Saves conv_out and identity (what the BatchNorm2d layers and the add
+    would have saved), never writes a BatchNorm2d's output or the sum."""
 
     @staticmethod
     def forward(ctx, conv_out, identity, cfg: FusedConfig, g_w, g_gamma, g_beta, g_rm, g_rv, bn_w, bn_b, bn_rm, bn_rv, bn_eps,
-                bn_momentum, g_nbt=None, bn_nbt=None):
+                bn_momentum, g_nbt=None, bn_nbt=None, bn2_w=None, bn2_b=None, bn2_rm=None, bn2_rv=None, bn2_eps=0.0,
+                bn2_momentum=0.0, bn2_nbt=None):
         _require_device(conv_out, "cnsn_forward_bn_block")
         with torch.cuda.device(conv_out.device):
             lib = _ffi.lib()
@@ -675,35 +702,26 @@ class FusedBnBlock(torch.autograd.Function):
             dev = x.device
             _context(prob, dev)
             gate = _GateBuffers(g_w, g_gamma, g_beta, g_rm, g_rv, g_nbt)
-            bw, bb = _f32(bn_w), _f32(bn_b)
-            if bn_nbt is not None and not (bn_nbt.dtype == torch.int64 and bn_nbt.is_cuda and bn_nbt.numel() == 1):
-                bn_nbt.add_(1)
-                bn_nbt = None
-            direct = (bn_rm.dtype == torch.float32 and bn_rm.is_contiguous() and bn_rv.dtype == torch.float32
-                      and bn_rv.is_contiguous())
-            rm = bn_rm.detach() if direct else _f32(bn_rm)
-            rv = bn_rv.detach() if direct else _f32(bn_rv)
-            head = _ffi.BnTail(C.sizeof(_ffi.BnTail), 1, float(bn_eps), float(bn_momentum), bw.data_ptr(), bb.data_ptr(),
-                               rm.data_ptr(), rv.data_ptr(), _ptr(bn_nbt))
+            head = _Bn2dBuffers(bn_w, bn_b, bn_rm, bn_rv, bn_eps, bn_momentum, bn_nbt)
+            skip = _Bn2dBuffers(bn2_w, bn2_b, bn2_rm, bn2_rv, bn2_eps, bn2_momentum, bn2_nbt) if bn2_w is not None else None
             y = _out_like(x)
             need_bwd = any(ctx.needs_input_grad)
             saved_floats, ws_bytes = _sizes(prob)[:2]
             saved = torch.empty(saved_floats, dtype=torch.float32, device=dev) if need_bwd else None
-            stats = torch.empty(4 * x.shape[1], dtype=torch.float32, device=dev)
+            stats = torch.empty((8 if skip else 4) * x.shape[1], dtype=torch.float32, device=dev)
             ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=dev)
             epi = _epilogue(cfg, idt)
-            st = lib.cnsn_forward_bn_block(C.byref(prob), C.byref(epi), C.byref(head), _ptr(x), C.byref(gate.c), _ptr(y),
-                                           _ptr(saved), _ptr(stats), _ptr(ws), ws_bytes, _stream(x))
+            st = lib.cnsn_forward_bn_block(C.byref(prob), C.byref(epi), C.byref(head.c), C.byref(skip.c) if skip else None, _ptr(x),
+                                           C.byref(gate.c), _ptr(y), _ptr(saved), _ptr(stats), _ptr(ws), ws_bytes, _stream(x))
             _ffi.check(st, "cnsn_forward_bn_block")
             gate.write_back()
-            if not direct:
-                bn_rm.copy_(rm)
-                bn_rv.copy_(rv)
+            head.write_back()
+            if skip:
+                skip.write_back()
             if need_bwd:
-                ctx.cfg, ctx.prob, ctx.gate = cfg, prob, gate
-                ctx.head_cfg = (float(bn_eps), float(bn_momentum))
-                ctx.param_dtypes = (g_w.dtype, g_gamma.dtype, g_beta.dtype, bn_w.dtype, bn_b.dtype)
-                ctx.bn_buffers = (bw, bb, rm, rv)
+                ctx.cfg, ctx.prob, ctx.gate, ctx.head, ctx.skip = cfg, prob, gate, head, skip
+                ctx.param_dtypes = (g_w.dtype, g_gamma.dtype, g_beta.dtype, bn_w.dtype, bn_b.dtype,
+                                    bn2_w.dtype if skip else None, bn2_b.dtype if skip else None)
                 ctx.save_for_backward(x, idt, saved, stats)
             return y
 
@@ -712,17 +730,16 @@ class FusedBnBlock(torch.autograd.Function):
         x, idt, saved, stats = ctx.saved_tensors
         with torch.cuda.device(x.device):
             lib = _ffi.lib()
-            cfg, prob, gate = ctx.cfg, ctx.prob, ctx.gate
+            cfg, prob, gate, head, skip = ctx.cfg, ctx.prob, ctx.gate, ctx.head, ctx.skip
             dev = x.device
             gy = _dense_cl(gy if gy.dtype == x.dtype else gy.to(x.dtype))
-            bw, bb, rm, rv = ctx.bn_buffers
-            eps, mom = ctx.head_cfg
-            head = _ffi.BnTail(C.sizeof(_ffi.BnTail), 1, eps, mom, bw.data_ptr(), bb.data_ptr(), rm.data_ptr(), rv.data_ptr(), None)
+            hs = head.struct()
+            ss = skip.struct() if skip else None
             Cn = x.shape[1]
             d_conv, d_idt = _out_like(x), _out_like(x)
-            flat = torch.empty(6 * Cn, dtype=torch.float32, device=dev)
+            flat = torch.empty(8 * Cn, dtype=torch.float32, device=dev)
             dw, dgam, dbet = flat[:2 * Cn].view(Cn, 1, 2), flat[2 * Cn:3 * Cn], flat[3 * Cn:4 * Cn]
-            dbw, dbb = flat[4 * Cn:5 * Cn], flat[5 * Cn:]
+            dbw, dbb, d2w, d2b = flat[4 * Cn:5 * Cn], flat[5 * Cn:6 * Cn], flat[6 * Cn:7 * Cn], flat[7 * Cn:]
             gg = _ffi.GateGrad(_ptr(dw), _ptr(dgam), _ptr(dbet))
             ws_bytes = _sizes(prob)[1]
             _context(prob, dev)
@@ -730,14 +747,17 @@ class FusedBnBlock(torch.autograd.Function):
                 prob.context, prob.context_bytes = None, 0
             ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=dev)
             epi = _epilogue(cfg, idt)
-            st = lib.cnsn_backward_bn_block(C.byref(prob), C.byref(epi), C.byref(head), _ptr(gy), _ptr(x), C.byref(gate.c),
-                                            _ptr(saved), _ptr(stats), _ptr(d_conv), _ptr(d_idt), C.byref(gg), _ptr(dbw), _ptr(dbb),
-                                            _ptr(ws), ws_bytes, _stream(x))
+            st = lib.cnsn_backward_bn_block(C.byref(prob), C.byref(epi), C.byref(hs), C.byref(ss) if ss else None, _ptr(gy), _ptr(x),
+                                            C.byref(gate.c), _ptr(saved), _ptr(stats), _ptr(d_conv), _ptr(d_idt), C.byref(gg),
+                                            _ptr(dbw), _ptr(dbb), _ptr(d2w) if skip else None, _ptr(d2b) if skip else None, _ptr(ws),
+                                            ws_bytes, _stream(x))
             _ffi.check(st, "cnsn_backward_bn_block")
             pd = ctx.param_dtypes
             outs = [t if t.dtype == pd[i] else t.to(pd[i]) for i, t in enumerate((dw, dgam, dbet, dbw, dbb))]
+            o2 = [None, None] if not skip else [t if t.dtype == pd[5 + i] else t.to(pd[5 + i]) for i, t in enumerate((d2w, d2b))]
             #       conv   identity cfg  g_w      g_gamma  g_beta  g_rm  g_rv  bn_w     bn_b    bn_rm bn_rv eps   mom   nbt   nbt
-            return (d_conv, d_idt, None, outs[0], outs[1], outs[2], None, None, outs[3], outs[4], None, None, None, None, None, None)
+            return (d_conv, d_idt, None, outs[0], outs[1], outs[2], None, None, outs[3], outs[4], None, None, None, None, None, None,
+                    o2[0], o2[1], None, None, None, None, None)
 
 
 def _glue_cfg(cfg: FusedConfig, need_bwd: bool):

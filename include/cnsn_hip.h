@@ -325,17 +325,26 @@ int cnsn_sn_cluster_plan(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi,
  *     returns CNSN_E_UNSUPPORTED: the caller then runs BatchNorm2d itself and cnsn_forward_fused, as the reference does.
  *   - bn: BatchNorm2d's parameters and buffers (the struct of the fused tail); running statistics and num_batches_tracked are
  *     updated by the forward as nn.BatchNorm2d does (momentum; running_var takes the unbiased variance).
- *   - bn_stats: float32 (4, C) — batch mean, rstd and the two coefficients x = alpha*conv_out + beta was evaluated with;
- *     forward writes, backward reads.  `saved`: cnsn_saved_floats(), as for cnsn_forward_fused; workspace: cnsn_workspace_bytes().
- *   - backward: grad_conv_out and grad_identity (the gradient of the sum) are both written; d_bn_weight / d_bn_bias: (C). */
+ *   - bn_skip (may be NULL): the skip path ends in a BatchNorm2d of its own — the block's `downsample` (resnet_cnsn.py:99-100,
+ *     the first block of every stage).  epi->addend is then the INPUT of that BatchNorm2d (the 1x1 convolution's output) and
+ *       y = act( CNSN( BatchNorm2d(conv_out) + BatchNorm2d_skip(addend) ) ):
+ *     the sum is affine in both convolution outputs per channel, the same plane sums serve both normalisations, and the
+ *     backward writes the gradient of the skip convolution's output into grad_identity.  Same tensor passes: the downsample's
+ *     BatchNorm2d costs nothing.
+ *   - bn_stats: float32 (4, C) — batch mean, rstd and the two coefficients x = alpha*conv_out + beta was evaluated with
+ *     ((8, C) with bn_skip: its four rows follow); forward writes, backward reads.  `saved`: cnsn_saved_floats(), as for
+ *     cnsn_forward_fused; workspace: cnsn_workspace_bytes().
+ *   - backward: grad_conv_out and grad_identity (the gradient of the sum; with bn_skip: of the skip convolution's output) are
+ *     both written; d_bn_weight / d_bn_bias (and d_bn_skip_*): (C). */
 int cnsn_bn_block_plan(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi);
-int cnsn_forward_bn_block(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const cnsn_bn_tail_t* bn, const void* conv_out,
-                          const cnsn_gate_t* g, void* y, float* saved, float* bn_stats, void* workspace, size_t workspace_bytes,
-                          void* stream);
-int cnsn_backward_bn_block(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const cnsn_bn_tail_t* bn, const void* grad_y,
-                           const void* conv_out, const cnsn_gate_t* g, const float* saved, const float* bn_stats,
-                           void* grad_conv_out, void* grad_identity, const cnsn_gate_grad_t* dg, float* d_bn_weight,
-                           float* d_bn_bias, void* workspace, size_t workspace_bytes, void* stream);
+int cnsn_forward_bn_block(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const cnsn_bn_tail_t* bn,
+                          const cnsn_bn_tail_t* bn_skip, const void* conv_out, const cnsn_gate_t* g, void* y, float* saved,
+                          float* bn_stats, void* workspace, size_t workspace_bytes, void* stream);
+int cnsn_backward_bn_block(const cnsn_problem_t* prob, const cnsn_epilogue_t* epi, const cnsn_bn_tail_t* bn,
+                           const cnsn_bn_tail_t* bn_skip, const void* grad_y, const void* conv_out, const cnsn_gate_t* g,
+                           const float* saved, const float* bn_stats, void* grad_conv_out, void* grad_identity,
+                           const cnsn_gate_grad_t* dg, float* d_bn_weight, float* d_bn_bias, float* d_bn_skip_weight,
+                           float* d_bn_skip_bias, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- persistent exchange context of the cluster-resident strategy --------------------------------
  * The resident kernels hand per-plane scalars from workgroup to workgroup through device memory.  Through the
