@@ -560,6 +560,11 @@ def model_workload(args, dist, world, rank, dev):
     if args.channels_last:
         net = net.to(memory_format=torch.channels_last)
         name += "; channels-last"
+        if args.workload in ("resnet50", "resnet50_jsd"):
+            from cnsn_amd import functional as _F
+            from cnsn_amd.callers import _sites
+            if _F._BN_BLOCK and _sites.FUSE_BLOCK:   # (round 6: profiles/r06_bn_block.md; CNSN_BN_BLOCK=0 calls the BatchNorm2d modules)
+                name += ", bn3 / downsample BatchNorm2d inside the op's launch"
     model = net
     if dist is not None:
         if dist.get_backend() == "nccl":
