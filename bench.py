@@ -321,7 +321,11 @@ def roofline_bf16(cnsn_amd, dev):
                                     ("block_256x256x56x56_channels_last", (256, 256, 56, 56), True, CL),
                                     ("block_256x512x28x28_channels_last", (256, 512, 28, 28), True, CL),
                                     ("block_256x1024x14x14_channels_last", (256, 1024, 14, 14), True, CL),
-                                    ("block_256x2048x7x7_channels_last", (256, 2048, 7, 7), True, CL)):
+                                    ("block_256x2048x7x7_channels_last", (256, 2048, 7, 7), True, CL),
+                                    # the whole bottleneck tail bn3 + add + SelfNorm + ReLU in ONE launch per direction (round 6,
+                                    # cnsn_forward_bn_block): conv_out, identity -> y = 3 passes; G, conv_out, identity -> two gradients = 5
+                                    ("bn_block_256x256x56x56_channels_last", (256, 256, 56, 56), "bn", CL),
+                                    ("bn_block_256x1024x14x14_channels_last", (256, 1024, 14, 14), "bn", CL)):
         n, c, h, w = shape
         eb = n * c * h * w * 2
         a = conditioned(shape, dev, torch.bfloat16, 61)
@@ -331,11 +335,14 @@ def roofline_bf16(cnsn_amd, dev):
             a, idt, gy = a.contiguous(memory_format=fmt), idt.contiguous(memory_format=fmt), gy.contiguous(memory_format=fmt)
         a, idt = a.detach().requires_grad_(), idt.detach().requires_grad_()
         mod = cnsn_amd.CNSN(None if block else cnsn_amd.CrossNorm("neither", 1), cnsn_amd.SelfNorm(c)).to(dev).train()
-        ins = [a] + ([idt] if block else []) + list(mod.parameters())
+        bn3 = torch.nn.BatchNorm2d(c).to(dev).train() if block == "bn" else None
+        ins = [a] + ([idt] if block else []) + list(mod.parameters()) + (list(bn3.parameters()) if bn3 is not None else [])
 
         def fwd():
             if mod.crossnorm is not None:
                 mod.crossnorm.active = True
+            if bn3 is not None:
+                return mod.forward_bn_block(a, bn3, idt, relu=True)
             return mod.forward_block(a, idt, add_mode="pre", relu=True) if block else mod(a)
 
         for _ in range(6):
@@ -351,8 +358,8 @@ def roofline_bf16(cnsn_amd, dev):
         torch.cuda.synchronize()
         tf = sorted(e[0].elapsed_time(e[1]) for e in ev)[15] * 1e-3
         tb = sorted(e[1].elapsed_time(e[2]) for e in ev)[15] * 1e-3
-        pf, pb = (3, 4) if block else (2, 3)
-        cfg = cnsn_amd.FusedConfig(cn_active=not block, sn_active=True, add_mode="pre" if block else "none", relu=block)
+        pf, pb = (3, 5) if block == "bn" else ((3, 4) if block else (2, 3))
+        cfg = cnsn_amd.FusedConfig(cn_active=not block, sn_active=True, add_mode="pre" if block else "none", relu=bool(block))
         res[name] = {"forward": {"kernel_us": round(tf * 1e6, 1), "bytes": pf * eb, "achieved": round(pf * eb / tf / 1e9, 1),
                                  "frac": round(pf * eb / tf / 1e9 / HBM_PEAK_GBS, 4)},
                      "backward": {"kernel_us": round(tb * 1e6, 1), "bytes": pb * eb, "achieved": round(pb * eb / tb / 1e9, 1),
@@ -361,9 +368,12 @@ def roofline_bf16(cnsn_amd, dev):
         if fmt is not None:
             res[name].pop("sn_cluster_kernels")
             res[name]["kernels"] = cnsn_amd.which_path(a, cfg)       # 'resident' = the single-launch kernels
-            res[name]["passes_moved"] = [5, 5]
-            res[name]["forward"]["achieved_on_bytes_moved"] = round(5 * eb / tf / 1e9, 1)
-            res[name]["backward"]["achieved_on_bytes_moved"] = round(5 * eb / tb / 1e9, 1)
+            mv = (5, 8) if block == "bn" else (5, 5)
+            res[name]["passes_moved"] = list(mv)
+            res[name]["forward"]["achieved_on_bytes_moved"] = round(mv[0] * eb / tf / 1e9, 1)
+            res[name]["backward"]["achieved_on_bytes_moved"] = round(mv[1] * eb / tb / 1e9, 1)
+            if block == "bn":
+                res[name]["unfused_passes"] = [8, 10]     # MIOpen's BatchNorm2d 3 + 5, the op's launches 5 + 5
         del a, idt, gy, mod
     return res
 
