@@ -33,6 +33,9 @@
 #pragma once
 #include "cnsn_nhwc_fused_kernels.h"
 
+#ifndef CNSN_BNHEAD_UA
+#define CNSN_BNHEAD_UA 2  // pixels of a thread's column in flight in the forward's statistics phase (two tensors each)
+#endif
 #ifndef CNSN_BNHEAD_WG_PER_CU
 #define CNSN_BNHEAD_WG_PER_CU 3  // (168 VGPRs: the backward's apply phase holds nine coefficients per channel of a lane's vector)
 #endif
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(kBlock, CNSN_BNHEAD_WG_PER_CU) void nhwc_bnhead_fwd
                     acc2[1][j] = fmaf(dc, db, acc2[1][j]);
                 }
             };
-            constexpr int U = 2;
+            constexpr int U = CNSN_BNHEAD_UA;
             int p = t.p0 + t.r;
             for (; p + (U - 1) * g.rows < t.p1; p += U * g.rows) {
                 Vec<T, VEC> vc[U], vb[U];
